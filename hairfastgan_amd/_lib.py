@@ -1,0 +1,73 @@
+"""ctypes binding of libhairfast_hip.so (the C ABI declared in include/hairfast_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``hairfastgan_amd/csrc/build.sh`` (hipcc, --offload-arch=gfx950).  There is no
+fallback: if the shared object is missing or a symbol is absent, importing the
+ops raises immediately.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhairfast_hip.so")
+
+_f = ctypes.c_void_p      # float* / const float* (device pointers)
+_i = ctypes.c_int
+_ll = ctypes.c_longlong
+_fl = ctypes.c_float
+_st = ctypes.c_void_p     # hipStream_t
+
+# name -> argtypes; every function returns int (0 == HF_OK) unless noted.
+SIGNATURES = {
+    "hf_upfirdn2d_f32": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _st],
+    "hf_fused_bias_act_f32": [_f, _f, _f, _ll, _i, _i, _fl, _fl, _st],
+    "hf_noise_bias_act_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _ll, _fl, _fl, _st],
+    "hf_modconv_prepare_f32": [_f, _f, _f, _i, _i, _i, _st],
+    "hf_modulation_f32": [_f, _f, _ll, _f, _f, _i, _i, _i, _st],
+    "hf_demod_f32": [_f, _f, _f, _i, _i, _i, _st],
+    "hf_modconv3x3_f32": [_f, _f, _f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _st],
+    "hf_modconv3x3_up_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _st],
+    "hf_blur_noise_bias_act_f32": [_f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _fl, _fl, _st],
+    "hf_torgb_f32": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st],
+}
+
+
+class HairfastLibError(RuntimeError):
+    pass
+
+
+def bind(cdll):
+    """Attach argtypes/restype for every entry point of the ABI; raises if one is missing."""
+    for name, args in SIGNATURES.items():
+        try:
+            fn = getattr(cdll, name)
+        except AttributeError as e:
+            raise HairfastLibError(f"{cdll._name}: missing symbol {name}") from e
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    cdll.hf_strerror.argtypes = [ctypes.c_int]
+    cdll.hf_strerror.restype = ctypes.c_char_p
+    cdll.hf_abi_version.argtypes = []
+    cdll.hf_abi_version.restype = ctypes.c_int
+    return cdll
+
+
+_LIB = None
+
+
+def load():
+    """Load (once) and return the bound HIP library.  No fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HairfastLibError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or hairfastgan_amd/csrc/build.sh (hipcc --offload-arch=gfx950). "
+                "hairfastgan_amd has no CPU / PyTorch fallback.")
+        _LIB = bind(ctypes.CDLL(LIB_PATH))
+    return _LIB
+
+
+def check(lib, code, what):
+    if code != 0:
+        raise RuntimeError(f"{what}: {lib.hf_strerror(code).decode()} (code {code})")

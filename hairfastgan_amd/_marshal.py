@@ -1,0 +1,152 @@
+"""Argument marshalling between torch tensors and the C ABI (include/hairfast_hip.h).
+
+Pure plumbing: shape arithmetic, output allocation through torch's caching
+allocator, ``data_ptr()`` extraction and error-code checking.  There is no
+arithmetic here and no alternative code path: every function ends in exactly one
+(or, for the upsampling conv, two) calls into the shared library it is given.
+The public ops in ``hairfastgan_amd.op`` / ``hairfastgan_amd.stylegan2`` call
+these with the HIP library and the current HIP stream after checking that all
+tensors live on the GPU.
+"""
+import torch
+
+from ._lib import check
+
+SQRT2 = 2 ** 0.5
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _c(t):
+    """fp32 + contiguous (the reference takes .contiguous() copies defensively too,
+    fused_bias_act_kernel.cu:58-60, upfirdn2d_kernel.cu:219-220)."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError(f"hairfastgan_amd kernels are fp32; got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def upfirdn2d(lib, st, x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    x, kernel = _c(x), _c(kernel)
+    n, c, h, w = x.shape
+    kh, kw = kernel.shape
+    out_h = (h * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
+    out_w = (w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
+    out = x.new_empty((n, c, out_h, out_w))
+    if out.numel():
+        check(lib, lib.hf_upfirdn2d_f32(_p(out), _p(x), _p(kernel), n * c, h, w, kh, kw, up_x, up_y, down_x,
+                                        down_y, pad_x0, pad_x1, pad_y0, pad_y1, st), "hf_upfirdn2d_f32")
+    return out
+
+
+def fused_bias_act(lib, st, x, bias, alpha, scale):
+    x, bias = _c(x), _c(bias)
+    out = torch.empty_like(x)
+    n = x.numel()
+    if n == 0:
+        return out
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    n_bias = bias.numel() if bias is not None else 0
+    if bias is not None and x.ndim >= 2 and n_bias != x.shape[1]:
+        raise ValueError("bias must have one entry per channel (dim 1)")
+    check(lib, lib.hf_fused_bias_act_f32(_p(out), _p(x), _p(bias), n, max(n_bias, 1), step_b, alpha, scale, st),
+          "hf_fused_bias_act_f32")
+    return out
+
+
+def _noise_args(noise, batch, hw):
+    if noise is None:
+        return None, 0
+    noise = _c(noise)
+    if noise.numel() == hw:
+        return noise, 0
+    if noise.numel() == batch * hw:
+        return noise, hw
+    raise ValueError(f"noise must be [1,1,H,W] or [B,1,H,W]; got {tuple(noise.shape)}")
+
+
+def noise_bias_act(lib, st, x, noise, noise_w, bias, alpha=0.2, scale=SQRT2):
+    x, bias, noise_w = _c(x), _c(bias), _c(noise_w)
+    b, c, h, w = x.shape
+    noise, nbs = _noise_args(noise, b, h * w)
+    out = torch.empty_like(x)
+    check(lib, lib.hf_noise_bias_act_f32(_p(out), _p(x), _p(noise), _p(noise_w), _p(bias), b, c, h * w, nbs,
+                                         alpha, scale, st), "hf_noise_bias_act_f32")
+    return out
+
+
+def prepare_weights(lib, st, weight):
+    """weight [1,cout,cin,k,k] -> (wt [k*k,cin,cout], wsq [cout,cin])."""
+    weight = _c(weight)
+    _, cout, cin, k, _ = weight.shape
+    wt = weight.new_empty((k * k, cin, cout))
+    wsq = weight.new_empty((cout, cin))
+    check(lib, lib.hf_modconv_prepare_f32(_p(wt), _p(wsq), _p(weight), cout, cin, k, st), "hf_modconv_prepare_f32")
+    return wt, wsq
+
+
+def modulation(lib, st, style, mod_w, mod_b):
+    """style: [B, style_dim], possibly a strided row view of W+ (latent[:, i])."""
+    if style.dtype != torch.float32:
+        raise TypeError("style must be fp32")
+    if style.stride(-1) != 1:
+        style = style.contiguous()
+    b, sd = style.shape
+    mod_w, mod_b = _c(mod_w), _c(mod_b)
+    cin = mod_w.shape[0]
+    s = style.new_empty((b, cin))
+    check(lib, lib.hf_modulation_f32(_p(s), _p(style), style.stride(0) if b > 1 else sd, _p(mod_w), _p(mod_b),
+                                     b, cin, sd, st), "hf_modulation_f32")
+    return s
+
+
+def demod(lib, st, s, wsq):
+    b, cin = s.shape
+    cout = wsq.shape[0]
+    d = s.new_empty((b, cout))
+    check(lib, lib.hf_demod_f32(_p(d), _p(s), _p(wsq), b, cin, cout, st), "hf_demod_f32")
+    return d
+
+
+def modconv3x3(lib, st, x, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=SQRT2):
+    x = _c(x)
+    b, cin, h, w = x.shape
+    cout = wt.shape[2]
+    noise, nbs = _noise_args(noise, b, h * w)
+    out = x.new_empty((b, cout, h, w))
+    check(lib, lib.hf_modconv3x3_f32(_p(out), _p(x), _p(wt), _p(s), _p(d), _p(noise), _p(_c(noise_w)), nbs,
+                                     _p(_c(bias)), b, cin, cout, h, w, alpha, scale, st), "hf_modconv3x3_f32")
+    return out
+
+
+def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha=0.2, scale=SQRT2):
+    """conv_transpose(stride 2) -> [B,cout,2h+1,2w+1] scratch -> blur+noise+bias+act -> [B,cout,2h,2w]."""
+    x = _c(x)
+    b, cin, h, w = x.shape
+    cout = wt.shape[2]
+    tmp = x.new_empty((b, cout, 2 * h + 1, 2 * w + 1))
+    check(lib, lib.hf_modconv3x3_up_f32(_p(tmp), _p(x), _p(wt), _p(s), _p(d), b, cin, cout, h, w, st),
+          "hf_modconv3x3_up_f32")
+    noise, nbs = _noise_args(noise, b, 4 * h * w)
+    out = x.new_empty((b, cout, 2 * h, 2 * w))
+    check(lib, lib.hf_blur_noise_bias_act_f32(_p(out), _p(tmp), _p(_c(blur_kernel)), _p(noise), _p(_c(noise_w)),
+                                              nbs, _p(_c(bias)), b, cout, 2 * h + 1, 2 * w + 1, alpha, scale, st),
+          "hf_blur_noise_bias_act_f32")
+    return out
+
+
+def torgb(lib, st, x, wt, s, bias, skip, up_kernel):
+    x = _c(x)
+    b, cin, h, w = x.shape
+    skip = _c(skip)
+    if skip is not None and tuple(skip.shape) != (b, 3, h // 2, w // 2):
+        raise ValueError(f"skip must be [B,3,H/2,W/2]; got {tuple(skip.shape)} for x {tuple(x.shape)}")
+    out = x.new_empty((b, 3, h, w))
+    check(lib, lib.hf_torgb_f32(_p(out), _p(x), _p(wt), _p(s), _p(_c(bias)), _p(skip), _p(_c(up_kernel)), b, cin,
+                                h, w, st), "hf_torgb_f32")
+    return out

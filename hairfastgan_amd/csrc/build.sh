@@ -1,0 +1,16 @@
+#!/bin/bash
+# Builds libhairfast_hip.so in-tree for gfx950 (MI355X).  hipcc cross-compiles
+# without a GPU.  Usage: hairfastgan_amd/csrc/build.sh [extra hipcc flags]
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC $*"
+OBJS=""
+for f in api elementwise upfirdn2d style torgb modconv; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hf_common.h -nt $f.o ] || [ ../../include/hairfast_hip.h -nt $f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o $f.o
+  fi
+  OBJS="$OBJS $f.o"
+done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libhairfast_hip.so $OBJS
+echo built $(pwd)/libhairfast_hip.so

@@ -1,0 +1,118 @@
+// style.hip - per-layer style plumbing of ModulatedConv2d.
+//
+// hf_modconv_prepare_f32 : one-time weight re-layout (frozen params, model.py:223-225)
+// hf_modulation_f32      : EqualLinear of the modulation (model.py:153-163, :241)
+// hf_demod_f32           : demodulation coefficients (model.py:244-246)
+//
+// All three are tiny GEMV-shaped, weight-bandwidth bound problems
+// (<= 1 MB of weights per call): one wave per output row, 16 B per lane loads,
+// cross-lane sum by xor shuffles.
+#include "hf_common.h"
+
+namespace {
+
+// wt[tap][ci][co] = scale*w[co][ci][tap];  wsq[co][ci] = sum_tap (scale*w)^2
+__global__ __launch_bounds__(256) void prepare_weights(float *__restrict__ wt, float *__restrict__ wsq,
+                                                       const float *__restrict__ weight, int cout, int cin,
+                                                       int taps, float scale) {
+  long long n = (long long)cout * cin;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int ci = (int)(i % cin);
+    int co = (int)(i / cin);
+    const float *src = weight + i * taps;
+    float sq = 0.0f;
+    for (int t = 0; t < taps; ++t) {
+      float v = src[t] * scale;
+      wt[((long long)t * cin + ci) * cout + co] = v;
+      sq = fmaf(v, v, sq);
+    }
+    if (wsq) wsq[i] = sq;
+  }
+}
+
+// One wave per output channel ci; loops over the batch re-using the weight row
+// held in registers (style_dim <= 64*kMaxPerLane).
+constexpr int kMaxPerLane = 16;
+
+__global__ __launch_bounds__(256) void modulation_kernel(float *__restrict__ s,
+                                                         const float *__restrict__ latent,
+                                                         long long lat_stride,
+                                                         const float *__restrict__ mod_w,
+                                                         const float *__restrict__ mod_b, int batch, int cin,
+                                                         int style_dim, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ci >= cin) return;
+  float wrow[kMaxPerLane];
+  const int per_lane = (style_dim + 63) / 64;
+#pragma unroll
+  for (int k = 0; k < kMaxPerLane; ++k) {
+    int j = k * 64 + lane;
+    wrow[k] = (k < per_lane && j < style_dim) ? mod_w[(long long)ci * style_dim + j] * scale : 0.0f;
+  }
+  const float bias = mod_b[ci];
+  for (int b = 0; b < batch; ++b) {
+    const float *lat = latent + (long long)b * lat_stride;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxPerLane; ++k) {
+      int j = k * 64 + lane;
+      if (k < per_lane && j < style_dim) acc = fmaf(lat[j], wrow[k], acc);
+    }
+    acc = hf_wave_sum(acc);
+    if (lane == 0) s[(long long)b * cin + ci] = acc + bias;
+  }
+}
+
+// One wave per (b, co): d = rsqrt(sum_ci wsq[co,ci]*s[b,ci]^2 + eps)
+__global__ __launch_bounds__(256) void demod_kernel(float *__restrict__ d, const float *__restrict__ s,
+                                                    const float *__restrict__ wsq, int batch, int cin,
+                                                    int cout) {
+  const int lane = threadIdx.x & 63;
+  const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (co >= cout) return;
+  const float *wr = wsq + (long long)co * cin;
+  const float *sr = s + (long long)b * cin;
+  float acc = 0.0f;
+  for (int j = lane; j < cin; j += 64) {
+    float sv = sr[j];
+    acc = fmaf(wr[j], sv * sv, acc);
+  }
+  acc = hf_wave_sum(acc);
+  if (lane == 0) d[(long long)b * cout + co] = rsqrtf(acc + 1e-8f);
+}
+
+}  // namespace
+
+extern "C" int hf_modconv_prepare_f32(float *wt, float *wsq, const float *weight, int cout, int cin, int k,
+                                      void *stream) {
+  if (!wt || !weight || cout <= 0 || cin <= 0 || (k != 1 && k != 3)) return HF_E_INVALID;
+  const float scale = 1.0f / sqrtf((float)(cin * k * k));
+  long long n = (long long)cout * cin;
+  long long g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(prepare_weights, dim3((int)g), dim3(256), 0, (hipStream_t)stream, wt, wsq, weight, cout,
+                     cin, k * k, scale);
+  return hf_launch_status();
+}
+
+extern "C" int hf_modulation_f32(float *s, const float *latent, long long lat_stride, const float *mod_w,
+                                 const float *mod_b, int batch, int cin, int style_dim, void *stream) {
+  if (!s || !latent || !mod_w || !mod_b || batch <= 0 || cin <= 0 || style_dim <= 0 ||
+      style_dim > 64 * kMaxPerLane)
+    return HF_E_INVALID;
+  const float scale = 1.0f / sqrtf((float)style_dim);
+  hipLaunchKernelGGL(modulation_kernel, dim3(hf_cdiv(cin, 4)), dim3(256), 0, (hipStream_t)stream, s, latent,
+                     lat_stride, mod_w, mod_b, batch, cin, style_dim, scale);
+  return hf_launch_status();
+}
+
+extern "C" int hf_demod_f32(float *d, const float *s, const float *wsq, int batch, int cin, int cout,
+                            void *stream) {
+  if (!d || !s || !wsq || batch <= 0 || cin <= 0 || cout <= 0 || batch > 65535) return HF_E_INVALID;
+  hipLaunchKernelGGL(demod_kernel, dim3(hf_cdiv(cout, 4), batch), dim3(256), 0, (hipStream_t)stream, d, s,
+                     wsq, batch, cin, cout);
+  return hf_launch_status();
+}

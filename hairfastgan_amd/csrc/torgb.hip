@@ -1,0 +1,123 @@
+// torgb.hip - ToRGB: 1x1 modulated conv (no demodulation) + bias + upsampled skip.
+// Reference: models/stylegan2/model.py:356-365 (ToRGB.forward), :49-53 (Upsample,
+// upfirdn2d up=2 pad=(2,1), i.e. upfirdn2d_kernel.cu mode 3).
+//
+// HBM-bound: per image it streams the whole feature map once (cin*H*W*4 B) and
+// writes 3*H*W*4 B; the 3 x cin modulated weights sit in LDS.  Each thread owns
+// VEC consecutive pixels (16 B accesses for VEC=4), lanes cover consecutive
+// pixel groups so every channel-plane read is a coalesced row segment; the
+// channel loop is unrolled 8x to keep 8 independent 16 B loads in flight.
+#include "hf_common.h"
+
+namespace {
+
+template <int VEC>
+__global__ __launch_bounds__(256) void torgb_kernel(float *__restrict__ out, const float *__restrict__ x,
+                                                    const float *__restrict__ wt,
+                                                    const float *__restrict__ s,
+                                                    const float *__restrict__ bias,
+                                                    const float *__restrict__ skip,
+                                                    const float *__restrict__ kernel4x4, int cin, int h,
+                                                    int w) {
+  HF_DYN_LDS;
+  float *wm = reinterpret_cast<float *>(hf_dyn_lds);  // wm[c*cin + ci] = wt[ci][c] * s[b][ci]
+  const int b = blockIdx.y;
+  const int hw = h * w;
+  for (int i = threadIdx.x; i < cin; i += blockDim.x) {
+    float sv = s ? s[(long long)b * cin + i] : 1.0f;
+    wm[i] = wt[i * 3 + 0] * sv;
+    wm[cin + i] = wt[i * 3 + 1] * sv;
+    wm[2 * cin + i] = wt[i * 3 + 2] * sv;
+  }
+  __syncthreads();
+
+  const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (p0 >= hw) return;
+  const float *xb = x + (long long)b * cin * hw + p0;
+  float acc[3][VEC];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[c][v] = 0.0f;
+
+#pragma unroll 8
+  for (int ci = 0; ci < cin; ++ci) {
+    float xv[VEC];
+    if constexpr (VEC == 4) {
+      float4 t = *reinterpret_cast<const float4 *>(xb + (long long)ci * hw);
+      xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+    } else {
+      xv[0] = xb[(long long)ci * hw];
+    }
+    const float w0 = wm[ci], w1 = wm[cin + ci], w2 = wm[2 * cin + ci];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc[0][v] = fmaf(w0, xv[v], acc[0][v]);
+      acc[1][v] = fmaf(w1, xv[v], acc[1][v]);
+      acc[2][v] = fmaf(w2, xv[v], acc[2][v]);
+    }
+  }
+
+  const int sh = h >> 1, sw = w >> 1;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float bc = bias ? bias[c] : 0.0f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float r = acc[c][v] + bc;
+      if (skip) {
+        // zero-insert x2, pad (2,1), 4x4 true convolution: only taps with the
+        // parity of (y, x) hit non-zero samples -> 2x2 taps per output.
+        const int p = p0 + v;
+        const int y = p / w, xx = p - y * w;
+        const float *sp = skip + ((long long)b * 3 + c) * sh * sw;
+        float up = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int ky = (y & 1) + 2 * a;
+          const int iy = (y + ky - 2) >> 1;  // (y+ky-2) is even; >= -1
+          if (iy < 0 || iy >= sh) continue;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int kx = (xx & 1) + 2 * e;
+            const int ix = (xx + kx - 2) >> 1;
+            if (ix < 0 || ix >= sw) continue;
+            up = fmaf(sp[iy * sw + ix], kernel4x4[(3 - ky) * 4 + (3 - kx)], up);
+          }
+        }
+        r += up;
+      }
+      acc[c][v] = r;
+    }
+    float *o = out + ((long long)b * 3 + c) * hw + p0;
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4 *>(o) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+    } else {
+      o[0] = acc[c][0];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int hf_torgb_f32(float *out, const float *x, const float *wt, const float *s, const float *bias,
+                            const float *skip, const float *kernel4x4, int batch, int cin, int h, int w,
+                            void *stream) {
+  if (!out || !x || !wt || batch <= 0 || batch > 65535 || cin <= 0 || h <= 0 || w <= 0) return HF_E_INVALID;
+  if (skip && (!kernel4x4 || (h & 1) || (w & 1))) return HF_E_INVALID;
+  const size_t lds = (size_t)3 * cin * sizeof(float);
+  if (lds > 64 * 1024) return HF_E_INVALID;
+  const int hw = h * w;
+  hipStream_t st = (hipStream_t)stream;
+  const bool aligned = ((((size_t)out) | ((size_t)x)) & 15) == 0;
+  if (hw % 4 == 0 && aligned) {
+    dim3 grid(hf_cdiv(hw / 4, 256), batch);
+    hipLaunchKernelGGL(torgb_kernel<4>, grid, dim3(256), lds, st, out, x, wt, s, bias, skip, kernel4x4, cin, h,
+                       w);
+  } else {
+    dim3 grid(hf_cdiv(hw, 256), batch);
+    hipLaunchKernelGGL(torgb_kernel<1>, grid, dim3(256), lds, st, out, x, wt, s, bias, skip, kernel4x4, cin, h,
+                       w);
+  }
+  return hf_launch_status();
+}

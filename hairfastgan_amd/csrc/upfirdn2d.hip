@@ -1,0 +1,157 @@
+// upfirdn2d.hip - FIR resampling kernels.
+//
+// hf_upfirdn2d_f32            : general upfirdn2d (any up/down/pad, taps <= 8x8);
+//                               reference op/upfirdn2d.py:145-200, upfirdn2d_kernel.cu:49-207.
+// hf_blur_noise_bias_act_f32  : the generator's hot instance (mode 1: up=down=1, 4x4,
+//                               pad (1,1); model.py:77-93 called at :263) fused with
+//                               NoiseInjection + FusedLeakyReLU (model.py:288-293, :341).
+//
+// Both are HBM-bound streaming kernels: algorithmic traffic is one read of the
+// input plane and one write of the output plane (8 B per output element, plus
+// the (2H+1)^2 vs (2H)^2 rim).  Lanes map to consecutive output columns so all
+// global accesses are coalesced rows; the 4-row sliding window lives in
+// registers, so each input element is fetched from L1/L2 at most 4x by
+// neighbouring lanes and from HBM once.
+#include "hf_common.h"
+
+namespace {
+
+constexpr int kMaxTaps = 8;
+
+__global__ __launch_bounds__(256) void upfirdn2d_generic(
+    float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ kernel, int in_h,
+    int in_w, int out_h, int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+    int pad_y0, long long total) {
+  HF_DYN_LDS;
+  float *kf = reinterpret_cast<float *>(hf_dyn_lds);  // flipped taps: kf[ky][kx] = k[kh-1-ky][kw-1-kx]
+  for (int i = threadIdx.x; i < kh * kw; i += blockDim.x) {
+    int ky = i / kw, kx = i - ky * kw;
+    kf[i] = kernel[(kh - 1 - ky) * kw + (kw - 1 - kx)];
+  }
+  __syncthreads();
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    int ox = (int)(idx % out_w);
+    long long t = idx / out_w;
+    int oy = (int)(t % out_h);
+    long long plane = t / out_h;
+    const float *src = in + plane * (long long)in_h * in_w;
+    float acc = 0.0f;
+    for (int ky = 0; ky < kh; ++ky) {
+      int uy = oy * down_y + ky - pad_y0;  // row in the zero-inserted signal
+      if (uy < 0 || uy % up_y) continue;
+      int iy = uy / up_y;
+      if (iy >= in_h) continue;
+      for (int kx = 0; kx < kw; ++kx) {
+        int ux = ox * down_x + kx - pad_x0;
+        if (ux < 0 || ux % up_x) continue;
+        int ix = ux / up_x;
+        if (ix >= in_w) continue;
+        acc = fmaf(src[(long long)iy * in_w + ix], kf[ky * kw + kx], acc);
+      }
+    }
+    out[idx] = acc;
+  }
+}
+
+// Blur 4x4, pad (1,1): out[oy][ox] = sum_{ky,kx} kf[ky][kx] * in[oy+ky-1][ox+kx-1].
+// blockDim = (64 columns, 4 row segments); each thread walks kRowsPerThread
+// output rows keeping the 4x4 input window in registers.
+constexpr int kBlurCols = 64;
+constexpr int kBlurSegs = 4;
+constexpr int kRowsPerThread = 32;
+
+__global__ __launch_bounds__(256) void blur4x4_noise_bias_act(
+    float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ kernel4x4,
+    const float *__restrict__ noise, const float *__restrict__ noise_w, long long noise_bstride,
+    const float *__restrict__ bias, int channels, int in_h, int in_w, float alpha, float scale) {
+  const int out_h = in_h - 1, out_w = in_w - 1;
+  const int ox = blockIdx.x * kBlurCols + threadIdx.x;
+  const int oy0 = (blockIdx.y * kBlurSegs + threadIdx.y) * kRowsPerThread;
+  const int plane = blockIdx.z;
+  if (ox >= out_w || oy0 >= out_h) return;
+
+  float kf[4][4];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) kf[ky][kx] = kernel4x4[(3 - ky) * 4 + (3 - kx)];
+
+  const float *src = in + (long long)plane * in_h * in_w;
+  float *dst = out + (long long)plane * out_h * out_w;
+  const int c = plane % channels;
+  const int b = plane / channels;
+  const float bc = bias ? bias[c] : 0.0f;
+  const float nw = noise ? noise_w[0] : 0.0f;
+  const float *nz = noise ? noise + (long long)b * noise_bstride : nullptr;
+
+  // column validity of the 4 taps (input columns ox-1 .. ox+2)
+  bool cv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cv[j] = (ox - 1 + j) >= 0 && (ox - 1 + j) < in_w;
+
+  float win[4][4];  // win[r][j]: input row (oy-1+r), column (ox-1+j)
+  auto load_row = [&](int iy, float (&row)[4]) {
+    const bool rv = iy >= 0 && iy < in_h;
+    const float *p = src + (long long)iy * in_w + (ox - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row[j] = (rv && cv[j]) ? p[j] : 0.0f;
+  };
+#pragma unroll
+  for (int r = 0; r < 3; ++r) load_row(oy0 - 1 + r, win[r]);
+
+  const int oy_end = min(oy0 + kRowsPerThread, out_h);
+  for (int oy = oy0; oy < oy_end; ++oy) {
+    load_row(oy + 2, win[3]);
+    float acc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = fmaf(win[r][j], kf[r][j], acc);
+    if (nz) acc = fmaf(nw, nz[(long long)oy * out_w + ox], acc);
+    if (bias) acc = hf_lrelu(acc + bc, alpha, scale);
+    dst[(long long)oy * out_w + ox] = acc;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) win[r][j] = win[r + 1][j];
+  }
+}
+
+}  // namespace
+
+extern "C" int hf_upfirdn2d_f32(float *out, const float *in, const float *kernel, int major, int in_h,
+                                int in_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                                int pad_x0, int pad_x1, int pad_y0, int pad_y1, void *stream) {
+  if (!out || !in || !kernel || major <= 0 || in_h <= 0 || in_w <= 0 || kh <= 0 || kw <= 0 ||
+      kh > kMaxTaps || kw > kMaxTaps || up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
+    return HF_E_INVALID;
+  const int full_h = in_h * up_y + pad_y0 + pad_y1 - kh;
+  const int full_w = in_w * up_x + pad_x0 + pad_x1 - kw;
+  if (full_h < 0 || full_w < 0) return HF_E_INVALID;
+  const int out_h = full_h / down_y + 1, out_w = full_w / down_x + 1;
+  const long long total = (long long)major * out_h * out_w;
+  long long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(upfirdn2d_generic, dim3((int)g), dim3(256), kMaxTaps * kMaxTaps * sizeof(float),
+                     (hipStream_t)stream, out, in, kernel, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y,
+                     down_x, down_y, pad_x0, pad_y0, total);
+  return hf_launch_status();
+}
+
+extern "C" int hf_blur_noise_bias_act_f32(float *out, const float *in, const float *kernel4x4,
+                                          const float *noise, const float *noise_w,
+                                          long long noise_bstride, const float *bias, int batch,
+                                          int channels, int in_h, int in_w, float alpha, float scale,
+                                          void *stream) {
+  if (!out || !in || !kernel4x4 || batch <= 0 || channels <= 0 || in_h < 2 || in_w < 2 ||
+      (noise && !noise_w))
+    return HF_E_INVALID;
+  const long long planes = (long long)batch * channels;
+  if (planes > 65535LL * 32768) return HF_E_INVALID;
+  const int out_h = in_h - 1, out_w = in_w - 1;
+  dim3 grid(hf_cdiv(out_w, kBlurCols), hf_cdiv(out_h, kBlurSegs * kRowsPerThread), (unsigned)planes);
+  hipLaunchKernelGGL(blur4x4_noise_bias_act, grid, dim3(kBlurCols, kBlurSegs), 0, (hipStream_t)stream, out,
+                     in, kernel4x4, noise, noise_w, noise_bstride, bias, channels, in_h, in_w, alpha, scale);
+  return hf_launch_status();
+}

@@ -1,0 +1,140 @@
+/*
+ * hairfast_hip.h - C ABI of libhairfast_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the HairFastGAN generator hot path.  Every entry point
+ * takes raw DEVICE pointers (fp32, NCHW contiguous unless stated), plain ints
+ * and a hipStream_t passed as void*; none allocates, synchronises or touches
+ * torch types.  Return value: 0 on success, a negative HF_E_* code otherwise
+ * (hf_strerror() gives the text).  Kernels are enqueued asynchronously on the
+ * given stream; outputs never alias inputs.
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to the HairFastGAN tree).
+ */
+#ifndef HAIRFAST_HIP_H
+#define HAIRFAST_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HF_OK 0
+#define HF_E_INVALID (-1)   /* bad argument (null pointer, non-positive dim, unsupported size) */
+#define HF_E_LAUNCH (-2)    /* hipGetLastError() reported a launch failure */
+#define HF_E_WORKSPACE (-3) /* caller-provided workspace too small */
+
+const char *hf_strerror(int code);
+/* ABI version of this header; bumped on any signature change. */
+int hf_abi_version(void);
+
+/* ---------------------------------------------------------------------------
+ * upfirdn2d: upsample (zero insert) -> pad/crop -> FIR (true convolution) ->
+ * downsample, on `major` independent [in_h, in_w] planes (major = N*C).
+ * Replaces: models/stylegan2/op/upfirdn2d.cpp:12-19 `upfirdn2d(input, kernel,
+ * up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)` with input
+ * viewed as [major, in_h, in_w, 1] (op/upfirdn2d.py:99), and the kernels in
+ * models/stylegan2/op/upfirdn2d_kernel.cu:49-207.
+ * out must hold major*out_h*out_w floats, out_h = (in_h*up_y+pad_y0+pad_y1-kh)/down_y+1.
+ * kernel: device pointer, [kh, kw] row-major, kh,kw <= 8.
+ */
+int hf_upfirdn2d_f32(float *out, const float *in, const float *kernel, int major, int in_h, int in_w,
+                     int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                     int pad_y0, int pad_y1, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * y = leaky_relu(x + bias[(i / step_b) % n_bias], alpha) * scale
+ * Replaces: models/stylegan2/op/fused_bias_act.cpp:11-17 `fused_bias_act(input,
+ * bias, refer, act=3, grad=0, alpha, scale)` (fused_bias_act_kernel.cu:18-49,
+ * case 30; step_b as :69-71).  n elements; bias may be NULL (n_bias ignored).
+ */
+int hf_fused_bias_act_f32(float *out, const float *x, const float *bias, long long n, int n_bias,
+                          int step_b, float alpha, float scale, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Noise injection + FusedLeakyReLU in one pass:
+ *   y[b,c,p] = leaky_relu(x[b,c,p] + noise_w[0]*noise[b*noise_bstride + p] + bias[c], alpha) * scale
+ * Replaces: NoiseInjection.forward + FusedLeakyReLU.forward
+ * (models/stylegan2/model.py:288-293, op/fused_act.py:73-96).  noise_w is a
+ * DEVICE pointer to the scalar parameter; noise_bstride = 0 broadcasts one
+ * [1,1,H,W] map over the batch, H*W for per-sample noise.
+ */
+int hf_noise_bias_act_f32(float *out, const float *x, const float *noise, const float *noise_w,
+                          const float *bias, int batch, int channels, int hw, long long noise_bstride,
+                          float alpha, float scale, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * One-time re-layout of a ModulatedConv2d weight (frozen parameters):
+ *   wt[tap][ci][co]  = scale * weight[0][co][ci][tap],  scale = 1/sqrt(cin*k*k)
+ *   wsq[co][ci]      = sum_tap (scale * weight[0][co][ci][tap])^2
+ * weight: reference layout [1, cout, cin, k, k] (models/stylegan2/model.py:223-225,
+ * scale :219-220).  k = 1 or 3.  wsq may be NULL (ToRGB has no demodulation).
+ */
+int hf_modconv_prepare_f32(float *wt, float *wsq, const float *weight, int cout, int cin, int k,
+                           void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Modulation: s[b,ci] = sum_j latent[b*lat_stride + j] * (mod_w[ci,j] / sqrt(style_dim)) + mod_b[ci]
+ * Replaces: EqualLinear.forward of ModulatedConv2d.modulation
+ * (models/stylegan2/model.py:153-163 with lr_mul=1, called at :241).
+ * `latent` may be a strided row view of W+ (latent[:, i]; lat_stride = n_latent*style_dim).
+ */
+int hf_modulation_f32(float *s, const float *latent, long long lat_stride, const float *mod_w,
+                      const float *mod_b, int batch, int cin, int style_dim, void *stream);
+
+/* Demodulation coefficients: d[b,co] = rsqrt(sum_ci wsq[co,ci] * s[b,ci]^2 + 1e-8)
+ * Replaces: models/stylegan2/model.py:244-246 (algebraically equal: the
+ * per-sample weight is scale*W*s, so its squared norm factors through wsq). */
+int hf_demod_f32(float *d, const float *s, const float *wsq, int batch, int cin, int cout, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused StyledConv, same resolution (3x3, pad 1):
+ *   y[b,co] = act( d[b,co] * sum_{ci,tap} wt[tap,ci,co] * (s[b,ci]*x[b,ci] shifted by tap)
+ *                  + noise_w*noise + bias[co] ) * sqrt2-scale
+ * Replaces: ModulatedConv2d.forward (models/stylegan2/model.py:238-250,273-277)
+ * + NoiseInjection + FusedLeakyReLU (StyledConv.forward :337-343).  The
+ * modulation is applied to the activations and the demodulation to the
+ * outputs instead of materialising per-sample weights; fp32 MFMA accumulate.
+ * s, d: from hf_modulation_f32 / hf_demod_f32 (d NULL = no demodulation;
+ * s NULL = plain convolution).  noise NULL = no noise term; bias NULL = no
+ * bias/activation epilogue (raw conv output, alpha/scale ignored).
+ */
+int hf_modconv3x3_f32(float *out, const float *x, const float *wt, const float *s, const float *d,
+                      const float *noise, const float *noise_w, long long noise_bstride,
+                      const float *bias, int batch, int cin, int cout, int h, int w, float alpha,
+                      float scale, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Upsampling modulated conv, part 1: per-sample conv_transpose2d(stride 2,
+ * pad 0) of s*x with the 3x3 weights, demodulated: tmp[b,co,2h+1,2w+1].
+ * Replaces: models/stylegan2/model.py:252-262 (F.conv_transpose2d with
+ * groups=batch).  Part 2 is hf_blur_noise_bias_act_f32 below.
+ */
+int hf_modconv3x3_up_f32(float *tmp, const float *x, const float *wt, const float *s, const float *d,
+                         int batch, int cin, int cout, int h, int w, void *stream);
+
+/* Part 2: 4x4 FIR blur with pad (1,1) (upfirdn2d mode 1) fused with noise +
+ * bias + leaky relu: in [planes=batch*channels, in_h, in_w] -> out
+ * [planes, in_h-1, in_w-1].  Replaces: Blur.forward (models/stylegan2/model.py:
+ * 77-93, called :263) + NoiseInjection + FusedLeakyReLU.  kernel4x4: device
+ * pointer to the module's `blur.kernel` buffer (already multiplied by
+ * upsample_factor**2, model.py:83-84).  noise/bias NULL as in hf_modconv3x3_f32. */
+int hf_blur_noise_bias_act_f32(float *out, const float *in, const float *kernel4x4, const float *noise,
+                               const float *noise_w, long long noise_bstride, const float *bias,
+                               int batch, int channels, int in_h, int in_w, float alpha, float scale,
+                               void *stream);
+
+/* ---------------------------------------------------------------------------
+ * ToRGB: 1x1 modulated conv WITHOUT demodulation + bias + upsampled skip:
+ *   y[b,c] = sum_ci wt[ci,c] * s[b,ci] * x[b,ci] + bias[c] + upfirdn2d(skip, k4, up=2, pad=(2,1))[b,c]
+ * Replaces: ToRGB.forward (models/stylegan2/model.py:356-365) incl.
+ * Upsample.forward (:49-53).  wt: [cin, 3] from hf_modconv_prepare_f32 (k=1).
+ * skip: [batch,3,h/2,w/2] or NULL; kernel4x4: the `upsample.kernel` buffer.
+ */
+int hf_torgb_f32(float *out, const float *x, const float *wt, const float *s, const float *bias,
+                 const float *skip, const float *kernel4x4, int batch, int cin, int h, int w,
+                 void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAIRFAST_HIP_H */

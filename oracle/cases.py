@@ -1,0 +1,114 @@
+"""Shared case tables + input builders for golden vectors (TEST INFRASTRUCTURE).
+
+Used by oracle/make_golden.py (which runs the real reference on them) and by
+tests/ (which run the oracle and the HIP path on the very same inputs).  All
+inputs are formulas (oracle.synth), nothing is stored but outputs.
+"""
+import numpy as np
+import torch
+
+from . import synth
+
+UPFIRDN_CASES = {
+    "blur_2x5x9x9": dict(shape=(2, 5, 9, 9), up=1, down=1, pad=(1, 1)),
+    "blur_1x2x65x65": dict(shape=(1, 2, 65, 65), up=1, down=1, pad=(1, 1)),
+    "blur_1x3x33x17": dict(shape=(1, 3, 33, 17), up=1, down=1, pad=(1, 1)),
+    "blur_pad21_1x4x8x8": dict(shape=(1, 4, 8, 8), up=1, down=1, pad=(2, 1)),
+    "up2_1x3x7x7": dict(shape=(1, 3, 7, 7), up=2, down=1, pad=(2, 1)),
+    "up2_2x3x16x16": dict(shape=(2, 3, 16, 16), up=2, down=1, pad=(2, 1)),
+    "up2_1x3x64x64": dict(shape=(1, 3, 64, 64), up=2, down=1, pad=(2, 1)),
+    "down2_1x2x10x10": dict(shape=(1, 2, 10, 10), up=1, down=2, pad=(1, 1)),
+}
+
+ACT_CASES = {"act_2x7x5x5": (2, 7, 5, 5), "act_3x512": (3, 512), "act_1x32x16x16": (1, 32, 16, 16)}
+
+# name, cin, cout, style_dim, B, H, W
+MODCONV_SMALL = [
+    ("s16to8_h8", 16, 8, 32, 2, 8, 8),
+    ("s32to32_h16", 32, 32, 64, 3, 16, 16),
+    ("s64to32_h12x20", 64, 32, 512, 1, 12, 20),
+]
+
+# tag -> (size, channel_multiplier, n_mlp, batches, ranges)
+GENERATOR_CASES = {
+    "g64": (64, 2, 2, [2], [(0, 4), (0, 2), (2, 2), (3, 4)]),
+    "g1024": (1024, 2, 8, [1, 2], [(0, 8), (0, 3), (3, 3), (4, 8), (5, 8)]),
+}
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def blur_kernel4():
+    return t(synth.fill_value("x.blur.kernel", (4, 4)))
+
+
+def upfirdn_input(name):
+    return t(synth.pseudo_normal(f"upfirdn/{name}", UPFIRDN_CASES[name]["shape"]))
+
+
+def act_inputs(name):
+    shape = ACT_CASES[name]
+    return (t(synth.pseudo_normal(f"act/{name}", shape)),
+            t(synth.unit_uniform(f"act/{name}/bias", (shape[1],))))
+
+
+def styled_param_shapes(cin, cout, sdim, up):
+    S = {"conv.weight": (1, cout, cin, 3, 3)}
+    if up:
+        S["conv.blur.kernel"] = (4, 4)
+    S.update({"conv.modulation.weight": (cin, sdim), "conv.modulation.bias": (cin,),
+              "noise.weight": (1,), "activate.bias": (cout,)})
+    return S
+
+
+def rgb_param_shapes(cin, sdim):
+    return {"bias": (1, 3, 1, 1), "upsample.kernel": (4, 4), "conv.weight": (1, 3, cin, 1, 1),
+            "conv.modulation.weight": (cin, sdim), "conv.modulation.bias": (cin,)}
+
+
+def small_params(pre, shapes):
+    """Parameters for one small module; keys prefixed 'L.' (oracle prefix)."""
+    P = {}
+    for k, shp in shapes.items():
+        key = k if k.endswith("kernel") else f"{pre}.{k}"
+        P[f"L.{k}"] = t(synth.fill_value(key, shp))
+    return P
+
+
+def modconv_small_inputs(name):
+    for n, cin, cout, sdim, B, H, W in MODCONV_SMALL:
+        if n == name:
+            break
+    else:
+        raise KeyError(name)
+    d = dict(cin=cin, cout=cout, sdim=sdim, B=B, H=H, W=W)
+    d["x"] = t(synth.pseudo_normal(f"mc/{name}/x", (B, cin, H, W)))
+    d["w"] = t(synth.pseudo_normal(f"mc/{name}/w", (B, sdim)))
+    for up in (False, True):
+        pre = f"mc/{name}/up{int(up)}"
+        d[f"P_up{int(up)}"] = small_params(pre, styled_param_shapes(cin, cout, sdim, up))
+        oh, ow = (2 * H, 2 * W) if up else (H, W)
+        d[f"noise_up{int(up)}"] = t(synth.pseudo_normal(f"{pre}/noise", (B, 1, oh, ow)))
+    pre = f"mc/{name}/rgb"
+    d["P_rgb"] = small_params(pre, rgb_param_shapes(cout, sdim))
+    d["x_rgb"] = t(synth.pseudo_normal(f"{pre}/x", (B, cout, 2 * H, 2 * W)))
+    d["skip"] = t(synth.pseudo_normal(f"{pre}/skip", (B, 3, H, W)))
+    return d
+
+
+def generator_params(shapes):
+    return {k: t(v) for k, v in synth.fill_state_dict(shapes).items()}
+
+
+def generator_inputs(size, B, start_layer, cin_of_block=None):
+    """latent W+, explicit noise list, and layer_in for `start_layer` (or None)."""
+    log_size = int(np.log2(size))
+    lat = t(synth.latent_wplus(B, n_latent=2 * log_size - 2))
+    noise = [t(a) for a in synth.noise_maps(log_size=log_size)]
+    layer_in = None
+    if start_layer > 0:
+        r = 2 ** (start_layer + 1)  # block s consumes 2^(s+1), produces 2^(s+2)
+        layer_in = t(synth.pseudo_normal(f"layer_in/{start_layer}/{B}", (B, cin_of_block, r, r)))
+    return lat, noise, layer_in

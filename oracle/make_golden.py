@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference on CPU.
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the build container (needs
+/root/reference); never on the GPU box, never from tests/bench/smoke.  It
+imports the reference's own modules (models/stylegan2/model.py etc.) with two
+import stubs (torchvision is absent; the nvcc JIT `load()` is disabled so the
+reference takes its pure-torch CPU branches, op/fused_act.py:86-94 and
+op/upfirdn2d.py:146-149), fills them with oracle.synth's closed-form
+parameters, and stores inputs-by-formula + small outputs.  Nothing from the
+reference is copied: fixtures hold numbers only.
+
+It also reports how far oracle/ref_stylegan2.py is from the reference on every
+case (expected: bit-identical or <=1e-6, same ATen kernels).
+
+Usage:  python oracle/make_golden.py [--out tests/golden] [--skip-big]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference tree not present: golden vectors can only be made in the build container")
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class ToPILImage:  # only constructed at import time (model.py:13)
+        def __call__(self, x):
+            return x
+
+    tvt.ToPILImage = ToPILImage
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    import torch.utils.cpp_extension as ce
+
+    ce.load = lambda *a, **k: None
+    sys.path.insert(0, REF)
+    import models.stylegan2.model as ref_model
+    import models.stylegan2.op as ref_op
+
+    return ref_model, ref_op
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def stats(x):
+    x = x.detach().double()
+    return np.array([x.mean().item(), x.std().item(), x.min().item(), x.max().item()], dtype=np.float64)
+
+
+def strided_samples(x, n=1024):
+    f = x.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].clone().numpy()
+
+
+def maxdiff(a, b):
+    return float((a.detach().double() - b.detach().double()).abs().max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--skip-big", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_grad_enabled(False)
+    torch.manual_seed(0)
+
+    ref_model, ref_op = import_reference()
+    from oracle import ref_stylegan2 as O
+    from oracle import cases as C
+
+    report = {}
+
+    # ---------------- (i) upfirdn2d, modes 1 and 3 (+ one down=2 sanity case) ---
+    k4 = C.blur_kernel4()
+    g = {}
+    for name, c in C.UPFIRDN_CASES.items():
+        x = C.upfirdn_input(name)
+        y = ref_op.upfirdn2d(x, k4, up=c["up"], down=c["down"], pad=c["pad"])
+        yo = O.upfirdn2d(x, k4, up=c["up"], down=c["down"], pad=c["pad"])
+        report[f"upfirdn/{name}"] = maxdiff(y, yo)
+        if x.numel() <= 2000:
+            report[f"upfirdn_loops/{name}"] = maxdiff(y, O.upfirdn2d_loops(x, k4, c["up"], c["down"], c["pad"]))
+        g[name] = y.numpy()
+    np.savez_compressed(os.path.join(args.out, "upfirdn2d.npz"), **g)
+
+    # ---------------- (ii) fused bias + leaky relu -----------------------------
+    g = {}
+    for name in C.ACT_CASES:
+        x, b = C.act_inputs(name)
+        y = ref_op.fused_leaky_relu(x, b)
+        report[f"act/{name}"] = maxdiff(y, O.fused_leaky_relu(x, b))
+        g[name] = y.numpy()
+    np.savez_compressed(os.path.join(args.out, "fused_act.npz"), **g)
+
+    # ---------------- (iii) small modulated conv / styled conv / to_rgb --------
+    g = {}
+    for name, cin, cout, sdim, B, H, W in C.MODCONV_SMALL:
+        d = C.modconv_small_inputs(name)
+        x, w = d["x"], d["w"]
+        for up in (False, True):
+            m = ref_model.StyledConv(cin, cout, 3, sdim, upsample=up)
+            P = d[f"P_up{int(up)}"]
+            m.load_state_dict({k_[2:]: v_ for k_, v_ in P.items()})
+            nz = d[f"noise_up{int(up)}"]
+            y_conv = m.conv(x, w)
+            y = m(x, w, noise=nz)
+            yo_conv = O.modulated_conv2d(x, w, P["L.conv.weight"], P["L.conv.modulation.weight"],
+                                         P["L.conv.modulation.bias"], True, up, P.get("L.conv.blur.kernel"))
+            yo = O.styled_conv(P, "L", x, w, nz, up)
+            report[f"mc/{name}/up{int(up)}/conv"] = maxdiff(y_conv, yo_conv)
+            report[f"mc/{name}/up{int(up)}/styled"] = maxdiff(y, yo)
+            g[f"{name}_up{int(up)}_conv"] = y_conv.numpy()
+            g[f"{name}_up{int(up)}_styled"] = y.numpy()
+        m = ref_model.ToRGB(cout, sdim)
+        P = d["P_rgb"]
+        m.load_state_dict({k_[2:]: v_ for k_, v_ in P.items()})
+        for use_skip in (False, True):
+            sk = d["skip"] if use_skip else None
+            y = m(d["x_rgb"], w, sk)
+            yo = O.to_rgb(P, "L", d["x_rgb"], w, sk)
+            report[f"mc/{name}/rgb/skip{int(use_skip)}"] = maxdiff(y, yo)
+            g[f"{name}_rgb_skip{int(use_skip)}"] = y.numpy()
+    np.savez_compressed(os.path.join(args.out, "modconv_small.npz"), **g)
+
+    # ---------------- (iv) generators -----------------------------------------
+    def run_generator(tag):
+        size, cm, n_mlp, batches, ranges = C.GENERATOR_CASES[tag]
+        gen = ref_model.Generator(size, 512, n_mlp, channel_multiplier=cm).eval()
+        shapes = {k_: tuple(v_.shape) for k_, v_ in gen.state_dict().items()}
+        mine = O.generator_param_shapes(size, 512, n_mlp, cm)
+        assert mine == shapes, "state-dict layout mismatch between oracle and reference"
+        assert list(mine) == list(shapes), "state-dict key ORDER mismatch"
+        P = C.generator_params(shapes)
+        gen.load_state_dict(P)
+        log_size = int(np.log2(size))
+        out = {}
+        for B in batches:
+            for (s, e) in ranges:
+                cin = shapes[f"convs.{2 * s - 2}.conv.weight"][2] if s > 0 else None
+                lat, nz, layer_in = C.generator_inputs(size, B, s, cin)
+                inter = {}
+                hooks = []
+                if (s, e) == (0, log_size - 2) and B == batches[0]:
+                    for nm, mod in list(gen.named_modules()):
+                        if nm in ("conv1", "to_rgb1") or (nm.count(".") == 1 and nm.split(".")[0] in ("convs", "to_rgbs")):
+                            hooks.append(mod.register_forward_hook(
+                                lambda _m, _i, o, nm=nm: inter.__setitem__(
+                                    nm, np.concatenate([stats(o), strided_samples(o, 16).astype(np.float64)]))))
+                y, sk = gen([lat], input_is_latent=True, noise=nz, layer_in=layer_in,
+                            start_layer=s, end_layer=e)
+                for h in hooks:
+                    h.remove()
+                yo, sko = O.generator_forward(P, lat, nz, layer_in=layer_in, start_layer=s, end_layer=e,
+                                              log_size=log_size)
+                key = f"{tag}_B{B}_r{s}to{e}"
+                report[f"gen/{key}"] = maxdiff(y, yo)
+                if sk is not None:
+                    report[f"gen/{key}/skip"] = maxdiff(sk, sko)
+                out[f"{key}_stats"] = stats(y)
+                out[f"{key}_samples"] = strided_samples(y)
+                if y.numel() <= 100_000:
+                    out[f"{key}_full"] = y.numpy()
+                elif y.shape[1] == 3:
+                    c0 = y.shape[-1] // 2 - 32
+                    out[f"{key}_crop"] = y[:, :, c0:c0 + 64, c0:c0 + 64].numpy().copy()
+                else:  # feature map early exit: every 16th channel, full spatial
+                    out[f"{key}_chan16"] = y[:, ::16].numpy().copy()
+                if sk is not None:
+                    out[f"{key}_skip_stats"] = stats(sk)
+                    out[f"{key}_skip_samples"] = strided_samples(sk)
+                for nm, v in inter.items():
+                    out[f"{key}_inter_{nm}"] = v
+                print("done", key, report[f"gen/{key}"], flush=True)
+        return out
+
+    g = run_generator("g64")
+    np.savez_compressed(os.path.join(args.out, "generator_64.npz"), **g)
+    if not args.skip_big:
+        g = run_generator("g1024")
+        np.savez_compressed(os.path.join(args.out, "generator_1024.npz"), **g)
+
+    worst = max(report.values())
+    with open(os.path.join(args.out, "oracle_vs_reference.json"), "w") as f:
+        json.dump({"torch": torch.__version__, "max_abs_diff": report, "worst": worst}, f, indent=1, sort_keys=True)
+    print(json.dumps(report, indent=1, sort_keys=True))
+    print("worst oracle-vs-reference max-abs diff:", worst)
+
+
+if __name__ == "__main__":
+    main()

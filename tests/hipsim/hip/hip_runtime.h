@@ -1,0 +1,66 @@
+// TEST INFRASTRUCTURE - "hipsim": a tiny lock-step CPU interpreter for the HIP
+// kernel sources of hairfastgan_amd/csrc, used ONLY by the CPU test-suite
+// (tests/test_sim_*.py) to check kernel index arithmetic, LDS layouts, MFMA
+// fragment maps and barriers in a container that has no GPU.  It shadows
+// <hip/hip_runtime.h> when the .hip files are compiled as plain C++ by host
+// clang; the product library is never built against it and nothing here ships.
+//
+// Model: every thread of a block is a ucontext fiber on one OS thread;
+// __syncthreads and wave-wide ops (shuffles, v_mfma_f32_32x32x2_f32) are
+// rendezvous points resolved by a round-robin scheduler.  MFMA uses the
+// documented gfx950 fragment maps (cdna_hip_programming.md section 3):
+//   A[i][k] = lane(i + 32k).a,  B[k][j] = lane(j + 32k).b,
+//   D row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31, fmaf chain over k.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+
+namespace hipsim {
+struct Dim3 {
+  unsigned x, y, z;
+  Dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+extern Dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+void syncthreads();
+float shfl_xor(float v, int mask);
+f32x16 mfma32x32x2(float a, float b, f32x16 c);
+void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t shmem);
+unsigned char *dyn_lds();
+}  // namespace hipsim
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__
+#define threadIdx ::hipsim::threadIdx_
+#define blockIdx ::hipsim::blockIdx_
+#define blockDim ::hipsim::blockDim_
+#define gridDim ::hipsim::gridDim_
+#define HF_DYN_LDS unsigned char *hf_dyn_lds = ::hipsim::dyn_lds()
+
+typedef ::hipsim::Dim3 dim3;
+typedef void *hipStream_t;
+typedef int hipError_t;
+static const hipError_t hipSuccess = 0;
+inline hipError_t hipGetLastError() { return hipSuccess; }
+
+struct alignas(16) float4 {
+  float x, y, z, w;
+};
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+inline void __syncthreads() { ::hipsim::syncthreads(); }
+inline float __shfl_xor(float v, int mask, int /*width*/ = 64) { return ::hipsim::shfl_xor(v, mask); }
+inline float rsqrtf(float v) { return 1.0f / sqrtf(v); }
+template <class T> inline T min(T a, T b) { return a < b ? a : b; }
+template <class T> inline T max(T a, T b) { return a > b ? a : b; }
+
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) ::hipsim::mfma32x32x2((a), (b), (c))
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  ::hipsim::launch([=]() { (kernel)(__VA_ARGS__); }, (grid), (block), (shmem))

@@ -1,0 +1,171 @@
+// TEST INFRASTRUCTURE - scheduler of the hipsim CPU interpreter (see hip/hip_runtime.h).
+#include <ucontext.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "hip/hip_runtime.h"
+
+namespace hipsim {
+
+Dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
+alignas(16) static unsigned char g_lds[160 * 1024];
+unsigned char *dyn_lds() { return g_lds; }
+
+namespace {
+enum State { READY, WAIT_BLOCK, WAIT_WAVE, DONE };
+enum WaveOp { OP_NONE, OP_SHFL_XOR, OP_MFMA };
+
+struct Fiber {
+  ucontext_t ctx;
+  std::vector<unsigned char> stack;
+  State state = READY;
+  Dim3 tid;
+  // wave-op operands / results
+  WaveOp op = OP_NONE;
+  float a = 0, b = 0;
+  int imm = 0;
+  f32x16 c, d;
+  float fres = 0;
+};
+
+std::vector<Fiber> g_f;
+ucontext_t g_sched;
+int g_cur = -1;
+const std::function<void()> *g_body = nullptr;
+
+void trampoline() {
+  (*g_body)();
+  g_f[g_cur].state = DONE;
+  swapcontext(&g_f[g_cur].ctx, &g_sched);
+}
+
+void yield_to_sched() { swapcontext(&g_f[g_cur].ctx, &g_sched); }
+
+void resolve_wave(int w0, int w1) {
+  // all live lanes of the wave [w0, w1) are waiting: perform the op
+  WaveOp op = OP_NONE;
+  for (int i = w0; i < w1; ++i)
+    if (g_f[i].state == WAIT_WAVE) {
+      if (op == OP_NONE) op = g_f[i].op;
+      else if (op != g_f[i].op) { fprintf(stderr, "hipsim: divergent wave ops\n"); abort(); }
+    }
+  if (op == OP_SHFL_XOR) {
+    for (int i = w0; i < w1; ++i) {
+      if (g_f[i].state != WAIT_WAVE) continue;
+      int src = w0 + (((i - w0) ^ g_f[i].imm) & 63);
+      g_f[i].fres = (src < w1 && g_f[src].state == WAIT_WAVE) ? g_f[src].a : 0.0f;
+    }
+  } else if (op == OP_MFMA) {
+    if (w1 - w0 != 64) { fprintf(stderr, "hipsim: MFMA needs a full wave\n"); abort(); }
+    for (int i = w0; i < w1; ++i)
+      if (g_f[i].state != WAIT_WAVE) { fprintf(stderr, "hipsim: MFMA with exited lanes\n"); abort(); }
+    for (int l = 0; l < 64; ++l) {
+      Fiber &f = g_f[w0 + l];
+      const int col = l & 31;
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = f.c[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(g_f[w0 + row + 32 * k].a, g_f[w0 + col + 32 * k].b, acc);
+        f.d[r] = acc;
+      }
+    }
+  }
+  for (int i = w0; i < w1; ++i)
+    if (g_f[i].state == WAIT_WAVE) g_f[i].state = READY;
+}
+
+void run_block(int nthreads) {
+  for (int i = 0; i < nthreads; ++i) {
+    Fiber &f = g_f[i];
+    f.state = READY;
+    f.op = OP_NONE;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack.data();
+    f.ctx.uc_stack.ss_size = f.stack.size();
+    f.ctx.uc_link = &g_sched;
+    makecontext(&f.ctx, trampoline, 0);
+  }
+  const int nwaves = (nthreads + 63) / 64;
+  for (;;) {
+    bool progressed = false;
+    int done = 0;
+    for (int i = 0; i < nthreads; ++i) {
+      if (g_f[i].state == DONE) { ++done; continue; }
+      if (g_f[i].state != READY) continue;
+      g_cur = i;
+      threadIdx_ = g_f[i].tid;
+      swapcontext(&g_sched, &g_f[i].ctx);
+      progressed = true;
+    }
+    if (done == nthreads) return;
+    // wave rendezvous
+    for (int w = 0; w < nwaves; ++w) {
+      const int w0 = w * 64, w1 = std::min(nthreads, w0 + 64);
+      int waiting = 0, live = 0;
+      for (int i = w0; i < w1; ++i) {
+        if (g_f[i].state != DONE) ++live;
+        if (g_f[i].state == WAIT_WAVE) ++waiting;
+      }
+      if (live > 0 && waiting == live) { resolve_wave(w0, w1); progressed = true; }
+    }
+    // block barrier
+    int waiting = 0, live = 0;
+    for (int i = 0; i < nthreads; ++i) {
+      if (g_f[i].state != DONE) ++live;
+      if (g_f[i].state == WAIT_BLOCK) ++waiting;
+    }
+    if (live > 0 && waiting == live) {
+      for (int i = 0; i < nthreads; ++i)
+        if (g_f[i].state == WAIT_BLOCK) g_f[i].state = READY;
+      progressed = true;
+    }
+    if (!progressed) { fprintf(stderr, "hipsim: deadlock (mixed barrier / wave waits)\n"); abort(); }
+  }
+}
+}  // namespace
+
+void syncthreads() {
+  g_f[g_cur].state = WAIT_BLOCK;
+  yield_to_sched();
+}
+
+float shfl_xor(float v, int mask) {
+  Fiber &f = g_f[g_cur];
+  f.op = OP_SHFL_XOR; f.a = v; f.imm = mask; f.state = WAIT_WAVE;
+  yield_to_sched();
+  return g_f[g_cur].fres;
+}
+
+f32x16 mfma32x32x2(float a, float b, f32x16 c) {
+  Fiber &f = g_f[g_cur];
+  f.op = OP_MFMA; f.a = a; f.b = b; f.c = c; f.state = WAIT_WAVE;
+  yield_to_sched();
+  return g_f[g_cur].d;
+}
+
+void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t shmem) {
+  if (shmem > sizeof(g_lds)) { fprintf(stderr, "hipsim: LDS request %zu too large\n", shmem); abort(); }
+  const int nthreads = block.x * block.y * block.z;
+  if ((int)g_f.size() < nthreads) {
+    g_f.resize(nthreads);
+    for (auto &f : g_f)
+      if (f.stack.empty()) f.stack.resize(256 * 1024);
+  }
+  for (int i = 0; i < nthreads; ++i)
+    g_f[i].tid = Dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
+  g_body = &body;
+  blockDim_ = block;
+  gridDim_ = grid;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        blockIdx_ = Dim3(bx, by, bz);
+        memset(g_lds, 0xA5, shmem);  // poison: uninitialised LDS reads show up as garbage
+        run_block(nthreads);
+      }
+}
+
+}  // namespace hipsim

@@ -1,0 +1,128 @@
+"""CPU tests: the HIP kernel SOURCES interpreted by tests/hipsim vs the oracle and the
+golden vectors produced by the real reference.  They validate index arithmetic, LDS
+layouts, the MFMA fragment maps and tile geometry before any GPU time is spent; the
+numerical parity proper is re-established on the GPU by the -m gpu tests."""
+import numpy as np
+import pytest
+import torch
+
+from hairfastgan_amd import _marshal as M
+from oracle import cases as C
+from oracle import ref_stylegan2 as O
+
+TOL = 2e-5
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+@pytest.mark.parametrize("name", list(C.UPFIRDN_CASES))
+def test_upfirdn2d(simlib, golden, name):
+    c = C.UPFIRDN_CASES[name]
+    x, k = C.upfirdn_input(name), C.blur_kernel4()
+    y = M.upfirdn2d(simlib, None, x, k, c["up"], c["up"], c["down"], c["down"], c["pad"][0], c["pad"][1],
+                    c["pad"][0], c["pad"][1])
+    ref = torch.from_numpy(golden("upfirdn2d.npz")[name])
+    assert y.shape == ref.shape
+    assert maxdiff(y, ref) < TOL
+
+
+@pytest.mark.parametrize("name", list(C.ACT_CASES))
+def test_fused_bias_act(simlib, golden, name):
+    x, b = C.act_inputs(name)
+    y = M.fused_bias_act(simlib, None, x, b, 0.2, 2 ** 0.5)
+    assert maxdiff(y, torch.from_numpy(golden("fused_act.npz")[name])) < 1e-6
+
+
+def test_noise_bias_act(simlib):
+    x = torch.randn(2, 5, 6, 6)
+    nz = torch.randn(1, 1, 6, 6)
+    nw = torch.tensor([0.3])
+    b = torch.randn(5)
+    y = M.noise_bias_act(simlib, None, x, nz, nw, b)
+    assert maxdiff(y, O.fused_leaky_relu(x + nw * nz, b)) < 1e-6
+    nzb = torch.randn(2, 1, 6, 6)
+    y = M.noise_bias_act(simlib, None, x, nzb, nw, b)
+    assert maxdiff(y, O.fused_leaky_relu(x + nw * nzb, b)) < 1e-6
+    x = torch.randn(2, 3, 5, 3)  # hw not a multiple of 4 -> scalar kernel
+    nz = torch.randn(2, 1, 5, 3)
+    y = M.noise_bias_act(simlib, None, x, nz, nw, b[:3].contiguous())
+    assert maxdiff(y, O.fused_leaky_relu(x + nw * nz, b[:3])) < 1e-6
+
+
+def _style(simlib, P, w):
+    wt, wsq = M.prepare_weights(simlib, None, P["L.conv.weight"])
+    s = M.modulation(simlib, None, w, P["L.conv.modulation.weight"], P["L.conv.modulation.bias"])
+    return wt, wsq, s
+
+
+@pytest.mark.parametrize("name", [c[0] for c in C.MODCONV_SMALL])
+def test_style_and_demod(simlib, name):
+    d = C.modconv_small_inputs(name)
+    P = d["P_up0"]
+    wt, wsq, s = _style(simlib, P, d["w"])
+    s_ref = O.equal_linear(d["w"], P["L.conv.modulation.weight"], P["L.conv.modulation.bias"])
+    assert maxdiff(s, s_ref) < 1e-5
+    cin = d["cin"]
+    wref = P["L.conv.weight"][0] / (cin * 9) ** 0.5
+    assert maxdiff(wt, wref.permute(2, 3, 1, 0).reshape(9, cin, -1)) < 1e-7
+    dm = M.demod(simlib, None, s, wsq)
+    dref = torch.rsqrt(((wref[None] * s_ref[:, None, :, None, None]) ** 2).sum([2, 3, 4]) + 1e-8)
+    assert maxdiff(dm, dref) / float(dref.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("name", [c[0] for c in C.MODCONV_SMALL])
+@pytest.mark.parametrize("up", [False, True])
+def test_styled_conv(simlib, golden, name, up):
+    d = C.modconv_small_inputs(name)
+    P = d[f"P_up{int(up)}"]
+    wt, wsq, s = _style(simlib, P, d["w"])
+    dm = M.demod(simlib, None, s, wsq)
+    G = golden("modconv_small.npz")
+    if up:
+        y_conv = M.modconv3x3_up(simlib, None, d["x"], wt, s, dm, P["L.conv.blur.kernel"], None, None, None)
+        y = M.modconv3x3_up(simlib, None, d["x"], wt, s, dm, P["L.conv.blur.kernel"], d["noise_up1"],
+                            P["L.noise.weight"], P["L.activate.bias"])
+    else:
+        y_conv = M.modconv3x3(simlib, None, d["x"], wt, s, dm, None, None, None)
+        y = M.modconv3x3(simlib, None, d["x"], wt, s, dm, d["noise_up0"], P["L.noise.weight"], P["L.activate.bias"])
+    ref_conv = torch.from_numpy(G[f"{name}_up{int(up)}_conv"])
+    ref = torch.from_numpy(G[f"{name}_up{int(up)}_styled"])
+    assert y_conv.shape == ref_conv.shape
+    assert maxdiff(y_conv, ref_conv) < TOL * max(1.0, float(ref_conv.abs().max()))
+    assert maxdiff(y, ref) < TOL * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("name", [c[0] for c in C.MODCONV_SMALL])
+@pytest.mark.parametrize("use_skip", [False, True])
+def test_torgb(simlib, golden, name, use_skip):
+    d = C.modconv_small_inputs(name)
+    P = d["P_rgb"]
+    wt, _ = M.prepare_weights(simlib, None, P["L.conv.weight"])
+    s = M.modulation(simlib, None, d["w"], P["L.conv.modulation.weight"], P["L.conv.modulation.bias"])
+    y = M.torgb(simlib, None, d["x_rgb"], wt, s, P["L.bias"], d["skip"] if use_skip else None,
+                P["L.upsample.kernel"])
+    ref = torch.from_numpy(golden("modconv_small.npz")[f"{name}_rgb_skip{int(use_skip)}"])
+    assert maxdiff(y, ref) < TOL * max(1.0, float(ref.abs().max()))
+
+
+def test_modconv_tile_geometries(simlib):
+    """Shapes that exercise every tile family: multi-image tiles (4x4), >1 tile per
+    plane with ragged edges, cout not a multiple of 32 / of 4, cin not a multiple of 8."""
+    torch.manual_seed(1)
+    for (B, cin, cout, H, W) in [(3, 8, 8, 4, 4), (1, 12, 34, 40, 72), (2, 16, 33, 9, 5), (5, 8, 64, 2, 2)]:
+        x = torch.randn(B, cin, H, W)
+        wgt = torch.randn(1, cout, cin, 3, 3)
+        mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+        wt, wsq = M.prepare_weights(simlib, None, wgt)
+        s = M.modulation(simlib, None, sty, mw, mb)
+        dm = M.demod(simlib, None, s, wsq)
+        for up in (False, True):
+            ref = O.modulated_conv2d(x, sty, wgt, mw, mb, True, up)
+            if up:
+                y = M.modconv3x3_up(simlib, None, x, wt, s, dm, O.blur_kernel_1d_to_2d(gain=4.0), None, None, None)
+            else:
+                y = M.modconv3x3(simlib, None, x, wt, s, dm, None, None, None)
+            assert y.shape == ref.shape
+            assert maxdiff(y, ref) < TOL * max(1.0, float(ref.abs().max())), (B, cin, cout, H, W, up)
