@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py - StyleGAN2 1024^2 generator forward on MI355X (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8]
+
+A "step" is one full generator forward (range 0->8) of one batch of W+ latents that are
+already resident in HBM; noise is drawn fresh per layer like HairFast's callers do
+(noise=None, models/stylegan2/model.py:289-291).  Weights are the closed-form synthetic
+fill of oracle/synth.py (no checkpoints / network on the box); timing is weight-independent.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel = the fp32-MFMA modulated conv (modconv_mfma<2,2,2,2>, the
+                64^2..256^2 same-resolution layers): algorithmic FLOPs of its launches /
+                their HIP-event durations, measured during the timed steps on the launch
+                stream, against the 157.3 TFLOP/s fp32 MFMA peak.
+  cpu_baseline  the CPU oracle (bit-identical restatement of the reference's PyTorch CPU
+                path) timed on this host: batch-1 forwards, all host cores (rank 0, N=1 only).
+For N>1 (torchrun, one rank per GPU over RCCL) every rank runs the same per-GPU batch
+(weak scaling) and the uint8 result images of each step are all-gathered (async, overlapped
+with the next step's compute).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+GFLOP_PER_IMAGE = 148.52       # modulated-conv FLOPs of one 0->8 forward
+
+
+def build_generator(dev):
+    import numpy as np
+
+    from hairfastgan_amd.stylegan2.model import Generator
+    from oracle import synth  # closed-form parameter fill only (data, not compute)
+
+    g = Generator(1024, 512, 8, channel_multiplier=2).eval()
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in
+          synth.fill_state_dict({k: tuple(v.shape) for k, v in g.state_dict().items()}).items()}
+    g.load_state_dict(sd)
+    return g.to(dev), sd
+
+
+def cpu_baseline(sd, budget_s=25.0):
+    """Oracle forward, batch 1, explicit noise, all host cores; median of up to 5 runs."""
+    from oracle import cases as C
+    from oracle import ref_stylegan2 as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    lat, nz, _ = C.generator_inputs(1024, 1, 0)
+    times = []
+    t_start = time.time()
+    with torch.inference_mode():
+        O.generator_forward(sd, lat, nz)  # warm-up
+        while len(times) < 5 and (time.time() - t_start) < budget_s:
+            t0 = time.time()
+            O.generator_forward(sd, lat, nz)
+            times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "ms_per_image": round(med * 1e3, 1),
+            "sample": f"oracle (CPU restatement, bit-identical to the reference's PyTorch CPU path) generator "
+                      f"0->8, batch 1, explicit noise, {len(times)} timed forwards after 1 warm-up, "
+                      f"torch {torch.__version__} with {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    from hairfastgan_amd import _marshal, parallel
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    g, sd = build_generator(dev)
+    B = args.batch
+    torch.manual_seed(3407 + rank)  # the reference's default seed (utils/seed.py:19)
+    latent = torch.randn(B, 18, 512, device=dev)
+
+    import torch.distributed as dist
+
+    gather_note = None
+    pending = None
+
+    def step():
+        nonlocal pending, gather_note
+        with torch.inference_mode():
+            img, _ = g([latent], input_is_latent=True)
+            if world > 1:
+                try:
+                    u8 = parallel.to_uint8_image(img)
+                    if pending is not None:
+                        pending[1].wait()
+                    pending = parallel.all_gather_images(u8, async_op=True)
+                except Exception as e:  # recorded in the JSON, never silent
+                    gather_note = f"all_gather failed: {type(e).__name__}: {e}"
+        return img
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if pending is not None:
+        pending[1].wait()
+    barrier()
+    prof = None if args.no_kernel_events else []
+    _marshal.PROFILE = prof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if pending is not None:
+        pending[1].wait()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _marshal.PROFILE = None
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = B * args.steps * world / elapsed
+        out = {
+            "metric": "stylegan2_generator_fwd_1024_images_per_sec", "value": round(value, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "ms_per_image": round(ms_step / B, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "StyleGAN2 1024^2 generator forward (range 0->8), random W+, fresh noise per layer, "
+                                   "HIP modulated-conv + upfirdn2d kernels (BASELINE.json configs[1])",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"replica x{world}",
+                       "weights": "synthetic closed-form (oracle/synth.py)"},
+            "mfma_fraction_whole_forward": round(value * GFLOP_PER_IMAGE / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4),
+        }
+        if gather_note:
+            out["config"]["gather"] = gather_note
+        elif world > 1:
+            out["config"]["gather"] = "async RCCL all_gather_into_tensor of uint8 images, one per step"
+        if prof:
+            agg = {}
+            for label, flops, e0, e1 in prof:
+                a = agg.setdefault(label, [0.0, 0.0, 0])
+                a[0] += flops
+                a[1] += e0.elapsed_time(e1) * 1e-3
+                a[2] += 1
+            fams = {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "avg_launch_ms": round(v[1] / v[2] * 1e3, 4),
+                        "launches": v[2], "share_of_step": round(v[1] / elapsed, 4)} for k, v in agg.items()}
+            dom = max(agg, key=lambda k: agg[k][1])
+            d = agg[dom]
+            ach = d[0] / d[1] / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
+                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "avg_launch_ms": round(d[1] / d[2] * 1e3, 4), "launches": d[2],
+                               "flops_per_launch_avg": d[0] / d[2]}
+            out["kernels"] = fams
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

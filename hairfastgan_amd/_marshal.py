@@ -14,6 +14,36 @@ from ._lib import check
 
 SQRT2 = 2 ** 0.5
 
+# bench.py sets this to a list to bracket every modulated-conv launch with HIP events
+# recorded on the launch stream: entries are (kernel label, algorithmic flops, start, end).
+PROFILE = None
+
+
+def modconv_variant(cout, pixels, up):
+    """Name of the kernel instantiation hf_modconv3x3[_up]_f32 dispatches to (mirrors the
+    rule at the bottom of csrc/modconv.hip; used only to label profile records)."""
+    if up:
+        return "modconv_mfma<1,1,1,4,up>" if cout <= 32 else "modconv_mfma<1,1,2,2,up>"
+    if cout <= 32:
+        return "modconv_mfma<1,2,1,4>"
+    if pixels <= 8192:
+        return "modconv_mfma<1,1,2,2>"
+    if cout <= 64:
+        return "modconv_mfma<2,2,1,4>"
+    return "modconv_mfma<2,2,2,2>"
+
+
+def _launch_profiled(label, flops, fn):
+    if PROFILE is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    PROFILE.append((label, flops, e0, e1))
+    return r
+
 
 def _p(t):
     return None if t is None else t.data_ptr()
@@ -119,8 +149,12 @@ def modconv3x3(lib, st, x, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=SQRT
     cout = wt.shape[2]
     noise, nbs = _noise_args(noise, b, h * w)
     out = x.new_empty((b, cout, h, w))
-    check(lib, lib.hf_modconv3x3_f32(_p(out), _p(x), _p(wt), _p(s), _p(d), _p(noise), _p(_c(noise_w)), nbs,
-                                     _p(_c(bias)), b, cin, cout, h, w, alpha, scale, st), "hf_modconv3x3_f32")
+    noise_w, bias = _c(noise_w), _c(bias)
+    code = _launch_profiled(
+        modconv_variant(cout, b * h * w, False), 2.0 * cin * cout * 9 * h * w * b,
+        lambda: lib.hf_modconv3x3_f32(_p(out), _p(x), _p(wt), _p(s), _p(d), _p(noise), _p(noise_w), nbs, _p(bias),
+                                      b, cin, cout, h, w, alpha, scale, st))
+    check(lib, code, "hf_modconv3x3_f32")
     return out
 
 
@@ -130,8 +164,10 @@ def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha
     b, cin, h, w = x.shape
     cout = wt.shape[2]
     tmp = x.new_empty((b, cout, 2 * h + 1, 2 * w + 1))
-    check(lib, lib.hf_modconv3x3_up_f32(_p(tmp), _p(x), _p(wt), _p(s), _p(d), b, cin, cout, h, w, st),
-          "hf_modconv3x3_up_f32")
+    code = _launch_profiled(
+        modconv_variant(cout, b * h * w, True), 2.0 * cin * cout * 9 * h * w * b,
+        lambda: lib.hf_modconv3x3_up_f32(_p(tmp), _p(x), _p(wt), _p(s), _p(d), b, cin, cout, h, w, st))
+    check(lib, code, "hf_modconv3x3_up_f32")
     noise, nbs = _noise_args(noise, b, 4 * h * w)
     out = x.new_empty((b, cout, 2 * h, 2 * w))
     check(lib, lib.hf_blur_noise_bias_act_f32(_p(out), _p(tmp), _p(_c(blur_kernel)), _p(noise), _p(_c(noise_w)),

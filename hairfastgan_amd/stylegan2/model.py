@@ -1,0 +1,322 @@
+"""StyleGAN2 generator on the MI355X kernels - host-side mirror of the reference's
+models/stylegan2/model.py (all file:line below refer to that file).
+
+Same class names, constructor arguments, parameter/buffer names (state-dict
+compatible: 171 entries for Generator(1024, 512, 8, 2)) and `forward` signatures
+/ return conventions, so reference-style callers
+
+    net.generator([latent], input_is_latent=True, return_latents=False,
+                  start_layer=4, end_layer=8, layer_in=F)        # -> (tensor, tensor|None)
+
+work unchanged.  What differs is the execution: a StyledConv is 3 kernel launches
+(modulation, demodulation coefficients, fused fp32-MFMA conv + noise + bias +
+leaky-ReLU; 5 for the upsampling variant), a ToRGB 2, instead of the reference's
+6-8 ATen calls on materialised per-sample weights (:238-279).
+
+Forward / inference only: parameters are frozen in HairFast (models/Net.py:44-46)
+and every stage runs under torch.inference_mode().
+"""
+import math
+import random
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .. import _marshal as M
+from .._runtime import lib, require_gpu, stream
+from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
+
+
+class PixelNorm(nn.Module):  # :16-21 (mapping network only; not on the HairFast hot path)
+    def forward(self, input):
+        return input * torch.rsqrt(torch.mean(input ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+def make_kernel(k):  # :24-32
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+class Upsample(nn.Module):  # :35-53
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class Downsample(nn.Module):  # :56-74
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=1, down=self.factor, pad=self.pad)
+
+
+class Blur(nn.Module):  # :77-93
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        kernel = make_kernel(kernel)
+        if upsample_factor > 1:
+            kernel = kernel * (upsample_factor ** 2)
+        self.register_buffer("kernel", kernel)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class EqualLinear(nn.Module):  # :134-168
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, input):
+        # Only the z->w mapping network reaches this generic form (plain GEMM, not on
+        # HairFast's path: input_is_latent=True everywhere); the 26 modulation linears go
+        # through hf_modulation_f32 inside ModulatedConv2d.
+        if self.activation:
+            out = F.linear(input, self.weight * self.scale)
+            return fused_leaky_relu(out, self.bias * self.lr_mul)
+        return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+
+
+class ModulatedConv2d(nn.Module):  # :183-279
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if downsample:
+            raise NotImplementedError("downsample=True is Discriminator-only in the reference (out of scope)")
+        if kernel_size not in (1, 3):
+            raise NotImplementedError("kernel_size must be 1 (ToRGB) or 3 (StyledConv)")
+        if upsample and kernel_size != 3:
+            raise NotImplementedError("upsample needs kernel_size 3")
+        if kernel_size == 1 and (out_channel != 3 or demodulate):
+            raise NotImplementedError("the 1x1 modulated conv exists only as ToRGB (3 outputs, no demodulation)")
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        self.downsample = downsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+        self._prep = None  # (key, wt [k*k,cin,cout], wsq [cout,cin]) - derived, not in the state dict
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
+                f"upsample={self.upsample}, downsample={self.downsample})")
+
+    # -- derived, frozen-parameter state --------------------------------------------------
+    def prepared(self):
+        """Batch-shared re-layout of the weight: wt[tap][ci][co] = scale*W, wsq[co][ci] = sum_tap wt^2."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._prep is None or self._prep[0] != key:
+            require_gpu(w)
+            wt, wsq = M.prepare_weights(lib(), stream(), w.detach())
+            self._prep = (key, wt, wsq)
+        return self._prep[1], self._prep[2]
+
+    def style_coefficients(self, style):
+        """s[b,ci] (EqualLinear :241) and d[b,co] (:244-246; None when demodulate=False)."""
+        wt, wsq = self.prepared()
+        s = M.modulation(lib(), stream(), style, self.modulation.weight.detach(), self.modulation.bias.detach())
+        d = M.demod(lib(), stream(), s, wsq) if self.demodulate else None
+        return wt, s, d
+
+    def forward(self, input, style):
+        require_gpu(input, style)
+        wt, s, d = self.style_coefficients(style)
+        if self.kernel_size == 1:
+            return M.torgb(lib(), stream(), input, wt, s, None, None, None)
+        if self.upsample:
+            if tuple(self.blur.pad) != (1, 1) or tuple(self.blur.kernel.shape) != (4, 4):
+                raise NotImplementedError("fused upsampling path expects the [1,3,3,1] blur with pad (1,1)")
+            return M.modconv3x3_up(lib(), stream(), input, wt, s, d, self.blur.kernel, None, None, None)
+        return M.modconv3x3(lib(), stream(), input, wt, s, d, None, None, None)
+
+
+class NoiseInjection(nn.Module):  # :282-293
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def forward(self, image, noise=None):
+        require_gpu(image)
+        if noise is None:
+            batch, _, height, width = image.shape
+            noise = image.new_empty(batch, 1, height, width).normal_()
+        return M.noise_bias_act(lib(), stream(), image, noise, self.weight.detach(), None, 1.0, 1.0)
+
+
+class ConstantInput(nn.Module):  # :296-306
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, input):
+        return self.input.repeat(input.shape[0], 1, 1, 1)
+
+
+class StyledConv(nn.Module):  # :309-343
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False,
+                 blur_kernel=[1, 3, 3, 1], demodulate=True):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, noise=None):
+        """conv -> +noise -> bias -> leaky-ReLU*sqrt2 with the last three fused into the
+        producing kernel's epilogue (same-res) or into the blur pass (upsample)."""
+        require_gpu(input, style, noise)
+        conv = self.conv
+        wt, s, d = conv.style_coefficients(style)
+        b, _, h, w = input.shape
+        oh, ow = (2 * h, 2 * w) if conv.upsample else (h, w)
+        if noise is None:  # fresh N(0,1) per call, drawn from torch's device RNG like :289-291
+            noise = input.new_empty(b, 1, oh, ow).normal_()
+        act = self.activate
+        if conv.upsample:
+            return M.modconv3x3_up(lib(), stream(), input, wt, s, d, conv.blur.kernel, noise,
+                                   self.noise.weight.detach(), act.bias.detach(), act.negative_slope, act.scale)
+        return M.modconv3x3(lib(), stream(), input, wt, s, d, noise, self.noise.weight.detach(),
+                            act.bias.detach(), act.negative_slope, act.scale)
+
+
+class ToRGB(nn.Module):  # :346-365
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, input, style, skip=None):
+        require_gpu(input, style, skip)
+        wt, s, _ = self.conv.style_coefficients(style)
+        kern = None
+        if skip is not None:
+            kern = self.upsample.kernel
+            if tuple(kern.shape) != (4, 4) or self.upsample.factor != 2 or tuple(self.upsample.pad) != (2, 1):
+                raise NotImplementedError("fused skip path expects the [1,3,3,1] x2 upsampler")
+        return M.torgb(lib(), stream(), input, wt, s, self.bias.detach(), skip, kern)
+
+
+class Generator(nn.Module):  # :368-565
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01):
+        super().__init__()
+        self.size = size
+        self.style_dim = style_dim
+        layers = [PixelNorm()]
+        for _ in range(n_mlp):
+            layers.append(EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation="fused_lrelu"))
+        self.style = nn.Sequential(*layers)
+        self.channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier,
+                         128: 128 * channel_multiplier, 256: 64 * channel_multiplier,
+                         512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+        self.input = ConstantInput(self.channels[4])
+        self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel)
+        self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False)
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.convs = nn.ModuleList()
+        self.upsamples = nn.ModuleList()
+        self.to_rgbs = nn.ModuleList()
+        self.noises = nn.Module()
+        for layer_idx in range(self.num_layers):
+            res = (layer_idx + 5) // 2
+            self.noises.register_buffer(f"noise_{layer_idx}", torch.randn(1, 1, 2 ** res, 2 ** res))
+        in_channel = self.channels[4]
+        for i in range(3, self.log_size + 1):
+            out_channel = self.channels[2 ** i]
+            self.convs.append(StyledConv(in_channel, out_channel, 3, style_dim, upsample=True,
+                                         blur_kernel=blur_kernel))
+            self.convs.append(StyledConv(out_channel, out_channel, 3, style_dim, blur_kernel=blur_kernel))
+            self.to_rgbs.append(ToRGB(out_channel, style_dim))
+            in_channel = out_channel
+        self.n_latent = self.log_size * 2 - 2
+
+    def make_noise(self):  # :455-464
+        device = self.input.input.device
+        noises = [torch.randn(1, 1, 2 ** 2, 2 ** 2, device=device)]
+        for i in range(3, self.log_size + 1):
+            for _ in range(2):
+                noises.append(torch.randn(1, 1, 2 ** i, 2 ** i, device=device))
+        return noises
+
+    def mean_latent(self, n_latent):  # :466-472
+        latent_in = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
+        return self.style(latent_in).mean(0, keepdim=True)
+
+    def get_latent(self, input):
+        return self.style(input)
+
+    def forward(self, styles, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                input_is_latent=False, noise=None, randomize_noise=True, layer_in=None, skip=None,
+                start_layer=0, end_layer=8, return_rgb=False):
+        """Layer-range executor with the reference's semantics (:477-565): returns
+        (image, latent|None) after the last block, (feature, skip) on early exit."""
+        if not input_is_latent:
+            styles = [self.style(s) for s in styles]
+        if noise is None:
+            if randomize_noise:
+                noise = [None] * self.num_layers
+            else:
+                noise = [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
+        if truncation < 1:
+            styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
+        if len(styles) < 2:
+            inject_index = self.n_latent
+            latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1) if styles[0].ndim < 3 else styles[0]
+        else:
+            if inject_index is None:
+                inject_index = random.randint(1, self.n_latent - 1)
+            latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                                styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+
+        out = self.input(latent)
+        if start_layer == 0:
+            out = self.conv1(out, latent[:, 0], noise=noise[0])
+            skip = self.to_rgb1(out, latent[:, 1])
+        if end_layer == 0:
+            return out, skip
+        i = 1
+        for block in range(1, self.log_size - 1):
+            conv_up, conv_same, to_rgb = self.convs[2 * block - 2], self.convs[2 * block - 1], self.to_rgbs[block - 1]
+            if block < start_layer:
+                pass
+            elif block != start_layer and block > end_layer:
+                return out, skip
+            else:
+                src = layer_in if block == start_layer else out
+                out = conv_up(src, latent[:, i], noise=noise[2 * block - 1])
+                out = conv_same(out, latent[:, i + 1], noise=noise[2 * block])
+                skip = to_rgb(out, latent[:, i + 2], skip)
+            i += 2
+        image = skip
+        return (image, latent) if return_latents else (image, None)

@@ -1,0 +1,252 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the product API and hence the
+C ABI, against (a) the committed golden vectors produced by the real reference and
+(b) the CPU oracle on the same seeded inputs.
+
+Tolerance: fp32 everywhere.  The HIP path reassociates the contraction (MFMA k-order,
+modulation applied to activations, demodulation to outputs), so results differ from the
+reference's ATen kernels at fp32 round-off: we require max-abs <= 1e-4 * max(1, |ref|max)
+and MSE <= 1e-8 * max(1, var) (SURVEY.md section 8c measured the reference's own
+fp32-vs-fp64 noise floor at 8.9e-6 max-abs); north_star's pixel-MSE bar is 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases as C
+from oracle import ref_stylegan2 as O
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (torch.cuda.is_available() is False)")
+    return torch.device("cuda:0")
+
+
+def close(y, ref, rel=REL):
+    y = y.detach().cpu().double()
+    ref = ref.detach().cpu().double() if torch.is_tensor(ref) else torch.from_numpy(np.asarray(ref)).double()
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((y - ref).abs().max())
+    mse = float(((y - ref) ** 2).mean())
+    assert err <= rel * scale, f"max-abs {err:.3e} > {rel * scale:.3e}"
+    assert mse <= 1e-8 * max(1.0, float(ref.var())), f"mse {mse:.3e}"
+    return err
+
+
+def test_native_library_is_loaded():
+    from hairfastgan_amd import _lib
+
+    lib = _lib.load()
+    assert lib.hf_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libhairfast_hip.so" in maps
+
+
+@pytest.mark.parametrize("name", list(C.UPFIRDN_CASES))
+def test_upfirdn2d(golden, name):
+    from hairfastgan_amd.stylegan2.op import upfirdn2d
+
+    dev = _dev()
+    c = C.UPFIRDN_CASES[name]
+    y = upfirdn2d(C.upfirdn_input(name).to(dev), C.blur_kernel4().to(dev), up=c["up"], down=c["down"], pad=c["pad"])
+    close(y, golden("upfirdn2d.npz")[name], 1e-5)
+
+
+@pytest.mark.parametrize("name", list(C.ACT_CASES))
+def test_fused_leaky_relu(golden, name):
+    from hairfastgan_amd.stylegan2.op import FusedLeakyReLU, fused_leaky_relu
+
+    dev = _dev()
+    x, b = C.act_inputs(name)
+    close(fused_leaky_relu(x.to(dev), b.to(dev)), golden("fused_act.npz")[name], 1e-6)
+    m = FusedLeakyReLU(b.numel()).to(dev)
+    m.bias.data.copy_(b)
+    close(m(x.to(dev)), golden("fused_act.npz")[name], 1e-6)
+    # empty input
+    assert fused_leaky_relu(x[:0].to(dev), b.to(dev)).shape == x[:0].shape
+
+
+def _load_small(mod, P, dev):
+    mod.load_state_dict({k[2:]: v for k, v in P.items()})
+    return mod.to(dev).eval()
+
+
+@pytest.mark.parametrize("name", [c[0] for c in C.MODCONV_SMALL])
+def test_small_modules_vs_reference_golden(golden, name):
+    import hairfastgan_amd.stylegan2.model as model
+
+    dev = _dev()
+    d = C.modconv_small_inputs(name)
+    G = golden("modconv_small.npz")
+    x, w = d["x"].to(dev), d["w"].to(dev)
+    with torch.inference_mode():
+        for up in (False, True):
+            m = _load_small(model.StyledConv(d["cin"], d["cout"], 3, d["sdim"], upsample=up), d[f"P_up{int(up)}"], dev)
+            close(m.conv(x, w), G[f"{name}_up{int(up)}_conv"])
+            close(m(x, w, noise=d[f"noise_up{int(up)}"].to(dev)), G[f"{name}_up{int(up)}_styled"])
+        m = _load_small(model.ToRGB(d["cout"], d["sdim"]), d["P_rgb"], dev)
+        close(m(d["x_rgb"].to(dev), w, None), G[f"{name}_rgb_skip0"])
+        close(m(d["x_rgb"].to(dev), w, d["skip"].to(dev)), G[f"{name}_rgb_skip1"])
+
+
+def test_modconv_tile_geometries_vs_oracle():
+    """Ragged / tiny / odd shapes: multi-image tiles, partial tiles, cout % 32 != 0,
+    cout % 4 != 0, cin % 8 != 0, 1-pixel planes, and each kernel instantiation."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = _dev()
+    torch.manual_seed(1)
+    shapes = [(3, 8, 8, 4, 4), (1, 12, 34, 40, 72), (2, 16, 33, 9, 5), (5, 8, 64, 2, 2), (1, 8, 8, 1, 1),
+              (2, 64, 128, 72, 72), (1, 128, 64, 130, 66), (9, 32, 32, 32, 32), (2, 40, 256, 16, 16)]
+    for (B, cin, cout, H, W) in shapes:
+        x = torch.randn(B, cin, H, W)
+        wgt = torch.randn(1, cout, cin, 3, 3)
+        mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+        wt, wsq = M.prepare_weights(lib(), stream(), wgt.to(dev))
+        s = M.modulation(lib(), stream(), sty.to(dev), mw.to(dev), mb.to(dev))
+        dm = M.demod(lib(), stream(), s, wsq)
+        for up in (False, True):
+            ref = O.modulated_conv2d(x, sty, wgt, mw, mb, True, up)
+            if up:
+                y = M.modconv3x3_up(lib(), stream(), x.to(dev), wt, s, dm, O.blur_kernel_1d_to_2d(gain=4.0).to(dev),
+                                    None, None, None)
+            else:
+                y = M.modconv3x3(lib(), stream(), x.to(dev), wt, s, dm, None, None, None)
+            close(y, ref)
+
+
+def _gpu_generator(tag, dev):
+    import hairfastgan_amd.stylegan2.model as model
+
+    size, cm, n_mlp, batches, ranges = C.GENERATOR_CASES[tag]
+    g = model.Generator(size, 512, n_mlp, channel_multiplier=cm).eval()
+    shapes = {k: tuple(v.shape) for k, v in g.state_dict().items()}
+    g.load_state_dict(C.generator_params(shapes))
+    return g.to(dev), shapes, size, batches, ranges
+
+
+def _run_range(g, shapes, size, B, s, e, dev):
+    cin = shapes[f"convs.{2 * s - 2}.conv.weight"][2] if s > 0 else None
+    lat, nz, layer_in = C.generator_inputs(size, B, s, cin)
+    with torch.inference_mode():
+        return g([lat.to(dev)], input_is_latent=True, noise=[n.to(dev) for n in nz],
+                 layer_in=None if layer_in is None else layer_in.to(dev), start_layer=s, end_layer=e)
+
+
+def _strided(y, n=1024):
+    f = y.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n]
+
+
+def _check_against_golden(G, key, y, sk):
+    scale = max(1.0, abs(float(G[f"{key}_stats"][2])), abs(float(G[f"{key}_stats"][3])))
+    st = G[f"{key}_stats"]
+    yd = y.double()
+    got = np.array([yd.mean().item(), yd.std().item(), yd.min().item(), yd.max().item()])
+    assert np.allclose(got, st, rtol=0, atol=REL * scale), (got, st)
+    close(_strided(y), G[f"{key}_samples"])
+    if f"{key}_full" in G:
+        close(y, G[f"{key}_full"])
+    if f"{key}_crop" in G:
+        c0 = y.shape[-1] // 2 - 32
+        close(y[:, :, c0:c0 + 64, c0:c0 + 64], G[f"{key}_crop"])
+    if f"{key}_chan16" in G:
+        close(y[:, ::16], G[f"{key}_chan16"])
+    if f"{key}_skip_samples" in G:
+        close(_strided(sk), G[f"{key}_skip_samples"])
+    else:
+        assert sk is None
+
+
+def test_generator64_all_ranges_vs_reference_golden(golden):
+    dev = _dev()
+    g, shapes, size, batches, ranges = _gpu_generator("g64", dev)
+    G = golden("generator_64.npz")
+    for B in batches:
+        for (s, e) in ranges:
+            y, sk = _run_range(g, shapes, size, B, s, e, dev)
+            _check_against_golden(G, f"g64_B{B}_r{s}to{e}", y, sk)
+
+
+def test_generator1024_all_ranges_vs_reference_golden(golden):
+    """BASELINE.json configs[0]/[2] shapes: every layer range HairFast uses
+    (0->8, 0->3, 3->3, 4->8, 5->8; Embedding.py:52,78,90, Alignment.py:63, Blending.py:62,68)."""
+    dev = _dev()
+    g, shapes, size, batches, ranges = _gpu_generator("g1024", dev)
+    G = golden("generator_1024.npz")
+    for B in batches:
+        for (s, e) in ranges:
+            y, sk = _run_range(g, shapes, size, B, s, e, dev)
+            _check_against_golden(G, f"g1024_B{B}_r{s}to{e}", y, sk)
+
+
+def test_generator1024_intermediates_localise(golden):
+    """Per-layer checkpoints of the full forward (stats + 16 samples per module output)."""
+    dev = _dev()
+    g, shapes, size, batches, _ = _gpu_generator("g1024", dev)
+    G = golden("generator_1024.npz")
+    B = batches[0]
+    got = {}
+    hooks = []
+    for nm, mod in g.named_modules():
+        if nm in ("conv1", "to_rgb1") or (nm.count(".") == 1 and nm.split(".")[0] in ("convs", "to_rgbs")):
+            hooks.append(mod.register_forward_hook(lambda _m, _i, o, nm=nm: got.__setitem__(nm, o)))
+    _run_range(g, shapes, size, B, 0, 8, dev)
+    for h in hooks:
+        h.remove()
+    assert len(got) == 2 + 16 + 8
+    for nm, o in got.items():
+        ref = G[f"g1024_B{B}_r0to8_inter_{nm}"]
+        od = o.double()
+        stats = np.array([od.mean().item(), od.std().item(), od.min().item(), od.max().item()])
+        scale = max(1.0, abs(ref[2]), abs(ref[3]))
+        assert np.allclose(stats, ref[:4], rtol=0, atol=REL * scale), (nm, stats, ref[:4])
+        close(_strided(o, 16), ref[4:], REL)
+
+
+def test_full_size_properties_batch8():
+    """BASELINE.json configs[1] size (batch 8, 1024^2), no oracle needed:
+    batch independence (sample i of a batch == the same sample alone, bit-exact since the
+    kernels share weights across the batch), determinism, and linearity of ToRGB in its bias."""
+    dev = _dev()
+    g, shapes, size, _, _ = _gpu_generator("g1024", dev)
+    lat8, nz, _ = C.generator_inputs(size, 8, 0)
+    nz = [n.to(dev) for n in nz]
+    lat8 = lat8.to(dev)
+    with torch.inference_mode():
+        y8, _ = g([lat8], input_is_latent=True, noise=nz)
+        y8b, _ = g([lat8], input_is_latent=True, noise=nz)
+        assert torch.equal(y8, y8b)
+        assert torch.isfinite(y8).all()
+        for i in (0, 5):
+            yi, _ = g([lat8[i:i + 1]], input_is_latent=True, noise=nz)
+            assert float((yi[0] - y8[i]).abs().max()) <= 1e-6 * max(1.0, float(y8[i].abs().max()))
+        old = g.to_rgbs[7].bias.data.clone()
+        g.to_rgbs[7].bias.data += 0.5
+        y_shift, _ = g([lat8[:1]], input_is_latent=True, noise=nz)
+        g.to_rgbs[7].bias.data.copy_(old)
+        assert float((y_shift - y8[:1] - 0.5).abs().max()) < 1e-5
+    assert y8.shape == (8, 3, 1024, 1024)
+
+
+def test_random_noise_path_statistics():
+    """noise=None draws fresh N(0,1) maps (model.py:289-291): two calls differ, and the
+    difference has the scale predicted by the noise weights."""
+    dev = _dev()
+    g, shapes, size, _, _ = _gpu_generator("g64", dev)
+    lat, _, _ = C.generator_inputs(size, 2, 0)
+    with torch.inference_mode():
+        torch.manual_seed(0)
+        a, _ = g([lat.to(dev)], input_is_latent=True)
+        b, _ = g([lat.to(dev)], input_is_latent=True)
+        torch.manual_seed(0)
+        a2, _ = g([lat.to(dev)], input_is_latent=True)
+    assert not torch.equal(a, b)
+    assert torch.equal(a, a2)

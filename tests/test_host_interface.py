@@ -1,0 +1,99 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol
+the header declares, the host mirror keeps the reference's names / signatures /
+state-dict layout, and the product refuses to run without the GPU (no fallback)."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for fn in os.listdir(inc):
+        if fn.endswith(".h"):
+            txt = open(os.path.join(inc, fn)).read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            names |= set(re.findall(r"\b(hf_\w+)\s*\(", txt))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from hairfastgan_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert set(_lib.SIGNATURES) | {"hf_strerror", "hf_abi_version"} == declared
+    bound = _lib.bind(lib)
+    assert bound.hf_abi_version() == 1
+    assert bound.hf_strerror(-1) == b"invalid argument"
+
+
+def test_ops_refuse_cpu_tensors():
+    from hairfastgan_amd.stylegan2.op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
+
+    x = torch.randn(1, 3, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        upfirdn2d(x, torch.ones(4, 4), pad=(1, 1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fused_leaky_relu(x, torch.zeros(3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FusedLeakyReLU(3)(x)
+    from hairfastgan_amd.stylegan2.model import Generator
+
+    g = Generator(8, 512, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        g([torch.randn(1, 4, 512)], input_is_latent=True)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from hairfastgan_amd import _lib
+
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.HairfastLibError, match="no CPU / PyTorch fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "hairfastgan_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{f} imports the oracle"
+                assert "/root/reference" not in src
+
+
+def test_generator_surface_matches_reference_contract():
+    from hairfastgan_amd.stylegan2.model import Generator
+    from oracle.ref_stylegan2 import generator_param_shapes
+
+    g = Generator(1024, 512, 8, channel_multiplier=2)
+    sd = g.state_dict()
+    want = generator_param_shapes(1024, 512, 8, 2)  # verified == the reference's 171 entries by make_golden.py
+    assert len(sd) == 171
+    assert list(sd) == list(want)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == want
+    sig = inspect.signature(g.forward)
+    assert list(sig.parameters) == ["styles", "return_latents", "inject_index", "truncation", "truncation_latent",
+                                    "input_is_latent", "noise", "randomize_noise", "layer_in", "skip",
+                                    "start_layer", "end_layer", "return_rgb"]
+    assert sig.parameters["end_layer"].default == 8 and sig.parameters["start_layer"].default == 0
+    assert g.n_latent == 18 and g.num_layers == 17 and g.log_size == 10
+    from hairfastgan_amd.stylegan2 import op
+
+    assert inspect.signature(op.upfirdn2d).parameters["pad"].default == (0, 0)
+    assert inspect.signature(op.fused_leaky_relu).parameters["negative_slope"].default == 0.2
