@@ -47,29 +47,36 @@ def build_generator(dev):
     return g.to(dev), sd
 
 
-def cpu_baseline(sd, budget_s=25.0):
-    """Oracle forward, batch 1, explicit noise, all host cores; median of up to 5 runs."""
+def cpu_baseline(sd, budget_s=30.0):
+    """Oracle forward (generator 0->8, batch 1, explicit noise) timed on this host with all
+    cores and, because very wide hosts oversubscribe ATen's grouped convs, with 32 threads;
+    the faster setting is reported with the thread count it used."""
     from oracle import cases as C
     from oracle import ref_stylegan2 as O
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     lat, nz, _ = C.generator_inputs(1024, 1, 0)
-    times = []
+    tried = {}
     t_start = time.time()
-    with torch.inference_mode():
-        O.generator_forward(sd, lat, nz)  # warm-up
-        while len(times) < 5 and (time.time() - t_start) < budget_s:
-            t0 = time.time()
-            O.generator_forward(sd, lat, nz)
-            times.append(time.time() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+    for threads in sorted({ncpu, min(ncpu, 32)}, reverse=True):
+        torch.set_num_threads(threads)
+        times = []
+        with torch.inference_mode():
+            O.generator_forward(sd, lat, nz)  # warm-up
+            while len(times) < 3 and (not times or (time.time() - t_start) < budget_s):
+                t0 = time.time()
+                O.generator_forward(sd, lat, nz)
+                times.append(time.time() - t0)
+        times.sort()
+        tried[threads] = (times[len(times) // 2], len(times))
+    cores = min(tried, key=lambda k: tried[k][0])
+    med, n = tried[cores]
     return {"value": round(1.0 / med, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "ms_per_image": round(med * 1e3, 1),
             "sample": f"oracle (CPU restatement, bit-identical to the reference's PyTorch CPU path) generator "
-                      f"0->8, batch 1, explicit noise, {len(times)} timed forwards after 1 warm-up, "
-                      f"torch {torch.__version__} with {cores} threads"}
+                      f"0->8, batch 1, explicit noise; median of {n} timed forwards after 1 warm-up, torch "
+                      f"{torch.__version__}; thread counts tried: "
+                      + ", ".join(f"{k}T={v[0] * 1e3:.0f}ms" for k, v in sorted(tried.items()))}
 
 
 def main():

@@ -38,7 +38,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC = 8;            // input channels per LDS stage (4 MFMA k-steps)
 constexpr int kThreads = 256;    // 4 waves
-constexpr int kMaxElemPerCi = 3; // halo-tile elements per thread per channel
+constexpr int kMaxElemPerCi = 4; // halo-tile elements per thread per channel
 
 struct TileGeom {
   int y0, x0;      // origin of this tile family in the pixel domain
@@ -280,6 +280,7 @@ inline TileGeom make_geom(int y0, int x0, int dh, int dw, int batch, int pt, int
   int th = pow2_ceil(dh);
   if (th > pt / tw) th = pt / tw;
   int nb = pt / (tw * th);
+  if (nb > pow2_ceil(batch)) nb = pow2_ceil(batch);  // never stage images that do not exist
   g.lg_tw = ilog2(tw); g.lg_th = ilog2(th); g.lg_nb = ilog2(nb);
   g.tiles_x = hf_cdiv(dw, tw);
   g.tiles_y = hf_cdiv(dh, th);

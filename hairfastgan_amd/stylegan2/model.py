@@ -133,7 +133,8 @@ class ModulatedConv2d(nn.Module):  # :183-279
     def prepared(self):
         """Batch-shared re-layout of the weight: wt[tap][ci][co] = scale*W, wsq[co][ci] = sum_tap wt^2."""
         w = self.weight
-        key = (w.data_ptr(), w._version, w.device)
+        # inference tensors (module moved/loaded under torch.inference_mode()) carry no version counter
+        key = (w.data_ptr(), None if w.is_inference() else w._version, w.device)
         if self._prep is None or self._prep[0] != key:
             require_gpu(w)
             wt, wsq = M.prepare_weights(lib(), stream(), w.detach())

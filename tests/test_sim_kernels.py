@@ -111,7 +111,7 @@ def test_modconv_tile_geometries(simlib):
     """Shapes that exercise every tile family: multi-image tiles (4x4), >1 tile per
     plane with ragged edges, cout not a multiple of 32 / of 4, cin not a multiple of 8."""
     torch.manual_seed(1)
-    for (B, cin, cout, H, W) in [(3, 8, 8, 4, 4), (1, 12, 34, 40, 72), (2, 16, 33, 9, 5), (5, 8, 64, 2, 2)]:
+    for (B, cin, cout, H, W) in [(3, 8, 8, 4, 4), (1, 12, 34, 40, 72), (2, 16, 33, 9, 5), (5, 8, 64, 2, 2), (1, 8, 8, 1, 1), (2, 8, 40, 70, 1)]:
         x = torch.randn(B, cin, H, W)
         wgt = torch.randn(1, cout, cin, 3, 3)
         mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (gpurun_out/prof_*) into the small summaries
+committed under profiles/.  Usage: tools/summarize_prof.py <tag> <stats_dir> [fetch_dir write_dir mfma_dir]"""
+import collections
+import csv
+import os
+import sys
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0][:60]
+
+
+def main():
+    tag, stats = sys.argv[1], sys.argv[2]
+    out = [f"# rocprofv3 summary {tag}", "", "## --kernel-trace --stats (python bench.py --steps 3 --warmup 1)", "",
+           "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
+    for r in csv.DictReader(open(os.path.join(stats, "bench_kernel_stats.csv"))):
+        if float(r["Percentage"]) < 0.05:
+            continue
+        out.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | "
+                   f"{float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+    if len(sys.argv) > 3:
+        def agg(d, counter):
+            acc = collections.defaultdict(lambda: [0.0, 0])
+            for r in csv.DictReader(open(os.path.join(d, "bench_counter_collection.csv"))):
+                if r["Counter_Name"] == counter:
+                    a = acc[short(r["Kernel_Name"])]
+                    a[0] += float(r["Counter_Value"])
+                    a[1] += 1
+            return acc
+        f, w = agg(sys.argv[3], "FETCH_SIZE"), agg(sys.argv[4], "WRITE_SIZE")
+        busy, gui = agg(sys.argv[5], "SQ_VALU_MFMA_BUSY_CYCLES"), agg(sys.argv[5], "GRBM_GUI_ACTIVE")
+        out += ["", "## PMC passes (separate runs, --steps 1 --warmup 1; averages per launch)", "",
+                "FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; FETCH_SIZE is NOT doubled here "
+                "(MI355X_MICROARCH.md: it under-counts wide 16 B/lane streaming reads by 2x; uncalibrated for the "
+                "dword halo loads of modconv).  MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs).",
+                "", "| kernel | launches | FETCH MB | WRITE MB | MFMA util |", "|---|---|---|---|---|"]
+        for k in sorted(f, key=lambda k: -f[k][0]):
+            if f[k][0] / f[k][1] < 1000 and k not in busy:
+                continue
+            util = ""
+            if k in busy and gui[k][0] > 0 and busy[k][0] > 0:
+                util = f"{busy[k][0] / (gui[k][0] / 8 * 1024):.3f}"
+            out.append(f"| {k} | {f[k][1]} | {f[k][0] / f[k][1] / 1024:.1f} | "
+                       f"{(w[k][0] / max(1, w[k][1])) / 1024:.1f} | {util} |")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
