@@ -9,8 +9,8 @@ already resident in HBM; noise is drawn fresh per layer like HairFast's callers 
 fill of oracle/synth.py (no checkpoints / network on the box); timing is weight-independent.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel = the fp32-MFMA modulated conv (modconv_mfma<2,2,2,2>, the
-                64^2..256^2 same-resolution layers): algorithmic FLOPs of its launches /
+  roofline      dominant kernel = the fp32-MFMA modulated-conv instantiation with the largest share
+                of the step (per-launch labels come from hf_debug_last_path): algorithmic FLOPs of its launches /
                 their HIP-event durations, measured during the timed steps on the launch
                 stream, against the 157.3 TFLOP/s fp32 MFMA peak.
   cpu_baseline  the CPU oracle (bit-identical restatement of the reference's PyTorch CPU

@@ -25,10 +25,12 @@ SIGNATURES = {
     "hf_modconv_prepare_f32": [_f, _f, _f, _i, _i, _i, _st],
     "hf_modulation_f32": [_f, _f, _ll, _f, _f, _i, _i, _i, _st],
     "hf_demod_f32": [_f, _f, _f, _i, _i, _i, _st],
-    "hf_modconv3x3_f32": [_f, _f, _f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _st],
-    "hf_modconv3x3_up_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _st],
+    "hf_modconv3x3_f32": [_f, _f, _f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _f, _ll, _st],
+    "hf_modconv3x3_up_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _ll, _st],
     "hf_blur_noise_bias_act_f32": [_f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _fl, _fl, _st],
     "hf_torgb_f32": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st],
+    "hf_debug_set_dispatch": [_i, _i],
+    "hf_debug_last_path": [],
 }
 
 
@@ -47,6 +49,8 @@ def bind(cdll):
         fn.restype = ctypes.c_int
     cdll.hf_strerror.argtypes = [ctypes.c_int]
     cdll.hf_strerror.restype = ctypes.c_char_p
+    cdll.hf_modconv_workspace_floats.argtypes = [_i, _i, _i, _i, _i, _i]
+    cdll.hf_modconv_workspace_floats.restype = ctypes.c_longlong
     cdll.hf_abi_version.argtypes = []
     cdll.hf_abi_version.restype = ctypes.c_int
     return cdll

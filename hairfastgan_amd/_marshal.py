@@ -19,21 +19,15 @@ SQRT2 = 2 ** 0.5
 PROFILE = None
 
 
-def modconv_variant(cout, pixels, up):
-    """Name of the kernel instantiation hf_modconv3x3[_up]_f32 dispatches to (mirrors the
-    rule at the bottom of csrc/modconv.hip; used only to label profile records)."""
-    if up:
-        return "modconv_mfma<1,1,1,4,up>" if cout <= 32 else "modconv_mfma<1,1,2,2,up>"
-    if cout <= 32:
-        return "modconv_mfma<1,2,1,4>"
-    if pixels <= 8192:
-        return "modconv_mfma<1,1,2,2>"
-    if cout <= 64:
-        return "modconv_mfma<2,2,1,4>"
-    return "modconv_mfma<2,2,2,2>"
+KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modconv.hip dispatch)
+    211: "modconv_mfma_pipe<2,2,2,4>", 212: "modconv_mfma_pipe<2,2,1,4>", 213: "modconv_mfma_pipe<1,2,1,4>",
+    214: "modconv_mfma_pipe<2,2,2,2>", 215: "modconv_mfma_pipe<1,1,2,2>", 216: "modconv_mfma_pipe<1,4,1,4>",
+    221: "modconv_mfma_pipe<1,2,2,2,up>", 222: "modconv_mfma_pipe<1,2,1,4,up>", 223: "modconv_mfma_pipe<1,1,2,2,up>",
+    224: "modconv_mfma_pipe<1,2,2,4,up>", 225: "modconv_mfma_pipe<1,1,1,4,up>", 300: "modconv_mfma<1,1,2,2> split-K",
+}
 
 
-def _launch_profiled(label, flops, fn):
+def _launch_profiled(lib, flops, fn):
     if PROFILE is None:
         return fn()
     e0 = torch.cuda.Event(enable_timing=True)
@@ -41,7 +35,8 @@ def _launch_profiled(label, flops, fn):
     e0.record()
     r = fn()
     e1.record()
-    PROFILE.append((label, flops, e0, e1))
+    code = lib.hf_debug_last_path()
+    PROFILE.append((KERNEL_NAMES.get(code, f"modconv_mfma (general, code {code})"), flops, e0, e1))
     return r
 
 
@@ -143,6 +138,14 @@ def demod(lib, st, s, wsq):
     return d
 
 
+def _workspace(lib, like, b, cin, cout, h, w, up):
+    """Split-K scratch for the small-plane layers (size dictated by the library)."""
+    n = lib.hf_modconv_workspace_floats(b, cin, cout, h, w, 1 if up else 0)
+    if n <= 0:
+        return None, 0
+    return like.new_empty((n,)), n
+
+
 def modconv3x3(lib, st, x, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=SQRT2):
     x = _c(x)
     b, cin, h, w = x.shape
@@ -150,10 +153,11 @@ def modconv3x3(lib, st, x, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=SQRT
     noise, nbs = _noise_args(noise, b, h * w)
     out = x.new_empty((b, cout, h, w))
     noise_w, bias = _c(noise_w), _c(bias)
+    ws, ws_n = _workspace(lib, x, b, cin, cout, h, w, False)
     code = _launch_profiled(
-        modconv_variant(cout, b * h * w, False), 2.0 * cin * cout * 9 * h * w * b,
+        lib, 2.0 * cin * cout * 9 * h * w * b,
         lambda: lib.hf_modconv3x3_f32(_p(out), _p(x), _p(wt), _p(s), _p(d), _p(noise), _p(noise_w), nbs, _p(bias),
-                                      b, cin, cout, h, w, alpha, scale, st))
+                                      b, cin, cout, h, w, alpha, scale, _p(ws), ws_n, st))
     check(lib, code, "hf_modconv3x3_f32")
     return out
 
@@ -164,9 +168,10 @@ def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha
     b, cin, h, w = x.shape
     cout = wt.shape[2]
     tmp = x.new_empty((b, cout, 2 * h + 1, 2 * w + 1))
+    ws, ws_n = _workspace(lib, x, b, cin, cout, h, w, True)
     code = _launch_profiled(
-        modconv_variant(cout, b * h * w, True), 2.0 * cin * cout * 9 * h * w * b,
-        lambda: lib.hf_modconv3x3_up_f32(_p(tmp), _p(x), _p(wt), _p(s), _p(d), b, cin, cout, h, w, st))
+        lib, 2.0 * cin * cout * 9 * h * w * b,
+        lambda: lib.hf_modconv3x3_up_f32(_p(tmp), _p(x), _p(wt), _p(s), _p(d), b, cin, cout, h, w, _p(ws), ws_n, st))
     check(lib, code, "hf_modconv3x3_up_f32")
     noise, nbs = _noise_args(noise, b, 4 * h * w)
     out = x.new_empty((b, cout, 2 * h, 2 * w))

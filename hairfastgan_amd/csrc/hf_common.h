@@ -13,6 +13,18 @@
 #define HF_DYN_LDS extern __shared__ __attribute__((aligned(16))) unsigned char hf_dyn_lds[]
 #endif
 
+// Async 16-byte-per-lane global -> LDS copy (global_load_lds_dwordx4).  The LDS
+// destination is wave-uniform base + lane*16 (the base is taken from the first
+// active lane); the global source is per lane.  Completion is tracked by vmcnt:
+// hipcc drains it before the next __syncthreads().
+#ifndef HF_GLDS16_DEFINED
+#define HF_GLDS16_DEFINED
+__device__ __forceinline__ void hf_glds16(const float *gsrc_lane, float *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+#endif
+
 static inline int hf_launch_status() {
   return hipGetLastError() == hipSuccess ? HF_OK : HF_E_LAUNCH;
 }

@@ -35,6 +35,9 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct __attribute__((packed, aligned(4))) f32x2u {  // 8-byte value with 4-byte alignment
+  float x, y;
+};
 
 constexpr int KC = 8;            // input channels per LDS stage (4 MFMA k-steps)
 constexpr int kThreads = 256;    // 4 waves
@@ -58,8 +61,130 @@ struct ConvParams {
   float alpha, scale;
   int n_geom;
   int xs_max;                  // LDS floats reserved per staged channel
+  int splits;                  // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps); 1 = off
+  int chunks_per_split;
+  float *partial;              // splits > 1: raw accumulators go to partial[z][b][co][oh][ow]
   TileGeom g[3];
 };
+
+
+// One K chunk: 9 taps x KC/2 k-steps of v_mfma_f32_32x32x2_f32 per (co tile, pixel group).
+// a_base: &wl[lh][wave_co + li] (A operand: 32 consecutive co, lanes 32-63 the next ci);
+// b_base: &xl[lh * xstride]      (B operand: the lane's pixel, shifted per tap).
+struct NoSideWork {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// `side(step)` is called once per step (step is a compile-time constant after unrolling)
+// between the operand prefetch and the step's MFMAs: the pipelined kernel uses it to
+// spread its staging instructions (weight DMA, halo loads, LDS writes) over the chunk, so
+// that they issue under matrix-pipe time instead of ahead of the first MFMA.
+template <int CT_TILES, int PG, int CT, bool UP, class Side, int NPH = (UP ? 4 : 1)>
+__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NPH][CT_TILES][PG], const float *a_base,
+                                           const float *b_base, int xstride, const int (&pixoff)[PG], int wp,
+                                           Side &&side) {
+  // 36 steps = 9 taps x KC/2 k-steps, software pipelined: the A/B fragments of step
+  // n+1 are read from LDS before the MFMAs of step n issue, so the ~100-cycle
+  // ds_read latency sits under 64*CT_TILES*PG cycles of matrix-pipe work.
+  constexpr int NSTEP = 9 * (KC / 2);
+  float a[2][CT_TILES], bq[2][PG];
+  auto fetch = [&](int step, float (&av)[CT_TILES], float (&bv)[PG]) {
+    const int tap = step / (KC / 2), kk = step % (KC / 2);
+    const int ky = tap / 3, kx = tap % 3;
+    // LDS offset of the tap's source pixel relative to pixoff.  UP: output phase
+    // (pr,pc) = (ky&1, kx&1) reads x[Y - (ky==2), X - (kx==2)]; the halo tile starts at (-1,-1).
+    const int toff = UP ? ((ky == 2 ? 0 : 1) * wp + (kx == 2 ? 0 : 1)) : (ky * wp + kx);
+#pragma unroll
+    for (int ct = 0; ct < CT_TILES; ++ct) av[ct] = a_base[(tap * KC + 2 * kk) * CT + ct * 32];
+#pragma unroll
+    for (int g = 0; g < PG; ++g) bv[g] = b_base[2 * kk * xstride + pixoff[g] + toff];
+  };
+  fetch(0, a[0], bq[0]);
+#pragma unroll
+  for (int step = 0; step < NSTEP; ++step) {
+    const int cur = step & 1;
+    if (step + 1 < NSTEP) fetch(step + 1, a[cur ^ 1], bq[cur ^ 1]);
+    side(step);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's MFMAs
+    const int tap = step / (KC / 2);
+    const int ph = UP ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) : 0;
+#pragma unroll
+    for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+      for (int g = 0; g < PG; ++g)
+        acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][ct], bq[cur][g], acc[ph][ct][g], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Epilogue.  MFMA D layout: row (= co) = (r&3) + 8*(r>>2) + 4*(lane>>5), col (= pixel) = lane&31.
+// Per pixel group the 16*CT_TILES demodulation / bias values of the lane's output
+// channels are fetched with independent loads up front (no load->wait->store chains).
+template <int CT_TILES, int PG, bool UP, int NPH = (UP ? 4 : 1)>
+__device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &G,
+                                           f32x16 (&acc)[NPH][CT_TILES][PG], int co_wave, int wave_pg, int li,
+                                           int lh, int ty0, int tx0, int b0) {
+  const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
+  const long long oplane = (long long)P.out_h * P.out_w;
+  const bool partial = P.splits > 1;  // split-K: raw sums, epilogue runs in splitk_reduce
+  const float nw = (!UP && !partial && P.noise) ? P.noise_w[0] : 0.0f;
+#pragma unroll
+  for (int g = 0; g < PG; ++g) {
+    const int p = (wave_pg + g) * 32 + li;
+    const int px = p & (tw - 1);
+    const int py = (p >> G.lg_tw) & (th - 1);
+    const int im = p >> (G.lg_tw + G.lg_th);
+    const int Y = ty0 + py, X = tx0 + px, b = b0 + im;
+    const bool pv = (Y < G.y0 + G.dh) && (X < G.x0 + G.dw) && (b < P.batch);
+    if (!pv) continue;
+    float dmv[CT_TILES][16], bsv[CT_TILES][16];
+#pragma unroll
+    for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int cc = min(co, P.cout - 1);
+        dmv[ct][r] = (P.d && !partial) ? P.d[(long long)b * P.cout + cc] : 1.0f;
+        bsv[ct][r] = (!UP && !partial && P.bias) ? P.bias[cc] : 0.0f;
+      }
+    float nz = 0.0f;
+    if (!UP && !partial && P.noise) nz = nw * P.noise[(long long)b * P.noise_bstride + (long long)Y * P.w + X];
+    float *obase = partial ? P.partial + (long long)blockIdx.z * P.batch * P.cout * oplane : P.out;
+#pragma unroll
+    for (int ct = 0; ct < CT_TILES; ++ct) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co >= P.cout) continue;
+        float *ob = obase + ((long long)b * P.cout + co) * oplane;
+        const float dm = dmv[ct][r];
+        if (UP) {
+          // phases (pr,0) and (pr,1) are neighbouring columns: one 8-byte store per row
+          // (rows of the (2h+1)x(2w+1) plane are only 4-byte aligned: unaligned-dword store)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const int ro = 2 * Y + pr, cc = 2 * X;
+            if (ro >= P.out_h) continue;
+            float *q = ob + (long long)ro * P.out_w + cc;
+            const float v0 = acc[2 * pr][ct][g][r] * dm, v1 = acc[2 * pr + 1][ct][g][r] * dm;
+            if (cc + 1 < P.out_w) {
+              f32x2u pair;
+              pair.x = v0;
+              pair.y = v1;
+              *reinterpret_cast<f32x2u *>(q) = pair;
+            } else {
+              q[0] = v0;
+            }
+          }
+        } else {
+          float v = acc[0][ct][g][r] * dm + nz;
+          if (!partial && P.bias) v = hf_lrelu(v + bsv[ct][r], P.alpha, P.scale);
+          ob[(long long)Y * P.out_w + X] = v;
+        }
+      }
+    }
+  }
+}
 
 // CT_TILES x PG 32x32 MFMA tiles per wave; WAVES_CO x WAVES_PX = 4 waves.
 template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP>
@@ -148,7 +273,9 @@ __global__ __launch_bounds__(kThreads) void modconv_mfma(const ConvParams P) {
   const float *a_base = wl + lh * CT + wave_co + li;
   const float *b_base = xl + lh * P.xs_max;
 
-  for (int ci0 = 0; ci0 < P.cin; ci0 += KC) {
+  const int ci_begin = (P.splits > 1) ? (int)blockIdx.z * P.chunks_per_split * KC : 0;
+  const int ci_end = (P.splits > 1) ? min(P.cin, ci_begin + P.chunks_per_split * KC) : P.cin;
+  for (int ci0 = ci_begin; ci0 < ci_end; ci0 += KC) {
     __syncthreads();  // previous chunk fully consumed
 
     // ---- stage weights: wl[tap][kc][c] = wt[tap][ci0+kc][co0+c] ---------------
@@ -196,65 +323,176 @@ __global__ __launch_bounds__(kThreads) void modconv_mfma(const ConvParams P) {
     }
     __syncthreads();
 
-    // ---- MFMA over the chunk: 9 taps x KC/2 k-steps -----------------------------
+    mfma_chunk<CT_TILES, PG, CT, UP>(acc, a_base, b_base, P.xs_max, pixoff, wp, NoSideWork());
+  }
+
+  store_tile<CT_TILES, PG, UP>(P, G, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+}
+
+
+// ------------------------------------------------------------------------------
+// Pipelined variant for the large layers (the >95 % of the FLOPs).
+//
+// Preconditions (checked on the host): cin % KC == 0, cout % CT == 0, one tile
+// family whose tiles hold a single image (lg_nb == 0), xs <= XEP * NT.
+// Double-buffered LDS: while the waves run the MFMAs of chunk c out of buffer
+// c&1, the weights of chunk c+1 stream straight into the other buffer with
+// global_load_lds_dwordx4 (1 KiB per wave instruction, no VGPRs) and the halo
+// tile of chunk c+1 is prefetched into registers; it is multiplied by the
+// (block-uniform) modulation s[b,ci] and written to LDS after the MFMAs, then one
+// barrier per chunk.  Global latency is hidden behind 9*KC/2*CT_TILES*PG MFMAs.
+// ------------------------------------------------------------------------------
+// ABLATE (timing experiments only, results are wrong when != 0): 1 = no staging traffic
+// inside the loop (barriers kept), 2 = no staging and no barriers.
+template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int ABLATE = 0>
+__global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void modconv_mfma_pipe(const ConvParams P) {
+  constexpr int NW = WAVES_CO * WAVES_PX;
+  constexpr int NT = 64 * NW;
+  constexpr int CT = 32 * CT_TILES * WAVES_CO;
+  constexpr int PT = 32 * PG * WAVES_PX;
+  constexpr int NPH = UP ? 4 : 1;
+  constexpr int HALO = UP ? 1 : 2;
+  constexpr int XEP = ((PT / 32 + HALO) * (32 + HALO) + NT - 1) / NT;  // halo elements per thread per ci
+  constexpr int WCHUNK = 9 * KC * CT;                                   // floats of one weight stage
+  constexpr int NDMA = WCHUNK / 256;                                    // 1 KiB wave-instructions per stage
+  static_assert(WCHUNK % 256 == 0, "weight stage must be a whole number of 1 KiB DMA pieces");
+
+  HF_DYN_LDS;
+  float *wl0 = reinterpret_cast<float *>(hf_dyn_lds);  // [2][9][KC][CT]
+  float *xl0 = wl0 + 2 * WCHUNK;                        // [2][KC][xs_max]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int wave_co = (wave / WAVES_PX) * (32 * CT_TILES);
+  const int wave_pg = (wave % WAVES_PX) * PG;
+  const int co0 = blockIdx.y * CT;
+
+  int gi = 0;  // tile family (uniform): interior, or the rim row / column of the transposed conv
+  if (P.n_geom > 1 && (int)blockIdx.x >= P.g[1].first_block) gi = 1;
+  if (P.n_geom > 2 && (int)blockIdx.x >= P.g[2].first_block) gi = 2;
+  const TileGeom G = P.g[gi];
+  int t = blockIdx.x - G.first_block;
+  const int tx = t % G.tiles_x;
+  t /= G.tiles_x;
+  const int ty = t % G.tiles_y;
+  const int b0 = t / G.tiles_y;  // one image per tile
+  const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
+  const int wp = tw + HALO, hp = th + HALO;
+  const int xs = hp * wp;
+  const int ty0 = G.y0 + ty * th;
+  const int tx0 = G.x0 + tx * tw;
+  const long long plane = (long long)P.h * P.w;
+  const float *xb = P.x + (long long)b0 * P.cin * plane;
+  const float *sb = P.s ? P.s + (long long)b0 * P.cin : nullptr;
+
+  int e_ofs[XEP];  // offset of the thread's halo elements inside a channel plane, -1 = zero
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap % 3;
-      // LDS offset of the tap's source pixel relative to pixoff
-      const int toff = UP ? ((ky == 2 ? 0 : 1) * wp + (kx == 2 ? 0 : 1)) : (ky * wp + kx);
-      const int ph = UP ? ((ky & 1) * 2 + (kx & 1)) : 0;
-#pragma unroll
-      for (int kk = 0; kk < KC / 2; ++kk) {
-        float a[CT_TILES], bq[PG];
-#pragma unroll
-        for (int ct = 0; ct < CT_TILES; ++ct) a[ct] = a_base[(tap * KC + 2 * kk) * CT + ct * 32];
-#pragma unroll
-        for (int g = 0; g < PG; ++g) bq[g] = b_base[2 * kk * P.xs_max + pixoff[g] + toff];
-#pragma unroll
-        for (int ct = 0; ct < CT_TILES; ++ct)
-#pragma unroll
-          for (int g = 0; g < PG; ++g)
-            acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct], bq[g], acc[ph][ct][g], 0, 0, 0);
-      }
+  for (int e = 0; e < XEP; ++e) {
+    const int idx = tid + e * NT;
+    e_ofs[e] = -1;
+    if (idx < xs) {
+      const int hy = idx / wp, hx = idx - hy * wp;
+      const int ys = ty0 + hy - 1, xc = tx0 + hx - 1;
+      if (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) e_ofs[e] = ys * P.w + xc;
     }
   }
 
-  // ---- epilogue: D[row = co, col = pixel]; row = (r&3) + 8*(r>>2) + 4*lh, col = li ----
-  const long long oplane = (long long)P.out_h * P.out_w;
-  const float nw = (!UP && P.noise) ? P.noise_w[0] : 0.0f;
+  int pixoff[PG];
 #pragma unroll
   for (int g = 0; g < PG; ++g) {
     const int p = (wave_pg + g) * 32 + li;
-    const int px = p & (tw - 1);
-    const int py = (p >> G.lg_tw) & (th - 1);
-    const int im = p >> (G.lg_tw + G.lg_th);
-    const int Y = ty0 + py, X = tx0 + px, b = b0 + im;
-    const bool pv = (Y < G.y0 + G.dh) && (X < G.x0 + G.dw) && (b < P.batch);
-    if (!pv) continue;
-    float nz = 0.0f;
-    if (!UP && P.noise) nz = nw * P.noise[(long long)b * P.noise_bstride + (long long)Y * P.w + X];
-#pragma unroll
-    for (int ct = 0; ct < CT_TILES; ++ct) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wave_co + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co >= P.cout) continue;
-        const float dm = P.d ? P.d[(long long)b * P.cout + co] : 1.0f;
-        float *ob = P.out + ((long long)b * P.cout + co) * oplane;
-        if (UP) {
-#pragma unroll
-          for (int ph = 0; ph < 4; ++ph) {
-            const int ro = 2 * Y + (ph >> 1), cc = 2 * X + (ph & 1);
-            if (ro < P.out_h && cc < P.out_w) ob[(long long)ro * P.out_w + cc] = acc[ph][ct][g][r] * dm;
-          }
-        } else {
-          float v = acc[0][ct][g][r] * dm + nz;
-          if (P.bias) v = hf_lrelu(v + P.bias[co], P.alpha, P.scale);
-          ob[(long long)Y * P.out_w + X] = v;
-        }
-      }
-    }
+    pixoff[g] = ((p >> G.lg_tw) & (th - 1)) * wp + (p & (tw - 1));
   }
+
+  f32x16 acc[NPH][CT_TILES][PG];
+#pragma unroll
+  for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+    for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+      for (int g = 0; g < PG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ph][ct][g][r] = 0.0f;
+
+  // Staging work items of one chunk (per thread): ND weight-DMA pieces, NL halo loads
+  // and NL LDS writes.  Piece j of the DMA covers floats [256 j, 256 j + 256) of the stage
+  // image [tap][kc][c]; a lane moves 4 floats of row (tap,kc) = f / CT at column f % CT.
+  constexpr int ND = (NDMA + NW - 1) / NW;
+  constexpr int NL = KC * XEP;
+  auto dma_piece = [&](int i, int ci0, float *wl) {  // i-th piece of this wave
+    const int j = wave + i * NW;
+    if (j < NDMA) {
+      const int f = j * 256 + lane * 4;
+      const int row = f / CT, col = f % CT;
+      const int tap = row / KC, kc = row % KC;
+      hf_glds16(P.wt + ((long long)tap * P.cin + ci0 + kc) * P.cout + co0 + col, wl + j * 256);
+    }
+  };
+  float xr[KC][XEP];
+  float sr[KC];  // modulation of the prefetched channels (fetched with the halo, not at write time)
+  auto load_piece = [&](int i, int ci0) {
+    const int kc = i / XEP, e = i % XEP;
+    xr[kc][e] = (e_ofs[e] >= 0) ? xb[(long long)(ci0 + kc) * plane + e_ofs[e]] : 0.0f;
+    if (e == 0) sr[kc] = sb ? sb[ci0 + kc] : 1.0f;
+  };
+  auto write_piece = [&](int i, int /*ci0*/, float *xl) {
+    const int kc = i / XEP, e = i % XEP;
+    const int idx = tid + e * NT;
+    if (idx < xs) xl[kc * P.xs_max + idx] = xr[kc][e] * sr[kc];
+  };
+
+  // prologue: chunk 0 into buffer 0
+#pragma unroll
+  for (int i = 0; i < ND; ++i) dma_piece(i, 0, wl0);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) load_piece(i, 0);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) write_piece(i, 0, xl0);
+  __syncthreads();
+
+  // Slots of the 36-step chunk: DMA pieces first, halo loads next, LDS writes of the
+  // prefetched halo last (>= 12 steps = ~6 k matrix-pipe cycles after the loads issued).
+  constexpr int NSTEP = 9 * (KC / 2);
+  constexpr int DPS = (ND + 7) / 8;                 // DMA pieces per step
+  constexpr int D_STEPS = (ND + DPS - 1) / DPS;
+  constexpr int LPS = (NL + 11) / 12;               // loads (and writes) per step
+  constexpr int L_STEPS = (NL + LPS - 1) / LPS;
+  constexpr int W_FIRST = NSTEP - L_STEPS;
+  static_assert(D_STEPS + L_STEPS <= W_FIRST, "staging schedule does not fit the chunk");
+
+  const int nchunks = P.cin / KC;
+  for (int c = 0; c < nchunks; ++c) {
+    const int cur = c & 1;
+    const bool more = (c + 1 < nchunks) && ABLATE == 0;
+    const int ci_next = (c + 1) * KC;
+    float *wl_next = wl0 + (cur ^ 1) * WCHUNK;
+    float *xl_next = xl0 + (cur ^ 1) * KC * P.xs_max;
+    auto side = [&](int step) {
+      if (!more) return;
+      if (step < D_STEPS) {
+#pragma unroll
+        for (int q = 0; q < DPS; ++q)
+          if (step * DPS + q < ND) dma_piece(step * DPS + q, ci_next, wl_next);
+      } else if (step < D_STEPS + L_STEPS) {
+#pragma unroll
+        for (int q = 0; q < LPS; ++q)
+          if ((step - D_STEPS) * LPS + q < NL) load_piece((step - D_STEPS) * LPS + q, ci_next);
+      } else if (step >= W_FIRST) {
+#pragma unroll
+        for (int q = 0; q < LPS; ++q)
+          if ((step - W_FIRST) * LPS + q < NL) write_piece((step - W_FIRST) * LPS + q, ci_next, xl_next);
+      }
+    };
+    const float *a_base = wl0 + cur * WCHUNK + lh * CT + wave_co + li;
+    const float *b_base = xl0 + (cur * KC + lh) * P.xs_max;
+    mfma_chunk<CT_TILES, PG, CT, UP>(acc, a_base, b_base, P.xs_max, pixoff, wp, side);
+    if (ABLATE < 2) __syncthreads();  // also drains the weight DMA (vmcnt) before anyone reads the other buffer
+  }
+
+  store_tile<CT_TILES, PG, UP>(P, G, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
 // ------------------------------------------------------------------------------
@@ -271,7 +509,8 @@ inline int pow2_ceil(int v) { return (v & (v - 1)) ? (pow2_floor(v) << 1) : v; }
 
 // Tiles of `pt` pixels over a dh x dw domain (per image) of `batch` images.
 // Prefers full 32-pixel rows; small planes put several images in one tile.
-inline TileGeom make_geom(int y0, int x0, int dh, int dw, int batch, int pt, int first_block) {
+inline TileGeom make_geom(int y0, int x0, int dh, int dw, int batch, int pt, int first_block,
+                          bool one_image = false) {
   TileGeom g;
   g.y0 = y0; g.x0 = x0; g.dh = dh; g.dw = dw;
   int tw = pow2_ceil(dw);
@@ -279,6 +518,11 @@ inline TileGeom make_geom(int y0, int x0, int dh, int dw, int batch, int pt, int
   if (tw > pt) tw = pt;
   int th = pow2_ceil(dh);
   if (th > pt / tw) th = pt / tw;
+  if (one_image) {  // rim families of the pipelined kernel: stretch the tile instead of batching
+    // images; two rows (columns) so that the halo tile stays within the staging budget
+    if (dh == 1) { th = 2; tw = pt / 2; }
+    else { tw = 2; th = pt / 2; }
+  }
   int nb = pt / (tw * th);
   if (nb > pow2_ceil(batch)) nb = pow2_ceil(batch);  // never stage images that do not exist
   g.lg_tw = ilog2(tw); g.lg_th = ilog2(th); g.lg_nb = ilog2(nb);
@@ -321,18 +565,114 @@ int launch_modconv(ConvParams &P, hipStream_t st) {
     if (((long long)P.cin << P.g[i].lg_nb) * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
   P.xs_max = (xs_max + 3) & ~3;
   const size_t lds = (size_t)(9 * KC * CT + KC * P.xs_max) * sizeof(float);
-  dim3 grid(nblocks, hf_cdiv(P.cout, CT));
+  if (P.splits < 1) P.splits = 1;
+  dim3 grid(nblocks, hf_cdiv(P.cout, CT), P.splits);
   if (grid.y > 65535) return HF_E_INVALID;
   hipLaunchKernelGGL((modconv_mfma<CT_TILES, PG, WAVES_CO, WAVES_PX, UP>), grid, dim3(kThreads), lds, st, P);
   return hf_launch_status();
 }
 
+
+// Pipelined launch of the interior tile family; returns HF_E_INVALID if the shape
+// does not meet the kernel's preconditions (caller then uses the general kernel).
+template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int ABLATE = 0>
+int launch_modconv_pipe(ConvParams &P, hipStream_t st) {
+  constexpr int NT = 64 * WAVES_CO * WAVES_PX;
+  constexpr int CT = 32 * CT_TILES * WAVES_CO;
+  constexpr int PT = 32 * PG * WAVES_PX;
+  constexpr int HALO = UP ? 1 : 2;
+  constexpr int XEP = ((PT / 32 + HALO) * (32 + HALO) + NT - 1) / NT;
+  if (P.cin % KC || P.cout % CT || (P.cout & 3)) return HF_E_INVALID;
+  if ((((size_t)P.wt) & 15) != 0) return HF_E_INVALID;
+  P.splits = 1;
+  P.n_geom = 1;
+  P.g[0] = make_geom(0, 0, P.h, P.w, P.batch, PT, 0);
+  int nblocks = geom_blocks(P.g[0]);
+  if (UP) {  // + the Y = h row (incl. corner) and the X = w column of the (h+1)x(w+1) phase domain
+    P.n_geom = 3;
+    P.g[1] = make_geom(P.h, 0, 1, P.w + 1, P.batch, PT, nblocks, true);
+    nblocks += geom_blocks(P.g[1]);
+    P.g[2] = make_geom(0, P.w, P.h, 1, P.batch, PT, nblocks, true);
+    nblocks += geom_blocks(P.g[2]);
+  }
+  int xs = 0;
+  for (int i = 0; i < P.n_geom; ++i) {
+    if (P.g[i].lg_nb != 0) return HF_E_INVALID;  // the pipelined kernel wants one image per tile
+    xs = max(xs, geom_xs(P.g[i], HALO));
+  }
+  if (xs > XEP * NT) return HF_E_INVALID;
+  if ((long long)P.cin * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
+  P.xs_max = (xs + 3) & ~3;
+  const size_t lds = (size_t)2 * (9 * KC * CT + KC * P.xs_max) * sizeof(float);
+  if (lds > 160 * 1024) return HF_E_INVALID;
+  dim3 grid(nblocks, P.cout / CT);
+  if (grid.y > 65535) return HF_E_INVALID;
+  hipLaunchKernelGGL((modconv_mfma_pipe<CT_TILES, PG, WAVES_CO, WAVES_PX, UP, ABLATE>), grid, dim3(NT), lds, st, P);
+  return hf_launch_status();
+}
+
+// Split-K second pass: out = epilogue(d * sum_z partial[z]) - deterministic (fixed z order).
+__global__ __launch_bounds__(256) void splitk_reduce(const ConvParams P, long long slab, int with_epilogue) {
+  const long long oplane = (long long)P.out_h * P.out_w;
+  const float nw = (with_epilogue && P.noise) ? P.noise_w[0] : 0.0f;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slab; i += stride) {
+    float v = 0.0f;
+    for (int z = 0; z < P.splits; ++z) v += P.partial[(long long)z * slab + i];
+    const long long pl = i / oplane;
+    const int co = (int)(pl % P.cout);
+    const long long b = pl / P.cout;
+    if (P.d) v *= P.d[b * P.cout + co];
+    if (with_epilogue) {
+      if (P.noise) v = fmaf(nw, P.noise[b * P.noise_bstride + (i - pl * oplane)], v);
+      if (P.bias) v = hf_lrelu(v + P.bias[co], P.alpha, P.scale);
+    }
+    P.out[i] = v;
+  }
+}
+
+// Split-K plan for the small-plane layers: few (co tile, pixel tile) pairs but up to
+// 64 K-chunks.  Pure function of the shape so that callers can size the workspace.
+inline int splitk_plan(int batch, int cin, int cout, int h, int w, bool up) {
+  const int PT = 64, CT = 64;  // the small-plane configuration <1,1,2,2>
+  const long long per_img = ((long long)h * w + PT - 1) / PT;
+  const long long base = batch * per_img * ((cout + CT - 1) / CT);
+  if (base >= 256) return 1;  // the 64x64 tiling already fills the chip
+  (void)up;
+  const int nchunks = (cin + KC - 1) / KC;
+  int s = (int)((512 + base - 1) / base);
+  if (s > nchunks) s = nchunks;
+  if (s > 64) s = 64;
+  return s < 2 ? 1 : s;
+}
+
+int launch_splitk_reduce(ConvParams &P, bool with_epilogue, hipStream_t st) {
+  const long long slab = (long long)P.batch * P.cout * P.out_h * P.out_w;
+  long long g = (slab + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(splitk_reduce, dim3((int)g), dim3(256), 0, st, P, slab, with_epilogue ? 1 : 0);
+  return hf_launch_status();
+}
+
+// Tuning hook (hf_debug_set_dispatch): 0 = built-in heuristics.
+int g_force_same = 0, g_force_up = 0;
+int g_last_cfg = 0;   // tile configuration id of the last modulated-conv call (see the dispatch switches)
+int g_last_path = 0;  // 1 = general kernel, 2 = pipelined kernel, 3 = split-K (general kernel + reduce)
+
 }  // namespace
+
+extern "C" long long hf_modconv_workspace_floats(int batch, int cin, int cout, int h, int w, int upsample) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+  const int s = splitk_plan(batch, cin, cout, h, w, upsample != 0);
+  if (s <= 1) return 0;
+  const long long oh = upsample ? 2 * h + 1 : h, ow = upsample ? 2 * w + 1 : w;
+  return (long long)s * batch * cout * oh * ow;
+}
 
 extern "C" int hf_modconv3x3_f32(float *out, const float *x, const float *wt, const float *s, const float *d,
                                  const float *noise, const float *noise_w, long long noise_bstride,
                                  const float *bias, int batch, int cin, int cout, int h, int w, float alpha,
-                                 float scale, void *stream) {
+                                 float scale, float *workspace, long long workspace_floats, void *stream) {
   if (!out || !x || !wt || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (noise && !noise_w))
     return HF_E_INVALID;
   ConvParams P{};
@@ -342,22 +682,113 @@ extern "C" int hf_modconv3x3_f32(float *out, const float *x, const float *wt, co
   P.alpha = alpha; P.scale = scale;
   hipStream_t st = (hipStream_t)stream;
   const long long pixels = (long long)batch * h * w;
-  if (cout <= 32) return launch_modconv<1, 2, 1, 4, false>(P, st);       // 32 co x 256 px
-  if (pixels <= 8192 || cout <= 64) {
-    if (pixels <= 8192) return launch_modconv<1, 1, 2, 2, false>(P, st); // 64 co x 64 px (small planes)
-    return launch_modconv<2, 2, 1, 4, false>(P, st);                      // 64 co x 256 px
+  {  // split-K for the small planes (deterministic two-pass reduction through `workspace`)
+    const int sk = (g_force_same == 0) ? splitk_plan(batch, cin, cout, h, w, false) : 1;
+    if (sk > 1) {
+      if (!workspace || workspace_floats < (long long)sk * batch * cout * h * w) return HF_E_WORKSPACE;
+      const int nchunks = (cin + KC - 1) / KC;
+      P.splits = sk;
+      P.chunks_per_split = (nchunks + sk - 1) / sk;
+      P.partial = workspace;
+      int rc = launch_modconv<1, 1, 2, 2, false>(P, st);
+      if (rc != HF_OK) return rc;
+      g_last_path = 3;
+      return launch_splitk_reduce(P, true, st);
+    }
   }
+  int cfg = g_force_same;
+  if (cfg == 0) {
+    // Built-in heuristics (tools/bench_layers.py sweeps, MI355X): the largest tile that
+    // still yields >= ~1.5-2 blocks per CU; 256 CUs.
+    const long long per_img256 = ((long long)h * w + 255) / 256, per_img64 = ((long long)h * w + 63) / 64;
+    const long long nb11 = batch * per_img256 * (cout / 128), nb13 = batch * per_img256 * (cout / 32);
+    const long long nb15 = batch * per_img64 * (cout / 64);
+    if (cout % 128 == 0 && nb11 >= 384) cfg = 11;
+    else if (cout % 32 == 0 && nb13 >= 512) cfg = 13;
+    else if (cout % 64 == 0 && nb15 >= 256) cfg = 15;
+    else if (cout % 32 == 0) cfg = 13;
+    else cfg = 2;
+  }
+  g_last_cfg = cfg;
+  int rc = HF_E_INVALID;
+  switch (cfg) {  // 1x: pipelined (fall through to the general kernel when the shape does not qualify)
+    case 11: rc = launch_modconv_pipe<2, 2, 2, 4, false>(P, st); break;  // 128 co x 256 px, 8 waves
+    case 12: rc = launch_modconv_pipe<2, 2, 1, 4, false>(P, st); break;  //  64 co x 256 px, 4 waves
+    case 13: rc = launch_modconv_pipe<1, 2, 1, 4, false>(P, st); break;  //  32 co x 256 px, 4 waves
+    case 14: rc = launch_modconv_pipe<2, 2, 2, 2, false>(P, st); break;  // 128 co x 128 px, 4 waves
+    case 15: rc = launch_modconv_pipe<1, 1, 2, 2, false>(P, st); break;  //  64 co x  64 px, 4 waves
+    case 16: rc = launch_modconv_pipe<1, 4, 1, 4, false>(P, st); break;  //  32 co x 512 px, 4 waves
+    case 91: rc = launch_modconv_pipe<2, 2, 2, 4, false, 1>(P, st); break;  // timing ablations of cfg 11
+    case 92: rc = launch_modconv_pipe<2, 2, 2, 4, false, 2>(P, st); break;
+    default: break;
+  }
+  g_last_path = 2;
+  if (rc != HF_E_INVALID) return rc;
+  g_last_path = 1;
+  switch (cfg) {
+    case 1: case 11: case 14: if (cout > 64) return launch_modconv<2, 2, 2, 2, false>(P, st); break;
+    case 2: case 15: return launch_modconv<1, 1, 2, 2, false>(P, st);
+    case 3: case 12: if (cout > 32) return launch_modconv<2, 2, 1, 4, false>(P, st); break;
+    default: break;
+  }
+  if (cout <= 32) return launch_modconv<1, 2, 1, 4, false>(P, st);       // 32 co x 256 px
+  if (pixels <= 8192) return launch_modconv<1, 1, 2, 2, false>(P, st);   // 64 co x 64 px (small planes)
+  if (cout <= 64) return launch_modconv<2, 2, 1, 4, false>(P, st);       // 64 co x 256 px
   return launch_modconv<2, 2, 2, 2, false>(P, st);                        // 128 co x 128 px
 }
 
 extern "C" int hf_modconv3x3_up_f32(float *tmp, const float *x, const float *wt, const float *s,
                                     const float *d, int batch, int cin, int cout, int h, int w,
-                                    void *stream) {
+                                    float *workspace, long long workspace_floats, void *stream) {
   if (!tmp || !x || !wt || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return HF_E_INVALID;
   ConvParams P{};
   P.out = tmp; P.x = x; P.wt = wt; P.s = s; P.d = d;
   P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = 2 * h + 1; P.out_w = 2 * w + 1;
   hipStream_t st = (hipStream_t)stream;
+  {
+    const int sk = (g_force_up == 0) ? splitk_plan(batch, cin, cout, h, w, true) : 1;
+    if (sk > 1) {
+      if (!workspace || workspace_floats < (long long)sk * batch * cout * P.out_h * P.out_w) return HF_E_WORKSPACE;
+      const int nchunks = (cin + KC - 1) / KC;
+      P.splits = sk;
+      P.chunks_per_split = (nchunks + sk - 1) / sk;
+      P.partial = workspace;
+      int rc = launch_modconv<1, 1, 2, 2, true>(P, st);
+      if (rc != HF_OK) return rc;
+      g_last_path = 3;
+      return launch_splitk_reduce(P, false, st);
+    }
+  }
+  int cfg = g_force_up;
+  if (cfg == 0) {
+    const long long per_img256 = ((long long)h * w + 255) / 256;
+    const long long nb24 = batch * per_img256 * (cout / 64);
+    if (cout % 64 == 0 && nb24 >= 256) cfg = 24;
+    else if (cout % 64 == 0) cfg = 23;
+    else if (cout % 32 == 0) cfg = 25;
+    else cfg = 1;
+  }
+  g_last_cfg = cfg;
+  int rc = HF_E_INVALID;
+  switch (cfg) {
+    case 21: rc = launch_modconv_pipe<1, 2, 2, 2, true>(P, st); break;  // 64 co x 128 px x 4 phases, 4 waves
+    case 22: rc = launch_modconv_pipe<1, 2, 1, 4, true>(P, st); break;  // 32 co x 256 px x 4 phases, 4 waves
+    case 23: rc = launch_modconv_pipe<1, 1, 2, 2, true>(P, st); break;  // 64 co x  64 px x 4 phases, 4 waves
+    case 24: rc = launch_modconv_pipe<1, 2, 2, 4, true>(P, st); break;  // 64 co x 256 px x 4 phases, 8 waves
+    case 25: rc = launch_modconv_pipe<1, 1, 1, 4, true>(P, st); break;  // 32 co x 128 px x 4 phases, 4 waves
+    default: break;
+  }
+  g_last_path = 2;
+  if (rc != HF_E_INVALID) return rc;  // interior + rim families in one pipelined launch
+  g_last_path = 1;
   if (cout <= 32) return launch_modconv<1, 1, 1, 4, true>(P, st);  // 32 co x 128 px x 4 phases
   return launch_modconv<1, 1, 2, 2, true>(P, st);                   // 64 co x 64 px x 4 phases
+}
+
+extern "C" int hf_debug_last_path(void) { return g_last_path * 100 + (g_last_path == 3 ? 0 : g_last_cfg); }
+
+extern "C" int hf_debug_set_dispatch(int same_cfg, int up_cfg) {
+  g_force_same = same_cfg;
+  g_force_up = up_cfg;
+  return HF_OK;
 }

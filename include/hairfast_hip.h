@@ -97,11 +97,18 @@ int hf_demod_f32(float *d, const float *s, const float *wsq, int batch, int cin,
  * s, d: from hf_modulation_f32 / hf_demod_f32 (d NULL = no demodulation;
  * s NULL = plain convolution).  noise NULL = no noise term; bias NULL = no
  * bias/activation epilogue (raw conv output, alpha/scale ignored).
+ * workspace: see hf_modconv_workspace_floats.
  */
 int hf_modconv3x3_f32(float *out, const float *x, const float *wt, const float *s, const float *d,
                       const float *noise, const float *noise_w, long long noise_bstride,
                       const float *bias, int batch, int cin, int cout, int h, int w, float alpha,
-                      float scale, void *stream);
+                      float scale, float *workspace, long long workspace_floats, void *stream);
+
+/* Scratch (in floats) the two modulated-conv entry points need for this shape: the
+ * small-plane layers (4x4 .. 16x16) run split-K over the input channels and reduce the
+ * partial sums in a second, deterministic pass.  0 = no workspace needed (workspace
+ * may then be NULL).  Too small a workspace returns HF_E_WORKSPACE. */
+long long hf_modconv_workspace_floats(int batch, int cin, int cout, int h, int w, int upsample);
 
 /* ---------------------------------------------------------------------------
  * Upsampling modulated conv, part 1: per-sample conv_transpose2d(stride 2,
@@ -110,7 +117,8 @@ int hf_modconv3x3_f32(float *out, const float *x, const float *wt, const float *
  * groups=batch).  Part 2 is hf_blur_noise_bias_act_f32 below.
  */
 int hf_modconv3x3_up_f32(float *tmp, const float *x, const float *wt, const float *s, const float *d,
-                         int batch, int cin, int cout, int h, int w, void *stream);
+                         int batch, int cin, int cout, int h, int w, float *workspace,
+                         long long workspace_floats, void *stream);
 
 /* Part 2: 4x4 FIR blur with pad (1,1) (upfirdn2d mode 1) fused with noise +
  * bias + leaky relu: in [planes=batch*channels, in_h, in_w] -> out
@@ -133,6 +141,19 @@ int hf_blur_noise_bias_act_f32(float *out, const float *in, const float *kernel4
 int hf_torgb_f32(float *out, const float *x, const float *wt, const float *s, const float *bias,
                  const float *skip, const float *kernel4x4, int batch, int cin, int h, int w,
                  void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Tuning / debugging hook (no reference counterpart): force the tile
+ * configuration hf_modconv3x3_f32 / hf_modconv3x3_up_f32 dispatch to
+ * (see the switch statements at the bottom of csrc/modconv.hip); 0 restores the
+ * built-in heuristics.  Shapes a forced configuration cannot handle fall back
+ * to the general kernel.  Process-global, not thread-safe: benchmarks only.
+ */
+int hf_debug_set_dispatch(int same_cfg, int up_cfg);
+/* Which kernel the last modulated-conv call used: 100 * family + tile configuration id,
+ * family 1 = general, 2 = pipelined (double-buffered DMA), 3 = split-K (id 0).  Tests use
+ * it to make sure a shape exercises the path it is meant to; bench.py to label launches. */
+int hf_debug_last_path(void);
 
 #ifdef __cplusplus
 }

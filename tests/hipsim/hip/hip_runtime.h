@@ -27,6 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 void syncthreads();
 float shfl_xor(float v, int mask);
 f32x16 mfma32x32x2(float a, float b, f32x16 c);
+void glds16(const float *gsrc_lane, float *lds_wave_base);
 void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t shmem);
 unsigned char *dyn_lds();
 }  // namespace hipsim
@@ -60,6 +61,10 @@ inline float rsqrtf(float v) { return 1.0f / sqrtf(v); }
 template <class T> inline T min(T a, T b) { return a < b ? a : b; }
 template <class T> inline T max(T a, T b) { return a > b ? a : b; }
 
+#define HF_GLDS16_DEFINED
+inline void hf_glds16(const float *gsrc_lane, float *lds_wave_base) { ::hipsim::glds16(gsrc_lane, lds_wave_base); }
+
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) ::hipsim::mfma32x32x2((a), (b), (c))
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \

@@ -16,7 +16,7 @@ unsigned char *dyn_lds() { return g_lds; }
 
 namespace {
 enum State { READY, WAIT_BLOCK, WAIT_WAVE, DONE };
-enum WaveOp { OP_NONE, OP_SHFL_XOR, OP_MFMA };
+enum WaveOp { OP_NONE, OP_SHFL_XOR, OP_MFMA, OP_GLDS };
 
 struct Fiber {
   ucontext_t ctx;
@@ -27,6 +27,8 @@ struct Fiber {
   WaveOp op = OP_NONE;
   float a = 0, b = 0;
   int imm = 0;
+  const float *gsrc = nullptr;
+  float *ldst = nullptr;
   f32x16 c, d;
   float fres = 0;
 };
@@ -58,6 +60,13 @@ void resolve_wave(int w0, int w1) {
       int src = w0 + (((i - w0) ^ g_f[i].imm) & 63);
       g_f[i].fres = (src < w1 && g_f[src].state == WAIT_WAVE) ? g_f[src].a : 0.0f;
     }
+  } else if (op == OP_GLDS) {
+    // LDS destination = base of the first active lane + lane*16 bytes (M0 semantics)
+    float *base = nullptr;
+    for (int i = w0; i < w1 && !base; ++i)
+      if (g_f[i].state == WAIT_WAVE) base = g_f[i].ldst;
+    for (int i = w0; i < w1; ++i)
+      if (g_f[i].state == WAIT_WAVE) memcpy(base + 4 * (i - w0), g_f[i].gsrc, 16);
   } else if (op == OP_MFMA) {
     if (w1 - w0 != 64) { fprintf(stderr, "hipsim: MFMA needs a full wave\n"); abort(); }
     for (int i = w0; i < w1; ++i)
@@ -144,6 +153,12 @@ f32x16 mfma32x32x2(float a, float b, f32x16 c) {
   f.op = OP_MFMA; f.a = a; f.b = b; f.c = c; f.state = WAIT_WAVE;
   yield_to_sched();
   return g_f[g_cur].d;
+}
+
+void glds16(const float *gsrc_lane, float *lds_wave_base) {
+  Fiber &f = g_f[g_cur];
+  f.op = OP_GLDS; f.gsrc = gsrc_lane; f.ldst = lds_wave_base; f.state = WAIT_WAVE;
+  yield_to_sched();
 }
 
 void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t shmem) {

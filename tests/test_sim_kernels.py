@@ -126,3 +126,41 @@ def test_modconv_tile_geometries(simlib):
                 y = M.modconv3x3(simlib, None, x, wt, s, dm, None, None, None)
             assert y.shape == ref.shape
             assert maxdiff(y, ref) < TOL * max(1.0, float(ref.abs().max())), (B, cin, cout, H, W, up)
+
+
+@pytest.mark.parametrize("cfg,shape", [
+    (11, (2, 16, 128, 16, 32)),   # 128 co x 256 px, 8 waves
+    (12, (1, 16, 64, 24, 40)),    # 64 co x 256 px, ragged plane
+    (13, (2, 8, 32, 16, 16)),     # 32 co x 256 px, 16-wide rows
+    (14, (1, 16, 128, 8, 32)),
+    (15, (2, 8, 64, 8, 8)),
+    (16, (1, 8, 32, 32, 32)),
+    (21, (2, 16, 64, 8, 32)),     # up: 64 co x 128 px x 4 phases (+ rim launch)
+    (22, (1, 8, 32, 16, 32)),
+    (23, (1, 8, 64, 6, 40)),
+    (24, (1, 8, 64, 16, 32)),
+    (25, (2, 8, 32, 4, 32)),
+])
+def test_modconv_pipelined_configs(simlib, cfg, shape):
+    """Every instantiation of the double-buffered (global_load_lds + register prefetch) kernel."""
+    B, cin, cout, H, W = shape
+    torch.manual_seed(cfg)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+    wt, wsq = M.prepare_weights(simlib, None, wgt)
+    s = M.modulation(simlib, None, sty, mw, mb)
+    dm = M.demod(simlib, None, s, wsq)
+    up = cfg >= 20
+    ref = O.modulated_conv2d(x, sty, wgt, mw, mb, True, up)
+    try:
+        simlib.hf_debug_set_dispatch(0 if up else cfg, cfg if up else 0)
+        if up:
+            y = M.modconv3x3_up(simlib, None, x, wt, s, dm, O.blur_kernel_1d_to_2d(gain=4.0), None, None, None)
+        else:
+            y = M.modconv3x3(simlib, None, x, wt, s, dm, None, None, None)
+        assert simlib.hf_debug_last_path() == 200 + cfg, "shape fell back from the pipelined kernel"
+    finally:
+        simlib.hf_debug_set_dispatch(0, 0)
+    assert y.shape == ref.shape
+    assert maxdiff(y, ref) < TOL * max(1.0, float(ref.abs().max()))
