@@ -127,6 +127,98 @@ __global__ __launch_bounds__(256) void blur4x4_noise_bias_act(
   }
 }
 
+
+// Vector form for out_w % 4 == 0 (every generator layer): a thread owns 4 consecutive
+// output columns c0..c0+3 and needs input columns c0-1..c0+5 of each row.  It loads
+// columns c0..c0+3 with one unaligned 16-byte load (input rows have odd length 2W+1);
+// the three edge columns come from the neighbouring lanes' registers (wave shuffles),
+// only the first / last lane of a wave touch memory for them.  Two output rows per
+// iteration keep two row loads in flight; one aligned 16-byte store per output row.
+// blockDim = (cq column quads, 256/cq row segments), cq = min(64, out_w/4).
+struct __attribute__((packed, aligned(4))) f32x4u {
+  float x, y, z, w;
+};
+
+__global__ __launch_bounds__(256) void blur4x4_noise_bias_act_vec4(
+    float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ kernel4x4,
+    const float *__restrict__ noise, const float *__restrict__ noise_w, long long noise_bstride,
+    const float *__restrict__ bias, int channels, int in_h, int in_w, float alpha, float scale,
+    int rows_per_thread) {
+  const int out_h = in_h - 1, out_w = in_w - 1;
+  const int c0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int oy0 = (blockIdx.y * blockDim.y + threadIdx.y) * rows_per_thread;
+  const int plane = blockIdx.z;
+  // no early return: every lane takes part in the shuffles; inactive ones just do not store
+  const bool active = c0 < out_w && oy0 < out_h;
+  const int lane = (threadIdx.y * blockDim.x + threadIdx.x) & 63;
+  // neighbours within the wave AND within the same row segment hold columns c0-4.. / c0+4..
+  const bool nb_left = lane > 0 && threadIdx.x > 0;
+  const bool nb_right = lane < 63 && threadIdx.x + 1 < blockDim.x && c0 + 4 < out_w;  // neighbour must be active
+
+  float kf[4][4];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) kf[ky][kx] = kernel4x4[(3 - ky) * 4 + (3 - kx)];
+
+  const float *src = in + (long long)plane * in_h * in_w;
+  float *dst = out + (long long)plane * out_h * out_w;
+  const int c = plane % channels;
+  const int b = plane / channels;
+  const float bc = bias ? bias[c] : 0.0f;
+  const float nw = noise ? noise_w[0] : 0.0f;
+  const float *nz = noise ? noise + (long long)b * noise_bstride : nullptr;
+
+  float win[6][7];  // win[r][j]: input row oy-1+r, column c0-1+j
+  auto load_row = [&](int iy, float (&row)[7]) {
+    const bool rv = active && iy >= 0 && iy < in_h;
+    const float *p = src + (long long)iy * in_w + c0;
+    f32x4u m = {0.f, 0.f, 0.f, 0.f};
+    if (rv) m = *reinterpret_cast<const f32x4u *>(p);
+    row[1] = m.x; row[2] = m.y; row[3] = m.z; row[4] = m.w;
+    const float l = __shfl_up(m.w, 1, 64), r0 = __shfl_down(m.x, 1, 64), r1 = __shfl_down(m.y, 1, 64);
+    row[0] = nb_left ? l : ((rv && c0 > 0) ? p[-1] : 0.0f);
+    row[5] = nb_right ? r0 : ((rv && c0 + 4 < in_w) ? p[4] : 0.0f);
+    row[6] = nb_right ? r1 : ((rv && c0 + 5 < in_w) ? p[5] : 0.0f);
+  };
+#pragma unroll
+  for (int r = 0; r < 4; ++r) load_row(oy0 - 1 + r, win[r]);
+
+  const int oy_end = min(oy0 + rows_per_thread, out_h);
+  for (int oy = oy0; oy < oy0 + rows_per_thread; oy += 2) {  // uniform trip count (shuffles inside)
+    load_row(oy + 3, win[4]);
+    load_row(oy + 4, win[5]);
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = fmaf(win[q2 + r][q + j], kf[r][j], acc[q]);
+      const int oyy = oy + q2;
+      if (active && oyy < oy_end) {
+        if (nz) {
+          const float4 z = *reinterpret_cast<const float4 *>(nz + (long long)oyy * out_w + c0);
+          acc[0] = fmaf(nw, z.x, acc[0]); acc[1] = fmaf(nw, z.y, acc[1]);
+          acc[2] = fmaf(nw, z.z, acc[2]); acc[3] = fmaf(nw, z.w, acc[3]);
+        }
+        if (bias) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = hf_lrelu(acc[q] + bc, alpha, scale);
+        }
+        *reinterpret_cast<float4 *>(dst + (long long)oyy * out_w + c0) =
+            make_float4(acc[0], acc[1], acc[2], acc[3]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) win[r][j] = win[r + 2][j];
+  }
+}
+
 }  // namespace
 
 extern "C" int hf_upfirdn2d_f32(float *out, const float *in, const float *kernel, int major, int in_h,
@@ -159,6 +251,18 @@ extern "C" int hf_blur_noise_bias_act_f32(float *out, const float *in, const flo
   const long long planes = (long long)batch * channels;
   if (planes > 65535LL * 32768) return HF_E_INVALID;
   const int out_h = in_h - 1, out_w = in_w - 1;
+  const bool aligned = ((((size_t)out) | ((size_t)noise)) & 15) == 0 && (noise_bstride & 3) == 0;
+  if ((out_w & 3) == 0 && aligned) {
+    int cq = 64;  // column quads per block row (power of two, <= out_w / 4 rounded up)
+    while (cq > 1 && cq * 4 >= 2 * out_w) cq >>= 1;
+    const int segs = 256 / cq;
+    int rpt = 32;  // rows per thread: even, shrink for short planes so that segments are not idle
+    while (rpt > 2 && segs * rpt >= 2 * out_h) rpt >>= 1;
+    dim3 grid(hf_cdiv(out_w, cq * 4), hf_cdiv(out_h, segs * rpt), (unsigned)planes);
+    hipLaunchKernelGGL(blur4x4_noise_bias_act_vec4, grid, dim3(cq, segs), 0, (hipStream_t)stream, out, in,
+                       kernel4x4, noise, noise_w, noise_bstride, bias, channels, in_h, in_w, alpha, scale, rpt);
+    return hf_launch_status();
+  }
   dim3 grid(hf_cdiv(out_w, kBlurCols), hf_cdiv(out_h, kBlurSegs * kRowsPerThread), (unsigned)planes);
   hipLaunchKernelGGL(blur4x4_noise_bias_act, grid, dim3(kBlurCols, kBlurSegs), 0, (hipStream_t)stream, out,
                      in, kernel4x4, noise, noise_w, noise_bstride, bias, channels, in_h, in_w, alpha, scale);

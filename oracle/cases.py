@@ -112,3 +112,76 @@ def generator_inputs(size, B, start_layer, cin_of_block=None):
         r = 2 ** (start_layer + 1)  # block s consumes 2^(s+1), produces 2^(s+2)
         layer_in = t(synth.pseudo_normal(f"layer_in/{start_layer}/{B}", (B, cin_of_block, r, r)))
     return lat, noise, layer_in
+
+
+# ------------------------------------------------------------------------------------
+# encoders (oracle/ref_encoders.py)
+# ------------------------------------------------------------------------------------
+# name -> (in_c, depth, stride, B, H, W)
+IRSE_UNIT_CASES = {"irse_16to32_s2": (16, 32, 2, 2, 12, 12), "irse_32to32_s1": (32, 32, 1, 1, 10, 14),
+                   "irse_32to32_s2": (32, 32, 2, 2, 9, 16)}
+IBASIC_CASES = {"ibasic_16to32_s2": (16, 32, 2, 2, 12, 12), "ibasic_32to32_s1": (32, 32, 1, 1, 10, 14)}
+# name -> (channels, spatial, B)
+STYLE_BLOCK_CASES = {"gsb_32_sp4": (32, 4, 3), "gsb_64_sp8": (64, 8, 2)}
+
+
+def params_from_shapes(prefix, shapes):
+    return {k: t(synth.fill_value(f"{prefix}.{k}", tuple(s))) for k, s in shapes.items()}
+
+
+def irse_unit_shapes(in_c, depth):
+    S = {}
+    if in_c != depth:
+        S["u.shortcut_layer.0.weight"] = (depth, in_c, 1, 1)
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            S[f"u.shortcut_layer.1.{k}"] = (depth,)
+    for k in ("weight", "bias", "running_mean", "running_var"):
+        S[f"u.res_layer.0.{k}"] = (in_c,)
+        S[f"u.res_layer.4.{k}"] = (depth,)
+    S["u.res_layer.1.weight"] = (depth, in_c, 3, 3)
+    S["u.res_layer.2.weight"] = (depth,)
+    S["u.res_layer.3.weight"] = (depth, depth, 3, 3)
+    S["u.res_layer.5.fc1.weight"] = (depth // 16, depth, 1, 1)
+    S["u.res_layer.5.fc2.weight"] = (depth, depth // 16, 1, 1)
+    return S
+
+
+def ibasic_shapes(in_c, planes, stride):
+    S = {}
+    for name, c in (("bn1", in_c), ("bn2", planes), ("bn3", planes)):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            S[f"u.{name}.{k}"] = (c,)
+    S["u.conv1.weight"] = (planes, in_c, 3, 3)
+    S["u.prelu.weight"] = (planes,)
+    S["u.conv2.weight"] = (planes, planes, 3, 3)
+    if stride != 1 or in_c != planes:
+        S["u.downsample.0.weight"] = (planes, in_c, 1, 1)
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            S[f"u.downsample.1.{k}"] = (planes,)
+    return S
+
+
+def style_block_shapes(c, spatial):
+    S = {}
+    for k in range(int(np.log2(spatial))):
+        S[f"u.convs.{2 * k}.weight"] = (c, c, 3, 3)
+        S[f"u.convs.{2 * k}.bias"] = (c,)
+    S["u.linear.weight"] = (c, c)
+    S["u.linear.bias"] = (c,)
+    return S
+
+
+def unit_input(name, shape):
+    return t(synth.pseudo_normal(f"enc/{name}/x", shape))
+
+
+def e4e_inputs(B=2):
+    x = t(synth.pseudo_normal(f"enc/e4e/x/{B}", (B, 3, 256, 256))) * 0.5
+    latent_avg = t(synth.pseudo_normal("enc/e4e/latent_avg", (18, 512))) * 0.1
+    return x, latent_avg
+
+
+def fs_inputs(B=2):
+    img = t(synth.pseudo_normal(f"enc/fs/img/{B}", (B, 3, 1024, 1024))) * 0.5
+    dlatent_avg = t(synth.pseudo_normal("enc/fs/dlatent_avg", (18, 512))) * 0.1
+    return img, dlatent_avg

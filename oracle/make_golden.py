@@ -196,6 +196,98 @@ def main():
         g = run_generator("g1024")
         np.savez_compressed(os.path.join(args.out, "generator_1024.npz"), **g)
 
+    # ---------------- (v) encoders: units, e4e, FeatureStyle encoder --------------------
+    from oracle import ref_encoders as E
+
+    tvm = types.ModuleType("torchvision.models")
+    tvu = types.ModuleType("torchvision.utils")
+    sys.modules.setdefault("torchvision.models", tvm)
+    sys.modules.setdefault("torchvision.utils", tvu)
+    from models.encoder4editing.models.encoders import helpers as ref_helpers
+    from models.encoder4editing.models.encoders import psp_encoders as ref_psp
+
+    sys.path.insert(0, os.path.join(REF, "models", "FeatureStyleEncoder"))
+    from arcface import iresnet as ref_iresnet
+
+    g = {}
+
+    def load_unit(mod, P):
+        sd = {k_[2:]: v_ for k_, v_ in P.items()}
+        missing = [k_ for k_ in mod.state_dict() if k_ not in sd and not k_.endswith("num_batches_tracked")]
+        assert not missing, missing
+        mod.load_state_dict(sd, strict=False)
+        return mod.eval()
+
+    for name, (in_c, depth, stride, B, H, W) in C.IRSE_UNIT_CASES.items():
+        P = C.params_from_shapes(name, C.irse_unit_shapes(in_c, depth))
+        x = C.unit_input(name, (B, in_c, H, W))
+        y = load_unit(ref_helpers.bottleneck_IR_SE(in_c, depth, stride), P)(x)
+        report[f"enc/{name}"] = maxdiff(y, E.ir_se_unit(P, "u", x, in_c, depth, stride))
+        g[name] = y.numpy()
+    for name, (in_c, planes, stride, B, H, W) in C.IBASIC_CASES.items():
+        P = C.params_from_shapes(name, C.ibasic_shapes(in_c, planes, stride))
+        x = C.unit_input(name, (B, in_c, H, W))
+        ds = None
+        if stride != 1 or in_c != planes:
+            ds = torch.nn.Sequential(ref_iresnet.conv1x1(in_c, planes, stride), torch.nn.BatchNorm2d(planes, eps=1e-05))
+        y = load_unit(ref_iresnet.IBasicBlock(in_c, planes, stride, ds), P)(x)
+        report[f"enc/{name}"] = maxdiff(y, E.ibasic_block(P, "u", x, stride))
+        g[name] = y.numpy()
+    for name, (c, spatial, B) in C.STYLE_BLOCK_CASES.items():
+        P = C.params_from_shapes(name, C.style_block_shapes(c, spatial))
+        x = C.unit_input(name, (B, c, spatial, spatial))
+        y = load_unit(ref_psp.GradualStyleBlock(c, c, spatial), P)(x)
+        report[f"enc/{name}"] = maxdiff(y, E.gradual_style_block(P, "u", x))
+        g[name] = y.numpy()
+    np.savez_compressed(os.path.join(args.out, "encoder_units.npz"), **g)
+
+    if not args.skip_big:
+        import argparse as _ap
+        import tempfile
+
+        g = {}
+        e4e = ref_psp.Encoder4Editing(50, "ir_se", _ap.Namespace(stylegan_size=1024)).eval()
+        shapes = {k_: tuple(v_.shape) for k_, v_ in e4e.state_dict().items()}
+        assert shapes == E.e4e_param_shapes() and list(shapes) == list(E.e4e_param_shapes())
+        P = C.params_from_shapes("e4e", shapes)
+        e4e.load_state_dict(P)
+        x, latent_avg = C.e4e_inputs(2)
+        w = e4e(x) + latent_avg.repeat(x.shape[0], 1, 1)  # get_latents, model_utils.py:9-13
+        wo, taps = E.e4e_forward(P, x, latent_avg=latent_avg, return_taps=True)
+        report["enc/e4e"] = maxdiff(w, wo)
+        g["e4e_w"] = w.numpy()
+        for nm, tap in zip(("c1", "c2", "c3"), taps):
+            g[f"e4e_{nm}_stats"] = stats(tap)
+            g[f"e4e_{nm}_samples"] = strided_samples(tap, 256)
+        print("done e4e", report["enc/e4e"], flush=True)
+
+        from nets.feature_style_encoder import fs_encoder_v2
+
+        tmp = tempfile.mktemp()
+        torch.save(ref_iresnet.iresnet50().state_dict(), tmp)
+        fs = fs_encoder_v2(n_styles=18, opts=_ap.Namespace(arcface_model_path=tmp), residual=False, use_coeff=False,
+                           resnet_layer=[4, 5, 6], stride=(2, 2)).eval()  # trainer.py:167-168, configs/001.yaml:26
+        os.remove(tmp)
+        shapes = {k_: tuple(v_.shape) for k_, v_ in fs.state_dict().items()}
+        assert shapes == E.fs_param_shapes() and list(shapes) == list(E.fs_param_shapes())
+        P = C.params_from_shapes("fs", shapes)
+        fs.load_state_dict(P)
+        img, dlat = C.fs_inputs(2)
+        x256 = img
+        for _ in range(2):  # trainer.py:61-64 downscale(x, 2, 'bilinear')
+            x256 = torch.nn.functional.interpolate(x256, scale_factor=0.5, mode="bilinear")
+        s_ref, content = fs(x256)
+        s_ref = s_ref + dlat  # trainer.py:289
+        so, co = E.fs_encoder_test(P, img, dlat)
+        report["enc/fs_s"] = maxdiff(s_ref, so)
+        report["enc/fs_content"] = maxdiff(content, co)
+        g["fs_s"] = s_ref.numpy()
+        g["fs_content_chan16"] = content[:, ::16].numpy().copy()
+        g["fs_content_stats"] = stats(content)
+        g["fs_x256_samples"] = strided_samples(x256, 256)
+        print("done fs", report["enc/fs_s"], report["enc/fs_content"], flush=True)
+        np.savez_compressed(os.path.join(args.out, "encoders.npz"), **g)
+
     worst = max(report.values())
     with open(os.path.join(args.out, "oracle_vs_reference.json"), "w") as f:
         json.dump({"torch": torch.__version__, "max_abs_diff": report, "worst": worst}, f, indent=1, sort_keys=True)

@@ -73,7 +73,22 @@ def fill_value(key, shape):
         return np.zeros(shape, dtype=np.int64)
     if leaf == "bias" or "running_mean" in key:
         return (np.float32(0.1) * unit_uniform(key, shape)).astype(np.float32)
+    # ---- encoder parameters (plain Conv2d / BatchNorm2d / PReLU / Linear, no runtime scale) ----
+    if leaf == "weight" and len(shape) == 4:  # conv [cout, cin, k, k]: keep activations O(1)
+        fan_in = shape[1] * shape[2] * shape[3]
+        return (unit_uniform(key, shape) * np.float32(0.7 / np.sqrt(fan_in))).astype(np.float32)
+    if leaf == "weight" and len(shape) == 1:  # BatchNorm gamma / PReLU slope: positive, < 1
+        return (np.float32(0.1) + np.float32(0.8) * uniform01(key, shape)).astype(np.float32)
+    if leaf == "weight" and len(shape) == 2 and _is_plain_linear(key):  # nn.Linear (FS encoder heads)
+        return (unit_uniform(key, shape) * np.float32(1.0 / np.sqrt(shape[1]))).astype(np.float32)
     return unit_uniform(key, shape)
+
+
+def _is_plain_linear(key):
+    """`styles.<i>.weight` of the FeatureStyle encoder (nn.Linear, no equalised-lr scale);
+    the e4e heads are `styles.<i>.linear.weight` (EqualLinear, scaled at run time)."""
+    parts = key.split(".")
+    return len(parts) >= 3 and parts[-3] == "styles" and parts[-2].isdigit()
 
 
 def fill_state_dict(shapes):

@@ -26,6 +26,7 @@ extern Dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 void syncthreads();
 float shfl_xor(float v, int mask);
+float shfl_rel(float v, int delta);  // value of lane (lane + delta), own value if out of the wave
 f32x16 mfma32x32x2(float a, float b, f32x16 c);
 void glds16(const float *gsrc_lane, float *lds_wave_base);
 void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t shmem);
@@ -57,6 +58,8 @@ inline float4 make_float4(float x, float y, float z, float w) { return float4{x,
 
 inline void __syncthreads() { ::hipsim::syncthreads(); }
 inline float __shfl_xor(float v, int mask, int /*width*/ = 64) { return ::hipsim::shfl_xor(v, mask); }
+inline float __shfl_up(float v, int d, int /*width*/ = 64) { return ::hipsim::shfl_rel(v, -d); }
+inline float __shfl_down(float v, int d, int /*width*/ = 64) { return ::hipsim::shfl_rel(v, d); }
 inline float rsqrtf(float v) { return 1.0f / sqrtf(v); }
 template <class T> inline T min(T a, T b) { return a < b ? a : b; }
 template <class T> inline T max(T a, T b) { return a > b ? a : b; }

@@ -16,7 +16,7 @@ unsigned char *dyn_lds() { return g_lds; }
 
 namespace {
 enum State { READY, WAIT_BLOCK, WAIT_WAVE, DONE };
-enum WaveOp { OP_NONE, OP_SHFL_XOR, OP_MFMA, OP_GLDS };
+enum WaveOp { OP_NONE, OP_SHFL_XOR, OP_SHFL_REL, OP_MFMA, OP_GLDS };
 
 struct Fiber {
   ucontext_t ctx;
@@ -59,6 +59,13 @@ void resolve_wave(int w0, int w1) {
       if (g_f[i].state != WAIT_WAVE) continue;
       int src = w0 + (((i - w0) ^ g_f[i].imm) & 63);
       g_f[i].fres = (src < w1 && g_f[src].state == WAIT_WAVE) ? g_f[src].a : 0.0f;
+    }
+  } else if (op == OP_SHFL_REL) {
+    for (int i = w0; i < w1; ++i) {
+      if (g_f[i].state != WAIT_WAVE) continue;
+      const int src = i + g_f[i].imm;
+      const bool ok = src >= w0 && src < w0 + 64 && src < w1 && g_f[src].state == WAIT_WAVE;
+      g_f[i].fres = ok ? g_f[src].a : g_f[i].a;
     }
   } else if (op == OP_GLDS) {
     // LDS destination = base of the first active lane + lane*16 bytes (M0 semantics)
@@ -144,6 +151,13 @@ void syncthreads() {
 float shfl_xor(float v, int mask) {
   Fiber &f = g_f[g_cur];
   f.op = OP_SHFL_XOR; f.a = v; f.imm = mask; f.state = WAIT_WAVE;
+  yield_to_sched();
+  return g_f[g_cur].fres;
+}
+
+float shfl_rel(float v, int delta) {
+  Fiber &f = g_f[g_cur];
+  f.op = OP_SHFL_REL; f.a = v; f.imm = delta; f.state = WAIT_WAVE;
   yield_to_sched();
   return g_f[g_cur].fres;
 }
