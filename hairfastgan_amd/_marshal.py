@@ -20,10 +20,10 @@ PROFILE = None
 
 
 KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modconv.hip dispatch)
-    211: "modconv_mfma_pipe<2,2,2,4>", 212: "modconv_mfma_pipe<2,2,1,4>", 213: "modconv_mfma_pipe<1,2,1,4>",
-    214: "modconv_mfma_pipe<2,2,2,2>", 215: "modconv_mfma_pipe<1,1,2,2>", 216: "modconv_mfma_pipe<1,4,1,4>",
-    221: "modconv_mfma_pipe<1,2,2,2,up>", 222: "modconv_mfma_pipe<1,2,1,4,up>", 223: "modconv_mfma_pipe<1,1,2,2,up>",
-    224: "modconv_mfma_pipe<1,2,2,4,up>", 225: "modconv_mfma_pipe<1,1,1,4,up>", 300: "modconv_mfma<1,1,2,2> split-K",
+    211: "conv_mfma_pipe<2,2,2,4>", 212: "conv_mfma_pipe<2,2,1,4>", 213: "conv_mfma_pipe<1,2,1,4>",
+    214: "conv_mfma_pipe<2,2,2,2>", 215: "conv_mfma_pipe<1,1,2,2>", 216: "conv_mfma_pipe<1,4,1,4>",
+    221: "conv_mfma_pipe<1,2,2,2,up>", 222: "conv_mfma_pipe<1,2,1,4,up>", 223: "conv_mfma_pipe<1,1,2,2,up>",
+    224: "conv_mfma_pipe<1,2,2,4,up>", 225: "conv_mfma_pipe<1,1,1,4,up>", 300: "conv_mfma<1,1,2,2> split-K",
 }
 
 
@@ -36,7 +36,7 @@ def _launch_profiled(lib, flops, fn):
     r = fn()
     e1.record()
     code = lib.hf_debug_last_path()
-    PROFILE.append((KERNEL_NAMES.get(code, f"modconv_mfma (general, code {code})"), flops, e0, e1))
+    PROFILE.append((KERNEL_NAMES.get(code, f"conv_mfma (general, code {code})"), flops, e0, e1))
     return r
 
 
@@ -190,4 +190,124 @@ def torgb(lib, st, x, wt, s, bias, skip, up_kernel):
     out = x.new_empty((b, 3, h, w))
     check(lib, lib.hf_torgb_f32(_p(out), _p(x), _p(wt), _p(s), _p(_c(bias)), _p(skip), _p(_c(up_kernel)), b, cin,
                                 h, w, st), "hf_torgb_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# encoders
+# ----------------------------------------------------------------------------------------
+ACT_NONE, ACT_LRELU, ACT_PRELU = 0, 1, 2
+
+
+def conv_prepare(lib, st, weight, scale=1.0):
+    """Conv2d weight [cout,cin,k,k] -> wt [k*k,cin,cout]."""
+    weight = _c(weight)
+    cout, cin, k, _ = weight.shape
+    wt = weight.new_empty((k * k, cin, cout))
+    check(lib, lib.hf_conv_prepare_f32(_p(wt), _p(weight), cout, cin, k, scale, st), "hf_conv_prepare_f32")
+    return wt
+
+
+def bn_fold(lib, st, gamma, beta, mean, var, eps, conv_bias=None):
+    gamma, beta, mean, var, conv_bias = _c(gamma), _c(beta), _c(mean), _c(var), _c(conv_bias)
+    n = gamma.numel()
+    scale, shift = gamma.new_empty(n), gamma.new_empty(n)
+    check(lib, lib.hf_bn_fold_f32(_p(scale), _p(shift), _p(gamma), _p(beta), _p(mean), _p(var), _p(conv_bias),
+                                  float(eps), n, st), "hf_bn_fold_f32")
+    return scale, shift
+
+
+def conv2d(lib, st, x, wt, k, stride=1, in_scale=None, in_shift=None, out_scale=None, bias=None, act=ACT_NONE,
+           slope=None, alpha=0.0, residual=None):
+    x = _c(x)
+    b, cin, h, w = x.shape
+    cout = wt.shape[2]
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    out = x.new_empty((b, cout, oh, ow))
+    if residual is not None:
+        residual = _c(residual)
+        if tuple(residual.shape) != tuple(out.shape):
+            raise ValueError(f"residual {tuple(residual.shape)} != output {tuple(out.shape)}")
+    n = lib.hf_conv2d_workspace_floats(b, cin, cout, h, w, k, stride)
+    ws = x.new_empty((n,)) if n > 0 else None
+    code = _launch_profiled(
+        lib, 2.0 * cin * cout * k * k * oh * ow * b,
+        lambda: lib.hf_conv2d_f32(_p(out), _p(x), _p(wt), _p(in_scale), _p(in_shift), _p(out_scale), _p(bias), act,
+                                  _p(slope), float(alpha), _p(residual), b, cin, cout, h, w, k, stride, _p(ws),
+                                  max(n, 0), st))
+    check(lib, code, "hf_conv2d_f32")
+    return out
+
+
+def plane_mean(lib, st, x):
+    x = _c(x)
+    b, c, h, w = x.shape
+    out = x.new_empty((b, c))
+    check(lib, lib.hf_plane_mean_f32(_p(out), _p(x), b * c, h * w, st), "hf_plane_mean_f32")
+    return out
+
+
+def se_gate(lib, st, pooled, fc1, fc2):
+    b, c = pooled.shape
+    cr = fc1.shape[0]
+    gate = pooled.new_empty((b, c))
+    check(lib, lib.hf_se_gate_f32(_p(gate), _p(pooled), _p(_c(fc1)), _p(_c(fc2)), b, c, cr, st), "hf_se_gate_f32")
+    return gate
+
+
+def scale_shortcut_add(lib, st, r, gate, shortcut, sc_stride=1):
+    r, shortcut = _c(r), _c(shortcut)
+    b, c, oh, ow = r.shape
+    sh, sw = shortcut.shape[2], shortcut.shape[3]
+    out = torch.empty_like(r)
+    check(lib, lib.hf_scale_shortcut_add_f32(_p(out), _p(r), _p(gate), _p(shortcut), sc_stride, b, c, oh, ow, sh, sw,
+                                             st), "hf_scale_shortcut_add_f32")
+    return out
+
+
+def upsample_bilinear_add(lib, st, x, y):
+    x, y = _c(x), _c(y)
+    b, c, h, w = x.shape
+    oh, ow = y.shape[2], y.shape[3]
+    out = torch.empty_like(y)
+    check(lib, lib.hf_upsample_bilinear_add_f32(_p(out), _p(x), _p(y), b * c, h, w, oh, ow, st),
+          "hf_upsample_bilinear_add_f32")
+    return out
+
+
+def adaptive_avgpool_into(lib, st, out, x, c_off):
+    """AdaptiveAvgPool2d(out.shape[2:]) of x written into out[:, c_off:c_off+C]."""
+    x = _c(x)
+    b, c, h, w = x.shape
+    check(lib, lib.hf_adaptive_avgpool_f32(_p(out), _p(x), b, c, h, w, out.shape[2], out.shape[3], out.shape[1], c_off,
+                                           st), "hf_adaptive_avgpool_f32")
+
+
+def downscale2x(lib, st, x):
+    x = _c(x)
+    b, c, h, w = x.shape
+    out = x.new_empty((b, c, h // 2, w // 2))
+    check(lib, lib.hf_downscale2x_f32(_p(out), _p(x), b * c, h, w, st), "hf_downscale2x_f32")
+    return out
+
+
+def linear(lib, st, x, weight, bias, scale=1.0):
+    """x [B,in] (row stride may exceed in), weight [out,in] -> [B,out]; B <= 8 per launch."""
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    b, k = x.shape
+    weight = _c(weight)
+    n = weight.shape[0]
+    out = x.new_empty((b, n))
+    for b0 in range(0, b, 8):
+        nb = min(8, b - b0)
+        check(lib, lib.hf_linear_f32(out[b0:].data_ptr(), x[b0:].data_ptr(), x.stride(0) if b > 1 else k, _p(weight),
+                                     _p(_c(bias)), nb, k, n, float(scale), st), "hf_linear_f32")
+    return out
+
+
+def add_bcast(lib, st, a, bvec):
+    a, bvec = _c(a), _c(bvec)
+    out = torch.empty_like(a)
+    check(lib, lib.hf_add_bcast_f32(_p(out), _p(a), _p(bvec), a.numel(), bvec.numel(), st), "hf_add_bcast_f32")
     return out

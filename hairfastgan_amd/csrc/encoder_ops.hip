@@ -1,0 +1,316 @@
+// encoder_ops.hip - the small operators around the convolutions of the two encoders
+// (e4e: models/encoder4editing/models/encoders/{psp_encoders,helpers}.py;
+//  FeatureStyle: models/FeatureStyleEncoder/nets/feature_style_encoder.py, arcface/iresnet.py,
+//  trainer.py:61-64).  All are streaming / latency-bound kernels on tensors of at most a
+//  few MB; the FLOPs of the encoders live in modconv.hip (hf_conv2d_f32).
+//
+//   hf_conv_prepare_f32          Conv2d weight [cout,cin,k,k] -> wt[tap][ci][co]     (once per checkpoint)
+//   hf_bn_fold_f32               BatchNorm2d (inference) -> per-channel scale/shift  (once per checkpoint)
+//   hf_plane_mean_f32            AdaptiveAvgPool2d(1) of SEModule (helpers.py:60,68)
+//   hf_se_gate_f32               fc1 -> ReLU -> fc2 -> sigmoid of SEModule (helpers.py:69-73)
+//   hf_scale_shortcut_add_f32    res * gate + shortcut, shortcut optionally MaxPool2d(1, stride)
+//                                (helpers.py:95-96, :118-120)
+//   hf_upsample_bilinear_add_f32 _upsample_add (helpers.py:123-140; align_corners=True)
+//   hf_adaptive_avgpool_f32      AdaptiveAvgPool2d((3,3)) + channel concat (feature_style_encoder.py:44, 52-61)
+//   hf_downscale2x_f32           F.interpolate(scale_factor=0.5, 'bilinear') (trainer.py:61-64)
+//   hf_linear_f32                nn.Linear / EqualLinear heads (weight-bandwidth bound GEMV batch)
+//   hf_add_bcast_f32             w0 + delta_i, + latent_avg (psp_encoders.py:199, model_utils.py:9-13)
+#include "hf_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void conv_prepare(float *__restrict__ wt, const float *__restrict__ weight,
+                                                    int cout, int cin, int taps, float scale) {
+  const long long n = (long long)cout * cin;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int ci = (int)(i % cin);
+    const int co = (int)(i / cin);
+    for (int t = 0; t < taps; ++t) wt[((long long)t * cin + ci) * cout + co] = weight[i * taps + t] * scale;
+  }
+}
+
+// scale = gamma / sqrt(var + eps); shift = beta + (conv_bias - mean) * scale
+__global__ void bn_fold(float *__restrict__ scale, float *__restrict__ shift, const float *__restrict__ gamma,
+                        const float *__restrict__ beta, const float *__restrict__ mean,
+                        const float *__restrict__ var, const float *__restrict__ conv_bias, float eps, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = gamma[i] / sqrtf(var[i] + eps);
+  scale[i] = g;
+  shift[i] = beta[i] + ((conv_bias ? conv_bias[i] : 0.0f) - mean[i]) * g;
+}
+
+// one wave per plane
+__global__ __launch_bounds__(256) void plane_mean(float *__restrict__ out, const float *__restrict__ x,
+                                                  int planes, int hw) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= planes) return;
+  const float *src = x + (long long)p * hw;
+  float acc = 0.0f;
+  for (int i = lane; i < hw; i += 64) acc += src[i];
+  acc = hf_wave_sum(acc);
+  if (lane == 0) out[p] = acc / (float)hw;
+}
+
+// one block per image: hidden = relu(fc1 . pooled); gate = sigmoid(fc2 . hidden)
+__global__ __launch_bounds__(256) void se_gate(float *__restrict__ gate, const float *__restrict__ pooled,
+                                               const float *__restrict__ fc1, const float *__restrict__ fc2,
+                                               int c, int cr) {
+  HF_DYN_LDS;
+  float *pl = reinterpret_cast<float *>(hf_dyn_lds);  // [c]
+  float *hid = pl + c;                                 // [cr]
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < c; i += blockDim.x) pl[i] = pooled[(long long)b * c + i];
+  __syncthreads();
+  for (int j = threadIdx.x; j < cr; j += blockDim.x) {
+    float acc = 0.0f;
+    for (int i = 0; i < c; ++i) acc = fmaf(fc1[(long long)j * c + i], pl[i], acc);
+    hid[j] = acc > 0.0f ? acc : 0.0f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    float acc = 0.0f;
+    for (int j = 0; j < cr; ++j) acc = fmaf(fc2[(long long)i * cr + j], hid[j], acc);
+    gate[(long long)b * c + i] = 1.0f / (1.0f + expf(-acc));
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_shortcut_add(float *__restrict__ out, const float *__restrict__ r,
+                                                          const float *__restrict__ gate,
+                                                          const float *__restrict__ shortcut, int sc_stride,
+                                                          int oh, int ow, int sh, int sw, long long total) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int oplane = oh * ow;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long pl = i / oplane;
+    const int p = (int)(i - pl * oplane);
+    const int y = p / ow, x = p - y * ow;
+    float v = r[i];
+    if (gate) v *= gate[pl];
+    v += shortcut[pl * (long long)sh * sw + (long long)(y * sc_stride) * sw + x * sc_stride];
+    out[i] = v;
+  }
+}
+
+// bilinear, align_corners=True: src = dst * (in-1)/(out-1)
+__global__ __launch_bounds__(256) void upsample_bilinear_add(float *__restrict__ out, const float *__restrict__ x,
+                                                             const float *__restrict__ y, int h, int w, int oh,
+                                                             int ow, long long total) {
+  const float ry = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.0f;
+  const float rx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.0f;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int oplane = oh * ow;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long pl = i / oplane;
+    const int p = (int)(i - pl * oplane);
+    const int oy = p / ow, ox = p - oy * ow;
+    const float fy = ry * oy, fx = rx * ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - y0, lx = fx - x0;
+    const float *src = x + pl * (long long)h * w;
+    const float top = (1.0f - lx) * src[y0 * w + x0] + lx * src[y0 * w + x1];
+    const float bot = (1.0f - lx) * src[y1 * w + x0] + lx * src[y1 * w + x1];
+    out[i] = (1.0f - ly) * top + ly * bot + y[i];
+  }
+}
+
+// one wave per (plane, output bin); bins [floor(i*H/oh), ceil((i+1)*H/oh))
+__global__ __launch_bounds__(256) void adaptive_avgpool(float *__restrict__ out, const float *__restrict__ x,
+                                                        int batch, int channels, int h, int w, int oh, int ow,
+                                                        int ctot, int c_off) {
+  const int lane = threadIdx.x & 63;
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nitems = (long long)batch * channels * oh * ow;
+  if (item >= nitems) return;
+  const int bin = (int)(item % (oh * ow));
+  const long long pl = item / (oh * ow);
+  const int c = (int)(pl % channels);
+  const int b = (int)(pl / channels);
+  const int by = bin / ow, bx = bin - by * ow;
+  const int y0 = (by * h) / oh, y1 = ((by + 1) * h + oh - 1) / oh;
+  const int x0 = (bx * w) / ow, x1 = ((bx + 1) * w + ow - 1) / ow;
+  const int bw = x1 - x0, n = (y1 - y0) * bw;
+  const float *src = x + pl * (long long)h * w;
+  float acc = 0.0f;
+  for (int i = lane; i < n; i += 64) acc += src[(y0 + i / bw) * w + x0 + i % bw];
+  acc = hf_wave_sum(acc);
+  if (lane == 0) out[(((long long)b * ctot + c_off + c) * oh + by) * ow + bx] = acc / (float)n;
+}
+
+// scale_factor 0.5, bilinear, align_corners=False: every output is the centre of a 2x2 cell;
+// same operation order as ATen's upsample_bilinear2d (rows blended, then columns).
+__global__ __launch_bounds__(256) void downscale2x(float *__restrict__ out, const float *__restrict__ x, int h,
+                                                   int w, long long total) {
+  const int oh = h / 2, ow = w / 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int oplane = oh * ow;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long pl = i / oplane;
+    const int p = (int)(i - pl * oplane);
+    const int oy = p / ow, ox = p - oy * ow;
+    const float *src = x + pl * (long long)h * w + (long long)(2 * oy) * w + 2 * ox;
+    const float2 a = *reinterpret_cast<const float2 *>(src);
+    const float2 b = *reinterpret_cast<const float2 *>(src + w);
+    out[i] = 0.5f * (0.5f * a.x + 0.5f * a.y) + 0.5f * (0.5f * b.x + 0.5f * b.y);
+  }
+}
+
+// out[b, n] = scale * sum_k x[b*x_stride + k] * w[n*in_f + k] + bias[n]; one wave per ROWS output
+// rows, the weight rows are streamed once (16 B per lane), x comes from L1/L2.
+constexpr int kLinRows = 4;
+constexpr int kLinMaxBatch = 8;
+
+__global__ __launch_bounds__(256) void linear_kernel(float *__restrict__ out, const float *__restrict__ x,
+                                                     long long x_stride, const float *__restrict__ w,
+                                                     const float *__restrict__ bias, int batch, int in_f,
+                                                     int out_f, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kLinRows;
+  if (n0 >= out_f) return;
+  float acc[kLinRows][kLinMaxBatch];
+#pragma unroll
+  for (int r = 0; r < kLinRows; ++r)
+#pragma unroll
+    for (int b = 0; b < kLinMaxBatch; ++b) acc[r][b] = 0.0f;
+  const bool vec = (in_f & 3) == 0 && (x_stride & 3) == 0;
+  if (vec) {
+    for (int k = lane * 4; k < in_f; k += 256) {
+      float4 xv[kLinMaxBatch];
+#pragma unroll
+      for (int b = 0; b < kLinMaxBatch; ++b)
+        xv[b] = (b < batch) ? *reinterpret_cast<const float4 *>(x + b * x_stride + k) : make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < kLinRows; ++r) {
+        const int n = min(n0 + r, out_f - 1);
+        const float4 wv = *reinterpret_cast<const float4 *>(w + (long long)n * in_f + k);
+#pragma unroll
+        for (int b = 0; b < kLinMaxBatch; ++b)
+          acc[r][b] = fmaf(wv.x, xv[b].x, fmaf(wv.y, xv[b].y, fmaf(wv.z, xv[b].z, fmaf(wv.w, xv[b].w, acc[r][b]))));
+      }
+    }
+  } else {
+    for (int k = lane; k < in_f; k += 64) {
+#pragma unroll
+      for (int r = 0; r < kLinRows; ++r) {
+        const int n = min(n0 + r, out_f - 1);
+        const float wv = w[(long long)n * in_f + k];
+#pragma unroll
+        for (int b = 0; b < kLinMaxBatch; ++b)
+          if (b < batch) acc[r][b] = fmaf(wv, x[b * x_stride + k], acc[r][b]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kLinRows; ++r)
+#pragma unroll
+    for (int b = 0; b < kLinMaxBatch; ++b) {
+      const float v = hf_wave_sum(acc[r][b]);
+      if (lane == 0 && b < batch && n0 + r < out_f)
+        out[(long long)b * out_f + n0 + r] = v * scale + (bias ? bias[n0 + r] : 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void add_bcast(float *__restrict__ out, const float *__restrict__ a,
+                                                 const float *__restrict__ b, long long n, long long period) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = a[i] + b[i % period];
+}
+
+inline int grid_for(long long n) {
+  long long g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int hf_conv_prepare_f32(float *wt, const float *weight, int cout, int cin, int k, float scale,
+                                   void *stream) {
+  if (!wt || !weight || cout <= 0 || cin <= 0 || (k != 1 && k != 3)) return HF_E_INVALID;
+  hipLaunchKernelGGL(conv_prepare, dim3(grid_for((long long)cout * cin)), dim3(256), 0, (hipStream_t)stream, wt,
+                     weight, cout, cin, k * k, scale);
+  return hf_launch_status();
+}
+
+extern "C" int hf_bn_fold_f32(float *scale, float *shift, const float *gamma, const float *beta, const float *mean,
+                              const float *var, const float *conv_bias, float eps, int n, void *stream) {
+  if (!scale || !shift || !gamma || !beta || !mean || !var || n <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(bn_fold, dim3(hf_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, scale, shift, gamma, beta,
+                     mean, var, conv_bias, eps, n);
+  return hf_launch_status();
+}
+
+extern "C" int hf_plane_mean_f32(float *out, const float *x, int planes, int hw, void *stream) {
+  if (!out || !x || planes <= 0 || hw <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(plane_mean, dim3(hf_cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, out, x, planes, hw);
+  return hf_launch_status();
+}
+
+extern "C" int hf_se_gate_f32(float *gate, const float *pooled, const float *fc1, const float *fc2, int batch,
+                              int channels, int reduced, void *stream) {
+  if (!gate || !pooled || !fc1 || !fc2 || batch <= 0 || channels <= 0 || reduced <= 0) return HF_E_INVALID;
+  const size_t lds = (size_t)(channels + reduced) * sizeof(float);
+  if (lds > 64 * 1024) return HF_E_INVALID;
+  hipLaunchKernelGGL(se_gate, dim3(batch), dim3(256), lds, (hipStream_t)stream, gate, pooled, fc1, fc2, channels,
+                     reduced);
+  return hf_launch_status();
+}
+
+extern "C" int hf_scale_shortcut_add_f32(float *out, const float *r, const float *gate, const float *shortcut,
+                                         int sc_stride, int batch, int channels, int oh, int ow, int sh, int sw,
+                                         void *stream) {
+  if (!out || !r || !shortcut || sc_stride < 1 || batch <= 0 || channels <= 0 || oh <= 0 || ow <= 0) return HF_E_INVALID;
+  if ((oh - 1) * sc_stride >= sh || (ow - 1) * sc_stride >= sw) return HF_E_INVALID;
+  const long long total = (long long)batch * channels * oh * ow;
+  hipLaunchKernelGGL(scale_shortcut_add, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, out, r, gate,
+                     shortcut, sc_stride, oh, ow, sh, sw, total);
+  return hf_launch_status();
+}
+
+extern "C" int hf_upsample_bilinear_add_f32(float *out, const float *x, const float *y, int planes, int h, int w,
+                                            int oh, int ow, void *stream) {
+  if (!out || !x || !y || planes <= 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0) return HF_E_INVALID;
+  const long long total = (long long)planes * oh * ow;
+  hipLaunchKernelGGL(upsample_bilinear_add, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, out, x, y, h,
+                     w, oh, ow, total);
+  return hf_launch_status();
+}
+
+extern "C" int hf_adaptive_avgpool_f32(float *out, const float *x, int batch, int channels, int h, int w, int oh,
+                                       int ow, int out_channels_total, int out_channel_offset, void *stream) {
+  if (!out || !x || batch <= 0 || channels <= 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 ||
+      out_channel_offset < 0 || out_channel_offset + channels > out_channels_total)
+    return HF_E_INVALID;
+  const long long nitems = (long long)batch * channels * oh * ow;
+  hipLaunchKernelGGL(adaptive_avgpool, dim3(hf_cdiv(nitems, 4)), dim3(256), 0, (hipStream_t)stream, out, x, batch,
+                     channels, h, w, oh, ow, out_channels_total, out_channel_offset);
+  return hf_launch_status();
+}
+
+extern "C" int hf_downscale2x_f32(float *out, const float *x, int planes, int h, int w, void *stream) {
+  if (!out || !x || planes <= 0 || h < 2 || w < 2 || (h & 1) || (w & 1)) return HF_E_INVALID;
+  const long long total = (long long)planes * (h / 2) * (w / 2);
+  hipLaunchKernelGGL(downscale2x, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, out, x, h, w, total);
+  return hf_launch_status();
+}
+
+extern "C" int hf_linear_f32(float *out, const float *x, long long x_stride, const float *w, const float *bias,
+                             int batch, int in_features, int out_features, float scale, void *stream) {
+  if (!out || !x || !w || batch <= 0 || batch > kLinMaxBatch || in_features <= 0 || out_features <= 0)
+    return HF_E_INVALID;
+  hipLaunchKernelGGL(linear_kernel, dim3(hf_cdiv(out_features, 4 * kLinRows)), dim3(256), 0, (hipStream_t)stream,
+                     out, x, x_stride, w, bias, batch, in_features, out_features, scale);
+  return hf_launch_status();
+}
+
+extern "C" int hf_add_bcast_f32(float *out, const float *a, const float *b, long long n, long long b_period,
+                                void *stream) {
+  if (!out || !a || !b || n <= 0 || b_period <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(add_bcast, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, a, b, n, b_period);
+  return hf_launch_status();
+}

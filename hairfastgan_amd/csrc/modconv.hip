@@ -1,35 +1,40 @@
-// modconv.hip - fp32 MFMA implicit-GEMM kernels for StyleGAN2's modulated 3x3 convs.
+// modconv.hip - fp32 MFMA implicit-GEMM convolution kernels.
 //
-// hf_modconv3x3_f32     same-resolution StyledConv: ModulatedConv2d (+demod) +
-//                       NoiseInjection + FusedLeakyReLU
-//                       (reference models/stylegan2/model.py:238-250, :273-277, :337-343)
-// hf_modconv3x3_up_f32  upsampling ModulatedConv2d, conv_transpose2d(stride 2) part
-//                       (model.py:252-262); the blur + noise + activation part is
-//                       hf_blur_noise_bias_act_f32 (upfirdn2d.hip).
+// Generator (reference models/stylegan2/model.py):
+//   hf_modconv3x3_f32     same-resolution StyledConv: ModulatedConv2d (+demod) +
+//                         NoiseInjection + FusedLeakyReLU  (:238-250, :273-277, :337-343)
+//   hf_modconv3x3_up_f32  upsampling ModulatedConv2d, conv_transpose2d(stride 2) part
+//                         (:252-262); blur + noise + activation: hf_blur_noise_bias_act_f32.
+// Encoders (e4e: models/encoder4editing/models/encoders/helpers.py:93-120, psp_encoders.py:34-55;
+// FeatureStyle: models/FeatureStyleEncoder/arcface/iresnet.py:28-57):
+//   hf_conv2d_f32         Conv2d 3x3 / 1x1, stride 1 / 2, with the surrounding BatchNorm2d
+//                         (inference statistics) folded in: a per-input-channel affine applied
+//                         to the activations while they are staged (the pre-conv BN cannot be
+//                         folded into the weights because of the zero padding), a per-output-
+//                         channel scale + bias (post-conv BN), PReLU / LeakyReLU and the
+//                         residual add in the epilogue.
 //
 // Formulation (MI355X-first, not the reference's per-sample grouped conv):
-//   y[b,co,p] = d[b,co] * sum_{tap,ci} wt[tap,ci,co] * (s[b,ci] * x[b,ci,p+tap])
+//   y[b,co,p] = d[b,co] * sum_{tap,ci} wt[tap,ci,co] * (s[b,ci] * x[b,ci,p+tap] + t[ci])
 // i.e. the modulation s is applied to the ACTIVATIONS while they are staged
 // into LDS and the demodulation d to the OUTPUTS in the epilogue, so one weight
 // tensor is shared by the whole batch: an implicit GEMM with M = cout,
-// N = batch*H*W pixels, K = 9*cin, run on v_mfma_f32_32x32x2_f32 (exact fp32,
+// N = batch*H*W pixels, K = taps*cin, run on v_mfma_f32_32x32x2_f32 (exact fp32,
 // bitwise an fmaf chain; 157 TFLOP/s peak = the roofline of these layers).
 //
 // Transposed conv without wasted zero-insert flops: output (2Y+pr, 2X+pc) only
 // receives taps with ky = pr, kx = pc (mod 2), so each of the 9 taps feeds one
 // of 4 phase accumulators: same MFMA count as a 3x3 conv at INPUT resolution.
 //
-// Work decomposition: block = 256 threads = 4 waves (64 lanes each); block tile
-// = CT output channels x PT pixels.  Pixels of a tile are (image, row, col)
-// triples described at run time by a TileGeom, so one kernel serves 1024^2
-// planes (8x32 tiles), 4x4 planes (8 whole images per tile) and the 1-pixel
-// wide rim tiles of the (2H+1)x(2W+1) transposed-conv output.
-// K loop: chunks of KC=8 input channels; per chunk the block stages
-// wt[9][KC][CT] and the modulated halo tile x[KC][images][rows+halo][cols+halo]
-// into LDS (coalesced row segments, 16 B weight loads), then every wave issues
-// 9*KC/2 MFMAs per (co tile, pixel group) reading one fp32 A and B operand per
-// lane with conflict-free ds_read_b32 (A: 32 consecutive co, B: 32 consecutive
-// pixels; lanes 32-63 take the next input channel).
+// Work decomposition: block = 4 or 8 waves (64 lanes each); block tile = CT
+// output channels x PT pixels.  Pixels of a tile are (image, row, col) triples
+// described at run time by a TileGeom, so one kernel serves 1024^2 planes (8x32
+// tiles), 4x4 planes (8 whole images per tile) and the rim tiles of the
+// (2H+1)x(2W+1) transposed-conv output.  K loop: chunks of KC=8 input channels
+// staged in LDS as wt[taps][KC][CT] and the halo tile x[KC][images][rows][cols];
+// every wave issues taps*KC/2 MFMAs per (co tile, pixel group), reading one fp32 A
+// and B operand per lane with conflict-free ds_read_b32 (A: 32 consecutive co,
+// B: 32 consecutive pixels; lanes 32-63 take the next input channel).
 #include "hf_common.h"
 
 namespace {
@@ -39,12 +44,14 @@ struct __attribute__((packed, aligned(4))) f32x2u {  // 8-byte value with 4-byte
   float x, y;
 };
 
-constexpr int KC = 8;            // input channels per LDS stage (4 MFMA k-steps)
-constexpr int kThreads = 256;    // 4 waves
-constexpr int kMaxElemPerCi = 4; // halo-tile elements per thread per channel
+constexpr int KC = 8;             // input channels per LDS stage (4 MFMA k-steps)
+constexpr int kThreads = 256;     // general kernel: 4 waves
+constexpr int kMaxElemPerCi = 4;  // general kernel: halo-tile elements per thread per channel
+
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_PRELU = 2 };
 
 struct TileGeom {
-  int y0, x0;      // origin of this tile family in the pixel domain
+  int y0, x0;      // origin of this tile family in the OUTPUT pixel domain
   int dh, dw;      // extent of the family (pixels)
   int lg_tw, lg_th;
   int lg_nb;       // images per tile = 1 << lg_nb ; (nb*th*tw == PT)
@@ -54,10 +61,19 @@ struct TileGeom {
 
 struct ConvParams {
   float *out;
-  const float *x, *wt, *s, *d, *noise, *noise_w, *bias;
+  const float *x, *wt;
+  const float *s;        // input scale  s[b*s_bstride + ci]   (modulation / pre-conv BN scale) or null
+  const float *t;        // input shift  t[ci]                 (pre-conv BN shift) or null
+  const float *d;        // output scale d[b*d_bstride + co]   (demodulation / post-conv BN scale) or null
+  const float *noise, *noise_w, *bias;
+  const float *slope;    // PReLU slopes [cout]
+  const float *residual; // added after the activation, same shape as out
   long long noise_bstride;
+  int s_bstride, d_bstride;
   int batch, cin, cout, h, w;  // input plane h x w
-  int out_h, out_w;            // output plane (same-res: h,w ; up: 2h+1, 2w+1)
+  int out_h, out_w;            // output plane (stride-1: h,w ; stride-2: ceil(h/2) ; up: 2h+1, 2w+1)
+  int stride;                  // 1 or 2 (general kernel only)
+  int act;
   float alpha, scale;
   int n_geom;
   int xs_max;                  // LDS floats reserved per staged channel
@@ -67,33 +83,31 @@ struct ConvParams {
   TileGeom g[3];
 };
 
-
-// One K chunk: 9 taps x KC/2 k-steps of v_mfma_f32_32x32x2_f32 per (co tile, pixel group).
-// a_base: &wl[lh][wave_co + li] (A operand: 32 consecutive co, lanes 32-63 the next ci);
-// b_base: &xl[lh * xstride]      (B operand: the lane's pixel, shifted per tap).
 struct NoSideWork {
   __device__ __forceinline__ void operator()(int) const {}
 };
 
-// `side(step)` is called once per step (step is a compile-time constant after unrolling)
-// between the operand prefetch and the step's MFMAs: the pipelined kernel uses it to
-// spread its staging instructions (weight DMA, halo loads, LDS writes) over the chunk, so
-// that they issue under matrix-pipe time instead of ahead of the first MFMA.
-template <int CT_TILES, int PG, int CT, bool UP, class Side, int NPH = (UP ? 4 : 1)>
+// One K chunk: TAPS x KC/2 steps of v_mfma_f32_32x32x2_f32 per (co tile, pixel group).
+// a_base: &wl[lh][wave_co + li] (A operand: 32 consecutive co, lanes 32-63 the next ci);
+// b_base: &xl[lh * xstride]      (B operand: the lane's pixel, shifted per tap).
+// Software pipelined: the A/B fragments of step n+1 are read from LDS before the MFMAs
+// of step n issue, so the ~100-cycle ds_read latency sits under 64*CT_TILES*PG cycles of
+// matrix-pipe work.  `side(step)` is called once per step (step is a compile-time
+// constant after unrolling) between the operand prefetch and the step's MFMAs: the
+// pipelined kernel uses it to spread its staging instructions (weight DMA, halo loads,
+// LDS writes) over the chunk, so that they issue under matrix-pipe time.
+template <int CT_TILES, int PG, int CT, bool UP, int TAPS, class Side, int NPH = (UP ? 4 : 1)>
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NPH][CT_TILES][PG], const float *a_base,
                                            const float *b_base, int xstride, const int (&pixoff)[PG], int wp,
                                            Side &&side) {
-  // 36 steps = 9 taps x KC/2 k-steps, software pipelined: the A/B fragments of step
-  // n+1 are read from LDS before the MFMAs of step n issue, so the ~100-cycle
-  // ds_read latency sits under 64*CT_TILES*PG cycles of matrix-pipe work.
-  constexpr int NSTEP = 9 * (KC / 2);
+  constexpr int NSTEP = TAPS * (KC / 2);
   float a[2][CT_TILES], bq[2][PG];
   auto fetch = [&](int step, float (&av)[CT_TILES], float (&bv)[PG]) {
     const int tap = step / (KC / 2), kk = step % (KC / 2);
     const int ky = tap / 3, kx = tap % 3;
     // LDS offset of the tap's source pixel relative to pixoff.  UP: output phase
     // (pr,pc) = (ky&1, kx&1) reads x[Y - (ky==2), X - (kx==2)]; the halo tile starts at (-1,-1).
-    const int toff = UP ? ((ky == 2 ? 0 : 1) * wp + (kx == 2 ? 0 : 1)) : (ky * wp + kx);
+    const int toff = (TAPS == 1) ? 0 : (UP ? ((ky == 2 ? 0 : 1) * wp + (kx == 2 ? 0 : 1)) : (ky * wp + kx));
 #pragma unroll
     for (int ct = 0; ct < CT_TILES; ++ct) av[ct] = a_base[(tap * KC + 2 * kk) * CT + ct * 32];
 #pragma unroll
@@ -117,9 +131,16 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NPH][CT_TILES][PG], con
   }
 }
 
+__device__ __forceinline__ float apply_act(float v, int act, float alpha, float scale, float slope) {
+  if (act == ACT_LRELU) return hf_lrelu(v, alpha, scale);
+  if (act == ACT_PRELU) return v > 0.0f ? v : v * slope;
+  return v;
+}
+
 // Epilogue.  MFMA D layout: row (= co) = (r&3) + 8*(r>>2) + 4*(lane>>5), col (= pixel) = lane&31.
-// Per pixel group the 16*CT_TILES demodulation / bias values of the lane's output
+// Per pixel group the 16*CT_TILES output-scale / bias / slope values of the lane's output
 // channels are fetched with independent loads up front (no load->wait->store chains).
+//   v = acc*d + noise_w*noise + bias ; v = act(v) ; v += residual
 template <int CT_TILES, int PG, bool UP, int NPH = (UP ? 4 : 1)>
 __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &G,
                                            f32x16 (&acc)[NPH][CT_TILES][PG], int co_wave, int wave_pg, int li,
@@ -127,7 +148,8 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
   const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
   const long long oplane = (long long)P.out_h * P.out_w;
   const bool partial = P.splits > 1;  // split-K: raw sums, epilogue runs in splitk_reduce
-  const float nw = (!UP && !partial && P.noise) ? P.noise_w[0] : 0.0f;
+  const bool full = !UP && !partial;
+  const float nw = (full && P.noise) ? P.noise_w[0] : 0.0f;
 #pragma unroll
   for (int g = 0; g < PG; ++g) {
     const int p = (wave_pg + g) * 32 + li;
@@ -137,18 +159,19 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
     const int Y = ty0 + py, X = tx0 + px, b = b0 + im;
     const bool pv = (Y < G.y0 + G.dh) && (X < G.x0 + G.dw) && (b < P.batch);
     if (!pv) continue;
-    float dmv[CT_TILES][16], bsv[CT_TILES][16];
+    float dmv[CT_TILES][16], bsv[CT_TILES][16], slv[CT_TILES][16];
 #pragma unroll
     for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int cc = min(co, P.cout - 1);
-        dmv[ct][r] = (P.d && !partial) ? P.d[(long long)b * P.cout + cc] : 1.0f;
-        bsv[ct][r] = (!UP && !partial && P.bias) ? P.bias[cc] : 0.0f;
+        dmv[ct][r] = (P.d && !partial) ? P.d[(long long)b * P.d_bstride + cc] : 1.0f;
+        bsv[ct][r] = (full && P.bias) ? P.bias[cc] : 0.0f;
+        slv[ct][r] = (full && P.act == ACT_PRELU) ? P.slope[cc] : 0.0f;
       }
     float nz = 0.0f;
-    if (!UP && !partial && P.noise) nz = nw * P.noise[(long long)b * P.noise_bstride + (long long)Y * P.w + X];
+    if (full && P.noise) nz = nw * P.noise[(long long)b * P.noise_bstride + (long long)Y * P.out_w + X];
     float *obase = partial ? P.partial + (long long)blockIdx.z * P.batch * P.cout * oplane : P.out;
 #pragma unroll
     for (int ct = 0; ct < CT_TILES; ++ct) {
@@ -156,7 +179,8 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
       for (int r = 0; r < 16; ++r) {
         const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (co >= P.cout) continue;
-        float *ob = obase + ((long long)b * P.cout + co) * oplane;
+        const long long obofs = ((long long)b * P.cout + co) * oplane;
+        float *ob = obase + obofs;
         const float dm = dmv[ct][r];
         if (UP) {
           // phases (pr,0) and (pr,1) are neighbouring columns: one 8-byte store per row
@@ -177,27 +201,35 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
             }
           }
         } else {
-          float v = acc[0][ct][g][r] * dm + nz;
-          if (!partial && P.bias) v = hf_lrelu(v + bsv[ct][r], P.alpha, P.scale);
-          ob[(long long)Y * P.out_w + X] = v;
+          const long long pofs = (long long)Y * P.out_w + X;
+          float v = acc[0][ct][g][r] * dm;
+          if (full) {
+            v = apply_act(v + nz + bsv[ct][r], P.act, P.alpha, P.scale, slv[ct][r]);
+            if (P.residual) v += P.residual[obofs + pofs];
+          }
+          ob[pofs] = v;
         }
       }
     }
   }
 }
 
+// ------------------------------------------------------------------------------
+// General kernel: any channel counts, multi-image tiles, stride 1/2, 3x3 / 1x1,
+// split-K first pass.  Synchronous staging (load -> LDS -> barrier -> MFMA).
 // CT_TILES x PG 32x32 MFMA tiles per wave; WAVES_CO x WAVES_PX = 4 waves.
-template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP>
-__global__ __launch_bounds__(kThreads) void modconv_mfma(const ConvParams P) {
+// ------------------------------------------------------------------------------
+template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int TAPS>
+__global__ __launch_bounds__(kThreads) void conv_mfma(const ConvParams P) {
   static_assert(WAVES_CO * WAVES_PX == 4, "4 waves per block");
+  static_assert(!(UP && TAPS != 9), "transposed conv is 3x3");
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
-  constexpr int PT = 32 * PG * WAVES_PX;
   constexpr int NPH = UP ? 4 : 1;
-  constexpr int HALO = UP ? 1 : 2;  // UP needs x[Y-1], x[X-1] only; same-res needs +-1
+  constexpr int KH = (TAPS == 9) ? 3 : 1;
 
   HF_DYN_LDS;
-  float *wl = reinterpret_cast<float *>(hf_dyn_lds);  // [9][KC][CT]
-  float *xl = wl + 9 * KC * CT;                       // [KC][xs_max]
+  float *wl = reinterpret_cast<float *>(hf_dyn_lds);  // [TAPS][KC][CT]
+  float *xl = wl + TAPS * KC * CT;                    // [KC][xs_max]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -219,9 +251,13 @@ __global__ __launch_bounds__(kThreads) void modconv_mfma(const ConvParams P) {
   const int ty = t % G.tiles_y;
   const int tb = t / G.tiles_y;
   const int tw = 1 << G.lg_tw, th = 1 << G.lg_th, nb = 1 << G.lg_nb;
-  const int wp = tw + HALO, hp = th + HALO;
+  const int st = UP ? 1 : P.stride;
+  // input rows / cols a tile needs: UP x[Y-1..Y]; otherwise (th-1)*stride + KH
+  const int wp = UP ? tw + 1 : (tw - 1) * st + KH;
+  const int hp = UP ? th + 1 : (th - 1) * st + KH;
+  const int pad = UP ? 1 : KH / 2;
   const int xs = nb * hp * wp;         // LDS floats per staged channel (<= xs_max)
-  const int ty0 = G.y0 + ty * th;      // first pixel row / col of the tile
+  const int ty0 = G.y0 + ty * th;      // first output pixel row / col of the tile
   const int tx0 = G.x0 + tx * tw;
   const int b0 = tb * nb;
   const long long plane = (long long)P.h * P.w;
@@ -240,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void modconv_mfma(const ConvParams P) {
       const int rem = idx - im * (hp * wp);
       const int hy = rem / wp;
       const int hx = rem - hy * wp;
-      const int ys = ty0 + hy - 1, xc = tx0 + hx - 1;
+      const int ys = ty0 * st + hy - pad, xc = tx0 * st + hx - pad;
       if (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w && b0 + im < P.batch) {
         e_ofs[e] = (int)((long long)im * P.cin * plane + (long long)ys * P.w + xc);
         e_img[e] = im;
@@ -256,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void modconv_mfma(const ConvParams P) {
     const int px = p & (tw - 1);
     const int py = (p >> G.lg_tw) & (th - 1);
     const int im = p >> (G.lg_tw + G.lg_th);
-    pixoff[g] = im * hp * wp + py * wp + px;
+    pixoff[g] = im * hp * wp + py * st * wp + px * st;
   }
 
   f32x16 acc[NPH][CT_TILES][PG];
@@ -281,7 +317,7 @@ __global__ __launch_bounds__(kThreads) void modconv_mfma(const ConvParams P) {
     // ---- stage weights: wl[tap][kc][c] = wt[tap][ci0+kc][co0+c] ---------------
     if (cout_vec4) {
       constexpr int C4 = CT / 4;
-      for (int i = tid; i < 9 * KC * C4; i += kThreads) {
+      for (int i = tid; i < TAPS * KC * C4; i += kThreads) {
         const int c4 = i % C4;
         const int kc = (i / C4) % KC;
         const int tap = i / (C4 * KC);
@@ -292,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void modconv_mfma(const ConvParams P) {
         *reinterpret_cast<float4 *>(wl + (tap * KC + kc) * CT + c4 * 4) = v;
       }
     } else {
-      for (int i = tid; i < 9 * KC * CT; i += kThreads) {
+      for (int i = tid; i < TAPS * KC * CT; i += kThreads) {
         const int c = i % CT;
         const int kc = (i / CT) % KC;
         const int tap = i / (CT * KC);
@@ -303,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void modconv_mfma(const ConvParams P) {
       }
     }
 
-    // ---- stage the modulated halo tile: xl[kc][idx] = s[b,ci] * x[b,ci,ys,xc] ---
+    // ---- stage the halo tile: xl[kc][idx] = s[b,ci] * x[b,ci,ys,xc] + t[ci] (0 outside) ---
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       const int ci = ci0 + kc;
@@ -315,7 +351,8 @@ __global__ __launch_bounds__(kThreads) void modconv_mfma(const ConvParams P) {
           float v = 0.f;
           if (cv && e_ofs[e] >= 0) {
             v = xb[(long long)ci * plane + e_ofs[e]];
-            if (P.s) v *= P.s[(long long)(b0 + e_img[e]) * P.cin + ci];
+            if (P.s) v *= P.s[(long long)(b0 + e_img[e]) * P.s_bstride + ci];
+            if (P.t) v += P.t[ci];
           }
           xl[kc * P.xs_max + idx] = v;
         }
@@ -323,29 +360,28 @@ __global__ __launch_bounds__(kThreads) void modconv_mfma(const ConvParams P) {
     }
     __syncthreads();
 
-    mfma_chunk<CT_TILES, PG, CT, UP>(acc, a_base, b_base, P.xs_max, pixoff, wp, NoSideWork());
+    mfma_chunk<CT_TILES, PG, CT, UP, TAPS>(acc, a_base, b_base, P.xs_max, pixoff, wp, NoSideWork());
   }
 
   store_tile<CT_TILES, PG, UP>(P, G, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
-
 // ------------------------------------------------------------------------------
-// Pipelined variant for the large layers (the >95 % of the FLOPs).
+// Pipelined variant for the large 3x3 stride-1 layers (the >95 % of the FLOPs).
 //
-// Preconditions (checked on the host): cin % KC == 0, cout % CT == 0, one tile
-// family whose tiles hold a single image (lg_nb == 0), xs <= XEP * NT.
+// Preconditions (checked on the host): cin % KC == 0, cout % CT == 0, every tile
+// family holds a single image per tile (lg_nb == 0), xs <= XEP * NT.
 // Double-buffered LDS: while the waves run the MFMAs of chunk c out of buffer
 // c&1, the weights of chunk c+1 stream straight into the other buffer with
 // global_load_lds_dwordx4 (1 KiB per wave instruction, no VGPRs) and the halo
 // tile of chunk c+1 is prefetched into registers; it is multiplied by the
-// (block-uniform) modulation s[b,ci] and written to LDS after the MFMAs, then one
-// barrier per chunk.  Global latency is hidden behind 9*KC/2*CT_TILES*PG MFMAs.
-// ------------------------------------------------------------------------------
+// (block-uniform) input scale and written to LDS late in the chunk, then one
+// barrier per chunk.  The staging instructions are spread one per MFMA step.
 // ABLATE (timing experiments only, results are wrong when != 0): 1 = no staging traffic
 // inside the loop (barriers kept), 2 = no staging and no barriers.
+// ------------------------------------------------------------------------------
 template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int ABLATE = 0>
-__global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void modconv_mfma_pipe(const ConvParams P) {
+__global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const ConvParams P) {
   constexpr int NW = WAVES_CO * WAVES_PX;
   constexpr int NT = 64 * NW;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
@@ -386,7 +422,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void modconv_mfma_pipe(co
   const int tx0 = G.x0 + tx * tw;
   const long long plane = (long long)P.h * P.w;
   const float *xb = P.x + (long long)b0 * P.cin * plane;
-  const float *sb = P.s ? P.s + (long long)b0 * P.cin : nullptr;
+  const float *sb = P.s ? P.s + (long long)b0 * P.s_bstride : nullptr;
 
   int e_ofs[XEP];  // offset of the thread's halo elements inside a channel plane, -1 = zero
 #pragma unroll
@@ -432,16 +468,19 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void modconv_mfma_pipe(co
     }
   };
   float xr[KC][XEP];
-  float sr[KC];  // modulation of the prefetched channels (fetched with the halo, not at write time)
+  float sr[KC], tr[KC];  // input affine of the prefetched channels (fetched with the halo)
   auto load_piece = [&](int i, int ci0) {
     const int kc = i / XEP, e = i % XEP;
     xr[kc][e] = (e_ofs[e] >= 0) ? xb[(long long)(ci0 + kc) * plane + e_ofs[e]] : 0.0f;
-    if (e == 0) sr[kc] = sb ? sb[ci0 + kc] : 1.0f;
+    if (e == 0) {
+      sr[kc] = sb ? sb[ci0 + kc] : 1.0f;
+      tr[kc] = P.t ? P.t[ci0 + kc] : 0.0f;
+    }
   };
-  auto write_piece = [&](int i, int /*ci0*/, float *xl) {
+  auto write_piece = [&](int i, float *xl) {
     const int kc = i / XEP, e = i % XEP;
     const int idx = tid + e * NT;
-    if (idx < xs) xl[kc * P.xs_max + idx] = xr[kc][e] * sr[kc];
+    if (idx < xs) xl[kc * P.xs_max + idx] = (e_ofs[e] >= 0) ? fmaf(xr[kc][e], sr[kc], tr[kc]) : 0.0f;
   };
 
   // prologue: chunk 0 into buffer 0
@@ -450,7 +489,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void modconv_mfma_pipe(co
 #pragma unroll
   for (int i = 0; i < NL; ++i) load_piece(i, 0);
 #pragma unroll
-  for (int i = 0; i < NL; ++i) write_piece(i, 0, xl0);
+  for (int i = 0; i < NL; ++i) write_piece(i, xl0);
   __syncthreads();
 
   // Slots of the 36-step chunk: DMA pieces first, halo loads next, LDS writes of the
@@ -483,16 +522,38 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void modconv_mfma_pipe(co
       } else if (step >= W_FIRST) {
 #pragma unroll
         for (int q = 0; q < LPS; ++q)
-          if ((step - W_FIRST) * LPS + q < NL) write_piece((step - W_FIRST) * LPS + q, ci_next, xl_next);
+          if ((step - W_FIRST) * LPS + q < NL) write_piece((step - W_FIRST) * LPS + q, xl_next);
       }
     };
     const float *a_base = wl0 + cur * WCHUNK + lh * CT + wave_co + li;
     const float *b_base = xl0 + (cur * KC + lh) * P.xs_max;
-    mfma_chunk<CT_TILES, PG, CT, UP>(acc, a_base, b_base, P.xs_max, pixoff, wp, side);
+    mfma_chunk<CT_TILES, PG, CT, UP, 9>(acc, a_base, b_base, P.xs_max, pixoff, wp, side);
     if (ABLATE < 2) __syncthreads();  // also drains the weight DMA (vmcnt) before anyone reads the other buffer
   }
 
   store_tile<CT_TILES, PG, UP>(P, G, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+}
+
+// Split-K second pass: out = epilogue(d * sum_z partial[z]) - deterministic (fixed z order).
+__global__ __launch_bounds__(256) void splitk_reduce(const ConvParams P, long long slab, int with_epilogue) {
+  const long long oplane = (long long)P.out_h * P.out_w;
+  const float nw = (with_epilogue && P.noise) ? P.noise_w[0] : 0.0f;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slab; i += stride) {
+    float v = 0.0f;
+    for (int z = 0; z < P.splits; ++z) v += P.partial[(long long)z * slab + i];
+    const long long pl = i / oplane;
+    const int co = (int)(pl % P.cout);
+    const long long b = pl / P.cout;
+    if (P.d) v *= P.d[b * P.d_bstride + co];
+    if (with_epilogue) {
+      if (P.noise) v = fmaf(nw, P.noise[b * P.noise_bstride + (i - pl * oplane)], v);
+      if (P.bias) v += P.bias[co];
+      v = apply_act(v, P.act, P.alpha, P.scale, P.act == ACT_PRELU ? P.slope[co] : 0.0f);
+      if (P.residual) v += P.residual[i];
+    }
+    P.out[i] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------
@@ -507,7 +568,7 @@ inline int ilog2(int v) {
 inline int pow2_floor(int v) { return 1 << ilog2(v); }
 inline int pow2_ceil(int v) { return (v & (v - 1)) ? (pow2_floor(v) << 1) : v; }
 
-// Tiles of `pt` pixels over a dh x dw domain (per image) of `batch` images.
+// Tiles of `pt` pixels over a dh x dw OUTPUT domain (per image) of `batch` images.
 // Prefers full 32-pixel rows; small planes put several images in one tile.
 inline TileGeom make_geom(int y0, int x0, int dh, int dw, int batch, int pt, int first_block,
                           bool one_image = false) {
@@ -533,15 +594,18 @@ inline TileGeom make_geom(int y0, int x0, int dh, int dw, int batch, int pt, int
   return g;
 }
 inline int geom_blocks(const TileGeom &g) { return g.tiles_x * g.tiles_y * g.tiles_b; }
-inline int geom_xs(const TileGeom &g, int halo) {
-  return (1 << g.lg_nb) * ((1 << g.lg_th) + halo) * ((1 << g.lg_tw) + halo);
+// LDS floats per staged channel; ext = extra rows/cols beyond (t-1)*stride + 1
+inline int geom_xs(const TileGeom &g, int stride, int ext) {
+  const int hp = ((1 << g.lg_th) - 1) * stride + 1 + ext, wp = ((1 << g.lg_tw) - 1) * stride + 1 + ext;
+  return (1 << g.lg_nb) * hp * wp;
 }
 
-template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP>
-int launch_modconv(ConvParams &P, hipStream_t st) {
+template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int TAPS>
+int launch_conv(ConvParams &P, hipStream_t st) {
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
   constexpr int PT = 32 * PG * WAVES_PX;
-  constexpr int HALO = UP ? 1 : 2;
+  const int ext = UP ? 1 : (TAPS == 9 ? 2 : 0);
+  const int stride = UP ? 1 : P.stride;
   int nblocks = 0;
   if (UP) {
     // (2h+1)x(2w+1) output = phases of the (h+1)x(w+1) (Y,X) domain: interior h x w
@@ -555,34 +619,34 @@ int launch_modconv(ConvParams &P, hipStream_t st) {
     nblocks += geom_blocks(P.g[2]);
   } else {
     P.n_geom = 1;
-    P.g[0] = make_geom(0, 0, P.h, P.w, P.batch, PT, 0);
+    P.g[0] = make_geom(0, 0, P.out_h, P.out_w, P.batch, PT, 0);
     nblocks = geom_blocks(P.g[0]);
   }
   int xs_max = 0;
-  for (int i = 0; i < P.n_geom; ++i) xs_max = max(xs_max, geom_xs(P.g[i], HALO));
+  for (int i = 0; i < P.n_geom; ++i) xs_max = max(xs_max, geom_xs(P.g[i], stride, ext));
   if (xs_max > kMaxElemPerCi * kThreads) return HF_E_INVALID;
   for (int i = 0; i < P.n_geom; ++i)  // staging offsets are 32-bit, relative to the tile's first image
     if (((long long)P.cin << P.g[i].lg_nb) * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
   P.xs_max = (xs_max + 3) & ~3;
-  const size_t lds = (size_t)(9 * KC * CT + KC * P.xs_max) * sizeof(float);
+  const size_t lds = (size_t)(TAPS * KC * CT + KC * P.xs_max) * sizeof(float);
   if (P.splits < 1) P.splits = 1;
   dim3 grid(nblocks, hf_cdiv(P.cout, CT), P.splits);
   if (grid.y > 65535) return HF_E_INVALID;
-  hipLaunchKernelGGL((modconv_mfma<CT_TILES, PG, WAVES_CO, WAVES_PX, UP>), grid, dim3(kThreads), lds, st, P);
+  hipLaunchKernelGGL((conv_mfma<CT_TILES, PG, WAVES_CO, WAVES_PX, UP, TAPS>), grid, dim3(kThreads), lds, st, P);
   return hf_launch_status();
 }
 
-
-// Pipelined launch of the interior tile family; returns HF_E_INVALID if the shape
-// does not meet the kernel's preconditions (caller then uses the general kernel).
+// Pipelined launch (interior + rim families in one launch); returns HF_E_INVALID if the
+// shape does not meet the kernel's preconditions (caller then uses the general kernel).
 template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int ABLATE = 0>
-int launch_modconv_pipe(ConvParams &P, hipStream_t st) {
+int launch_conv_pipe(ConvParams &P, hipStream_t st) {
   constexpr int NT = 64 * WAVES_CO * WAVES_PX;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
   constexpr int PT = 32 * PG * WAVES_PX;
   constexpr int HALO = UP ? 1 : 2;
   constexpr int XEP = ((PT / 32 + HALO) * (32 + HALO) + NT - 1) / NT;
   if (P.cin % KC || P.cout % CT || (P.cout & 3)) return HF_E_INVALID;
+  if (!UP && P.stride != 1) return HF_E_INVALID;
   if ((((size_t)P.wt) & 15) != 0) return HF_E_INVALID;
   P.splits = 1;
   P.n_geom = 1;
@@ -598,7 +662,7 @@ int launch_modconv_pipe(ConvParams &P, hipStream_t st) {
   int xs = 0;
   for (int i = 0; i < P.n_geom; ++i) {
     if (P.g[i].lg_nb != 0) return HF_E_INVALID;  // the pipelined kernel wants one image per tile
-    xs = max(xs, geom_xs(P.g[i], HALO));
+    xs = max(xs, geom_xs(P.g[i], 1, HALO));
   }
   if (xs > XEP * NT) return HF_E_INVALID;
   if ((long long)P.cin * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
@@ -607,38 +671,17 @@ int launch_modconv_pipe(ConvParams &P, hipStream_t st) {
   if (lds > 160 * 1024) return HF_E_INVALID;
   dim3 grid(nblocks, P.cout / CT);
   if (grid.y > 65535) return HF_E_INVALID;
-  hipLaunchKernelGGL((modconv_mfma_pipe<CT_TILES, PG, WAVES_CO, WAVES_PX, UP, ABLATE>), grid, dim3(NT), lds, st, P);
+  hipLaunchKernelGGL((conv_mfma_pipe<CT_TILES, PG, WAVES_CO, WAVES_PX, UP, ABLATE>), grid, dim3(NT), lds, st, P);
   return hf_launch_status();
 }
 
-// Split-K second pass: out = epilogue(d * sum_z partial[z]) - deterministic (fixed z order).
-__global__ __launch_bounds__(256) void splitk_reduce(const ConvParams P, long long slab, int with_epilogue) {
-  const long long oplane = (long long)P.out_h * P.out_w;
-  const float nw = (with_epilogue && P.noise) ? P.noise_w[0] : 0.0f;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slab; i += stride) {
-    float v = 0.0f;
-    for (int z = 0; z < P.splits; ++z) v += P.partial[(long long)z * slab + i];
-    const long long pl = i / oplane;
-    const int co = (int)(pl % P.cout);
-    const long long b = pl / P.cout;
-    if (P.d) v *= P.d[b * P.cout + co];
-    if (with_epilogue) {
-      if (P.noise) v = fmaf(nw, P.noise[b * P.noise_bstride + (i - pl * oplane)], v);
-      if (P.bias) v = hf_lrelu(v + P.bias[co], P.alpha, P.scale);
-    }
-    P.out[i] = v;
-  }
-}
-
-// Split-K plan for the small-plane layers: few (co tile, pixel tile) pairs but up to
-// 64 K-chunks.  Pure function of the shape so that callers can size the workspace.
-inline int splitk_plan(int batch, int cin, int cout, int h, int w, bool up) {
+// Split-K plan for layers with few (co tile, pixel tile) pairs but many K-chunks.
+// Pure function of the shape so that callers can size the workspace.
+inline int splitk_plan(int batch, int cin, int cout, int out_h, int out_w) {
   const int PT = 64, CT = 64;  // the small-plane configuration <1,1,2,2>
-  const long long per_img = ((long long)h * w + PT - 1) / PT;
+  const long long per_img = ((long long)out_h * out_w + PT - 1) / PT;
   const long long base = batch * per_img * ((cout + CT - 1) / CT);
   if (base >= 256) return 1;  // the 64x64 tiling already fills the chip
-  (void)up;
   const int nchunks = (cin + KC - 1) / KC;
   int s = (int)((512 + base - 1) / base);
   if (s > nchunks) s = nchunks;
@@ -656,45 +699,30 @@ int launch_splitk_reduce(ConvParams &P, bool with_epilogue, hipStream_t st) {
 
 // Tuning hook (hf_debug_set_dispatch): 0 = built-in heuristics.
 int g_force_same = 0, g_force_up = 0;
-int g_last_cfg = 0;   // tile configuration id of the last modulated-conv call (see the dispatch switches)
+int g_last_cfg = 0;   // tile configuration id of the last conv call (see the dispatch switches)
 int g_last_path = 0;  // 1 = general kernel, 2 = pipelined kernel, 3 = split-K (general kernel + reduce)
 
-}  // namespace
-
-extern "C" long long hf_modconv_workspace_floats(int batch, int cin, int cout, int h, int w, int upsample) {
-  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
-  const int s = splitk_plan(batch, cin, cout, h, w, upsample != 0);
-  if (s <= 1) return 0;
-  const long long oh = upsample ? 2 * h + 1 : h, ow = upsample ? 2 * w + 1 : w;
-  return (long long)s * batch * cout * oh * ow;
+// split-K through `workspace` with the small-plane general configuration
+template <bool UP, int TAPS>
+int run_splitk(ConvParams &P, int sk, float *workspace, long long workspace_floats, hipStream_t st) {
+  if (!workspace || workspace_floats < (long long)sk * P.batch * P.cout * P.out_h * P.out_w) return HF_E_WORKSPACE;
+  const int nchunks = (P.cin + KC - 1) / KC;
+  P.splits = sk;
+  P.chunks_per_split = (nchunks + sk - 1) / sk;
+  P.partial = workspace;
+  int rc = launch_conv<1, 1, 2, 2, UP, TAPS>(P, st);
+  if (rc != HF_OK) return rc;
+  g_last_path = 3;
+  return launch_splitk_reduce(P, !UP, st);
 }
 
-extern "C" int hf_modconv3x3_f32(float *out, const float *x, const float *wt, const float *s, const float *d,
-                                 const float *noise, const float *noise_w, long long noise_bstride,
-                                 const float *bias, int batch, int cin, int cout, int h, int w, float alpha,
-                                 float scale, float *workspace, long long workspace_floats, void *stream) {
-  if (!out || !x || !wt || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (noise && !noise_w))
-    return HF_E_INVALID;
-  ConvParams P{};
-  P.out = out; P.x = x; P.wt = wt; P.s = s; P.d = d; P.noise = noise; P.noise_w = noise_w; P.bias = bias;
-  P.noise_bstride = noise_bstride;
-  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = h; P.out_w = w;
-  P.alpha = alpha; P.scale = scale;
-  hipStream_t st = (hipStream_t)stream;
-  const long long pixels = (long long)batch * h * w;
-  {  // split-K for the small planes (deterministic two-pass reduction through `workspace`)
-    const int sk = (g_force_same == 0) ? splitk_plan(batch, cin, cout, h, w, false) : 1;
-    if (sk > 1) {
-      if (!workspace || workspace_floats < (long long)sk * batch * cout * h * w) return HF_E_WORKSPACE;
-      const int nchunks = (cin + KC - 1) / KC;
-      P.splits = sk;
-      P.chunks_per_split = (nchunks + sk - 1) / sk;
-      P.partial = workspace;
-      int rc = launch_modconv<1, 1, 2, 2, false>(P, st);
-      if (rc != HF_OK) return rc;
-      g_last_path = 3;
-      return launch_splitk_reduce(P, true, st);
-    }
+// 3x3 stride-1 convolution (modulated or plain): pipelined kernel when the shape
+// qualifies, else the general one.
+int run_conv3x3_s1(ConvParams &P, float *workspace, long long workspace_floats, hipStream_t st) {
+  const int batch = P.batch, cout = P.cout, h = P.h, w = P.w;
+  {
+    const int sk = (g_force_same == 0) ? splitk_plan(batch, P.cin, cout, h, w) : 1;
+    if (sk > 1) return run_splitk<false, 9>(P, sk, workspace, workspace_floats, st);
   }
   int cfg = g_force_same;
   if (cfg == 0) {
@@ -712,29 +740,51 @@ extern "C" int hf_modconv3x3_f32(float *out, const float *x, const float *wt, co
   g_last_cfg = cfg;
   int rc = HF_E_INVALID;
   switch (cfg) {  // 1x: pipelined (fall through to the general kernel when the shape does not qualify)
-    case 11: rc = launch_modconv_pipe<2, 2, 2, 4, false>(P, st); break;  // 128 co x 256 px, 8 waves
-    case 12: rc = launch_modconv_pipe<2, 2, 1, 4, false>(P, st); break;  //  64 co x 256 px, 4 waves
-    case 13: rc = launch_modconv_pipe<1, 2, 1, 4, false>(P, st); break;  //  32 co x 256 px, 4 waves
-    case 14: rc = launch_modconv_pipe<2, 2, 2, 2, false>(P, st); break;  // 128 co x 128 px, 4 waves
-    case 15: rc = launch_modconv_pipe<1, 1, 2, 2, false>(P, st); break;  //  64 co x  64 px, 4 waves
-    case 16: rc = launch_modconv_pipe<1, 4, 1, 4, false>(P, st); break;  //  32 co x 512 px, 4 waves
-    case 91: rc = launch_modconv_pipe<2, 2, 2, 4, false, 1>(P, st); break;  // timing ablations of cfg 11
-    case 92: rc = launch_modconv_pipe<2, 2, 2, 4, false, 2>(P, st); break;
+    case 11: rc = launch_conv_pipe<2, 2, 2, 4, false>(P, st); break;  // 128 co x 256 px, 8 waves
+    case 12: rc = launch_conv_pipe<2, 2, 1, 4, false>(P, st); break;  //  64 co x 256 px, 4 waves
+    case 13: rc = launch_conv_pipe<1, 2, 1, 4, false>(P, st); break;  //  32 co x 256 px, 4 waves
+    case 14: rc = launch_conv_pipe<2, 2, 2, 2, false>(P, st); break;  // 128 co x 128 px, 4 waves
+    case 15: rc = launch_conv_pipe<1, 1, 2, 2, false>(P, st); break;  //  64 co x  64 px, 4 waves
+    case 16: rc = launch_conv_pipe<1, 4, 1, 4, false>(P, st); break;  //  32 co x 512 px, 4 waves
+    case 91: rc = launch_conv_pipe<2, 2, 2, 4, false, 1>(P, st); break;  // timing ablations of cfg 11
+    case 92: rc = launch_conv_pipe<2, 2, 2, 4, false, 2>(P, st); break;
     default: break;
   }
   g_last_path = 2;
   if (rc != HF_E_INVALID) return rc;
   g_last_path = 1;
-  switch (cfg) {
-    case 1: case 11: case 14: if (cout > 64) return launch_modconv<2, 2, 2, 2, false>(P, st); break;
-    case 2: case 15: return launch_modconv<1, 1, 2, 2, false>(P, st);
-    case 3: case 12: if (cout > 32) return launch_modconv<2, 2, 1, 4, false>(P, st); break;
-    default: break;
-  }
-  if (cout <= 32) return launch_modconv<1, 2, 1, 4, false>(P, st);       // 32 co x 256 px
-  if (pixels <= 8192) return launch_modconv<1, 1, 2, 2, false>(P, st);   // 64 co x 64 px (small planes)
-  if (cout <= 64) return launch_modconv<2, 2, 1, 4, false>(P, st);       // 64 co x 256 px
-  return launch_modconv<2, 2, 2, 2, false>(P, st);                        // 128 co x 128 px
+  const long long pixels = (long long)batch * h * w;
+  if (cout <= 32) return launch_conv<1, 2, 1, 4, false, 9>(P, st);       // 32 co x 256 px
+  if (pixels <= 8192) return launch_conv<1, 1, 2, 2, false, 9>(P, st);   // 64 co x 64 px (small planes)
+  if (cout <= 64) return launch_conv<2, 2, 1, 4, false, 9>(P, st);       // 64 co x 256 px
+  return launch_conv<2, 2, 2, 2, false, 9>(P, st);                        // 128 co x 128 px
+}
+
+}  // namespace
+
+extern "C" long long hf_modconv_workspace_floats(int batch, int cin, int cout, int h, int w, int upsample) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+  const int s = splitk_plan(batch, cin, cout, h, w);
+  if (s <= 1) return 0;
+  const long long oh = upsample ? 2 * h + 1 : h, ow = upsample ? 2 * w + 1 : w;
+  return (long long)s * batch * cout * oh * ow;
+}
+
+extern "C" int hf_modconv3x3_f32(float *out, const float *x, const float *wt, const float *s, const float *d,
+                                 const float *noise, const float *noise_w, long long noise_bstride,
+                                 const float *bias, int batch, int cin, int cout, int h, int w, float alpha,
+                                 float scale, float *workspace, long long workspace_floats, void *stream) {
+  if (!out || !x || !wt || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (noise && !noise_w))
+    return HF_E_INVALID;
+  ConvParams P{};
+  P.out = out; P.x = x; P.wt = wt; P.s = s; P.d = d; P.noise = noise; P.noise_w = noise_w; P.bias = bias;
+  P.s_bstride = cin; P.d_bstride = cout;
+  P.noise_bstride = noise_bstride;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = h; P.out_w = w;
+  P.stride = 1;
+  P.act = bias ? ACT_LRELU : ACT_NONE;
+  P.alpha = alpha; P.scale = scale;
+  return run_conv3x3_s1(P, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 extern "C" int hf_modconv3x3_up_f32(float *tmp, const float *x, const float *wt, const float *s,
@@ -743,21 +793,13 @@ extern "C" int hf_modconv3x3_up_f32(float *tmp, const float *x, const float *wt,
   if (!tmp || !x || !wt || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return HF_E_INVALID;
   ConvParams P{};
   P.out = tmp; P.x = x; P.wt = wt; P.s = s; P.d = d;
+  P.s_bstride = cin; P.d_bstride = cout;
   P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = 2 * h + 1; P.out_w = 2 * w + 1;
+  P.stride = 1;
   hipStream_t st = (hipStream_t)stream;
   {
-    const int sk = (g_force_up == 0) ? splitk_plan(batch, cin, cout, h, w, true) : 1;
-    if (sk > 1) {
-      if (!workspace || workspace_floats < (long long)sk * batch * cout * P.out_h * P.out_w) return HF_E_WORKSPACE;
-      const int nchunks = (cin + KC - 1) / KC;
-      P.splits = sk;
-      P.chunks_per_split = (nchunks + sk - 1) / sk;
-      P.partial = workspace;
-      int rc = launch_modconv<1, 1, 2, 2, true>(P, st);
-      if (rc != HF_OK) return rc;
-      g_last_path = 3;
-      return launch_splitk_reduce(P, false, st);
-    }
+    const int sk = (g_force_up == 0) ? splitk_plan(batch, cin, cout, h, w) : 1;
+    if (sk > 1) return run_splitk<true, 9>(P, sk, workspace, workspace_floats, st);
   }
   int cfg = g_force_up;
   if (cfg == 0) {
@@ -771,18 +813,60 @@ extern "C" int hf_modconv3x3_up_f32(float *tmp, const float *x, const float *wt,
   g_last_cfg = cfg;
   int rc = HF_E_INVALID;
   switch (cfg) {
-    case 21: rc = launch_modconv_pipe<1, 2, 2, 2, true>(P, st); break;  // 64 co x 128 px x 4 phases, 4 waves
-    case 22: rc = launch_modconv_pipe<1, 2, 1, 4, true>(P, st); break;  // 32 co x 256 px x 4 phases, 4 waves
-    case 23: rc = launch_modconv_pipe<1, 1, 2, 2, true>(P, st); break;  // 64 co x  64 px x 4 phases, 4 waves
-    case 24: rc = launch_modconv_pipe<1, 2, 2, 4, true>(P, st); break;  // 64 co x 256 px x 4 phases, 8 waves
-    case 25: rc = launch_modconv_pipe<1, 1, 1, 4, true>(P, st); break;  // 32 co x 128 px x 4 phases, 4 waves
+    case 21: rc = launch_conv_pipe<1, 2, 2, 2, true>(P, st); break;  // 64 co x 128 px x 4 phases, 4 waves
+    case 22: rc = launch_conv_pipe<1, 2, 1, 4, true>(P, st); break;  // 32 co x 256 px x 4 phases, 4 waves
+    case 23: rc = launch_conv_pipe<1, 1, 2, 2, true>(P, st); break;  // 64 co x  64 px x 4 phases, 4 waves
+    case 24: rc = launch_conv_pipe<1, 2, 2, 4, true>(P, st); break;  // 64 co x 256 px x 4 phases, 8 waves
+    case 25: rc = launch_conv_pipe<1, 1, 1, 4, true>(P, st); break;  // 32 co x 128 px x 4 phases, 4 waves
     default: break;
   }
   g_last_path = 2;
   if (rc != HF_E_INVALID) return rc;  // interior + rim families in one pipelined launch
   g_last_path = 1;
-  if (cout <= 32) return launch_modconv<1, 1, 1, 4, true>(P, st);  // 32 co x 128 px x 4 phases
-  return launch_modconv<1, 1, 2, 2, true>(P, st);                   // 64 co x 64 px x 4 phases
+  if (cout <= 32) return launch_conv<1, 1, 1, 4, true, 9>(P, st);  // 32 co x 128 px x 4 phases
+  return launch_conv<1, 1, 2, 2, true, 9>(P, st);                   // 64 co x 64 px x 4 phases
+}
+
+extern "C" long long hf_conv2d_workspace_floats(int batch, int cin, int cout, int h, int w, int k,
+                                                int stride) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || stride <= 0) return 0;
+  (void)k;
+  const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
+  const int s = splitk_plan(batch, cin, cout, oh, ow);
+  return s <= 1 ? 0 : (long long)s * batch * cout * oh * ow;
+}
+
+extern "C" int hf_conv2d_f32(float *out, const float *x, const float *wt, const float *in_scale,
+                             const float *in_shift, const float *out_scale, const float *bias, int act,
+                             const float *slope, float alpha, const float *residual, int batch, int cin,
+                             int cout, int h, int w, int k, int stride, float *workspace,
+                             long long workspace_floats, void *stream) {
+  if (!out || !x || !wt || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (k != 1 && k != 3) ||
+      (stride != 1 && stride != 2) || act < ACT_NONE || act > ACT_PRELU || (act == ACT_PRELU && !slope))
+    return HF_E_INVALID;
+  ConvParams P{};
+  P.out = out; P.x = x; P.wt = wt; P.s = in_scale; P.t = in_shift; P.d = out_scale; P.bias = bias;
+  P.slope = slope; P.residual = residual;
+  P.s_bstride = 0; P.d_bstride = 0;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w;
+  P.out_h = (h - 1) / stride + 1; P.out_w = (w - 1) / stride + 1;
+  P.stride = stride;
+  P.act = act; P.alpha = alpha; P.scale = 1.0f;
+  hipStream_t st = (hipStream_t)stream;
+  if (k == 3 && stride == 1) return run_conv3x3_s1(P, workspace, workspace_floats, st);
+  // strided 3x3 and 1x1: general kernel (a few % of the encoders' FLOPs), split-K when small
+  const int sk = splitk_plan(batch, cin, cout, P.out_h, P.out_w);
+  g_last_cfg = 2;
+  if (sk > 1) return (k == 3) ? run_splitk<false, 9>(P, sk, workspace, workspace_floats, st)
+                              : run_splitk<false, 1>(P, sk, workspace, workspace_floats, st);
+  g_last_path = 1;
+  const long long opix = (long long)batch * P.out_h * P.out_w;
+  if (k == 3) {
+    if (cout > 64 && opix > 8192) return launch_conv<2, 2, 2, 2, false, 9>(P, st);  // 128 co x 128 px
+    return launch_conv<1, 1, 2, 2, false, 9>(P, st);
+  }
+  if (cout > 64 && opix > 8192) return launch_conv<2, 2, 2, 2, false, 1>(P, st);
+  return launch_conv<1, 1, 2, 2, false, 1>(P, st);
 }
 
 extern "C" int hf_debug_last_path(void) { return g_last_path * 100 + (g_last_path == 3 ? 0 : g_last_cfg); }

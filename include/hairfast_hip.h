@@ -142,6 +142,68 @@ int hf_torgb_f32(float *out, const float *x, const float *wt, const float *s, co
                  const float *skip, const float *kernel4x4, int batch, int cin, int h, int w,
                  void *stream);
 
+/* ===========================================================================
+ * Encoders (e4e Encoder4Editing, FeatureStyle fs_encoder_v2): the convolution with its
+ * surrounding inference-mode BatchNorm / activation / residual folded in, and the small
+ * operators around it.  All tensors NCHW fp32.
+ * =========================================================================== */
+
+/* Conv2d weight [cout,cin,k,k] (torch layout) -> wt[k*k][cin][cout] * scale; k = 1 or 3.
+ * One-time re-layout of frozen parameters. */
+int hf_conv_prepare_f32(float *wt, const float *weight, int cout, int cin, int k, float scale, void *stream);
+
+/* BatchNorm2d with running statistics -> affine: scale = gamma/sqrt(var+eps),
+ * shift = beta + (conv_bias - mean)*scale (conv_bias may be NULL).  Replaces the
+ * F.batch_norm(..., training=False) calls of helpers.py:100-115 / iresnet.py:45-52. */
+int hf_bn_fold_f32(float *scale, float *shift, const float *gamma, const float *beta, const float *mean,
+                   const float *var, const float *conv_bias, float eps, int n, void *stream);
+
+/* y = act( out_scale[co] * conv_{k x k, stride, pad k/2}( in_scale[ci]*x + in_shift[ci] ) + bias[co] ) + residual
+ *   in_scale / in_shift : the BatchNorm BEFORE the conv (applied to real pixels only, the zero
+ *                          padding stays zero - which is why it cannot be folded into the weights);
+ *   out_scale / bias    : the BatchNorm AFTER the conv (and/or the conv's own bias);
+ *   act                 : 0 none, 1 LeakyReLU(alpha), 2 PReLU(slope[co]);
+ *   residual            : [batch,cout,oh,ow] added last (IBasicBlock's `out += identity`).
+ * Any of the pointers may be NULL.  k in {1,3}, stride in {1,2}; oh = (h-1)/stride + 1.
+ * Replaces: nn.Conv2d + BatchNorm2d + PReLU/LeakyReLU (+ add) chains of
+ * helpers.py:99-115, psp_encoders.py:41-47, iresnet.py:44-56, feature_style_encoder.py:33-40.
+ * workspace: hf_conv2d_workspace_floats() floats (0 -> may be NULL). */
+int hf_conv2d_f32(float *out, const float *x, const float *wt, const float *in_scale, const float *in_shift,
+                  const float *out_scale, const float *bias, int act, const float *slope, float alpha,
+                  const float *residual, int batch, int cin, int cout, int h, int w, int k, int stride,
+                  float *workspace, long long workspace_floats, void *stream);
+long long hf_conv2d_workspace_floats(int batch, int cin, int cout, int h, int w, int k, int stride);
+
+/* out[p] = mean of plane p (AdaptiveAvgPool2d(1) of SEModule, helpers.py:60,68). */
+int hf_plane_mean_f32(float *out, const float *x, int planes, int hw, void *stream);
+/* gate[b,c] = sigmoid(fc2 . relu(fc1 . pooled[b])) ; fc1 [reduced,channels], fc2 [channels,reduced]
+ * (the two bias-free 1x1 convs of SEModule, helpers.py:61-73). */
+int hf_se_gate_f32(float *gate, const float *pooled, const float *fc1, const float *fc2, int batch, int channels,
+                   int reduced, void *stream);
+/* out = r * gate[b,c] + shortcut[b,c, y*sc_stride, x*sc_stride]; gate may be NULL.
+ * SEModule's `module_input * x` + bottleneck_IR_SE's `res + shortcut` with the
+ * MaxPool2d(1, stride) shortcut (helpers.py:73, 95-96, 118-120). */
+int hf_scale_shortcut_add_f32(float *out, const float *r, const float *gate, const float *shortcut,
+                              int sc_stride, int batch, int channels, int oh, int ow, int sh, int sw,
+                              void *stream);
+/* out = bilinear_resize(x [planes,h,w] -> [oh,ow], align_corners=True) + y  (_upsample_add, helpers.py:123-140) */
+int hf_upsample_bilinear_add_f32(float *out, const float *x, const float *y, int planes, int h, int w, int oh,
+                                 int ow, void *stream);
+/* AdaptiveAvgPool2d((oh,ow)) of x [batch,channels,h,w], written into channels
+ * [offset, offset+channels) of out [batch,out_channels_total,oh,ow] (pool + torch.cat of
+ * feature_style_encoder.py:52-61). */
+int hf_adaptive_avgpool_f32(float *out, const float *x, int batch, int channels, int h, int w, int oh, int ow,
+                            int out_channels_total, int out_channel_offset, void *stream);
+/* F.interpolate(x, scale_factor=0.5, mode='bilinear') on [planes,h,w], h and w even (trainer.py:61-64). */
+int hf_downscale2x_f32(float *out, const float *x, int planes, int h, int w, void *stream);
+/* out[b,n] = scale * sum_k x[b*x_stride+k] * w[n*in_features+k] + bias[n]; batch <= 8.
+ * nn.Linear (scale 1; feature_style_encoder.py:46, 62-63) and EqualLinear (scale
+ * 1/sqrt(in_features); psp_encoders.py:48, 53). */
+int hf_linear_f32(float *out, const float *x, long long x_stride, const float *w, const float *bias, int batch,
+                  int in_features, int out_features, float scale, void *stream);
+/* out[i] = a[i] + b[i % b_period] */
+int hf_add_bcast_f32(float *out, const float *a, const float *b, long long n, long long b_period, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Tuning / debugging hook (no reference counterpart): force the tile
  * configuration hf_modconv3x3_f32 / hf_modconv3x3_up_f32 dispatch to

@@ -54,6 +54,9 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 struct alignas(16) float4 {
   float x, y, z, w;
 };
+struct alignas(8) float2 {
+  float x, y;
+};
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
 inline void __syncthreads() { ::hipsim::syncthreads(); }

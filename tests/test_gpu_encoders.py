@@ -1,0 +1,122 @@
+"""GPU parity tests (-m gpu) of the encoder forwards
+through the product API / C ABI, against golden vectors produced by the real reference.
+Tolerance: fp32 with reassociated contractions and BatchNorm folded into affines:
+max-abs <= 1e-4 * max(1, |ref|max) (outputs are O(1))."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from oracle import cases as C
+from oracle import ref_encoders as E
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    return torch.device("cuda:0")
+
+
+def close(y, ref, rel=REL):
+    y = y.detach().cpu().double()
+    ref = ref.detach().cpu().double() if torch.is_tensor(ref) else torch.from_numpy(np.asarray(ref)).double()
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    err = float((y - ref).abs().max())
+    scale = max(1.0, float(ref.abs().max()))
+    assert err <= rel * scale, f"max-abs {err:.3e} > {rel * scale:.3e}"
+    return err
+
+
+def _load(mod, P, dev, strip=2):
+    sd = {k[strip:]: v for k, v in P.items()}
+    for k in mod.state_dict():
+        if k.endswith("num_batches_tracked") and k not in sd:
+            sd[k] = torch.zeros((), dtype=torch.long)
+    mod.load_state_dict(sd)
+    return mod.eval().to(dev)
+
+
+def test_units_vs_reference_golden(golden):
+    from hairfastgan_amd.encoders.e4e import GradualStyleBlock, bottleneck_IR_SE
+    from hairfastgan_amd.encoders.fs_encoder import IBasicBlock
+
+    dev = _dev()
+    G = golden("encoder_units.npz")
+    with torch.inference_mode():
+        for name, (in_c, depth, stride, B, H, W) in C.IRSE_UNIT_CASES.items():
+            m = _load(bottleneck_IR_SE(in_c, depth, stride), C.params_from_shapes(name, C.irse_unit_shapes(in_c, depth)), dev)
+            close(m(C.unit_input(name, (B, in_c, H, W)).to(dev)), G[name])
+        for name, (in_c, planes, stride, B, H, W) in C.IBASIC_CASES.items():
+            ds = None
+            if stride != 1 or in_c != planes:
+                ds = nn.Sequential(nn.Conv2d(in_c, planes, 1, stride, bias=False), nn.BatchNorm2d(planes, eps=1e-05))
+            m = _load(IBasicBlock(in_c, planes, stride, ds), C.params_from_shapes(name, C.ibasic_shapes(in_c, planes, stride)), dev)
+            close(m(C.unit_input(name, (B, in_c, H, W)).to(dev)), G[name])
+        for name, (c, spatial, B) in C.STYLE_BLOCK_CASES.items():
+            m = _load(GradualStyleBlock(c, c, spatial), C.params_from_shapes(name, C.style_block_shapes(c, spatial)), dev)
+            close(m(C.unit_input(name, (B, c, spatial, spatial)).to(dev)), G[name])
+
+
+def test_conv2d_ragged_shapes_vs_torch():
+    """hf_conv2d_f32 on odd shapes: stride 2, 1x1, cin/cout not multiples of the tiles, 1-pixel
+    planes, with every epilogue option - vs the same composition in torch CPU."""
+    import torch.nn.functional as F
+
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = _dev()
+    torch.manual_seed(5)
+    for (k, stride, B, cin, cout, H, W) in [(3, 2, 2, 16, 24, 9, 13), (1, 2, 1, 12, 40, 10, 7), (3, 1, 1, 3, 64, 20, 36),
+                                            (3, 2, 1, 8, 8, 1, 1), (3, 1, 3, 64, 128, 64, 64), (3, 2, 3, 128, 128, 64, 64),
+                                            (1, 2, 3, 64, 128, 128, 128), (3, 2, 2, 512, 512, 4, 4), (1, 1, 3, 256, 512, 32, 32)]:
+        x = torch.randn(B, cin, H, W)
+        w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+        a, t = torch.rand(cin) + 0.5, torch.randn(cin) * 0.2
+        g, bsh, slope = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2, torch.rand(cout) * 0.5
+        ref = F.prelu(F.conv2d(x * a.view(1, -1, 1, 1) + t.view(1, -1, 1, 1), w, stride=stride, padding=k // 2)
+                      * g.view(1, -1, 1, 1) + bsh.view(1, -1, 1, 1), slope)
+        res = torch.randn_like(ref)
+        wt = M.conv_prepare(lib(), stream(), w.to(dev))
+        y = M.conv2d(lib(), stream(), x.to(dev), wt, k, stride, in_scale=a.to(dev), in_shift=t.to(dev),
+                     out_scale=g.to(dev), bias=bsh.to(dev), act=M.ACT_PRELU, slope=slope.to(dev), residual=res.to(dev))
+        close(y, ref + res)
+
+
+def test_e4e_vs_reference_golden(golden):
+    from hairfastgan_amd.encoders import Encoder4Editing, get_latents
+
+    dev = _dev()
+    G = golden("encoders.npz")
+    enc = Encoder4Editing(50, "ir_se", argparse.Namespace(stylegan_size=1024))
+    enc = _load(enc, C.params_from_shapes("e4e", E.e4e_param_shapes()), dev, strip=0)
+    x, latent_avg = C.e4e_inputs(2)
+    net = argparse.Namespace(encoder=enc, opts=argparse.Namespace(start_from_latent_avg=True), latent_avg=latent_avg.to(dev))
+    with torch.inference_mode():
+        w = get_latents(net, x.to(dev))
+        w2 = get_latents(net, x.to(dev))
+    assert torch.equal(w, w2)
+    close(w, G["e4e_w"])
+
+
+def test_fs_encoder_vs_reference_golden(golden):
+    from hairfastgan_amd.encoders import FSEncoder
+
+    dev = _dev()
+    G = golden("encoders.npz")
+    fs = FSEncoder()
+    _load(fs.enc, C.params_from_shapes("fs", E.fs_param_shapes()), dev, strip=0)
+    img, dlat = C.fs_inputs(2)
+    fs = fs.to(dev)
+    fs.dlatent_avg.copy_(dlat)
+    out = fs.test(img=img.to(dev), return_latent=True)
+    fea = out.pop()
+    s = out.pop()
+    assert out[1] is None and out[0].shape == (2, 3, 1024, 1024)
+    close(s, G["fs_s"])
+    close(fea[:, ::16], G["fs_content_chan16"])

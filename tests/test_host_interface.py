@@ -35,9 +35,9 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 12
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
-    assert set(_lib.SIGNATURES) | {"hf_strerror", "hf_abi_version", "hf_modconv_workspace_floats"} == declared
+    assert set(_lib.SIGNATURES) | {"hf_strerror", "hf_abi_version", "hf_modconv_workspace_floats", "hf_conv2d_workspace_floats"} == declared
     bound = _lib.bind(lib)
-    assert bound.hf_abi_version() == 2
+    assert bound.hf_abi_version() == 3
     assert bound.hf_strerror(-1) == b"invalid argument"
 
 

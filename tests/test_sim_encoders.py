@@ -1,0 +1,136 @@
+"""CPU tests of the encoder kernels and module mirrors (kernel sources interpreted by
+tests/hipsim) against the oracle and the golden vectors produced by the real reference."""
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hairfastgan_amd import _marshal as M
+from oracle import cases as C
+from oracle import ref_encoders as E
+
+TOL = 2e-5
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+@pytest.fixture()
+def sim_backend(simlib, monkeypatch):
+    import hairfastgan_amd.encoders  # noqa: F401
+
+    mods = [sys.modules[n] for n in ("hairfastgan_amd.encoders._fused", "hairfastgan_amd.encoders.e4e",
+                                     "hairfastgan_amd.encoders.fs_encoder")]
+    for mod in mods:
+        monkeypatch.setattr(mod, "lib", lambda: simlib)
+        monkeypatch.setattr(mod, "stream", lambda: None)
+        monkeypatch.setattr(mod, "require_gpu", lambda *a: None)
+    return mods
+
+
+@pytest.mark.parametrize("k,stride,B,cin,cout,H,W", [(3, 2, 2, 16, 24, 9, 13), (1, 2, 1, 12, 40, 10, 7), (1, 1, 3, 8, 8, 5, 5),
+                                                      (3, 1, 1, 3, 64, 20, 36), (3, 2, 1, 8, 8, 1, 1), (3, 1, 2, 16, 64, 16, 32)])
+def test_conv2d_variants(simlib, k, stride, B, cin, cout, H, W):
+    torch.manual_seed(k * 10 + stride + cin)
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    a, t = torch.rand(cin) + 0.5, torch.randn(cin) * 0.2
+    g, bsh, slope = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2, torch.rand(cout) * 0.5
+    wt = M.conv_prepare(simlib, None, w)
+    ref_core = F.conv2d(x * a.view(1, -1, 1, 1) + t.view(1, -1, 1, 1), w, stride=stride, padding=k // 2)
+    ref = F.prelu(ref_core * g.view(1, -1, 1, 1) + bsh.view(1, -1, 1, 1), slope)
+    res = torch.randn_like(ref)
+    y = M.conv2d(simlib, None, x, wt, k, stride, in_scale=a, in_shift=t, out_scale=g, bias=bsh, act=M.ACT_PRELU,
+                 slope=slope, residual=res)
+    assert maxdiff(y, ref + res) < TOL * max(1.0, float(ref.abs().max()))
+    y = M.conv2d(simlib, None, x, wt, k, stride, bias=bsh, act=M.ACT_LRELU, alpha=0.01)
+    ref = F.leaky_relu(F.conv2d(x, w, bsh, stride=stride, padding=k // 2), 0.01)
+    assert maxdiff(y, ref) < TOL * max(1.0, float(ref.abs().max()))
+
+
+def test_small_ops(simlib):
+    torch.manual_seed(0)
+    x, y = torch.randn(2, 3, 5, 7), torch.randn(2, 3, 10, 14)
+    assert maxdiff(M.upsample_bilinear_add(simlib, None, x, y),
+                   F.interpolate(x, size=(10, 14), mode="bilinear", align_corners=True) + y) < 1e-6
+    x = torch.randn(2, 5, 16, 8)
+    out = torch.zeros(2, 9, 3, 3)
+    M.adaptive_avgpool_into(simlib, None, out, x, 2)
+    assert maxdiff(out[:, 2:7], F.adaptive_avg_pool2d(x, (3, 3))) < 1e-6 and float(out[:, :2].abs().max()) == 0
+    x = torch.randn(2, 3, 8, 12)
+    assert maxdiff(M.downscale2x(simlib, None, x), F.interpolate(x, scale_factor=0.5, mode="bilinear")) < 1e-6
+    x, w, b = torch.randn(3, 40), torch.randn(7, 40), torch.randn(7)
+    assert maxdiff(M.linear(simlib, None, x, w, b, 0.5), F.linear(x, w * 0.5, b)) < 1e-5
+    x, w = torch.randn(2, 33), torch.randn(5, 33)  # unaligned K -> scalar path
+    assert maxdiff(M.linear(simlib, None, x, w, None, 1.0), F.linear(x, w)) < 1e-5
+    x = torch.randn(2, 4, 6, 6)
+    pm = M.plane_mean(simlib, None, x)
+    assert maxdiff(pm, x.mean((2, 3))) < 1e-6
+    fc1, fc2 = torch.randn(2, 4), torch.randn(4, 2)
+    gate = M.se_gate(simlib, None, pm, fc1, fc2)
+    assert maxdiff(gate, torch.sigmoid(F.linear(F.relu(F.linear(pm, fc1)), fc2))) < 1e-6
+    sc = torch.randn(2, 4, 12, 12)
+    assert maxdiff(M.scale_shortcut_add(simlib, None, x, gate, sc, 2), x * gate[:, :, None, None] + sc[:, :, ::2, ::2]) < 1e-6
+    g, be, mu, var, cb = torch.rand(6) + 0.5, torch.randn(6), torch.randn(6), torch.rand(6) + 0.5, torch.randn(6)
+    s, t = M.bn_fold(simlib, None, g, be, mu, var, 1e-5, cb)
+    assert maxdiff(s, g / torch.sqrt(var + 1e-5)) < 1e-6 and maxdiff(t, be + (cb - mu) * g / torch.sqrt(var + 1e-5)) < 1e-5
+    a, bvec = torch.randn(3, 10), torch.randn(10)
+    assert maxdiff(M.add_bcast(simlib, None, a, bvec), a + bvec) == 0
+
+
+def _load(mod, P):
+    sd = {k[2:]: v for k, v in P.items()}
+    for k in mod.state_dict():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+    mod.load_state_dict(sd)
+    return mod.eval()
+
+
+@pytest.mark.parametrize("name", list(C.IRSE_UNIT_CASES))
+def test_irse_unit(sim_backend, golden, name):
+    from hairfastgan_amd.encoders.e4e import bottleneck_IR_SE
+
+    in_c, depth, stride, B, H, W = C.IRSE_UNIT_CASES[name]
+    m = _load(bottleneck_IR_SE(in_c, depth, stride), C.params_from_shapes(name, C.irse_unit_shapes(in_c, depth)))
+    y = m(C.unit_input(name, (B, in_c, H, W)))
+    assert maxdiff(y, torch.from_numpy(golden("encoder_units.npz")[name])) < TOL
+
+
+@pytest.mark.parametrize("name", list(C.IBASIC_CASES))
+def test_ibasic_block(sim_backend, golden, name):
+    from hairfastgan_amd.encoders.fs_encoder import IBasicBlock
+    from torch import nn
+
+    in_c, planes, stride, B, H, W = C.IBASIC_CASES[name]
+    ds = None
+    if stride != 1 or in_c != planes:
+        ds = nn.Sequential(nn.Conv2d(in_c, planes, 1, stride, bias=False), nn.BatchNorm2d(planes, eps=1e-05))
+    m = _load(IBasicBlock(in_c, planes, stride, ds), C.params_from_shapes(name, C.ibasic_shapes(in_c, planes, stride)))
+    y = m(C.unit_input(name, (B, in_c, H, W)))
+    assert maxdiff(y, torch.from_numpy(golden("encoder_units.npz")[name])) < TOL
+
+
+@pytest.mark.parametrize("name", list(C.STYLE_BLOCK_CASES))
+def test_gradual_style_block(sim_backend, golden, name):
+    from hairfastgan_amd.encoders.e4e import GradualStyleBlock
+
+    c, spatial, B = C.STYLE_BLOCK_CASES[name]
+    m = _load(GradualStyleBlock(c, c, spatial), C.params_from_shapes(name, C.style_block_shapes(c, spatial)))
+    y = m(C.unit_input(name, (B, c, spatial, spatial)))
+    assert maxdiff(y, torch.from_numpy(golden("encoder_units.npz")[name])) < TOL
+
+
+def test_state_dicts_match_reference_layout():
+    import argparse
+
+    from hairfastgan_amd.encoders import Encoder4Editing, fs_encoder_v2
+
+    e = Encoder4Editing(50, "ir_se", argparse.Namespace(stylegan_size=1024))
+    assert {k: tuple(v.shape) for k, v in e.state_dict().items()} == E.e4e_param_shapes()
+    assert list(e.state_dict()) == list(E.e4e_param_shapes())
+    f = fs_encoder_v2(stride=(2, 2))
+    assert {k: tuple(v.shape) for k, v in f.state_dict().items()} == E.fs_param_shapes()
+    assert list(f.state_dict()) == list(E.fs_param_shapes())
