@@ -22,6 +22,7 @@ PROFILE = None
 KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modconv.hip dispatch)
     211: "conv_mfma_pipe<2,2,2,4>", 212: "conv_mfma_pipe<2,2,1,4>", 213: "conv_mfma_pipe<1,2,1,4>",
     214: "conv_mfma_pipe<2,2,2,2>", 215: "conv_mfma_pipe<1,1,2,2>", 216: "conv_mfma_pipe<1,4,1,4>",
+    231: "conv_mfma_dma<2,2,2,4>", 232: "conv_mfma_dma<2,2,1,4>", 233: "conv_mfma_dma<1,2,1,4>", 234: "conv_mfma_dma<2,2,2,2>",
     221: "conv_mfma_pipe<1,2,2,2,up>", 222: "conv_mfma_pipe<1,2,1,4,up>", 223: "conv_mfma_pipe<1,1,2,2,up>",
     224: "conv_mfma_pipe<1,2,2,4,up>", 225: "conv_mfma_pipe<1,1,1,4,up>", 300: "conv_mfma<1,1,2,2> split-K",
 }

@@ -23,6 +23,19 @@ __device__ __forceinline__ void hf_glds16(const float *gsrc_lane, float *lds_wav
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
+// 4-byte-per-lane variant (global_load_lds_dword): LDS destination = base + lane*4.
+__device__ __forceinline__ void hf_glds4(const float *gsrc_lane, float *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
+}
+// Lane-masked forms: only lanes with `active` copy (the others' LDS slots keep their
+// contents).  Separate helpers so that the CPU kernel interpreter can model the EXEC mask.
+__device__ __forceinline__ void hf_glds16_if(bool active, const float *gsrc_lane, float *lds_wave_base) {
+  if (active) hf_glds16(gsrc_lane, lds_wave_base);
+}
+__device__ __forceinline__ void hf_glds4_if(bool active, const float *gsrc_lane, float *lds_wave_base) {
+  if (active) hf_glds4(gsrc_lane, lds_wave_base);
+}
 #endif
 
 static inline int hf_launch_status() {

@@ -96,22 +96,17 @@ struct NoSideWork {
 // constant after unrolling) between the operand prefetch and the step's MFMAs: the
 // pipelined kernel uses it to spread its staging instructions (weight DMA, halo loads,
 // LDS writes) over the chunk, so that they issue under matrix-pipe time.
-template <int CT_TILES, int PG, int CT, bool UP, int TAPS, class Side, int NPH = (UP ? 4 : 1)>
-__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NPH][CT_TILES][PG], const float *a_base,
-                                           const float *b_base, int xstride, const int (&pixoff)[PG], int wp,
-                                           Side &&side) {
+template <int CT_TILES, int PG, int CT, bool UP, int TAPS, class BLoad, class Side, int NPH = (UP ? 4 : 1)>
+__device__ __forceinline__ void mfma_chunk_g(f32x16 (&acc)[NPH][CT_TILES][PG], const float *a_base, BLoad &&bload,
+                                             Side &&side) {
   constexpr int NSTEP = TAPS * (KC / 2);
   float a[2][CT_TILES], bq[2][PG];
   auto fetch = [&](int step, float (&av)[CT_TILES], float (&bv)[PG]) {
     const int tap = step / (KC / 2), kk = step % (KC / 2);
-    const int ky = tap / 3, kx = tap % 3;
-    // LDS offset of the tap's source pixel relative to pixoff.  UP: output phase
-    // (pr,pc) = (ky&1, kx&1) reads x[Y - (ky==2), X - (kx==2)]; the halo tile starts at (-1,-1).
-    const int toff = (TAPS == 1) ? 0 : (UP ? ((ky == 2 ? 0 : 1) * wp + (kx == 2 ? 0 : 1)) : (ky * wp + kx));
 #pragma unroll
     for (int ct = 0; ct < CT_TILES; ++ct) av[ct] = a_base[(tap * KC + 2 * kk) * CT + ct * 32];
 #pragma unroll
-    for (int g = 0; g < PG; ++g) bv[g] = b_base[2 * kk * xstride + pixoff[g] + toff];
+    for (int g = 0; g < PG; ++g) bv[g] = bload(tap, kk, g);
   };
   fetch(0, a[0], bq[0]);
 #pragma unroll
@@ -129,6 +124,21 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NPH][CT_TILES][PG], con
         acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][ct], bq[cur][g], acc[ph][ct][g], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// B operand from a rectangular halo tile: b_base[2kk*xstride + pixoff[g] + tap offset].
+// UP: output phase (pr,pc) = (ky&1, kx&1) reads x[Y - (ky==2), X - (kx==2)]; the halo tile
+// starts at (-1,-1).
+template <int CT_TILES, int PG, int CT, bool UP, int TAPS, class Side, int NPH = (UP ? 4 : 1)>
+__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NPH][CT_TILES][PG], const float *a_base,
+                                           const float *b_base, int xstride, const int (&pixoff)[PG], int wp,
+                                           Side &&side) {
+  auto bload = [&](int tap, int kk, int g) {
+    const int ky = tap / 3, kx = tap % 3;
+    const int toff = (TAPS == 1) ? 0 : (UP ? ((ky == 2 ? 0 : 1) * wp + (kx == 2 ? 0 : 1)) : (ky * wp + kx));
+    return b_base[2 * kk * xstride + pixoff[g] + toff];
+  };
+  mfma_chunk_g<CT_TILES, PG, CT, UP, TAPS>(acc, a_base, bload, side);
 }
 
 __device__ __forceinline__ float apply_act(float v, int act, float alpha, float scale, float slope) {
@@ -159,29 +169,27 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
     const int Y = ty0 + py, X = tx0 + px, b = b0 + im;
     const bool pv = (Y < G.y0 + G.dh) && (X < G.x0 + G.dw) && (b < P.batch);
     if (!pv) continue;
-    float dmv[CT_TILES][16], bsv[CT_TILES][16], slv[CT_TILES][16];
-#pragma unroll
-    for (int ct = 0; ct < CT_TILES; ++ct)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int cc = min(co, P.cout - 1);
-        dmv[ct][r] = (P.d && !partial) ? P.d[(long long)b * P.d_bstride + cc] : 1.0f;
-        bsv[ct][r] = (full && P.bias) ? P.bias[cc] : 0.0f;
-        slv[ct][r] = (full && P.act == ACT_PRELU) ? P.slope[cc] : 0.0f;
-      }
     float nz = 0.0f;
     if (full && P.noise) nz = nw * P.noise[(long long)b * P.noise_bstride + (long long)Y * P.out_w + X];
     float *obase = partial ? P.partial + (long long)blockIdx.z * P.batch * P.cout * oplane : P.out;
 #pragma unroll
     for (int ct = 0; ct < CT_TILES; ++ct) {
+      float dmv[16], bsv[16], slv[16];  // one co tile at a time: 48 live registers, not 48*CT_TILES
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int cc = min(co, P.cout - 1);
+        dmv[r] = (P.d && !partial) ? P.d[(long long)b * P.d_bstride + cc] : 1.0f;
+        bsv[r] = (full && P.bias) ? P.bias[cc] : 0.0f;
+        slv[r] = (full && P.act == ACT_PRELU) ? P.slope[cc] : 0.0f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (co >= P.cout) continue;
         const long long obofs = ((long long)b * P.cout + co) * oplane;
         float *ob = obase + obofs;
-        const float dm = dmv[ct][r];
+        const float dm = dmv[r];
         if (UP) {
           // phases (pr,0) and (pr,1) are neighbouring columns: one 8-byte store per row
           // (rows of the (2h+1)x(2w+1) plane are only 4-byte aligned: unaligned-dword store)
@@ -204,7 +212,7 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
           const long long pofs = (long long)Y * P.out_w + X;
           float v = acc[0][ct][g][r] * dm;
           if (full) {
-            v = apply_act(v + nz + bsv[ct][r], P.act, P.alpha, P.scale, slv[ct][r]);
+            v = apply_act(v + nz + bsv[r], P.act, P.alpha, P.scale, slv[r]);
             if (P.residual) v += P.residual[obofs + pofs];
           }
           ob[pofs] = v;
@@ -534,6 +542,162 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const
   store_tile<CT_TILES, PG, UP>(P, G, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
+// ------------------------------------------------------------------------------
+// DMA-staged variant of the pipelined kernel for same-resolution 3x3 layers whose
+// planes are tiled by full 32-pixel rows (tw == 32, W % 4 == 0, no pre-conv shift).
+//
+// Per chunk the weights [9][KC][CT] and the interior of the halo tile [KC][hp][32] (rows of
+// 128 B = 8 lanes x 16 B) arrive by global_load_lds into the other LDS buffer with no VGPR
+// involved; out-of-image rows are never written and stay zero from a one-time clear.  Only
+// the two edge columns (KC*hp*2 values, at most one per thread) go through a register.
+// They are stored in a second array with the SAME row / channel strides as the interior,
+// so a B fragment read is `base[kx][group] + immediate`: the per-lane base selects the
+// interior (column px+kx-1) or, for lanes px=0 / px=31, the edge array - no address
+// arithmetic in the MFMA loop.  The modulation s[b,ci] is applied to the B fragment after
+// the LDS read (one v_mul per fragment; the same fp32 product as scaling before staging).
+// ------------------------------------------------------------------------------
+template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool MOD>
+__global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_dma(const ConvParams P) {
+  constexpr int NW = WAVES_CO * WAVES_PX;
+  constexpr int NT = 64 * NW;
+  constexpr int CT = 32 * CT_TILES * WAVES_CO;
+  constexpr int TH = PG * WAVES_PX;   // tile = TH rows x 32 columns
+  constexpr int HP = TH + 2;          // staged rows
+  constexpr int WCHUNK = 9 * KC * CT;
+  constexpr int XI = KC * HP * 32;    // interior floats per stage; the edge array has the same shape
+  constexpr int BUF = WCHUNK + 2 * XI;
+  constexpr int N_W = WCHUNK / 256, N_XI = XI / 256;
+  constexpr int NPIECE = N_W + N_XI;
+  constexpr int ND = (NPIECE + NW - 1) / NW;  // DMA instructions per wave per chunk
+  constexpr int NEDGE = KC * HP * 2;
+  static_assert(WCHUNK % 256 == 0 && XI % 256 == 0, "stage images must be whole 1 KiB DMA pieces");
+  static_assert(NEDGE <= NT, "one edge value per thread");
+
+  HF_DYN_LDS;
+  float *lds = reinterpret_cast<float *>(hf_dyn_lds);  // [2][BUF] then s[cin]
+  float *sl = lds + 2 * BUF;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int wave_co = (wave / WAVES_PX) * (32 * CT_TILES);
+  const int wave_pg = (wave % WAVES_PX) * PG;
+  const int co0 = blockIdx.y * CT;
+
+  const TileGeom G = P.g[0];
+  int t = blockIdx.x;
+  const int tx = t % G.tiles_x;
+  t /= G.tiles_x;
+  const int ty = t % G.tiles_y;
+  const int b0 = t / G.tiles_y;
+  const int ty0 = ty * TH, tx0 = tx * 32;
+  const long long plane = (long long)P.h * P.w;
+  const float *xb = P.x + (long long)b0 * P.cin * plane;
+
+  // one-time clear of the halo regions of both buffers (+ modulation vector into LDS)
+  for (int i = tid; i < 4 * XI; i += NT) lds[(i / (2 * XI)) * BUF + WCHUNK + i % (2 * XI)] = 0.0f;
+  if (MOD)
+    for (int i = tid; i < P.cin; i += NT) sl[i] = P.s[(long long)b0 * P.s_bstride + i];
+
+  // per-lane DMA source offsets within channel ci0 (chunk invariant; -1: lane idle)
+  int d_src[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int pc = wave + i * NW;
+    d_src[i] = -1;
+    if (pc >= N_W && pc < NPIECE) {  // interior: 8 rows of 8 x 16 B per piece
+      const int r = (pc - N_W) * 8 + (lane >> 3), q = lane & 7;
+      const int kc = r / HP, row = r % HP;
+      const int ys = ty0 + row - 1, xc = tx0 + 4 * q;
+      if (ys >= 0 && ys < P.h && xc < P.w) d_src[i] = (int)(kc * plane + (long long)ys * P.w + xc);
+    }
+  }
+  auto dma_piece = [&](int i, int ci0, float *buf) {
+    const int pc = wave + i * NW;
+    if (pc < N_W) {
+      const int f = pc * 256 + lane * 4;
+      const int row = f / CT, col = f % CT;
+      const int tap = row / KC, kc = row % KC;
+      hf_glds16(P.wt + ((long long)tap * P.cin + ci0 + kc) * P.cout + co0 + col, buf + pc * 256);
+    } else if (pc < NPIECE) {
+      hf_glds16_if(d_src[i] >= 0, xb + (long long)ci0 * plane + d_src[i], buf + WCHUNK + (pc - N_W) * 256);
+    }
+  };
+  // edge columns: thread e < NEDGE owns (kc, row, side)
+  int e_src = -1, e_dst = 0;
+  if (tid < NEDGE) {
+    const int kc = tid / (HP * 2), row = (tid / 2) % HP, side = tid & 1;
+    const int ys = ty0 + row - 1, xc = side ? tx0 + 32 : tx0 - 1;
+    if (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) e_src = (int)(kc * plane + (long long)ys * P.w + xc);
+    e_dst = WCHUNK + XI + (kc * HP + row) * 32 + side;
+  }
+  float e_val = 0.0f;
+
+  // B-fragment base per (kx, group): interior column li+kx-1, or the edge array for li=0 / li=31
+  int bbase[3][PG];
+#pragma unroll
+  for (int g = 0; g < PG; ++g) {
+    const int rowbase = (wave_pg + g) * 32 + lh * (HP * 32);  // one 32-pixel row per pixel group
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int c = li + kx - 1;
+      bbase[kx][g] = WCHUNK + rowbase + ((c >= 0 && c < 32) ? c : XI + (c < 0 ? 0 : 1));
+    }
+  }
+
+  f32x16 acc[1][CT_TILES][PG];
+#pragma unroll
+  for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+    for (int g = 0; g < PG; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][ct][g][r] = 0.0f;
+
+  __syncthreads();  // clear + s visible before the first DMA lands next to it
+#pragma unroll
+  for (int i = 0; i < ND; ++i) dma_piece(i, 0, lds);
+  if (e_src >= 0) lds[e_dst] = xb[e_src];
+  __syncthreads();  // drains vmcnt: stage 0 resident
+
+  constexpr int NSTEP = 9 * (KC / 2);
+  constexpr int DPS = (ND + NSTEP / 2 - 1) / (NSTEP / 2);  // DMA instructions per step (first half of the chunk)
+  constexpr int D_STEPS = (ND + DPS - 1) / DPS;
+  const int nchunks = P.cin / KC;
+  for (int c = 0; c < nchunks; ++c) {
+    const int cur = c & 1;
+    const bool more = c + 1 < nchunks;
+    const int ci0 = c * KC, ci_next = ci0 + KC;
+    float *buf = lds + cur * BUF, *buf_next = lds + (cur ^ 1) * BUF;
+    float sreg[KC / 2];
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk) sreg[kk] = MOD ? sl[ci0 + 2 * kk + lh] : 1.0f;
+    auto side = [&](int step) {
+      if (!more) return;
+      if (step < D_STEPS) {
+#pragma unroll
+        for (int q = 0; q < DPS; ++q)
+          if (step * DPS + q < ND) dma_piece(step * DPS + q, ci_next, buf_next);
+      } else if (step == D_STEPS) {
+        if (e_src >= 0) e_val = xb[(long long)ci_next * plane + e_src];
+      } else if (step == NSTEP - 1) {
+        if (e_src >= 0) buf_next[e_dst] = e_val;
+      }
+    };
+    auto bload = [&](int tap, int kk, int g) {
+      const int ky = tap / 3, kx = tap % 3;
+      const float v = buf[bbase[kx][g] + ky * 32 + 2 * kk * (HP * 32)];
+      return MOD ? v * sreg[kk] : v;
+    };
+    const float *a_base = buf + lh * CT + wave_co + li;
+    mfma_chunk_g<CT_TILES, PG, CT, false, 9>(acc, a_base, bload, side);
+    __syncthreads();  // drains the DMA of the next stage (vmcnt) and frees the current one
+  }
+
+  store_tile<CT_TILES, PG, false>(P, G, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+}
+
 // Split-K second pass: out = epilogue(d * sum_z partial[z]) - deterministic (fixed z order).
 __global__ __launch_bounds__(256) void splitk_reduce(const ConvParams P, long long slab, int with_epilogue) {
   const long long oplane = (long long)P.out_h * P.out_w;
@@ -675,6 +839,36 @@ int launch_conv_pipe(ConvParams &P, hipStream_t st) {
   return hf_launch_status();
 }
 
+// All-DMA launch (same-resolution 3x3, rows of 32 pixels); HF_E_INVALID if the shape does not qualify.
+template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX>
+int launch_conv_dma(ConvParams &P, hipStream_t st) {
+  constexpr int NT = 64 * WAVES_CO * WAVES_PX;
+  constexpr int CT = 32 * CT_TILES * WAVES_CO;
+  constexpr int TH = PG * WAVES_PX, HP = TH + 2;
+  if (P.cin % KC || P.cout % CT || (P.cout & 3) || P.stride != 1 || P.t) return HF_E_INVALID;
+  if ((P.w & 3) || P.w < 32 || P.h < TH) return HF_E_INVALID;
+  if ((((size_t)P.wt) | ((size_t)P.x)) & 15) return HF_E_INVALID;
+  if ((long long)P.cin * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
+  P.splits = 1;
+  P.n_geom = 1;
+  TileGeom g{};
+  g.y0 = 0; g.x0 = 0; g.dh = P.h; g.dw = P.w;
+  g.lg_tw = 5; g.lg_th = ilog2(TH); g.lg_nb = 0;
+  g.tiles_x = hf_cdiv(P.w, 32); g.tiles_y = hf_cdiv(P.h, TH); g.tiles_b = P.batch; g.first_block = 0;
+  P.g[0] = g;
+  const int XI = KC * HP * 32;
+  if (KC * HP * 2 > NT) return HF_E_INVALID;
+  const size_t lds = ((size_t)2 * (9 * KC * CT + 2 * XI) + (P.s ? P.cin : 0)) * sizeof(float);
+  if (lds > 160 * 1024) return HF_E_INVALID;
+  dim3 grid(geom_blocks(g), P.cout / CT);
+  if (grid.y > 65535) return HF_E_INVALID;
+  if (P.s)
+    hipLaunchKernelGGL((conv_mfma_dma<CT_TILES, PG, WAVES_CO, WAVES_PX, true>), grid, dim3(NT), lds, st, P);
+  else
+    hipLaunchKernelGGL((conv_mfma_dma<CT_TILES, PG, WAVES_CO, WAVES_PX, false>), grid, dim3(NT), lds, st, P);
+  return hf_launch_status();
+}
+
 // Split-K plan for layers with few (co tile, pixel tile) pairs but many K-chunks.
 // Pure function of the shape so that callers can size the workspace.
 inline int splitk_plan(int batch, int cin, int cout, int out_h, int out_w) {
@@ -724,31 +918,43 @@ int run_conv3x3_s1(ConvParams &P, float *workspace, long long workspace_floats, 
     const int sk = (g_force_same == 0) ? splitk_plan(batch, P.cin, cout, h, w) : 1;
     if (sk > 1) return run_splitk<false, 9>(P, sk, workspace, workspace_floats, st);
   }
-  int cfg = g_force_same;
-  if (cfg == 0) {
-    // Built-in heuristics (tools/bench_layers.py sweeps, MI355X): the largest tile that
-    // still yields >= ~1.5-2 blocks per CU; 256 CUs.
+  // Candidate tile configurations, tried in order until one accepts the shape.
+  // 3x = DMA-staged (rows of 32 pixels), 1x = register-staged pipelined kernel.
+  int cands[3] = {g_force_same, 0, 0};
+  if (g_force_same == 0) {
+    // Built-in heuristics (tools/bench_layers.py sweeps on MI355X, profiles/): the largest tile
+    // that still yields >= ~1.5-2 resident blocks per CU (256 CUs).
     const long long per_img256 = ((long long)h * w + 255) / 256, per_img64 = ((long long)h * w + 63) / 64;
-    const long long nb11 = batch * per_img256 * (cout / 128), nb13 = batch * per_img256 * (cout / 32);
-    const long long nb15 = batch * per_img64 * (cout / 64);
-    if (cout % 128 == 0 && nb11 >= 384) cfg = 11;
-    else if (cout % 32 == 0 && nb13 >= 512) cfg = 13;
-    else if (cout % 64 == 0 && nb15 >= 256) cfg = 15;
-    else if (cout % 32 == 0) cfg = 13;
-    else cfg = 2;
+    const long long nb128 = batch * per_img256 * (cout / 128), nb64 = batch * per_img256 * (cout / 64);
+    const long long nb32 = batch * per_img256 * (cout / 32), nb15 = batch * per_img64 * (cout / 64);
+    if (cout % 128 == 0 && nb128 >= 384) { cands[0] = 31; cands[1] = 11; }
+    else if (cout % 64 == 0 && nb64 >= 512) { cands[0] = 32; cands[1] = 12; }
+    else if (cout % 32 == 0 && nb32 >= 512) {
+      if (P.cin >= 64) { cands[0] = 33; cands[1] = 13; } else cands[0] = 13;  // few chunks: DMA prologue not amortised
+    }
+    else if (cout % 64 == 0 && nb15 >= 256) cands[0] = 15;
+    else if (cout % 32 == 0) cands[0] = 13;
+    else cands[0] = 2;
   }
-  g_last_cfg = cfg;
   int rc = HF_E_INVALID;
-  switch (cfg) {  // 1x: pipelined (fall through to the general kernel when the shape does not qualify)
-    case 11: rc = launch_conv_pipe<2, 2, 2, 4, false>(P, st); break;  // 128 co x 256 px, 8 waves
-    case 12: rc = launch_conv_pipe<2, 2, 1, 4, false>(P, st); break;  //  64 co x 256 px, 4 waves
-    case 13: rc = launch_conv_pipe<1, 2, 1, 4, false>(P, st); break;  //  32 co x 256 px, 4 waves
-    case 14: rc = launch_conv_pipe<2, 2, 2, 2, false>(P, st); break;  // 128 co x 128 px, 4 waves
-    case 15: rc = launch_conv_pipe<1, 1, 2, 2, false>(P, st); break;  //  64 co x  64 px, 4 waves
-    case 16: rc = launch_conv_pipe<1, 4, 1, 4, false>(P, st); break;  //  32 co x 512 px, 4 waves
-    case 91: rc = launch_conv_pipe<2, 2, 2, 4, false, 1>(P, st); break;  // timing ablations of cfg 11
-    case 92: rc = launch_conv_pipe<2, 2, 2, 4, false, 2>(P, st); break;
-    default: break;
+  for (int ci = 0; ci < 3 && rc == HF_E_INVALID && cands[ci] != 0; ++ci) {
+    const int cfg = cands[ci];
+    g_last_cfg = cfg;
+    switch (cfg) {
+      case 11: rc = launch_conv_pipe<2, 2, 2, 4, false>(P, st); break;  // 128 co x 256 px, 8 waves
+      case 12: rc = launch_conv_pipe<2, 2, 1, 4, false>(P, st); break;  //  64 co x 256 px, 4 waves
+      case 13: rc = launch_conv_pipe<1, 2, 1, 4, false>(P, st); break;  //  32 co x 256 px, 4 waves
+      case 14: rc = launch_conv_pipe<2, 2, 2, 2, false>(P, st); break;  // 128 co x 128 px, 4 waves
+      case 15: rc = launch_conv_pipe<1, 1, 2, 2, false>(P, st); break;  //  64 co x  64 px, 4 waves
+      case 16: rc = launch_conv_pipe<1, 4, 1, 4, false>(P, st); break;  //  32 co x 512 px, 4 waves
+      case 31: rc = launch_conv_dma<2, 2, 2, 4>(P, st); break;          // DMA-staged, tile shapes of 11..14
+      case 32: rc = launch_conv_dma<2, 2, 1, 4>(P, st); break;
+      case 33: rc = launch_conv_dma<1, 2, 1, 4>(P, st); break;
+      case 34: rc = launch_conv_dma<2, 2, 2, 2>(P, st); break;
+      case 91: rc = launch_conv_pipe<2, 2, 2, 4, false, 1>(P, st); break;  // timing ablations of cfg 11
+      case 92: rc = launch_conv_pipe<2, 2, 2, 4, false, 2>(P, st); break;
+      default: break;
+    }
   }
   g_last_path = 2;
   if (rc != HF_E_INVALID) return rc;

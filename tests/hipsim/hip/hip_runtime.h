@@ -29,6 +29,8 @@ float shfl_xor(float v, int mask);
 float shfl_rel(float v, int delta);  // value of lane (lane + delta), own value if out of the wave
 f32x16 mfma32x32x2(float a, float b, f32x16 c);
 void glds16(const float *gsrc_lane, float *lds_wave_base);
+void glds4(const float *gsrc_lane, float *lds_wave_base);
+void glds_masked(bool active, int bytes, const float *gsrc_lane, float *lds_wave_base);
 void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t shmem);
 unsigned char *dyn_lds();
 }  // namespace hipsim
@@ -69,6 +71,9 @@ template <class T> inline T max(T a, T b) { return a > b ? a : b; }
 
 #define HF_GLDS16_DEFINED
 inline void hf_glds16(const float *gsrc_lane, float *lds_wave_base) { ::hipsim::glds16(gsrc_lane, lds_wave_base); }
+inline void hf_glds4(const float *gsrc_lane, float *lds_wave_base) { ::hipsim::glds4(gsrc_lane, lds_wave_base); }
+inline void hf_glds16_if(bool a, const float *g, float *l) { ::hipsim::glds_masked(a, 16, g, l); }
+inline void hf_glds4_if(bool a, const float *g, float *l) { ::hipsim::glds_masked(a, 4, g, l); }
 
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) ::hipsim::mfma32x32x2((a), (b), (c))

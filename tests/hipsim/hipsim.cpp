@@ -16,7 +16,7 @@ unsigned char *dyn_lds() { return g_lds; }
 
 namespace {
 enum State { READY, WAIT_BLOCK, WAIT_WAVE, DONE };
-enum WaveOp { OP_NONE, OP_SHFL_XOR, OP_SHFL_REL, OP_MFMA, OP_GLDS };
+enum WaveOp { OP_NONE, OP_SHFL_XOR, OP_SHFL_REL, OP_MFMA, OP_GLDS, OP_GLDS4, OP_GLDS_MASKED };
 
 struct Fiber {
   ucontext_t ctx;
@@ -74,6 +74,21 @@ void resolve_wave(int w0, int w1) {
       if (g_f[i].state == WAIT_WAVE) base = g_f[i].ldst;
     for (int i = w0; i < w1; ++i)
       if (g_f[i].state == WAIT_WAVE) memcpy(base + 4 * (i - w0), g_f[i].gsrc, 16);
+  } else if (op == OP_GLDS_MASKED) {
+    // every lane arrives; `b` != 0 marks the lanes enabled in EXEC, imm = bytes per lane.
+    // The LDS base (M0) is taken from the first enabled lane.
+    float *base = nullptr;
+    for (int i = w0; i < w1 && !base; ++i)
+      if (g_f[i].state == WAIT_WAVE && g_f[i].b != 0.0f) base = g_f[i].ldst;
+    for (int i = w0; i < w1; ++i)
+      if (g_f[i].state == WAIT_WAVE && g_f[i].b != 0.0f)
+        memcpy(reinterpret_cast<char *>(base) + (size_t)g_f[i].imm * (i - w0), g_f[i].gsrc, g_f[i].imm);
+  } else if (op == OP_GLDS4) {
+    float *base = nullptr;
+    for (int i = w0; i < w1 && !base; ++i)
+      if (g_f[i].state == WAIT_WAVE) base = g_f[i].ldst;
+    for (int i = w0; i < w1; ++i)
+      if (g_f[i].state == WAIT_WAVE) base[i - w0] = *g_f[i].gsrc;
   } else if (op == OP_MFMA) {
     if (w1 - w0 != 64) { fprintf(stderr, "hipsim: MFMA needs a full wave\n"); abort(); }
     for (int i = w0; i < w1; ++i)
@@ -172,6 +187,19 @@ f32x16 mfma32x32x2(float a, float b, f32x16 c) {
 void glds16(const float *gsrc_lane, float *lds_wave_base) {
   Fiber &f = g_f[g_cur];
   f.op = OP_GLDS; f.gsrc = gsrc_lane; f.ldst = lds_wave_base; f.state = WAIT_WAVE;
+  yield_to_sched();
+}
+
+void glds4(const float *gsrc_lane, float *lds_wave_base) {
+  Fiber &f = g_f[g_cur];
+  f.op = OP_GLDS4; f.gsrc = gsrc_lane; f.ldst = lds_wave_base; f.state = WAIT_WAVE;
+  yield_to_sched();
+}
+
+void glds_masked(bool active, int bytes, const float *gsrc_lane, float *lds_wave_base) {
+  Fiber &f = g_f[g_cur];
+  f.op = OP_GLDS_MASKED; f.gsrc = gsrc_lane; f.ldst = lds_wave_base; f.b = active ? 1.0f : 0.0f; f.imm = bytes;
+  f.state = WAIT_WAVE;
   yield_to_sched();
 }
 

@@ -252,3 +252,40 @@ def test_random_noise_path_statistics():
         a2, _ = g([lat.to(dev)], input_is_latent=True)
     assert not torch.equal(a, b)
     assert torch.equal(a, a2)
+
+
+@pytest.mark.parametrize("cfg,shape", [
+    (11, (2, 64, 128, 40, 64)), (12, (1, 32, 64, 24, 40)), (13, (2, 16, 32, 48, 96)), (14, (1, 32, 128, 8, 32)),
+    (15, (2, 16, 64, 8, 8)), (16, (1, 16, 32, 32, 64)),
+    (31, (2, 64, 128, 40, 64)), (32, (1, 32, 64, 24, 64)), (33, (2, 16, 32, 44, 96)), (34, (1, 32, 128, 12, 32)),
+    (21, (2, 32, 64, 8, 32)), (22, (1, 16, 32, 16, 32)), (23, (1, 16, 64, 6, 40)), (24, (1, 32, 64, 16, 32)),
+    (25, (2, 16, 32, 4, 32)),
+])
+def test_every_pipelined_instantiation_vs_oracle(cfg, shape):
+    """Each double-buffered kernel instantiation (register-staged, DMA-staged, transposed),
+    forced through hf_debug_set_dispatch, on shapes with ragged tiles - and the assertion
+    that the forced kernel really ran (no silent fallback to the general kernel)."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = _dev()
+    B, cin, cout, H, W = shape
+    torch.manual_seed(cfg)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+    wt, wsq = M.prepare_weights(lib(), stream(), wgt.to(dev))
+    s = M.modulation(lib(), stream(), sty.to(dev), mw.to(dev), mb.to(dev))
+    dm = M.demod(lib(), stream(), s, wsq)
+    up = 20 <= cfg < 30
+    ref = O.modulated_conv2d(x, sty, wgt, mw, mb, True, up)
+    try:
+        lib().hf_debug_set_dispatch(0 if up else cfg, cfg if up else 0)
+        if up:
+            y = M.modconv3x3_up(lib(), stream(), x.to(dev), wt, s, dm, O.blur_kernel_1d_to_2d(gain=4.0).to(dev), None, None, None)
+        else:
+            y = M.modconv3x3(lib(), stream(), x.to(dev), wt, s, dm, None, None, None)
+        assert lib().hf_debug_last_path() == 200 + cfg
+    finally:
+        lib().hf_debug_set_dispatch(0, 0)
+    close(y, ref)

@@ -135,6 +135,10 @@ def test_modconv_tile_geometries(simlib):
     (14, (1, 16, 128, 8, 32)),
     (15, (2, 8, 64, 8, 8)),
     (16, (1, 8, 32, 32, 32)),
+    (31, (2, 16, 128, 16, 32)),   # DMA-staged variants (rows of 32 pixels)
+    (32, (1, 16, 64, 24, 64)),
+    (33, (2, 8, 32, 8, 96)),
+    (34, (1, 16, 128, 12, 32)),   # ragged: 12 rows with 4-row tiles
     (21, (2, 16, 64, 8, 32)),     # up: 64 co x 128 px x 4 phases (+ rim launch)
     (22, (1, 8, 32, 16, 32)),
     (23, (1, 8, 64, 6, 40)),
@@ -151,7 +155,7 @@ def test_modconv_pipelined_configs(simlib, cfg, shape):
     wt, wsq = M.prepare_weights(simlib, None, wgt)
     s = M.modulation(simlib, None, sty, mw, mb)
     dm = M.demod(simlib, None, s, wsq)
-    up = cfg >= 20
+    up = 20 <= cfg < 30
     ref = O.modulated_conv2d(x, sty, wgt, mw, mb, True, up)
     try:
         simlib.hf_debug_set_dispatch(0 if up else cfg, cfg if up else 0)
