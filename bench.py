@@ -82,6 +82,17 @@ def cpu_baseline(sd, budget_s=30.0):
                       + ", ".join(f"{k}T={v[0] * 1e3:.0f}ms" for k, v in sorted(tried.items()))}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json:
+    FETCH_SIZE + WRITE_SIZE collected in separate rocprofv3 --pmc runs of this bench), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"].get(kernel)
+        return None if k is None else round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def swap_schedule_bench(g, sd, dev, n_triples):
     """Seconds for `n_triples` replays of the per-triple hot-path schedule (after one warm-up)."""
     import numpy as np
@@ -232,7 +243,7 @@ def main():
             ach = d[0] / d[1] / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
                                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
                                "avg_launch_ms": round(d[1] / d[2] * 1e3, 4), "launches": d[2],
                                "flops_per_launch_avg": d[0] / d[2]}
             out["kernels"] = fams
