@@ -31,7 +31,7 @@ SIGNATURES = {
     "hf_torgb_f32": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st],
     "hf_conv_prepare_f32": [_f, _f, _i, _i, _i, _fl, _st],
     "hf_bn_fold_f32": [_f, _f, _f, _f, _f, _f, _f, _fl, _i, _st],
-    "hf_conv2d_f32": [_f, _f, _f, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _f, _ll, _st],
+    "hf_conv2d_f32": [_f, _f, _f, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _f, _ll, _st],
     "hf_plane_mean_f32": [_f, _f, _i, _i, _st],
     "hf_se_gate_f32": [_f, _f, _f, _f, _i, _i, _i, _st],
     "hf_scale_shortcut_add_f32": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _st],
@@ -62,7 +62,7 @@ def bind(cdll):
     cdll.hf_strerror.restype = ctypes.c_char_p
     cdll.hf_modconv_workspace_floats.argtypes = [_i, _i, _i, _i, _i, _i]
     cdll.hf_modconv_workspace_floats.restype = ctypes.c_longlong
-    cdll.hf_conv2d_workspace_floats.argtypes = [_i, _i, _i, _i, _i, _i, _i]
+    cdll.hf_conv2d_workspace_floats.argtypes = [_i, _i, _i, _i, _i, _i, _i, _i]
     cdll.hf_conv2d_workspace_floats.restype = ctypes.c_longlong
     cdll.hf_abi_version.argtypes = []
     cdll.hf_abi_version.restype = ctypes.c_int

@@ -23,6 +23,7 @@ KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modc
     211: "conv_mfma_pipe<2,2,2,4>", 212: "conv_mfma_pipe<2,2,1,4>", 213: "conv_mfma_pipe<1,2,1,4>",
     214: "conv_mfma_pipe<2,2,2,2>", 215: "conv_mfma_pipe<1,1,2,2>", 216: "conv_mfma_pipe<1,4,1,4>",
     231: "conv_mfma_dma<2,2,2,4>", 232: "conv_mfma_dma<2,2,1,4>", 233: "conv_mfma_dma<1,2,1,4>", 234: "conv_mfma_dma<2,2,2,2>",
+    244: "conv_mfma_pipe<2,2,2,2,stride2>", 245: "conv_mfma_pipe<1,1,2,2,stride2>",
     221: "conv_mfma_pipe<1,2,2,2,up>", 222: "conv_mfma_pipe<1,2,1,4,up>", 223: "conv_mfma_pipe<1,1,2,2,up>",
     224: "conv_mfma_pipe<1,2,2,4,up>", 225: "conv_mfma_pipe<1,1,1,4,up>", 300: "conv_mfma<1,1,2,2> split-K",
 }
@@ -219,23 +220,33 @@ def bn_fold(lib, st, gamma, beta, mean, var, eps, conv_bias=None):
 
 
 def conv2d(lib, st, x, wt, k, stride=1, in_scale=None, in_shift=None, out_scale=None, bias=None, act=ACT_NONE,
-           slope=None, alpha=0.0, residual=None):
+           slope=None, alpha=0.0, residual=None, groups=1, x_shared=True):
+    """groups == 1: x [B,cin,H,W], wt [k*k,cin,cout] -> [B,cout,oh,ow].
+    groups  > 1: wt [G,k*k,cin,cout], bias/out_scale/slope [G,cout]; x [B,cin,H,W] shared by all
+    groups (x_shared) or [G,B,cin,H,W]; returns [G,B,cout,oh,ow]."""
     x = _c(x)
-    b, cin, h, w = x.shape
-    cout = wt.shape[2]
+    if groups > 1 and not x_shared:
+        g_, b, cin, h, w = x.shape
+        if g_ != groups:
+            raise ValueError("x must be [groups, B, cin, H, W]")
+        x_gstride = b * cin * h * w
+    else:
+        b, cin, h, w = x.shape
+        x_gstride = 0
+    cout = wt.shape[-1]
     oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
-    out = x.new_empty((b, cout, oh, ow))
+    out = x.new_empty((groups, b, cout, oh, ow) if groups > 1 else (b, cout, oh, ow))
     if residual is not None:
         residual = _c(residual)
         if tuple(residual.shape) != tuple(out.shape):
             raise ValueError(f"residual {tuple(residual.shape)} != output {tuple(out.shape)}")
-    n = lib.hf_conv2d_workspace_floats(b, cin, cout, h, w, k, stride)
+    n = lib.hf_conv2d_workspace_floats(b, cin, cout, h, w, k, stride, groups)
     ws = x.new_empty((n,)) if n > 0 else None
     code = _launch_profiled(
-        lib, 2.0 * cin * cout * k * k * oh * ow * b,
-        lambda: lib.hf_conv2d_f32(_p(out), _p(x), _p(wt), _p(in_scale), _p(in_shift), _p(out_scale), _p(bias), act,
-                                  _p(slope), float(alpha), _p(residual), b, cin, cout, h, w, k, stride, _p(ws),
-                                  max(n, 0), st))
+        lib, 2.0 * cin * cout * k * k * oh * ow * b * groups,
+        lambda: lib.hf_conv2d_f32(_p(out), _p(x), _p(_c(wt)), _p(in_scale), _p(in_shift), _p(_c(out_scale)), _p(_c(bias)),
+                                  act, _p(_c(slope)), float(alpha), _p(residual), b, cin, cout, h, w, k, stride, groups,
+                                  x_gstride, _p(ws), max(n, 0), st))
     check(lib, code, "hf_conv2d_f32")
     return out
 

@@ -77,11 +77,39 @@ struct ConvParams {
   float alpha, scale;
   int n_geom;
   int xs_max;                  // LDS floats reserved per staged channel
+  int groups;                  // grouped launch: blockIdx.y = group * co_tiles + co_tile (0/1 = off)
+  int co_tiles;                // cout tiles per group
+  long long x_gstride;         // floats between the inputs of consecutive groups (0 = shared input)
+  long long wt_gstride;        // taps*cin*cout
+  long long zslab;             // split-K: floats per z slab of `partial` (= groups*batch*cout*oh*ow)
   int splits;                  // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps); 1 = off
   int chunks_per_split;
   float *partial;              // splits > 1: raw accumulators go to partial[z][b][co][oh][ow]
   TileGeom g[3];
 };
+
+// Grouped launch: G independent convolutions of identical shape in one grid (the style
+// heads of the e4e encoder).  Weights / per-channel vectors / outputs of group g follow
+// those of group g-1; the input is shared (x_gstride 0) or per group.  Offsets of this
+// block's group (all zero for ordinary launches); the kernel-argument struct itself is
+// never copied (a modified copy would live in scratch memory).
+struct GroupOfs {
+  long long x, wt, o;  // element offsets into x, wt and out / partial / residual
+  int c;               // offset into bias / slope / d
+  int co_tile;
+};
+__device__ __forceinline__ GroupOfs group_offsets(const ConvParams &P) {
+  GroupOfs go{0, 0, 0, 0, (int)blockIdx.y};
+  if (P.groups > 1) {
+    const int g = blockIdx.y / P.co_tiles;
+    go.co_tile = blockIdx.y - g * P.co_tiles;
+    go.x = (long long)g * P.x_gstride;
+    go.wt = (long long)g * P.wt_gstride;
+    go.o = (long long)g * P.batch * P.cout * P.out_h * P.out_w;
+    go.c = g * P.cout;  // per-channel vectors (d_bstride == 0 in grouped launches)
+  }
+  return go;
+}
 
 struct NoSideWork {
   __device__ __forceinline__ void operator()(int) const {}
@@ -152,7 +180,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha, float 
 // channels are fetched with independent loads up front (no load->wait->store chains).
 //   v = acc*d + noise_w*noise + bias ; v = act(v) ; v += residual
 template <int CT_TILES, int PG, bool UP, int NPH = (UP ? 4 : 1)>
-__device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &G,
+__device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &G, const GroupOfs &go,
                                            f32x16 (&acc)[NPH][CT_TILES][PG], int co_wave, int wave_pg, int li,
                                            int lh, int ty0, int tx0, int b0) {
   const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
@@ -171,7 +199,7 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
     if (!pv) continue;
     float nz = 0.0f;
     if (full && P.noise) nz = nw * P.noise[(long long)b * P.noise_bstride + (long long)Y * P.out_w + X];
-    float *obase = partial ? P.partial + (long long)blockIdx.z * P.batch * P.cout * oplane : P.out;
+    float *obase = (partial ? P.partial + (long long)blockIdx.z * P.zslab : P.out) + go.o;
 #pragma unroll
     for (int ct = 0; ct < CT_TILES; ++ct) {
       float dmv[16], bsv[16], slv[16];  // one co tile at a time: 48 live registers, not 48*CT_TILES
@@ -179,9 +207,9 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
       for (int r = 0; r < 16; ++r) {
         const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int cc = min(co, P.cout - 1);
-        dmv[r] = (P.d && !partial) ? P.d[(long long)b * P.d_bstride + cc] : 1.0f;
-        bsv[r] = (full && P.bias) ? P.bias[cc] : 0.0f;
-        slv[r] = (full && P.act == ACT_PRELU) ? P.slope[cc] : 0.0f;
+        dmv[r] = (P.d && !partial) ? P.d[(long long)b * P.d_bstride + go.c + cc] : 1.0f;
+        bsv[r] = (full && P.bias) ? P.bias[go.c + cc] : 0.0f;
+        slv[r] = (full && P.act == ACT_PRELU) ? P.slope[go.c + cc] : 0.0f;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -213,7 +241,7 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
           float v = acc[0][ct][g][r] * dm;
           if (full) {
             v = apply_act(v + nz + bsv[r], P.act, P.alpha, P.scale, slv[r]);
-            if (P.residual) v += P.residual[obofs + pofs];
+            if (P.residual) v += P.residual[go.o + obofs + pofs];
           }
           ob[pofs] = v;
         }
@@ -229,6 +257,8 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
 // ------------------------------------------------------------------------------
 template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int TAPS>
 __global__ __launch_bounds__(kThreads) void conv_mfma(const ConvParams P) {
+  const GroupOfs go = group_offsets(P);
+  const int co_tile = go.co_tile;
   static_assert(WAVES_CO * WAVES_PX == 4, "4 waves per block");
   static_assert(!(UP && TAPS != 9), "transposed conv is 3x3");
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
@@ -246,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const ConvParams P) {
   const int lh = lane >> 5;  // MFMA k index within the k=2 step
   const int wave_co = (wave / WAVES_PX) * (32 * CT_TILES);
   const int wave_pg = (wave % WAVES_PX) * PG;
-  const int co0 = blockIdx.y * CT;
+  const int co0 = co_tile * CT;
 
   // ---- which tile family / tile is this block? (uniform) --------------------
   int gi = 0;
@@ -269,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const ConvParams P) {
   const int tx0 = G.x0 + tx * tw;
   const int b0 = tb * nb;
   const long long plane = (long long)P.h * P.w;
-  const float *xb = P.x + (long long)b0 * P.cin * plane;
+  const float *xb = P.x + go.x + (long long)b0 * P.cin * plane;
 
   // ---- per-thread staging descriptors for the halo tile (chunk invariant) ----
   int e_ofs[kMaxElemPerCi];  // float offset from xb (channel 0), -1 = zero fill
@@ -332,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const ConvParams P) {
         const int ci = ci0 + kc, co = co0 + c4 * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ci < P.cin && co < P.cout)
-          v = *reinterpret_cast<const float4 *>(P.wt + ((long long)tap * P.cin + ci) * P.cout + co);
+          v = *reinterpret_cast<const float4 *>(P.wt + go.wt + ((long long)tap * P.cin + ci) * P.cout + co);
         *reinterpret_cast<float4 *>(wl + (tap * KC + kc) * CT + c4 * 4) = v;
       }
     } else {
@@ -342,7 +372,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const ConvParams P) {
         const int tap = i / (CT * KC);
         const int ci = ci0 + kc, co = co0 + c;
         float v = 0.f;
-        if (ci < P.cin && co < P.cout) v = P.wt[((long long)tap * P.cin + ci) * P.cout + co];
+        if (ci < P.cin && co < P.cout) v = P.wt[go.wt + ((long long)tap * P.cin + ci) * P.cout + co];
         wl[(tap * KC + kc) * CT + c] = v;
       }
     }
@@ -371,7 +401,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const ConvParams P) {
     mfma_chunk<CT_TILES, PG, CT, UP, TAPS>(acc, a_base, b_base, P.xs_max, pixoff, wp, NoSideWork());
   }
 
-  store_tile<CT_TILES, PG, UP>(P, G, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+  store_tile<CT_TILES, PG, UP>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
 // ------------------------------------------------------------------------------
@@ -388,15 +418,20 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const ConvParams P) {
 // ABLATE (timing experiments only, results are wrong when != 0): 1 = no staging traffic
 // inside the loop (barriers kept), 2 = no staging and no barriers.
 // ------------------------------------------------------------------------------
-template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int ABLATE = 0>
+template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int ABLATE = 0, int STRIDE = 1>
 __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const ConvParams P) {
+  static_assert(!(UP && STRIDE != 1), "the transposed conv has no strided form");
+  const GroupOfs go = group_offsets(P);
+  const int co_tile = go.co_tile;
   constexpr int NW = WAVES_CO * WAVES_PX;
   constexpr int NT = 64 * NW;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
   constexpr int PT = 32 * PG * WAVES_PX;
   constexpr int NPH = UP ? 4 : 1;
   constexpr int HALO = UP ? 1 : 2;
-  constexpr int XEP = ((PT / 32 + HALO) * (32 + HALO) + NT - 1) / NT;  // halo elements per thread per ci
+  // halo elements per thread per ci: a tile of PT/32 rows x 32 output pixels needs
+  // ((rows-1)*STRIDE + 1 + HALO) x (31*STRIDE + 1 + HALO) inputs
+  constexpr int XEP = (((PT / 32 - 1) * STRIDE + 1 + HALO) * (31 * STRIDE + 1 + HALO) + NT - 1) / NT;
   constexpr int WCHUNK = 9 * KC * CT;                                   // floats of one weight stage
   constexpr int NDMA = WCHUNK / 256;                                    // 1 KiB wave-instructions per stage
   static_assert(WCHUNK % 256 == 0, "weight stage must be a whole number of 1 KiB DMA pieces");
@@ -412,7 +447,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const
   const int lh = lane >> 5;
   const int wave_co = (wave / WAVES_PX) * (32 * CT_TILES);
   const int wave_pg = (wave % WAVES_PX) * PG;
-  const int co0 = blockIdx.y * CT;
+  const int co0 = co_tile * CT;
 
   int gi = 0;  // tile family (uniform): interior, or the rim row / column of the transposed conv
   if (P.n_geom > 1 && (int)blockIdx.x >= P.g[1].first_block) gi = 1;
@@ -424,12 +459,12 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const
   const int ty = t % G.tiles_y;
   const int b0 = t / G.tiles_y;  // one image per tile
   const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
-  const int wp = tw + HALO, hp = th + HALO;
+  const int wp = (tw - 1) * STRIDE + 1 + HALO, hp = (th - 1) * STRIDE + 1 + HALO;
   const int xs = hp * wp;
-  const int ty0 = G.y0 + ty * th;
+  const int ty0 = G.y0 + ty * th;  // first OUTPUT pixel of the tile
   const int tx0 = G.x0 + tx * tw;
   const long long plane = (long long)P.h * P.w;
-  const float *xb = P.x + (long long)b0 * P.cin * plane;
+  const float *xb = P.x + go.x + (long long)b0 * P.cin * plane;
   const float *sb = P.s ? P.s + (long long)b0 * P.s_bstride : nullptr;
 
   int e_ofs[XEP];  // offset of the thread's halo elements inside a channel plane, -1 = zero
@@ -439,7 +474,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const
     e_ofs[e] = -1;
     if (idx < xs) {
       const int hy = idx / wp, hx = idx - hy * wp;
-      const int ys = ty0 + hy - 1, xc = tx0 + hx - 1;
+      const int ys = ty0 * STRIDE + hy - 1, xc = tx0 * STRIDE + hx - 1;
       if (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) e_ofs[e] = ys * P.w + xc;
     }
   }
@@ -448,7 +483,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const
 #pragma unroll
   for (int g = 0; g < PG; ++g) {
     const int p = (wave_pg + g) * 32 + li;
-    pixoff[g] = ((p >> G.lg_tw) & (th - 1)) * wp + (p & (tw - 1));
+    pixoff[g] = ((p >> G.lg_tw) & (th - 1)) * STRIDE * wp + (p & (tw - 1)) * STRIDE;
   }
 
   f32x16 acc[NPH][CT_TILES][PG];
@@ -472,7 +507,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const
       const int f = j * 256 + lane * 4;
       const int row = f / CT, col = f % CT;
       const int tap = row / KC, kc = row % KC;
-      hf_glds16(P.wt + ((long long)tap * P.cin + ci0 + kc) * P.cout + co0 + col, wl + j * 256);
+      hf_glds16(P.wt + go.wt + ((long long)tap * P.cin + ci0 + kc) * P.cout + co0 + col, wl + j * 256);
     }
   };
   float xr[KC][XEP];
@@ -491,11 +526,16 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const
     if (idx < xs) xl[kc * P.xs_max + idx] = (e_ofs[e] >= 0) ? fmaf(xr[kc][e], sr[kc], tr[kc]) : 0.0f;
   };
 
-  // prologue: chunk 0 into buffer 0
+  // split-K: this block handles chunks [c_begin, c_end) and stores raw partial sums
+  const int nchunks = P.cin / KC;
+  const int c_begin = (P.splits > 1) ? (int)blockIdx.z * P.chunks_per_split : 0;
+  const int c_end = (P.splits > 1) ? min(nchunks, c_begin + P.chunks_per_split) : nchunks;
+
+  // prologue: first chunk into buffer 0
 #pragma unroll
-  for (int i = 0; i < ND; ++i) dma_piece(i, 0, wl0);
+  for (int i = 0; i < ND; ++i) dma_piece(i, c_begin * KC, wl0);
 #pragma unroll
-  for (int i = 0; i < NL; ++i) load_piece(i, 0);
+  for (int i = 0; i < NL; ++i) load_piece(i, c_begin * KC);
 #pragma unroll
   for (int i = 0; i < NL; ++i) write_piece(i, xl0);
   __syncthreads();
@@ -510,10 +550,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const
   constexpr int W_FIRST = NSTEP - L_STEPS;
   static_assert(D_STEPS + L_STEPS <= W_FIRST, "staging schedule does not fit the chunk");
 
-  const int nchunks = P.cin / KC;
-  for (int c = 0; c < nchunks; ++c) {
-    const int cur = c & 1;
-    const bool more = (c + 1 < nchunks) && ABLATE == 0;
+  for (int c = c_begin; c < c_end; ++c) {
+    const int cur = (c - c_begin) & 1;
+    const bool more = (c + 1 < c_end) && ABLATE == 0;
     const int ci_next = (c + 1) * KC;
     float *wl_next = wl0 + (cur ^ 1) * WCHUNK;
     float *xl_next = xl0 + (cur ^ 1) * KC * P.xs_max;
@@ -539,7 +578,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const
     if (ABLATE < 2) __syncthreads();  // also drains the weight DMA (vmcnt) before anyone reads the other buffer
   }
 
-  store_tile<CT_TILES, PG, UP>(P, G, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+  store_tile<CT_TILES, PG, UP>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
 // ------------------------------------------------------------------------------
@@ -695,25 +734,28 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_dma(const 
     __syncthreads();  // drains the DMA of the next stage (vmcnt) and frees the current one
   }
 
-  store_tile<CT_TILES, PG, false>(P, G, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+  store_tile<CT_TILES, PG, false>(P, G, GroupOfs{0, 0, 0, 0, 0}, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
 // Split-K second pass: out = epilogue(d * sum_z partial[z]) - deterministic (fixed z order).
 __global__ __launch_bounds__(256) void splitk_reduce(const ConvParams P, long long slab, int with_epilogue) {
   const long long oplane = (long long)P.out_h * P.out_w;
+  const long long ovol = (long long)P.batch * P.cout * oplane;  // one group
   const float nw = (with_epilogue && P.noise) ? P.noise_w[0] : 0.0f;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slab; i += stride) {
     float v = 0.0f;
     for (int z = 0; z < P.splits; ++z) v += P.partial[(long long)z * slab + i];
-    const long long pl = i / oplane;
+    const long long g = i / ovol;
+    const long long pl = (i - g * ovol) / oplane;
     const int co = (int)(pl % P.cout);
     const long long b = pl / P.cout;
-    if (P.d) v *= P.d[b * P.d_bstride + co];
+    const long long gc = g * P.cout + co;  // per-channel vectors of group g follow those of g-1
+    if (P.d) v *= P.d[b * P.d_bstride + gc];
     if (with_epilogue) {
-      if (P.noise) v = fmaf(nw, P.noise[b * P.noise_bstride + (i - pl * oplane)], v);
-      if (P.bias) v += P.bias[co];
-      v = apply_act(v, P.act, P.alpha, P.scale, P.act == ACT_PRELU ? P.slope[co] : 0.0f);
+      if (P.noise) v = fmaf(nw, P.noise[b * P.noise_bstride + (i % oplane)], v);
+      if (P.bias) v += P.bias[gc];
+      v = apply_act(v, P.act, P.alpha, P.scale, P.act == ACT_PRELU ? P.slope[gc] : 0.0f);
       if (P.residual) v += P.residual[i];
     }
     P.out[i] = v;
@@ -794,7 +836,9 @@ int launch_conv(ConvParams &P, hipStream_t st) {
   P.xs_max = (xs_max + 3) & ~3;
   const size_t lds = (size_t)(TAPS * KC * CT + KC * P.xs_max) * sizeof(float);
   if (P.splits < 1) P.splits = 1;
-  dim3 grid(nblocks, hf_cdiv(P.cout, CT), P.splits);
+  P.co_tiles = hf_cdiv(P.cout, CT);
+  P.zslab = (long long)max(1, P.groups) * P.batch * P.cout * P.out_h * P.out_w;
+  dim3 grid(nblocks, P.co_tiles * max(1, P.groups), P.splits);
   if (grid.y > 65535) return HF_E_INVALID;
   hipLaunchKernelGGL((conv_mfma<CT_TILES, PG, WAVES_CO, WAVES_PX, UP, TAPS>), grid, dim3(kThreads), lds, st, P);
   return hf_launch_status();
@@ -802,19 +846,19 @@ int launch_conv(ConvParams &P, hipStream_t st) {
 
 // Pipelined launch (interior + rim families in one launch); returns HF_E_INVALID if the
 // shape does not meet the kernel's preconditions (caller then uses the general kernel).
-template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int ABLATE = 0>
+template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int ABLATE = 0, int STRIDE = 1>
 int launch_conv_pipe(ConvParams &P, hipStream_t st) {
   constexpr int NT = 64 * WAVES_CO * WAVES_PX;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
   constexpr int PT = 32 * PG * WAVES_PX;
   constexpr int HALO = UP ? 1 : 2;
-  constexpr int XEP = ((PT / 32 + HALO) * (32 + HALO) + NT - 1) / NT;
+  constexpr int XEP = (((PT / 32 - 1) * STRIDE + 1 + HALO) * (31 * STRIDE + 1 + HALO) + NT - 1) / NT;
   if (P.cin % KC || P.cout % CT || (P.cout & 3)) return HF_E_INVALID;
-  if (!UP && P.stride != 1) return HF_E_INVALID;
-  if ((((size_t)P.wt) & 15) != 0) return HF_E_INVALID;
-  P.splits = 1;
+  if (!UP && P.stride != STRIDE) return HF_E_INVALID;
+  if ((((size_t)P.wt) & 15) != 0 || (P.wt_gstride & 3)) return HF_E_INVALID;
+  if (P.splits < 1) P.splits = 1;
   P.n_geom = 1;
-  P.g[0] = make_geom(0, 0, P.h, P.w, P.batch, PT, 0);
+  P.g[0] = UP ? make_geom(0, 0, P.h, P.w, P.batch, PT, 0) : make_geom(0, 0, P.out_h, P.out_w, P.batch, PT, 0);
   int nblocks = geom_blocks(P.g[0]);
   if (UP) {  // + the Y = h row (incl. corner) and the X = w column of the (h+1)x(w+1) phase domain
     P.n_geom = 3;
@@ -826,16 +870,19 @@ int launch_conv_pipe(ConvParams &P, hipStream_t st) {
   int xs = 0;
   for (int i = 0; i < P.n_geom; ++i) {
     if (P.g[i].lg_nb != 0) return HF_E_INVALID;  // the pipelined kernel wants one image per tile
-    xs = max(xs, geom_xs(P.g[i], 1, HALO));
+    xs = max(xs, geom_xs(P.g[i], STRIDE, HALO));
   }
   if (xs > XEP * NT) return HF_E_INVALID;
   if ((long long)P.cin * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
   P.xs_max = (xs + 3) & ~3;
   const size_t lds = (size_t)2 * (9 * KC * CT + KC * P.xs_max) * sizeof(float);
   if (lds > 160 * 1024) return HF_E_INVALID;
-  dim3 grid(nblocks, P.cout / CT);
+  P.co_tiles = P.cout / CT;
+  P.zslab = (long long)max(1, P.groups) * P.batch * P.cout * P.out_h * P.out_w;
+  dim3 grid(nblocks, P.co_tiles * max(1, P.groups), P.splits);
   if (grid.y > 65535) return HF_E_INVALID;
-  hipLaunchKernelGGL((conv_mfma_pipe<CT_TILES, PG, WAVES_CO, WAVES_PX, UP, ABLATE>), grid, dim3(NT), lds, st, P);
+  hipLaunchKernelGGL((conv_mfma_pipe<CT_TILES, PG, WAVES_CO, WAVES_PX, UP, ABLATE, STRIDE>), grid, dim3(NT), lds, st,
+                     P);
   return hf_launch_status();
 }
 
@@ -845,7 +892,7 @@ int launch_conv_dma(ConvParams &P, hipStream_t st) {
   constexpr int NT = 64 * WAVES_CO * WAVES_PX;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
   constexpr int TH = PG * WAVES_PX, HP = TH + 2;
-  if (P.cin % KC || P.cout % CT || (P.cout & 3) || P.stride != 1 || P.t) return HF_E_INVALID;
+  if (P.cin % KC || P.cout % CT || (P.cout & 3) || P.stride != 1 || P.t || P.groups > 1) return HF_E_INVALID;
   if ((P.w & 3) || P.w < 32 || P.h < TH) return HF_E_INVALID;
   if ((((size_t)P.wt) | ((size_t)P.x)) & 15) return HF_E_INVALID;
   if ((long long)P.cin * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
@@ -869,22 +916,31 @@ int launch_conv_dma(ConvParams &P, hipStream_t st) {
   return hf_launch_status();
 }
 
-// Split-K plan for layers with few (co tile, pixel tile) pairs but many K-chunks.
-// Pure function of the shape so that callers can size the workspace.
-inline int splitk_plan(int batch, int cin, int cout, int out_h, int out_w) {
+// Split-K plan (pure function of the shape, so that callers can size the workspace).
+// Regime 1: fewer than one 64x64 tile per CU -> split until ~2 blocks per CU.
+// Regime 2: 1-3 tiles per CU and a long K loop: such layers are bound by the per-chunk
+// round trip (global load -> LDS -> barrier), not by MFMA time; splitting K puts 3 blocks
+// on every CU so that their round trips overlap.
+inline int splitk_plan(int batch, int cin, int cout, int out_h, int out_w, bool allow_mid = true) {
   const int PT = 64, CT = 64;  // the small-plane configuration <1,1,2,2>
   const long long per_img = ((long long)out_h * out_w + PT - 1) / PT;
   const long long base = batch * per_img * ((cout + CT - 1) / CT);
-  if (base >= 256) return 1;  // the 64x64 tiling already fills the chip
   const int nchunks = (cin + KC - 1) / KC;
-  int s = (int)((512 + base - 1) / base);
-  if (s > nchunks) s = nchunks;
-  if (s > 64) s = 64;
+  int s = 1;
+  if (base < 256) {
+    s = (int)((512 + base - 1) / base);
+    if (s > nchunks) s = nchunks;
+    if (s > 64) s = 64;
+  } else if (allow_mid && base < 768 && nchunks >= 16) {
+    s = (int)((768 + base - 1) / base);
+    if (s > nchunks / 4) s = nchunks / 4;
+    if (s > 8) s = 8;
+  }
   return s < 2 ? 1 : s;
 }
 
 int launch_splitk_reduce(ConvParams &P, bool with_epilogue, hipStream_t st) {
-  const long long slab = (long long)P.batch * P.cout * P.out_h * P.out_w;
+  const long long slab = (long long)max(1, P.groups) * P.batch * P.cout * P.out_h * P.out_w;
   long long g = (slab + 255) / 256;
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(splitk_reduce, dim3((int)g), dim3(256), 0, st, P, slab, with_epilogue ? 1 : 0);
@@ -899,12 +955,18 @@ int g_last_path = 0;  // 1 = general kernel, 2 = pipelined kernel, 3 = split-K (
 // split-K through `workspace` with the small-plane general configuration
 template <bool UP, int TAPS>
 int run_splitk(ConvParams &P, int sk, float *workspace, long long workspace_floats, hipStream_t st) {
-  if (!workspace || workspace_floats < (long long)sk * P.batch * P.cout * P.out_h * P.out_w) return HF_E_WORKSPACE;
+  if (!workspace || workspace_floats < (long long)sk * max(1, P.groups) * P.batch * P.cout * P.out_h * P.out_w)
+    return HF_E_WORKSPACE;
   const int nchunks = (P.cin + KC - 1) / KC;
   P.splits = sk;
   P.chunks_per_split = (nchunks + sk - 1) / sk;
   P.partial = workspace;
-  int rc = launch_conv<1, 1, 2, 2, UP, TAPS>(P, st);
+  int rc = HF_E_INVALID;
+  if (!UP && TAPS == 9) {  // double-buffered 64 co x 64 px kernel when the shape qualifies
+    rc = (P.stride == 2) ? launch_conv_pipe<1, 1, 2, 2, false, 0, 2>(P, st) : launch_conv_pipe<1, 1, 2, 2, false, 0, 1>(P, st);
+    if (rc == HF_E_INVALID) P.splits = sk;
+  }
+  if (rc == HF_E_INVALID) rc = launch_conv<1, 1, 2, 2, UP, TAPS>(P, st);
   if (rc != HF_OK) return rc;
   g_last_path = 3;
   return launch_splitk_reduce(P, !UP, st);
@@ -913,7 +975,7 @@ int run_splitk(ConvParams &P, int sk, float *workspace, long long workspace_floa
 // 3x3 stride-1 convolution (modulated or plain): pipelined kernel when the shape
 // qualifies, else the general one.
 int run_conv3x3_s1(ConvParams &P, float *workspace, long long workspace_floats, hipStream_t st) {
-  const int batch = P.batch, cout = P.cout, h = P.h, w = P.w;
+  const int batch = P.batch * max(1, P.groups), cout = P.cout, h = P.h, w = P.w;  // block counts scale with groups
   {
     const int sk = (g_force_same == 0) ? splitk_plan(batch, P.cin, cout, h, w) : 1;
     if (sk > 1) return run_splitk<false, 9>(P, sk, workspace, workspace_floats, st);
@@ -927,9 +989,9 @@ int run_conv3x3_s1(ConvParams &P, float *workspace, long long workspace_floats, 
     const long long per_img256 = ((long long)h * w + 255) / 256, per_img64 = ((long long)h * w + 63) / 64;
     const long long nb128 = batch * per_img256 * (cout / 128), nb64 = batch * per_img256 * (cout / 64);
     const long long nb32 = batch * per_img256 * (cout / 32), nb15 = batch * per_img64 * (cout / 64);
-    if (cout % 128 == 0 && nb128 >= 384) { cands[0] = 31; cands[1] = 11; }
+    if (cout % 128 == 0 && nb128 >= 512) { cands[0] = 31; cands[1] = 11; }
     else if (cout % 64 == 0 && nb64 >= 512) { cands[0] = 32; cands[1] = 12; }
-    else if (cout % 32 == 0 && nb32 >= 512) {
+    else if (cout % 32 == 0 && nb32 >= 256) {
       if (P.cin >= 64) { cands[0] = 33; cands[1] = 13; } else cands[0] = 13;  // few chunks: DMA prologue not amortised
     }
     else if (cout % 64 == 0 && nb15 >= 256) cands[0] = 15;
@@ -970,7 +1032,7 @@ int run_conv3x3_s1(ConvParams &P, float *workspace, long long workspace_floats, 
 
 extern "C" long long hf_modconv_workspace_floats(int batch, int cin, int cout, int h, int w, int upsample) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
-  const int s = splitk_plan(batch, cin, cout, h, w);
+  const int s = splitk_plan(batch, cin, cout, h, w, !upsample);
   if (s <= 1) return 0;
   const long long oh = upsample ? 2 * h + 1 : h, ow = upsample ? 2 * w + 1 : w;
   return (long long)s * batch * cout * oh * ow;
@@ -985,6 +1047,7 @@ extern "C" int hf_modconv3x3_f32(float *out, const float *x, const float *wt, co
   ConvParams P{};
   P.out = out; P.x = x; P.wt = wt; P.s = s; P.d = d; P.noise = noise; P.noise_w = noise_w; P.bias = bias;
   P.s_bstride = cin; P.d_bstride = cout;
+  P.groups = 1;
   P.noise_bstride = noise_bstride;
   P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = h; P.out_w = w;
   P.stride = 1;
@@ -1000,11 +1063,12 @@ extern "C" int hf_modconv3x3_up_f32(float *tmp, const float *x, const float *wt,
   ConvParams P{};
   P.out = tmp; P.x = x; P.wt = wt; P.s = s; P.d = d;
   P.s_bstride = cin; P.d_bstride = cout;
+  P.groups = 1;
   P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = 2 * h + 1; P.out_w = 2 * w + 1;
   P.stride = 1;
   hipStream_t st = (hipStream_t)stream;
   {
-    const int sk = (g_force_up == 0) ? splitk_plan(batch, cin, cout, h, w) : 1;
+    const int sk = (g_force_up == 0) ? splitk_plan(batch, cin, cout, h, w, false) : 1;
     if (sk > 1) return run_splitk<true, 9>(P, sk, workspace, workspace_floats, st);
   }
   int cfg = g_force_up;
@@ -1034,22 +1098,24 @@ extern "C" int hf_modconv3x3_up_f32(float *tmp, const float *x, const float *wt,
 }
 
 extern "C" long long hf_conv2d_workspace_floats(int batch, int cin, int cout, int h, int w, int k,
-                                                int stride) {
-  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || stride <= 0) return 0;
+                                                int stride, int groups) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || stride <= 0 || groups <= 0) return 0;
   (void)k;
   const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
-  const int s = splitk_plan(batch, cin, cout, oh, ow);
-  return s <= 1 ? 0 : (long long)s * batch * cout * oh * ow;
+  const int s = splitk_plan(batch * groups, cin, cout, oh, ow);
+  return s <= 1 ? 0 : (long long)s * groups * batch * cout * oh * ow;
 }
 
 extern "C" int hf_conv2d_f32(float *out, const float *x, const float *wt, const float *in_scale,
                              const float *in_shift, const float *out_scale, const float *bias, int act,
                              const float *slope, float alpha, const float *residual, int batch, int cin,
-                             int cout, int h, int w, int k, int stride, float *workspace,
-                             long long workspace_floats, void *stream) {
+                             int cout, int h, int w, int k, int stride, int groups, long long x_group_stride,
+                             float *workspace, long long workspace_floats, void *stream) {
   if (!out || !x || !wt || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (k != 1 && k != 3) ||
-      (stride != 1 && stride != 2) || act < ACT_NONE || act > ACT_PRELU || (act == ACT_PRELU && !slope))
+      (stride != 1 && stride != 2) || act < ACT_NONE || act > ACT_PRELU || (act == ACT_PRELU && !slope) ||
+      groups < 1 || x_group_stride < 0)
     return HF_E_INVALID;
+  if (groups > 1 && (in_scale || in_shift)) return HF_E_INVALID;  // grouped form: plain conv + epilogue
   ConvParams P{};
   P.out = out; P.x = x; P.wt = wt; P.s = in_scale; P.t = in_shift; P.d = out_scale; P.bias = bias;
   P.slope = slope; P.residual = residual;
@@ -1058,19 +1124,30 @@ extern "C" int hf_conv2d_f32(float *out, const float *x, const float *wt, const 
   P.out_h = (h - 1) / stride + 1; P.out_w = (w - 1) / stride + 1;
   P.stride = stride;
   P.act = act; P.alpha = alpha; P.scale = 1.0f;
+  P.groups = groups; P.x_gstride = x_group_stride; P.wt_gstride = (long long)k * k * cin * cout;
   hipStream_t st = (hipStream_t)stream;
   if (k == 3 && stride == 1) return run_conv3x3_s1(P, workspace, workspace_floats, st);
-  // strided 3x3 and 1x1: general kernel (a few % of the encoders' FLOPs), split-K when small
-  const int sk = splitk_plan(batch, cin, cout, P.out_h, P.out_w);
+  // strided 3x3 and 1x1 (a few % of the encoders' FLOPs): split-K when the grid is small,
+  // the pipelined stride-2 kernel for the large 3x3 ones, else the general kernel
+  const int eb = batch * groups;
+  const int sk = splitk_plan(eb, cin, cout, P.out_h, P.out_w);
   g_last_cfg = 2;
   if (sk > 1) return (k == 3) ? run_splitk<false, 9>(P, sk, workspace, workspace_floats, st)
                               : run_splitk<false, 1>(P, sk, workspace, workspace_floats, st);
-  g_last_path = 1;
-  const long long opix = (long long)batch * P.out_h * P.out_w;
+  const long long opix = (long long)eb * P.out_h * P.out_w;
   if (k == 3) {
+    int rc = HF_E_INVALID;
+    const long long nb128 = (long long)eb * ((P.out_h * P.out_w + 127) / 128) * (cout / 128);
+    if (cout % 128 == 0 && nb128 >= 256) { g_last_cfg = 44; rc = launch_conv_pipe<2, 2, 2, 2, false, 0, 2>(P, st); }
+    if (rc == HF_E_INVALID && cout % 64 == 0) { g_last_cfg = 45; rc = launch_conv_pipe<1, 1, 2, 2, false, 0, 2>(P, st); }
+    g_last_path = 2;
+    if (rc != HF_E_INVALID) return rc;
+    g_last_cfg = 2;
+    g_last_path = 1;
     if (cout > 64 && opix > 8192) return launch_conv<2, 2, 2, 2, false, 9>(P, st);  // 128 co x 128 px
     return launch_conv<1, 1, 2, 2, false, 9>(P, st);
   }
+  g_last_path = 1;
   if (cout > 64 && opix > 8192) return launch_conv<2, 2, 2, 2, false, 1>(P, st);
   return launch_conv<1, 1, 2, 2, false, 1>(P, st);
 }

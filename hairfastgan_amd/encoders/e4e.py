@@ -142,16 +142,38 @@ class Encoder4Editing(FrozenPlanMixin, nn.Module):  # psp_encoders.py:124-200
                 taps[i] = x
         c1, c2, c3 = taps[6], taps[20], taps[23]
         L, st = lib(), stream()
-        w0 = self.styles[0](c3)
-        rows = [w0]
-        feats = c3
-        for i in range(1, self.style_count):
-            if i == self.coarse_ind:
-                feats = p2 = M.upsample_bilinear_add(L, st, c3, conv(c2, p["lat1"], 1, 1, bias=self.latlayer1.bias.detach()))
-            elif i == self.middle_ind:
-                feats = M.upsample_bilinear_add(L, st, p2, conv(c1, p["lat2"], 1, 1, bias=self.latlayer2.bias.detach()))
-            rows.append(M.add_bcast(L, st, self.styles[i](feats), w0))  # w[:, i] = w0 + delta_i
+        p2 = M.upsample_bilinear_add(L, st, c3, conv(c2, p["lat1"], 1, 1, bias=self.latlayer1.bias.detach()))
+        p1 = M.upsample_bilinear_add(L, st, p2, conv(c1, p["lat2"], 1, 1, bias=self.latlayer2.bias.detach()))
+        # The 18 style heads in three families that share their input feature map (c3 / p2 / p1,
+        # psp_encoders.py:187-199): each level of a family's conv chains is ONE grouped launch.
+        deltas = []
+        for (lo, hi), feats in (((0, self.coarse_ind), c3), ((self.coarse_ind, self.middle_ind), p2),
+                                ((self.middle_ind, self.style_count), p1)):
+            deltas += self._style_family(lo, hi, feats)
+        w0 = deltas[0]
+        rows = [w0] + [M.add_bcast(L, st, d, w0) for d in deltas[1:]]  # w[:, i] = w0 + delta_i
         return torch.stack(rows, dim=1)
+
+    def _style_family(self, lo, hi, feats):
+        """GradualStyleBlocks lo..hi-1 on the shared map `feats`: level-wise grouped convs, then the
+        per-head EqualLinear.  Returns the list of [B,512] outputs."""
+        L, st = lib(), stream()
+        key = f"family_{lo}"
+        if key not in self._plan:
+            heads = [self.styles[i] for i in range(lo, hi)]
+            convs = [[m for m in h.convs if isinstance(m, nn.Conv2d)] for h in heads]
+            levels = []
+            for lvl in range(len(convs[0])):
+                wt = torch.stack([M.conv_prepare(L, st, c[lvl].weight.detach()) for c in convs]).contiguous()
+                bias = torch.stack([c[lvl].bias.detach() for c in convs]).contiguous()
+                levels.append((wt, bias))
+            self._plan[key] = levels
+        G = hi - lo
+        x, shared = feats, True
+        for wt, bias in self._plan[key]:
+            x = M.conv2d(L, st, x, wt, 3, 2, bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=G, x_shared=shared)
+            shared = False
+        return [self.styles[lo + g].linear(x[g].reshape(-1, 512)) for g in range(G)]
 
 
 def get_latents(net, x):

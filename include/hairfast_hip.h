@@ -167,12 +167,17 @@ int hf_bn_fold_f32(float *scale, float *shift, const float *gamma, const float *
  * Any of the pointers may be NULL.  k in {1,3}, stride in {1,2}; oh = (h-1)/stride + 1.
  * Replaces: nn.Conv2d + BatchNorm2d + PReLU/LeakyReLU (+ add) chains of
  * helpers.py:99-115, psp_encoders.py:41-47, iresnet.py:44-56, feature_style_encoder.py:33-40.
+ * groups > 1: `groups` independent convolutions of this shape in one launch (the e4e style
+ * heads, psp_encoders.py:34-55): wt [groups][k*k][cin][cout], bias/out_scale/slope
+ * [groups][cout], out/residual [groups][batch][cout][oh][ow]; group g reads
+ * x + g*x_group_stride (0 = all groups share one input); in_scale/in_shift must be NULL.
  * workspace: hf_conv2d_workspace_floats() floats (0 -> may be NULL). */
 int hf_conv2d_f32(float *out, const float *x, const float *wt, const float *in_scale, const float *in_shift,
                   const float *out_scale, const float *bias, int act, const float *slope, float alpha,
                   const float *residual, int batch, int cin, int cout, int h, int w, int k, int stride,
-                  float *workspace, long long workspace_floats, void *stream);
-long long hf_conv2d_workspace_floats(int batch, int cin, int cout, int h, int w, int k, int stride);
+                  int groups, long long x_group_stride, float *workspace, long long workspace_floats,
+                  void *stream);
+long long hf_conv2d_workspace_floats(int batch, int cin, int cout, int h, int w, int k, int stride, int groups);
 
 /* out[p] = mean of plane p (AdaptiveAvgPool2d(1) of SEModule, helpers.py:60,68). */
 int hf_plane_mean_f32(float *out, const float *x, int planes, int hw, void *stream);

@@ -134,3 +134,32 @@ def test_state_dicts_match_reference_layout():
     f = fs_encoder_v2(stride=(2, 2))
     assert {k: tuple(v.shape) for k, v in f.state_dict().items()} == E.fs_param_shapes()
     assert list(f.state_dict()) == list(E.fs_param_shapes())
+
+
+def test_grouped_conv(simlib):
+    """Grouped launches (the e4e style heads): shared and per-group inputs, split-K and direct."""
+    torch.manual_seed(11)
+    G, B, cin, cout = 3, 2, 16, 24
+    for (H, W, shared) in [(8, 8, True), (9, 6, False)]:
+        w = torch.randn(G, cout, cin, 3, 3) / (cin * 9) ** 0.5
+        bias = torch.randn(G, cout) * 0.2
+        x = torch.randn(B, cin, H, W) if shared else torch.randn(G, B, cin, H, W)
+        wt = torch.stack([M.conv_prepare(simlib, None, w[g]) for g in range(G)])
+        y = M.conv2d(simlib, None, x, wt, 3, 2, bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=G, x_shared=shared)
+        for g in range(G):
+            xin = x if shared else x[g]
+            ref = F.leaky_relu(F.conv2d(xin, w[g], bias[g], stride=2, padding=1), 0.01)
+            assert maxdiff(y[g], ref) < TOL * max(1.0, float(ref.abs().max())), (H, W, shared, g)
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,code", [(4, 8, 64, 128, 128, 245), (2, 8, 128, 256, 256, 244)])
+def test_pipelined_stride2(simlib, B, cin, cout, H, W, code):
+    """The double-buffered kernel in its stride-2 form (large strided 3x3 convs of the encoders)."""
+    torch.manual_seed(B)
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    g, bsh = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2
+    y = M.conv2d(simlib, None, x, M.conv_prepare(simlib, None, w), 3, 2, out_scale=g, bias=bsh)
+    assert simlib.hf_debug_last_path() == code
+    ref = F.conv2d(x, w, stride=2, padding=1) * g.view(1, -1, 1, 1) + bsh.view(1, -1, 1, 1)
+    assert maxdiff(y, ref) < TOL * max(1.0, float(ref.abs().max()))
