@@ -117,4 +117,7 @@ def test_kernels_use_no_scratch_memory():
                               "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr[-2000:]
         sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
-        assert sizes and max(sizes) == 0, f"{f}: scratch {max(sizes)} bytes/lane"
+        if f == "api.hip":
+            continue  # no kernels
+        assert sizes, f"{f}: no kernel resource remarks"
+        assert max(sizes) == 0, f"{f}: scratch {max(sizes)} bytes/lane"
