@@ -152,11 +152,13 @@ def main():
     gather_note = None
     pending = None
 
+    use_dist = world > 1 or os.environ.get("HF_FORCE_DIST", "0") == "1"
+
     def step():
         nonlocal pending, gather_note
         with torch.inference_mode():
             img, _ = g([latent], input_is_latent=True)
-            if world > 1:
+            if use_dist:
                 try:
                     u8 = parallel.to_uint8_image(img)
                     if pending is not None:
@@ -167,7 +169,7 @@ def main():
         return img
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -187,7 +189,7 @@ def main():
     elapsed = time.perf_counter() - t0
     _marshal.PROFILE = None
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -198,7 +200,7 @@ def main():
     swap_info = None
     if args.swap_triples > 0:
         swap_s = swap_schedule_bench(g, sd, dev, args.swap_triples)
-        if world > 1:
+        if use_dist:
             t = torch.tensor([swap_s], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             swap_s = float(t.item())
@@ -227,7 +229,7 @@ def main():
         }
         if gather_note:
             out["config"]["gather"] = gather_note
-        elif world > 1:
+        elif use_dist:
             out["config"]["gather"] = "async RCCL all_gather_into_tensor of uint8 images, one per step"
         if prof:
             agg = {}
@@ -253,7 +255,7 @@ def main():
             out["swap_schedule"] = swap_info
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

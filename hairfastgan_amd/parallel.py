@@ -17,7 +17,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("HF_FORCE_DIST", "0") == "1"  # single-rank RCCL smoke test of the N>1 code path
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -50,7 +51,7 @@ def all_gather_images(local, n_total=None, group=None, async_op=False):
     Ranks may hold different counts (block partition): shorter shards are padded to the
     longest one for the collective and trimmed afterwards.  Returns the gathered tensor
     (or (tensor, work, finalize) when async_op=True)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and os.environ.get("HF_FORCE_DIST", "0") != "1"):
         return (local, None, lambda t: t) if async_op else local
     world = dist.get_world_size(group)
     if n_total is None:
