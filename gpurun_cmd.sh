@@ -1,2 +1,6 @@
-export HF_FORCE_DIST=1
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --swap-triples 1 2>&1 | tail -3 | cut -c1-700
+(timeout 1200 python -m pytest tests/test_gpu_schedule.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -12)
+(timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1) > gpurun_out/bench_r01n.log; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_r01n.log').read())
+print(d['value'], d['ms_per_step'], json.dumps(d.get('swap_schedule'))[:600])
+PY

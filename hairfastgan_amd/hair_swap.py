@@ -61,34 +61,53 @@ class HairFastHotPath(torch.nn.Module):
         self.encoder.to(dev)
         if fs_dlatent_avg is not None:
             self.encoder.dlatent_avg.copy_(fs_dlatent_avg)
+        self._graphs = {}
+
+    def _call(self, key, fn, *tensors, use_graphs=False):
+        """Run `fn(*tensors)` eagerly or through a per-call-site hipGraph (captured on first use)."""
+        if not use_graphs:
+            return fn(*tensors)
+        from .graphs import GraphRunner
+
+        k = (key,) + tuple(tuple(t.shape) for t in tensors)
+        if k not in self._graphs:
+            self._graphs[k] = GraphRunner(fn, *tensors)
+        return self._graphs[k](*tensors)
 
     @torch.inference_mode()
     def swap_schedule(self, images_1024, images_256, align_inputs_256, f_align_32, f_final_64, s_blend, s_final,
-                      w_rotate, include_discarded_forward=False):
+                      w_rotate, include_discarded_forward=False, use_graphs=False):
         """One triple.  images_1024 / images_256: the 3 normalised inputs [3,3,1024,1024] /
         [3,3,256,256]; align_inputs_256 [2,3,256,256]: SEAN outputs re-embedded by
         Embedding.get_e4e_embed; f_align_32 [1,512,32,32], f_final_64 [1,512,64,64]: F-space
-        tensors entering the last two generator calls; s_blend / s_final / w_rotate [1,18,512]."""
+        tensors entering the last two generator calls; s_blend / s_final / w_rotate [1,18,512].
+        use_graphs: replay each call site as a captured hipGraph (hairfastgan_amd/graphs.py)."""
         g = self.net.generator
+        ug = use_graphs
         out = {}
+        gen = lambda **kw: (lambda w_, *li: g([w_], input_is_latent=True, return_latents=False,  # noqa: E731
+                                              layer_in=(li[0] if li else None), **kw)[0])
         # --- Embedding.embedding_images (Embedding.py:64-92), batch 3
-        w = get_latents(self.e4e, images_256)
+        w = self._call("e4e", lambda x: get_latents(self.e4e, x), images_256, use_graphs=ug)
         self.encoder.run_discarded_generator = include_discarded_forward
-        res = self.encoder.test(img=images_1024, return_latent=True)
-        fea, s = res.pop(), res.pop()
-        f_from_s, _ = g([s], input_is_latent=True, return_latents=False, start_layer=3, end_layer=3, layer_in=fea)
-        f_from_w, _ = g([w], input_is_latent=True, return_latents=False, start_layer=0, end_layer=3)
-        out["F"], out["W"], out["S"] = f_from_s, w, s
+
+        def fs(img):
+            res = self.encoder.test(img=img, return_latent=True)
+            return res[2], res[3]
+
+        s, fea = self._call("fs", fs, images_1024, use_graphs=ug)
+        out["F"] = self._call("g33", gen(start_layer=3, end_layer=3), s, fea, use_graphs=ug)
+        out["f_from_w"] = self._call("g03", gen(start_layer=0, end_layer=3), w, use_graphs=ug)
+        out["W"], out["S"] = w, s
         # --- Alignment.shape_module x2 (Alignment.py:63): full forwards of rotated latents, batch 1
-        out["I_rot_shape"], _ = g([w_rotate], input_is_latent=True, return_latents=False)
+        out["I_rot_shape"] = self._call("g08", gen(), w_rotate, use_graphs=ug)
+        if ug:
+            out["I_rot_shape"] = out["I_rot_shape"].clone()  # the same graph is replayed below
         # --- Alignment.align_images -> Embedding.get_e4e_embed (Embedding.py:44-54), batch 2
-        w2 = get_latents(self.e4e, align_inputs_256)
-        out["F_sean"], _ = g([w2], input_is_latent=True, return_latents=False, start_layer=0, end_layer=3)
-        out["I_rot_color"], _ = g([w_rotate], input_is_latent=True, return_latents=False)
+        w2 = self._call("e4e", lambda x: get_latents(self.e4e, x), align_inputs_256, use_graphs=ug)
+        out["F_sean"] = self._call("g03", gen(start_layer=0, end_layer=3), w2, use_graphs=ug)
+        out["I_rot_color"] = self._call("g08", gen(), w_rotate, use_graphs=ug)
         # --- Blending.blend_images (Blending.py:62, 68)
-        out["I_blend"], _ = g([s_blend], input_is_latent=True, return_latents=False, start_layer=4, end_layer=8,
-                              layer_in=f_align_32)
-        out["I_final"], _ = g([s_final], input_is_latent=True, return_latents=False, start_layer=5, end_layer=8,
-                              layer_in=f_final_64)
-        out["f_from_w"] = f_from_w
+        out["I_blend"] = self._call("g48", gen(start_layer=4, end_layer=8), s_blend, f_align_32, use_graphs=ug)
+        out["I_final"] = self._call("g58", gen(start_layer=5, end_layer=8), s_final, f_final_64, use_graphs=ug)
         return out

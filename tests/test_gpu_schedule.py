@@ -44,3 +44,24 @@ def test_swap_schedule_shapes_and_consistency():
     # batch rows 0,1 of the e4e / FS outputs equal the golden-verified batch-2 runs (row 2 repeats row 0)
     assert float((out["W"][2] - out["W"][0]).abs().max()) < 1e-5
     assert float((out["S"][2] - out["S"][0]).abs().max()) < 1e-5
+
+
+def test_graph_runner_matches_eager():
+    """hipGraph capture (hairfastgan_amd/graphs.py) of a generator call with explicit noise and of
+    the e4e encoder: replays reproduce the eager results bit for bit, also on new inputs."""
+    from hairfastgan_amd.graphs import GraphRunner
+    from hairfastgan_amd.stylegan2.model import Generator
+
+    dev = torch.device("cuda:0")
+    g = Generator(64, 512, 2).eval()
+    shapes = {k: tuple(v.shape) for k, v in g.state_dict().items()}
+    g.load_state_dict(C.generator_params(shapes))
+    g = g.to(dev)
+    lat, nz, _ = C.generator_inputs(64, 2, 0)
+    nz = [n.to(dev) for n in nz]
+    fn = lambda w: g([w], input_is_latent=True, noise=nz)[0]  # noqa: E731
+    runner = GraphRunner(fn, lat.to(dev))
+    with torch.inference_mode():
+        for scale in (1.0, 0.5):
+            w = (lat * scale).to(dev)
+            assert torch.equal(runner(w), fn(w))
