@@ -1,6 +1,3 @@
-(timeout 1200 python -m pytest tests/test_gpu_schedule.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -12)
-(timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1) > gpurun_out/bench_r01n.log; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench_r01n.log').read())
-print(d['value'], d['ms_per_step'], json.dumps(d.get('swap_schedule'))[:600])
-PY
+(timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -3)
+python tools/bench_layers.py --batch 8 --iters 5 --only none 2>&1 | tail -9 | grep blur
+(timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --swap-triples 0 2>&1 | tail -1 | cut -c1-200)

@@ -169,17 +169,19 @@ def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha
     x = _c(x)
     b, cin, h, w = x.shape
     cout = wt.shape[2]
-    tmp = x.new_empty((b, cout, 2 * h + 1, 2 * w + 1))
+    pitch = lib.hf_modconv_up_pitch(w)  # rows padded to a multiple of 4 floats (aligned 16 B loads in the blur)
+    tmp = x.new_empty((b, cout, 2 * h + 1, pitch))
     ws, ws_n = _workspace(lib, x, b, cin, cout, h, w, True)
     code = _launch_profiled(
         lib, 2.0 * cin * cout * 9 * h * w * b,
-        lambda: lib.hf_modconv3x3_up_f32(_p(tmp), _p(x), _p(wt), _p(s), _p(d), b, cin, cout, h, w, _p(ws), ws_n, st))
+        lambda: lib.hf_modconv3x3_up_f32(_p(tmp), _p(x), _p(wt), _p(s), _p(d), b, cin, cout, h, w, pitch, _p(ws), ws_n,
+                                         st))
     check(lib, code, "hf_modconv3x3_up_f32")
     noise, nbs = _noise_args(noise, b, 4 * h * w)
     out = x.new_empty((b, cout, 2 * h, 2 * w))
     check(lib, lib.hf_blur_noise_bias_act_f32(_p(out), _p(tmp), _p(_c(blur_kernel)), _p(noise), _p(_c(noise_w)),
-                                              nbs, _p(_c(bias)), b, cout, 2 * h + 1, 2 * w + 1, alpha, scale, st),
-          "hf_blur_noise_bias_act_f32")
+                                              nbs, _p(_c(bias)), b, cout, 2 * h + 1, 2 * w + 1, pitch, alpha, scale,
+                                              st), "hf_blur_noise_bias_act_f32")
     return out
 
 

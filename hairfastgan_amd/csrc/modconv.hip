@@ -71,7 +71,8 @@ struct ConvParams {
   long long noise_bstride;
   int s_bstride, d_bstride;
   int batch, cin, cout, h, w;  // input plane h x w
-  int out_h, out_w;            // output plane (stride-1: h,w ; stride-2: ceil(h/2) ; up: 2h+1, 2w+1)
+  int out_h, out_w;            // output plane (stride-1: h,w ; stride-2: ceil(h/2) ; up: 2h+1 rows of pitch out_w)
+  int out_wv;                  // up: valid columns (2w+1) of the out_w-pitched rows; otherwise == out_w
   int stride;                  // 1 or 2 (general kernel only)
   int act;
   float alpha, scale;
@@ -227,7 +228,7 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
             if (ro >= P.out_h) continue;
             float *q = ob + (long long)ro * P.out_w + cc;
             const float v0 = acc[2 * pr][ct][g][r] * dm, v1 = acc[2 * pr + 1][ct][g][r] * dm;
-            if (cc + 1 < P.out_w) {
+            if (cc + 1 < P.out_wv) {
               f32x2u pair;
               pair.x = v0;
               pair.y = v1;
@@ -1034,7 +1035,7 @@ extern "C" long long hf_modconv_workspace_floats(int batch, int cin, int cout, i
   if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
   const int s = splitk_plan(batch, cin, cout, h, w, !upsample);
   if (s <= 1) return 0;
-  const long long oh = upsample ? 2 * h + 1 : h, ow = upsample ? 2 * w + 1 : w;
+  const long long oh = upsample ? 2 * h + 1 : h, ow = upsample ? ((2 * w + 1 + 3) & ~3) : w;
   return (long long)s * batch * cout * oh * ow;
 }
 
@@ -1049,22 +1050,26 @@ extern "C" int hf_modconv3x3_f32(float *out, const float *x, const float *wt, co
   P.s_bstride = cin; P.d_bstride = cout;
   P.groups = 1;
   P.noise_bstride = noise_bstride;
-  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = h; P.out_w = w;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = h; P.out_w = w; P.out_wv = w;
   P.stride = 1;
   P.act = bias ? ACT_LRELU : ACT_NONE;
   P.alpha = alpha; P.scale = scale;
   return run_conv3x3_s1(P, workspace, workspace_floats, (hipStream_t)stream);
 }
 
+extern "C" int hf_modconv_up_pitch(int w) { return (2 * w + 1 + 3) & ~3; }
+
 extern "C" int hf_modconv3x3_up_f32(float *tmp, const float *x, const float *wt, const float *s,
-                                    const float *d, int batch, int cin, int cout, int h, int w,
+                                    const float *d, int batch, int cin, int cout, int h, int w, int tmp_pitch,
                                     float *workspace, long long workspace_floats, void *stream) {
-  if (!tmp || !x || !wt || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return HF_E_INVALID;
+  if (!tmp || !x || !wt || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || tmp_pitch < 2 * w + 1)
+    return HF_E_INVALID;
   ConvParams P{};
   P.out = tmp; P.x = x; P.wt = wt; P.s = s; P.d = d;
   P.s_bstride = cin; P.d_bstride = cout;
   P.groups = 1;
-  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = 2 * h + 1; P.out_w = 2 * w + 1;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = 2 * h + 1; P.out_w = tmp_pitch;
+  P.out_wv = 2 * w + 1;
   P.stride = 1;
   hipStream_t st = (hipStream_t)stream;
   {
@@ -1121,7 +1126,7 @@ extern "C" int hf_conv2d_f32(float *out, const float *x, const float *wt, const 
   P.slope = slope; P.residual = residual;
   P.s_bstride = 0; P.d_bstride = 0;
   P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w;
-  P.out_h = (h - 1) / stride + 1; P.out_w = (w - 1) / stride + 1;
+  P.out_h = (h - 1) / stride + 1; P.out_w = (w - 1) / stride + 1; P.out_wv = P.out_w;
   P.stride = stride;
   P.act = act; P.alpha = alpha; P.scale = 1.0f;
   P.groups = groups; P.x_gstride = x_group_stride; P.wt_gstride = (long long)k * k * cin * cout;

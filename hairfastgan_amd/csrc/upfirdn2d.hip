@@ -64,7 +64,7 @@ constexpr int kRowsPerThread = 32;
 __global__ __launch_bounds__(256) void blur4x4_noise_bias_act(
     float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ kernel4x4,
     const float *__restrict__ noise, const float *__restrict__ noise_w, long long noise_bstride,
-    const float *__restrict__ bias, int channels, int in_h, int in_w, float alpha, float scale) {
+    const float *__restrict__ bias, int channels, int in_h, int in_w, int in_pitch, float alpha, float scale) {
   const int out_h = in_h - 1, out_w = in_w - 1;
   const int ox = blockIdx.x * kBlurCols + threadIdx.x;
   const int oy0 = (blockIdx.y * kBlurSegs + threadIdx.y) * kRowsPerThread;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void blur4x4_noise_bias_act(
 #pragma unroll
     for (int kx = 0; kx < 4; ++kx) kf[ky][kx] = kernel4x4[(3 - ky) * 4 + (3 - kx)];
 
-  const float *src = in + (long long)plane * in_h * in_w;
+  const float *src = in + (long long)plane * in_h * in_pitch;
   float *dst = out + (long long)plane * out_h * out_w;
   const int c = plane % channels;
   const int b = plane / channels;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void blur4x4_noise_bias_act(
   float win[7][4];  // win[r][j]: input row (oy-1+r), column (ox-1+j)
   auto load_row = [&](int iy, float (&row)[4]) {
     const bool rv = iy >= 0 && iy < in_h;
-    const float *p = src + (long long)iy * in_w + (ox - 1);
+    const float *p = src + (long long)iy * in_pitch + (ox - 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) row[j] = (rv && cv[j]) ? p[j] : 0.0f;
   };
@@ -142,7 +142,7 @@ struct __attribute__((packed, aligned(4))) f32x4u {
 __global__ __launch_bounds__(256) void blur4x4_noise_bias_act_vec4(
     float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ kernel4x4,
     const float *__restrict__ noise, const float *__restrict__ noise_w, long long noise_bstride,
-    const float *__restrict__ bias, int channels, int in_h, int in_w, float alpha, float scale,
+    const float *__restrict__ bias, int channels, int in_h, int in_w, int in_pitch, float alpha, float scale,
     int rows_per_thread) {
   const int out_h = in_h - 1, out_w = in_w - 1;
   const int c0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void blur4x4_noise_bias_act_vec4(
 #pragma unroll
     for (int kx = 0; kx < 4; ++kx) kf[ky][kx] = kernel4x4[(3 - ky) * 4 + (3 - kx)];
 
-  const float *src = in + (long long)plane * in_h * in_w;
+  const float *src = in + (long long)plane * in_h * in_pitch;
   float *dst = out + (long long)plane * out_h * out_w;
   const int c = plane % channels;
   const int b = plane / channels;
@@ -170,24 +170,43 @@ __global__ __launch_bounds__(256) void blur4x4_noise_bias_act_vec4(
   const float *nz = noise ? noise + (long long)b * noise_bstride : nullptr;
 
   float win[6][7];  // win[r][j]: input row oy-1+r, column c0-1+j
-  auto load_row = [&](int iy, float (&row)[7]) {
-    const bool rv = active && iy >= 0 && iy < in_h;
-    const float *p = src + (long long)iy * in_w + c0;
-    f32x4u m = {0.f, 0.f, 0.f, 0.f};
-    if (rv) m = *reinterpret_cast<const f32x4u *>(p);
-    row[1] = m.x; row[2] = m.y; row[3] = m.z; row[4] = m.w;
-    const float l = __shfl_up(m.w, 1, 64), r0 = __shfl_down(m.x, 1, 64), r1 = __shfl_down(m.y, 1, 64);
-    row[0] = nb_left ? l : ((rv && c0 > 0) ? p[-1] : 0.0f);
-    row[5] = nb_right ? r0 : ((rv && c0 + 4 < in_w) ? p[4] : 0.0f);
-    row[6] = nb_right ? r1 : ((rv && c0 + 5 < in_w) ? p[5] : 0.0f);
+  // A row is fetched in two steps so that several rows' loads are in flight together: `issue`
+  // starts the 16-byte load (+ the two edge dwords on the first/last lane of a segment),
+  // `finish` does the neighbour shuffles, which need the loaded data.
+  struct RowRaw {
+    f32x4u m;
+    float e0, e5, e6;
   };
-#pragma unroll
-  for (int r = 0; r < 4; ++r) load_row(oy0 - 1 + r, win[r]);
+  auto issue = [&](int iy) {
+    RowRaw r;
+    const bool rv = active && iy >= 0 && iy < in_h;
+    const float *p = src + (long long)iy * in_pitch + c0;
+    r.m = f32x4u{0.f, 0.f, 0.f, 0.f};
+    if (rv) r.m = *reinterpret_cast<const f32x4u *>(p);
+    r.e0 = (!nb_left && rv && c0 > 0) ? p[-1] : 0.0f;
+    r.e5 = (!nb_right && rv && c0 + 4 < in_w) ? p[4] : 0.0f;
+    r.e6 = (!nb_right && rv && c0 + 5 < in_w) ? p[5] : 0.0f;
+    return r;
+  };
+  auto finish = [&](const RowRaw &r, float (&row)[7]) {
+    row[1] = r.m.x; row[2] = r.m.y; row[3] = r.m.z; row[4] = r.m.w;
+    const float l = __shfl_up(r.m.w, 1, 64), r0 = __shfl_down(r.m.x, 1, 64), r1 = __shfl_down(r.m.y, 1, 64);
+    row[0] = nb_left ? l : r.e0;
+    row[5] = nb_right ? r0 : r.e5;
+    row[6] = nb_right ? r1 : r.e6;
+  };
+  {
+    RowRaw a = issue(oy0 - 1), b2 = issue(oy0), c2 = issue(oy0 + 1), d2 = issue(oy0 + 2);
+    finish(a, win[0]); finish(b2, win[1]); finish(c2, win[2]); finish(d2, win[3]);
+  }
 
   const int oy_end = min(oy0 + rows_per_thread, out_h);
+  RowRaw nx0 = issue(oy0 + 3), nx1 = issue(oy0 + 4);  // rows for the first iteration
   for (int oy = oy0; oy < oy0 + rows_per_thread; oy += 2) {  // uniform trip count (shuffles inside)
-    load_row(oy + 3, win[4]);
-    load_row(oy + 4, win[5]);
+    finish(nx0, win[4]);
+    finish(nx1, win[5]);
+    nx0 = issue(oy + 5);  // next iteration's rows: in flight during this iteration's FMAs / stores
+    nx1 = issue(oy + 6);
 #pragma unroll
     for (int q2 = 0; q2 < 2; ++q2) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -243,9 +262,9 @@ extern "C" int hf_upfirdn2d_f32(float *out, const float *in, const float *kernel
 extern "C" int hf_blur_noise_bias_act_f32(float *out, const float *in, const float *kernel4x4,
                                           const float *noise, const float *noise_w,
                                           long long noise_bstride, const float *bias, int batch,
-                                          int channels, int in_h, int in_w, float alpha, float scale,
-                                          void *stream) {
-  if (!out || !in || !kernel4x4 || batch <= 0 || channels <= 0 || in_h < 2 || in_w < 2 ||
+                                          int channels, int in_h, int in_w, int in_pitch, float alpha,
+                                          float scale, void *stream) {
+  if (!out || !in || !kernel4x4 || batch <= 0 || channels <= 0 || in_h < 2 || in_w < 2 || in_pitch < in_w ||
       (noise && !noise_w))
     return HF_E_INVALID;
   const long long planes = (long long)batch * channels;
@@ -260,11 +279,11 @@ extern "C" int hf_blur_noise_bias_act_f32(float *out, const float *in, const flo
     while (rpt > 2 && segs * rpt >= 2 * out_h) rpt >>= 1;
     dim3 grid(hf_cdiv(out_w, cq * 4), hf_cdiv(out_h, segs * rpt), (unsigned)planes);
     hipLaunchKernelGGL(blur4x4_noise_bias_act_vec4, grid, dim3(cq, segs), 0, (hipStream_t)stream, out, in,
-                       kernel4x4, noise, noise_w, noise_bstride, bias, channels, in_h, in_w, alpha, scale, rpt);
+                       kernel4x4, noise, noise_w, noise_bstride, bias, channels, in_h, in_w, in_pitch, alpha, scale, rpt);
     return hf_launch_status();
   }
   dim3 grid(hf_cdiv(out_w, kBlurCols), hf_cdiv(out_h, kBlurSegs * kRowsPerThread), (unsigned)planes);
   hipLaunchKernelGGL(blur4x4_noise_bias_act, grid, dim3(kBlurCols, kBlurSegs), 0, (hipStream_t)stream, out,
-                     in, kernel4x4, noise, noise_w, noise_bstride, bias, channels, in_h, in_w, alpha, scale);
+                     in, kernel4x4, noise, noise_w, noise_bstride, bias, channels, in_h, in_w, in_pitch, alpha, scale);
   return hf_launch_status();
 }

@@ -117,19 +117,23 @@ long long hf_modconv_workspace_floats(int batch, int cin, int cout, int h, int w
  * groups=batch).  Part 2 is hf_blur_noise_bias_act_f32 below.
  */
 int hf_modconv3x3_up_f32(float *tmp, const float *x, const float *wt, const float *s, const float *d,
-                         int batch, int cin, int cout, int h, int w, float *workspace,
+                         int batch, int cin, int cout, int h, int w, int tmp_pitch, float *workspace,
                          long long workspace_floats, void *stream);
+/* Row pitch (floats, multiple of 4 >= 2w+1) of the intermediate: tmp is
+ * [batch, cout, 2h+1, pitch]; the padding keeps the blur pass's 16-byte loads aligned. */
+int hf_modconv_up_pitch(int w);
 
 /* Part 2: 4x4 FIR blur with pad (1,1) (upfirdn2d mode 1) fused with noise +
  * bias + leaky relu: in [planes=batch*channels, in_h, in_w] -> out
  * [planes, in_h-1, in_w-1].  Replaces: Blur.forward (models/stylegan2/model.py:
- * 77-93, called :263) + NoiseInjection + FusedLeakyReLU.  kernel4x4: device
+ * 77-93, called :263) + NoiseInjection + FusedLeakyReLU.  Rows of `in` are in_pitch floats
+ * apart (in_pitch >= in_w; hf_modconv_up_pitch for the fused path).  kernel4x4: device
  * pointer to the module's `blur.kernel` buffer (already multiplied by
  * upsample_factor**2, model.py:83-84).  noise/bias NULL as in hf_modconv3x3_f32. */
 int hf_blur_noise_bias_act_f32(float *out, const float *in, const float *kernel4x4, const float *noise,
                                const float *noise_w, long long noise_bstride, const float *bias,
-                               int batch, int channels, int in_h, int in_w, float alpha, float scale,
-                               void *stream);
+                               int batch, int channels, int in_h, int in_w, int in_pitch, float alpha,
+                               float scale, void *stream);
 
 /* ---------------------------------------------------------------------------
  * ToRGB: 1x1 modulated conv WITHOUT demodulation + bias + upsampled skip:

@@ -66,9 +66,10 @@ def main():
                 L.hf_debug_set_dispatch(0 if up else c, c if up else 0)
                 try:
                     if up:
-                        tmp = torch.empty(B, cout, 2 * r + 1, 2 * r + 1, device=dev)
+                        pitch = L.hf_modconv_up_pitch(r)
+                        tmp = torch.empty(B, cout, 2 * r + 1, pitch, device=dev)
                         fn = lambda: L.hf_modconv3x3_up_f32(tmp.data_ptr(), x.data_ptr(), wt.data_ptr(), s.data_ptr(),
-                                                            d.data_ptr(), B, cin, cout, r, r, ws_p, ws_n, stream())
+                                                            d.data_ptr(), B, cin, cout, r, r, pitch, ws_p, ws_n, stream())
                     else:
                         out = torch.empty(B, cout, r, r, device=dev)
                         fn = lambda: L.hf_modconv3x3_f32(out.data_ptr(), x.data_ptr(), wt.data_ptr(), s.data_ptr(),
@@ -89,13 +90,14 @@ def main():
     k4 = torch.tensor([1., 3., 3., 1.], device=dev)
     k4 = (k4[None] * k4[:, None]) / 64 * 4
     for c, r in ((32, 1024), (64, 512), (128, 256), (256, 128)):
-        tmp = torch.randn(B, c, r + 1, r + 1, device=dev)
+        pitch = (r + 1 + 3) & ~3
+        tmp = torch.randn(B, c, r + 1, pitch, device=dev)
         noise = torch.randn(1, 1, r, r, device=dev)
         nw = torch.tensor([0.1], device=dev)
         bias = torch.randn(c, device=dev)
         t = timeit(lambda: M.noise_bias_act(L, stream(), tmp, None, nw, bias) if False else
                    L.hf_blur_noise_bias_act_f32(out_b.data_ptr(), tmp.data_ptr(), k4.data_ptr(), noise.data_ptr(),
-                                                nw.data_ptr(), 0, bias.data_ptr(), B, c, r + 1, r + 1, 0.2, 1.4142,
+                                                nw.data_ptr(), 0, bias.data_ptr(), B, c, r + 1, r + 1, pitch, 0.2, 1.4142,
                                                 stream()), args.iters) if (out_b := torch.empty(B, c, r, r, device=dev)) is not None else 0
         byts = 4.0 * B * c * ((r + 1) ** 2 + r * r)
         print(f"  blur+noise+act  c={c:4d} out={r:5d}: {t * 1e6:8.1f} us  {byts / t / 1e9:7.0f} GB/s")
