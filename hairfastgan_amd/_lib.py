@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhairfast_hip.so")
+# HAIRFAST_HIP_LIB: kernel-development override (experimental builds of the same ABI)
+LIB_PATH = os.environ.get("HAIRFAST_HIP_LIB") or os.path.join(_HERE, "csrc", "libhairfast_hip.so")
 
 _f = ctypes.c_void_p      # float* / const float* (device pointers)
 _i = ctypes.c_int
@@ -26,6 +27,8 @@ SIGNATURES = {
     "hf_modulation_f32": [_f, _f, _ll, _f, _f, _i, _i, _i, _st],
     "hf_demod_f32": [_f, _f, _f, _i, _i, _i, _st],
     "hf_modconv3x3_f32": [_f, _f, _f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _f, _ll, _st],
+    "hf_conv_split_weights_f16": [_f, _f, _f, _i, _i, _st],
+    "hf_modconv3x3_f16_f32": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _st],
     "hf_modconv3x3_up_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _ll, _st],
     "hf_modconv_up_pitch": [_i],
     "hf_blur_noise_bias_act_f32": [_f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _st],

@@ -164,6 +164,41 @@ def modconv3x3(lib, st, x, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=SQRT
     return out
 
 
+def split_weights_f16(lib, st, wt):
+    """Prepared fp32 weights [9, cin, cout] -> (hi, lo) fp16 tensors in the K-contiguous
+    layout of csrc/convh.hip ([cin/16][tap][2][cout][8])."""
+    wt = _c(wt)
+    taps, cin, cout = wt.shape
+    if taps != 9 or cin % 16:
+        raise ValueError(f"f16 MFMA path needs 3x3 weights with cin % 16 == 0; got {tuple(wt.shape)}")
+    hi = torch.empty((cin // 16, 9, 2, cout, 8), dtype=torch.float16, device=wt.device)
+    lo = torch.empty_like(hi)
+    check(lib, lib.hf_conv_split_weights_f16(_p(hi), _p(lo), _p(wt), cin, cout, st), "hf_conv_split_weights_f16")
+    return hi, lo
+
+
+def modconv3x3_f16_supported(cin, cout, h, w):
+    """Shapes hf_modconv3x3_f16_f32 takes (include/hairfast_hip.h)."""
+    return cin % 16 == 0 and w >= 32 and (h >= 8 if cout % 64 == 0 else (cout % 32 == 0 and h >= 16))
+
+
+def modconv3x3_f16(lib, st, x, wt_hi, wt_lo, nterms, s, d, noise, noise_w, bias, alpha=0.2, scale=SQRT2):
+    """hf_modconv3x3_f32 on the fp16 matrix cores (nterms 3: split operands, fp32-class
+    accuracy; nterms 1: fp16 operands); fp32 tensors and accumulation."""
+    x = _c(x)
+    b, cin, h, w = x.shape
+    cout = wt_hi.shape[3]
+    noise, nbs = _noise_args(noise, b, h * w)
+    out = x.new_empty((b, cout, h, w))
+    noise_w, bias = _c(noise_w), _c(bias)
+    code = _launch_profiled(
+        lib, 2.0 * cin * cout * 9 * h * w * b,
+        lambda: lib.hf_modconv3x3_f16_f32(_p(out), _p(x), _p(wt_hi), _p(wt_lo), nterms, _p(s), _p(d), _p(noise),
+                                          _p(noise_w), nbs, _p(bias), b, cin, cout, h, w, alpha, scale, st))
+    check(lib, code, "hf_modconv3x3_f16_f32")
+    return out
+
+
 def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha=0.2, scale=SQRT2):
     """conv_transpose(stride 2) -> [B,cout,2h+1,2w+1] scratch -> blur+noise+bias+act -> [B,cout,2h,2w]."""
     x = _c(x)

@@ -1,4 +1,6 @@
 """Device / stream plumbing shared by the public ops."""
+import os
+
 import torch
 
 from . import _lib
@@ -20,3 +22,35 @@ def stream():
     """Raw hipStream_t of torch's current stream (kernels are enqueued asynchronously on it,
     like the reference's at::cuda::getCurrentCUDAStream(), upfirdn2d_kernel.cu:213-215)."""
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---------------------------------------------------------------------------------------
+# Matrix-core mode of the 3x3 (modulated) convolutions.  Tensors are fp32 in HBM and the
+# accumulation is fp32 in every mode; the mode picks the MFMA the products run on:
+#   "f16x3" (default)  split-operand fp16 MFMA (csrc/convh.hip, nterms 3): each fp32 operand
+#                      is carried as an fp16 (hi, lo) pair, a*b = hi*hi + hi*lo + lo*hi;
+#                      products carry 22 operand bits - the result differs from the fp32 MFMA
+#                      one by ~1e-6 relative, the same class as an fp32 reassociation - at
+#                      ~2.7x the fp32 MFMA throughput.
+#   "f32"              v_mfma_f32_32x32x2_f32 only (csrc/modconv.hip): exact fp32 products.
+#   "f16"              plain fp16 operands (nterms 1): BASELINE.json configs[4]'s fp16 mode,
+#                      ~5e-4 relative error per product.
+# Layers whose shape the fp16 kernels do not take run the fp32 kernels in every mode.
+CONV_PRECISIONS = ("f16x3", "f32", "f16")
+_conv_precision = os.environ.get("HAIRFAST_CONV_PRECISION", "f16x3")
+if _conv_precision not in CONV_PRECISIONS:
+    raise ValueError(f"HAIRFAST_CONV_PRECISION must be one of {CONV_PRECISIONS}, got {_conv_precision!r}")
+
+
+def conv_precision():
+    return _conv_precision
+
+
+def set_conv_precision(mode):
+    """Process-wide; returns the previous mode.  Modules cache nothing mode-specific besides the
+    split weights, so the switch takes effect on the next forward (re-capture hipGraphs)."""
+    global _conv_precision
+    if mode not in CONV_PRECISIONS:
+        raise ValueError(f"conv precision must be one of {CONV_PRECISIONS}, got {mode!r}")
+    prev, _conv_precision = _conv_precision, mode
+    return prev

@@ -11,4 +11,4 @@ extern "C" const char *hf_strerror(int code) {
   }
 }
 
-extern "C" int hf_abi_version(void) { return 5; }
+extern "C" int hf_abi_version(void) { return 6; }

@@ -1,0 +1,211 @@
+// conv_common.h - declarations shared by the convolution kernels (modconv.hip: exact-fp32
+// MFMA; convh.hip: fp16-split MFMA): launch parameters, tile geometry, the epilogue.
+#pragma once
+#include "hf_common.h"
+
+namespace hf_detail {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct __attribute__((packed, aligned(4))) f32x2u {  // 8-byte value with 4-byte alignment
+  float x, y;
+};
+
+constexpr int KC = 8;             // input channels per LDS stage (4 MFMA k-steps)
+constexpr int kThreads = 256;     // general kernel: 4 waves
+constexpr int kMaxElemPerCi = 4;  // general kernel: halo-tile elements per thread per channel
+
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_PRELU = 2 };
+
+struct TileGeom {
+  int y0, x0;      // origin of this tile family in the OUTPUT pixel domain
+  int dh, dw;      // extent of the family (pixels)
+  int lg_tw, lg_th;
+  int lg_nb;       // images per tile = 1 << lg_nb ; (nb*th*tw == PT)
+  int tiles_x, tiles_y, tiles_b;
+  int first_block; // linear block id of the family's first tile
+};
+
+struct ConvParams {
+  float *out;
+  const float *x, *wt;
+  const float *s;        // input scale  s[b*s_bstride + ci]   (modulation / pre-conv BN scale) or null
+  const float *t;        // input shift  t[ci]                 (pre-conv BN shift) or null
+  const float *d;        // output scale d[b*d_bstride + co]   (demodulation / post-conv BN scale) or null
+  const float *noise, *noise_w, *bias;
+  const float *slope;    // PReLU slopes [cout]
+  const float *residual; // added after the activation, same shape as out
+  long long noise_bstride;
+  int s_bstride, d_bstride;
+  int batch, cin, cout, h, w;  // input plane h x w
+  int out_h, out_w;            // output plane (stride-1: h,w ; stride-2: ceil(h/2) ; up: 2h+1 rows of pitch out_w)
+  int out_wv;                  // up: valid columns (2w+1) of the out_w-pitched rows; otherwise == out_w
+  int stride;                  // 1 or 2 (general kernel only)
+  int act;
+  float alpha, scale;
+  int n_geom;
+  int xs_max;                  // LDS floats reserved per staged channel
+  int groups;                  // grouped launch: blockIdx.y = group * co_tiles + co_tile (0/1 = off)
+  int co_tiles;                // cout tiles per group
+  long long x_gstride;         // floats between the inputs of consecutive groups (0 = shared input)
+  long long wt_gstride;        // taps*cin*cout
+  long long zslab;             // split-K: floats per z slab of `partial` (= groups*batch*cout*oh*ow)
+  int splits;                  // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps); 1 = off
+  int chunks_per_split;
+  float *partial;              // splits > 1: raw accumulators go to partial[z][b][co][oh][ow]
+  TileGeom g[3];
+};
+
+// Grouped launch: G independent convolutions of identical shape in one grid (the style
+// heads of the e4e encoder).  Weights / per-channel vectors / outputs of group g follow
+// those of group g-1; the input is shared (x_gstride 0) or per group.  Offsets of this
+// block's group (all zero for ordinary launches); the kernel-argument struct itself is
+// never copied (a modified copy would live in scratch memory).
+struct GroupOfs {
+  long long x, wt, o;  // element offsets into x, wt and out / partial / residual
+  int c;               // offset into bias / slope / d
+  int co_tile;
+};
+__device__ __forceinline__ GroupOfs group_offsets(const ConvParams &P) {
+  GroupOfs go{0, 0, 0, 0, (int)blockIdx.y};
+  if (P.groups > 1) {
+    const int g = blockIdx.y / P.co_tiles;
+    go.co_tile = blockIdx.y - g * P.co_tiles;
+    go.x = (long long)g * P.x_gstride;
+    go.wt = (long long)g * P.wt_gstride;
+    go.o = (long long)g * P.batch * P.cout * P.out_h * P.out_w;
+    go.c = g * P.cout;  // per-channel vectors (d_bstride == 0 in grouped launches)
+  }
+  return go;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha, float scale, float slope) {
+  if (act == ACT_LRELU) return hf_lrelu(v, alpha, scale);
+  if (act == ACT_PRELU) return v > 0.0f ? v : v * slope;
+  return v;
+}
+
+// Epilogue.  MFMA D layout: row (= co) = (r&3) + 8*(r>>2) + 4*(lane>>5), col (= pixel) = lane&31.
+// Per pixel group the 16*CT_TILES output-scale / bias / slope values of the lane's output
+// channels are fetched with independent loads up front (no load->wait->store chains).
+//   v = acc*d + noise_w*noise + bias ; v = act(v) ; v += residual
+template <int CT_TILES, int PG, bool UP, int NPH = (UP ? 4 : 1)>
+__device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &G, const GroupOfs &go,
+                                           f32x16 (&acc)[NPH][CT_TILES][PG], int co_wave, int wave_pg, int li,
+                                           int lh, int ty0, int tx0, int b0) {
+  const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
+  const long long oplane = (long long)P.out_h * P.out_w;
+  const bool partial = P.splits > 1;  // split-K: raw sums, epilogue runs in splitk_reduce
+  const bool full = !UP && !partial;
+  const float nw = (full && P.noise) ? P.noise_w[0] : 0.0f;
+#pragma unroll
+  for (int g = 0; g < PG; ++g) {
+    const int p = (wave_pg + g) * 32 + li;
+    const int px = p & (tw - 1);
+    const int py = (p >> G.lg_tw) & (th - 1);
+    const int im = p >> (G.lg_tw + G.lg_th);
+    const int Y = ty0 + py, X = tx0 + px, b = b0 + im;
+    const bool pv = (Y < G.y0 + G.dh) && (X < G.x0 + G.dw) && (b < P.batch);
+    if (!pv) continue;
+    float nz = 0.0f;
+    if (full && P.noise) nz = nw * P.noise[(long long)b * P.noise_bstride + (long long)Y * P.out_w + X];
+    float *obase = (partial ? P.partial + (long long)blockIdx.z * P.zslab : P.out) + go.o;
+#pragma unroll
+    for (int ct = 0; ct < CT_TILES; ++ct) {
+      float dmv[16], bsv[16], slv[16];  // one co tile at a time: 48 live registers, not 48*CT_TILES
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int cc = min(co, P.cout - 1);
+        dmv[r] = (P.d && !partial) ? P.d[(long long)b * P.d_bstride + go.c + cc] : 1.0f;
+        bsv[r] = (full && P.bias) ? P.bias[go.c + cc] : 0.0f;
+        slv[r] = (full && P.act == ACT_PRELU) ? P.slope[go.c + cc] : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co >= P.cout) continue;
+        const long long obofs = ((long long)b * P.cout + co) * oplane;
+        float *ob = obase + obofs;
+        const float dm = dmv[r];
+        if (UP) {
+          // phases (pr,0) and (pr,1) are neighbouring columns: one 8-byte store per row
+          // (rows of the (2h+1)x(2w+1) plane are only 4-byte aligned: unaligned-dword store)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const int ro = 2 * Y + pr, cc = 2 * X;
+            if (ro >= P.out_h) continue;
+            float *q = ob + (long long)ro * P.out_w + cc;
+            const float v0 = acc[2 * pr][ct][g][r] * dm, v1 = acc[2 * pr + 1][ct][g][r] * dm;
+            if (cc + 1 < P.out_wv) {
+              f32x2u pair;
+              pair.x = v0;
+              pair.y = v1;
+              *reinterpret_cast<f32x2u *>(q) = pair;
+            } else {
+              q[0] = v0;
+            }
+          }
+        } else {
+          const long long pofs = (long long)Y * P.out_w + X;
+          float v = acc[0][ct][g][r] * dm;
+          if (full) {
+            v = apply_act(v + nz + bsv[r], P.act, P.alpha, P.scale, slv[r]);
+            if (P.residual) v += P.residual[go.o + obofs + pofs];
+          }
+          ob[pofs] = v;
+        }
+      }
+    }
+  }
+}
+
+inline int ilog2(int v) {
+  int l = 0;
+  while ((1 << (l + 1)) <= v) ++l;
+  return l;
+}
+inline int pow2_floor(int v) { return 1 << ilog2(v); }
+inline int pow2_ceil(int v) { return (v & (v - 1)) ? (pow2_floor(v) << 1) : v; }
+
+// Tiles of `pt` pixels over a dh x dw OUTPUT domain (per image) of `batch` images.
+// Prefers full 32-pixel rows; small planes put several images in one tile.
+inline TileGeom make_geom(int y0, int x0, int dh, int dw, int batch, int pt, int first_block,
+                          bool one_image = false) {
+  TileGeom g;
+  g.y0 = y0; g.x0 = x0; g.dh = dh; g.dw = dw;
+  int tw = pow2_ceil(dw);
+  if (tw > 32 && dh > 1) tw = 32;  // rows of 32 consecutive pixels when the domain is 2-D
+  if (tw > pt) tw = pt;
+  int th = pow2_ceil(dh);
+  if (th > pt / tw) th = pt / tw;
+  if (one_image) {  // rim families of the pipelined kernel: stretch the tile instead of batching
+    // images; two rows (columns) so that the halo tile stays within the staging budget
+    if (dh == 1) { th = 2; tw = pt / 2; }
+    else { tw = 2; th = pt / 2; }
+  }
+  int nb = pt / (tw * th);
+  if (nb > pow2_ceil(batch)) nb = pow2_ceil(batch);  // never stage images that do not exist
+  g.lg_tw = ilog2(tw); g.lg_th = ilog2(th); g.lg_nb = ilog2(nb);
+  g.tiles_x = hf_cdiv(dw, tw);
+  g.tiles_y = hf_cdiv(dh, th);
+  g.tiles_b = hf_cdiv(batch, nb);
+  g.first_block = first_block;
+  return g;
+}
+inline int geom_blocks(const TileGeom &g) { return g.tiles_x * g.tiles_y * g.tiles_b; }
+// LDS floats per staged channel; ext = extra rows/cols beyond (t-1)*stride + 1
+inline int geom_xs(const TileGeom &g, int stride, int ext) {
+  const int hp = ((1 << g.lg_th) - 1) * stride + 1 + ext, wp = ((1 << g.lg_tw) - 1) * stride + 1 + ext;
+  return (1 << g.lg_nb) * hp * wp;
+}
+
+
+// convh.hip: 3x3 stride-1 same-resolution convolution on v_mfma_f32_32x32x16_f16.
+// nterms 3: fp32 operands split into fp16 (hi, lo) pairs, hi*hi + hi*lo + lo*hi in fp32
+// accumulators (fp32-class accuracy, 5.3x the fp32 MFMA rate); nterms 1: plain fp16 operands.
+// Returns HF_E_INVALID when the shape does not qualify.
+int launch_conv_h(ConvParams &P, int nterms, const void *wt_hi, const void *wt_lo, hipStream_t st);
+extern int g_force_h;            // hf_debug_set_dispatch same_cfg 51/52: force the convh.hip tile configuration
+void note_path(int path, int cfg);  // records what hf_debug_last_path reports
+
+}  // namespace hf_detail

@@ -13,6 +13,39 @@
 #define HF_DYN_LDS extern __shared__ __attribute__((aligned(16))) unsigned char hf_dyn_lds[]
 #endif
 
+// Pins a float to its fp32-rounded value (an empty asm the optimiser cannot see through):
+// stops instruction selection from fusing a preceding multiply into a following fp16
+// conversion (v_fma_mixlo_f16 rounds the UNROUNDED product).
+#ifndef HF_OPAQUE_F32
+#define HF_OPAQUE_F32(v) asm volatile("" : "+v"(v))
+#endif
+
+// Hand-scheduled LDS-DMA pipeline primitives.  hipcc models global_load_lds as a FLAT access
+// to both address spaces ("pending flat"): while one is in flight EVERY wait it inserts is
+// vmcnt(0) / lgkmcnt(0), which serialises LDS fragment prefetch and register prefetch behind
+// the DMA.  Issuing the DMA from inline asm hides it from that bookkeeping; completion is then
+// the kernel's job: hf_barrier_keep_young<N>() before the data is read.
+//   hf_glds16_raw: same contract as hf_glds16 (LDS dst = wave-uniform base + lane*16).
+//   hf_barrier_keep_young<N>: workgroup barrier that drains LDS traffic and all but the
+//     youngest N vector-memory operations of the wave.  N > 0 is only sound when the operations
+//     that must have landed and the young ones are of the SAME kind: register loads retire in
+//     order among themselves, but LDS-DMA copies retire through the LDS path and are not
+//     ordered against register loads (measured: stale DMA data with N = the number of younger
+//     register loads).  With DMA copies pending use N = 0.
+#ifndef HF_BARRIER_KEEP_DEFINED
+#define HF_BARRIER_KEEP_DEFINED
+__device__ __forceinline__ void hf_glds16_raw(const float *gsrc_lane, float *lds_wave_base) {
+  const unsigned base = __builtin_amdgcn_readfirstlane(
+      (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(gsrc_lane) : "memory");
+}
+template <int NYOUNG>
+__device__ __forceinline__ void hf_barrier_keep_young() {
+  static_assert(NYOUNG >= 0 && NYOUNG < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NYOUNG) : "memory");
+}
+#endif
+
 // Async 16-byte-per-lane global -> LDS copy (global_load_lds_dwordx4).  The LDS
 // destination is wave-uniform base + lane*16 (the base is taken from the first
 // active lane); the global source is per lane.  Completion is tracked by vmcnt:

@@ -24,7 +24,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from .. import _marshal as M
-from .._runtime import lib, require_gpu, stream
+from .._runtime import conv_precision, lib, require_gpu, stream
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 
 
@@ -124,6 +124,7 @@ class ModulatedConv2d(nn.Module):  # :183-279
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
         self._prep = None  # (key, wt [k*k,cin,cout], wsq [cout,cin]) - derived, not in the state dict
+        self._prep_f16 = None  # (key, wt_hi, wt_lo) fp16 split of wt for the fp16 matrix-core path
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
@@ -141,6 +142,26 @@ class ModulatedConv2d(nn.Module):  # :183-279
             self._prep = (key, wt, wsq)
         return self._prep[1], self._prep[2]
 
+    def prepared_f16(self):
+        """(hi, lo) fp16 split of the prepared weight in csrc/convh.hip's layout (cached)."""
+        wt, _ = self.prepared()
+        key = self._prep[0]
+        if self._prep_f16 is None or self._prep_f16[0] != key:
+            hi, lo = M.split_weights_f16(lib(), stream(), wt)
+            self._prep_f16 = (key, hi, lo)
+        return self._prep_f16[1], self._prep_f16[2]
+
+    def conv_same_res(self, input, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=math.sqrt(2)):
+        """3x3 same-resolution modulated conv (+ fused noise/bias/lrelu epilogue) on the matrix
+        cores the process-wide mode selects (_runtime.conv_precision)."""
+        mode = conv_precision()
+        _, cin, h, w = input.shape
+        if mode != "f32" and M.modconv3x3_f16_supported(cin, self.out_channel, h, w):
+            hi, lo = self.prepared_f16()
+            return M.modconv3x3_f16(lib(), stream(), input, hi, lo, 3 if mode == "f16x3" else 1, s, d, noise,
+                                    noise_w, bias, alpha, scale)
+        return M.modconv3x3(lib(), stream(), input, wt, s, d, noise, noise_w, bias, alpha, scale)
+
     def style_coefficients(self, style):
         """s[b,ci] (EqualLinear :241) and d[b,co] (:244-246; None when demodulate=False)."""
         wt, wsq = self.prepared()
@@ -157,7 +178,7 @@ class ModulatedConv2d(nn.Module):  # :183-279
             if tuple(self.blur.pad) != (1, 1) or tuple(self.blur.kernel.shape) != (4, 4):
                 raise NotImplementedError("fused upsampling path expects the [1,3,3,1] blur with pad (1,1)")
             return M.modconv3x3_up(lib(), stream(), input, wt, s, d, self.blur.kernel, None, None, None)
-        return M.modconv3x3(lib(), stream(), input, wt, s, d, None, None, None)
+        return self.conv_same_res(input, wt, s, d, None, None, None)
 
 
 class NoiseInjection(nn.Module):  # :282-293
@@ -205,8 +226,8 @@ class StyledConv(nn.Module):  # :309-343
         if conv.upsample:
             return M.modconv3x3_up(lib(), stream(), input, wt, s, d, conv.blur.kernel, noise,
                                    self.noise.weight.detach(), act.bias.detach(), act.negative_slope, act.scale)
-        return M.modconv3x3(lib(), stream(), input, wt, s, d, noise, self.noise.weight.detach(),
-                            act.bias.detach(), act.negative_slope, act.scale)
+        return conv.conv_same_res(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
+                                  act.negative_slope, act.scale)
 
 
 class ToRGB(nn.Module):  # :346-365

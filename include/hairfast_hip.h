@@ -104,6 +104,26 @@ int hf_modconv3x3_f32(float *out, const float *x, const float *wt, const float *
                       const float *bias, int batch, int cin, int cout, int h, int w, float alpha,
                       float scale, float *workspace, long long workspace_floats, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * fp16-matrix-core variant of hf_modconv3x3_f32 (same contraction, same epilogue, fp32
+ * tensors in HBM, fp32 accumulation; v_mfma_f32_32x32x16_f16).  Reference counterpart:
+ * the fp16 autocast path the headline numbers of BASELINE.json configs[4] name; the
+ * reference itself runs ModulatedConv2d in fp32 (models/stylegan2/model.py:238-277).
+ *   nterms 3 ("f16x3"): operands split into fp16 (hi, lo) pairs, a*b = hi*hi + hi*lo + lo*hi
+ *            -> fp32-class accuracy (rel. error ~5e-7 per product) at 3/16 of the fp32
+ *            MFMA time; requires |s*x|, |w| < 65504.
+ *   nterms 1 ("f16"): operands rounded to fp16 (rel. error ~5e-4 per product).
+ * wt_hi / wt_lo: from hf_conv_split_weights_f16 (each 9*cin*cout fp16 values, layout
+ * [cin/16][tap][2][cout][8]); wt_lo may be NULL for nterms 1.
+ * Shapes: cin % 16 == 0, w >= 32 and (cout % 64 == 0, h >= 8) or (cout % 32 == 0, h >= 16);
+ * anything else returns HF_E_INVALID and the caller uses hf_modconv3x3_f32.
+ */
+int hf_conv_split_weights_f16(void *wt_hi, void *wt_lo, const float *wt, int cin, int cout, void *stream);
+int hf_modconv3x3_f16_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
+                          const float *s, const float *d, const float *noise, const float *noise_w,
+                          long long noise_bstride, const float *bias, int batch, int cin, int cout, int h,
+                          int w, float alpha, float scale, void *stream);
+
 /* Scratch (in floats) the two modulated-conv entry points need for this shape: the
  * small-plane layers (4x4 .. 16x16) run split-K over the input channels and reduce the
  * partial sums in a second, deterministic pass.  0 = no workspace needed (workspace
@@ -222,7 +242,8 @@ int hf_add_bcast_f32(float *out, const float *a, const float *b, long long n, lo
  */
 int hf_debug_set_dispatch(int same_cfg, int up_cfg);
 /* Which kernel the last modulated-conv call used: 100 * family + tile configuration id,
- * family 1 = general, 2 = pipelined (double-buffered DMA), 3 = split-K (id 0).  Tests use
+ * family 1 = general, 2 = pipelined (double-buffered DMA), 3 = split-K (id 0), 5 = fp16 matrix
+ * cores (hf_modconv3x3_f16_f32; ids 51/52, forced through same_cfg).  Tests use
  * it to make sure a shape exercises the path it is meant to; bench.py to label launches. */
 int hf_debug_last_path(void);
 

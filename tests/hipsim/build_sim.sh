@@ -6,7 +6,7 @@ cd "$(dirname "$0")"
 CXX=${HIPSIM_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 SRC=../../hairfastgan_amd/csrc
 OBJS=""
-for f in api elementwise upfirdn2d style torgb modconv encoder_ops; do
+for f in api elementwise upfirdn2d style torgb modconv convh encoder_ops; do
   $CXX -x c++ -std=c++17 -O2 -fPIC -Wno-psabi -I. -c $SRC/$f.hip -o /tmp/hipsim_$f.o
   OBJS="$OBJS /tmp/hipsim_$f.o"
 done

@@ -28,6 +28,7 @@ void syncthreads();
 float shfl_xor(float v, int mask);
 float shfl_rel(float v, int delta);  // value of lane (lane + delta), own value if out of the wave
 f32x16 mfma32x32x2(float a, float b, f32x16 c);
+f32x16 mfma32x32x16h(const float *a8, const float *b8, f32x16 c);
 void glds16(const float *gsrc_lane, float *lds_wave_base);
 void glds4(const float *gsrc_lane, float *lds_wave_base);
 void glds_masked(bool active, int bytes, const float *gsrc_lane, float *lds_wave_base);
@@ -75,8 +76,20 @@ inline void hf_glds4(const float *gsrc_lane, float *lds_wave_base) { ::hipsim::g
 inline void hf_glds16_if(bool a, const float *g, float *l) { ::hipsim::glds_masked(a, 16, g, l); }
 inline void hf_glds4_if(bool a, const float *g, float *l) { ::hipsim::glds_masked(a, 4, g, l); }
 
+#define HF_OPAQUE_F32(v) ((void)0)
+#define HF_BARRIER_KEEP_DEFINED
+template <int NYOUNG> inline void hf_barrier_keep_young() { ::hipsim::syncthreads(); }
+inline void hf_glds16_raw(const float *gsrc_lane, float *lds_wave_base) { ::hipsim::glds16(gsrc_lane, lds_wave_base); }
+
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) ::hipsim::mfma32x32x2((a), (b), (c))
+typedef _Float16 hipsim_half8 __attribute__((ext_vector_type(8)));
+inline ::hipsim::f32x16 hipsim_mfma_h(hipsim_half8 a, hipsim_half8 b, ::hipsim::f32x16 c) {
+  float fa[8], fb[8];
+  for (int k = 0; k < 8; ++k) { fa[k] = (float)a[k]; fb[k] = (float)b[k]; }
+  return ::hipsim::mfma32x32x16h(fa, fb, c);
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipsim_mfma_h((a), (b), (c))
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   ::hipsim::launch([=]() { (kernel)(__VA_ARGS__); }, (grid), (block), (shmem))

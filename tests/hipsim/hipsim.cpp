@@ -16,7 +16,7 @@ unsigned char *dyn_lds() { return g_lds; }
 
 namespace {
 enum State { READY, WAIT_BLOCK, WAIT_WAVE, DONE };
-enum WaveOp { OP_NONE, OP_SHFL_XOR, OP_SHFL_REL, OP_MFMA, OP_GLDS, OP_GLDS4, OP_GLDS_MASKED };
+enum WaveOp { OP_NONE, OP_SHFL_XOR, OP_SHFL_REL, OP_MFMA, OP_MFMA_H, OP_GLDS, OP_GLDS4, OP_GLDS_MASKED };
 
 struct Fiber {
   ucontext_t ctx;
@@ -26,6 +26,7 @@ struct Fiber {
   // wave-op operands / results
   WaveOp op = OP_NONE;
   float a = 0, b = 0;
+  float ha[8], hb[8];  // f16 MFMA operands (8 consecutive k per lane)
   int imm = 0;
   const float *gsrc = nullptr;
   float *ldst = nullptr;
@@ -100,6 +101,23 @@ void resolve_wave(int w0, int w1) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
         float acc = f.c[r];
         for (int k = 0; k < 2; ++k) acc = fmaf(g_f[w0 + row + 32 * k].a, g_f[w0 + col + 32 * k].b, acc);
+        f.d[r] = acc;
+      }
+    }
+  } else if (op == OP_MFMA_H) {
+    // v_mfma_f32_32x32x16_f16: lane l holds A[i = l&31][k = 8*(l>>5) + e], B[k][j = l&31]
+    // (layout checked on MI355X with tools/probes/mfma_f16_layout.hip); D as the fp32 MFMA
+    if (w1 - w0 != 64) { fprintf(stderr, "hipsim: MFMA needs a full wave\n"); abort(); }
+    for (int i = w0; i < w1; ++i)
+      if (g_f[i].state != WAIT_WAVE) { fprintf(stderr, "hipsim: MFMA with exited lanes\n"); abort(); }
+    for (int l = 0; l < 64; ++l) {
+      Fiber &f = g_f[w0 + l];
+      const int col = l & 31;
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = f.c[r];
+        for (int k = 0; k < 16; ++k)
+          acc = fmaf(g_f[w0 + row + 32 * (k >> 3)].ha[k & 7], g_f[w0 + col + 32 * (k >> 3)].hb[k & 7], acc);
         f.d[r] = acc;
       }
     }
@@ -180,6 +198,14 @@ float shfl_rel(float v, int delta) {
 f32x16 mfma32x32x2(float a, float b, f32x16 c) {
   Fiber &f = g_f[g_cur];
   f.op = OP_MFMA; f.a = a; f.b = b; f.c = c; f.state = WAIT_WAVE;
+  yield_to_sched();
+  return g_f[g_cur].d;
+}
+
+f32x16 mfma32x32x16h(const float *a8, const float *b8, f32x16 c) {
+  Fiber &f = g_f[g_cur];
+  f.op = OP_MFMA_H; f.c = c; f.state = WAIT_WAVE;
+  for (int k = 0; k < 8; ++k) { f.ha[k] = a8[k]; f.hb[k] = b8[k]; }
   yield_to_sched();
   return g_f[g_cur].d;
 }

@@ -42,7 +42,7 @@ def test_native_library_is_loaded():
     from hairfastgan_amd import _lib
 
     lib = _lib.load()
-    assert lib.hf_abi_version() == 5
+    assert lib.hf_abi_version() == 6
     maps = open("/proc/self/maps").read()
     assert "libhairfast_hip.so" in maps
 
@@ -289,3 +289,35 @@ def test_every_pipelined_instantiation_vs_oracle(cfg, shape):
     finally:
         lib().hf_debug_set_dispatch(0, 0)
     close(y, ref)
+
+
+@pytest.mark.parametrize("nterms,tol", [(3, 5e-6), (1, 4e-3)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 48, 128, 20, 70), (2, 512, 512, 64, 64), (1, 32, 32, 100, 64)])
+def test_modconv_f16_matrix_cores(nterms, tol, shape):
+    """csrc/convh.hip against the exact-fp32 MFMA kernel and (small shapes) the oracle:
+    split fp16 operands = fp32-class accuracy, plain fp16 = operand rounding only."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib as _lib_fn, stream
+
+    B, cin, cout, H, W = shape
+    torch.manual_seed(7)
+    dev = _dev()
+    lib = _lib_fn()
+    x = torch.randn(B, cin, H, W, device=dev)
+    wgt = torch.randn(1, cout, cin, 3, 3, device=dev)
+    mw, mb, sty = torch.randn(cin, 16, device=dev), torch.randn(cin, device=dev), torch.randn(B, 16, device=dev)
+    nz, nw, bias = torch.randn(B, 1, H, W, device=dev), torch.tensor([0.3], device=dev), torch.randn(cout, device=dev)
+    st = stream()
+    wt, wsq = M.prepare_weights(lib, st, wgt)
+    s = M.modulation(lib, st, sty, mw, mb)
+    dm = M.demod(lib, st, s, wsq)
+    hi, lo = M.split_weights_f16(lib, st, wt)
+    ref = M.modconv3x3(lib, st, x, wt, s, dm, nz, nw, bias)
+    y = M.modconv3x3_f16(lib, st, x, hi, lo, nterms, s, dm, nz, nw, bias)
+    torch.cuda.synchronize()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((y - ref).abs().max()) < tol * scale
+    if cin <= 64:
+        full = O.fused_leaky_relu(O.modulated_conv2d(x.cpu(), sty.cpu(), wgt.cpu(), mw.cpu(), mb.cpu(), True, False)
+                                  + nw.cpu() * nz.cpu(), bias.cpu())
+        assert float((y.cpu() - full).abs().max()) < (1e-5 if nterms == 3 else tol) * scale

@@ -168,3 +168,36 @@ def test_modconv_pipelined_configs(simlib, cfg, shape):
         simlib.hf_debug_set_dispatch(0, 0)
     assert y.shape == ref.shape
     assert maxdiff(y, ref) < TOL * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("nterms,tol", [(3, 5e-6), (1, 4e-3)])
+@pytest.mark.parametrize("cfg,shape", [(51, (2, 32, 64, 8, 32)), (51, (1, 48, 128, 20, 70)), (52, (1, 48, 64, 20, 40)), (53, (1, 16, 32, 16, 64))])
+def test_modconv_f16_matrix_cores(simlib, nterms, tol, cfg, shape):
+    """csrc/convh.hip: fp16 MFMA with split (hi, lo) operands reproduces the fp32 result to
+    fp32-class accuracy; with plain fp16 operands to fp16 operand rounding.  Odd chunk count,
+    ragged rows/columns, noise + bias + lrelu epilogue."""
+    B, cin, cout, H, W = shape
+    torch.manual_seed(7)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+    nz, nw, bias = torch.randn(B, 1, H, W), torch.tensor([0.3]), torch.randn(cout)
+    wt, wsq = M.prepare_weights(simlib, None, wgt)
+    s = M.modulation(simlib, None, sty, mw, mb)
+    dm = M.demod(simlib, None, s, wsq)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    # hi + lo carries the weight to 2^-22 relative
+    back = (hi.float() + lo.float()).permute(1, 0, 2, 4, 3).reshape(9, cin, cout)
+    assert maxdiff(back, wt) < 3e-7 * float(wt.abs().max())
+    ref = M.modconv3x3(simlib, None, x, wt, s, dm, nz, nw, bias)
+    try:
+        simlib.hf_debug_set_dispatch(cfg, 0)
+        y = M.modconv3x3_f16(simlib, None, x, hi, lo, nterms, s, dm, nz, nw, bias)
+        assert simlib.hf_debug_last_path() == 500 + cfg
+    finally:
+        simlib.hf_debug_set_dispatch(0, 0)
+    assert y.shape == ref.shape
+    assert maxdiff(y, ref) < tol * max(1.0, float(ref.abs().max()))
+    if nterms == 3:
+        full = O.fused_leaky_relu(O.modulated_conv2d(x, sty, wgt, mw, mb, True, False) + nw * nz, bias)
+        assert maxdiff(y, full) < TOL * max(1.0, float(full.abs().max()))

@@ -30,7 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--same", default="0,11,12,13,14,15,16")
+    ap.add_argument("--same", default="0,351,352,151,152")
     ap.add_argument("--up", default="0,21,22,23,24,25")
     ap.add_argument("--only", default="", help="restrict to e.g. 'same:64,up:128' (kind:input resolution)")
     ap.add_argument("--no-streaming", action="store_true")
@@ -43,8 +43,8 @@ def main():
     up_layers = [(ch[r], ch[2 * r], r) for r in (4, 8, 16, 32, 64, 128, 256, 512)]
     print(f"batch {B}; TFLOP/s per config (fp32 MFMA peak 157.3)")
     for up, layers, cfgs in ((False, same_layers, args.same), (True, up_layers, args.up)):
-        cfgs = [int(c) for c in cfgs.split(",")]
-        print(("UP  " if up else "SAME") + " cin  cout  res | " + " ".join(f"cfg{c:>3d}" for c in cfgs))
+        cfgs = [int(c) for c in cfgs.split(",") if c]
+        print(("UP  " if up else "SAME") + " cin  cout  res | " + " ".join(f"{c:>6d}" for c in cfgs))
         for cin, cout, r in layers:
             if args.only and f"{'up' if up else 'same'}:{r}" not in args.only.split(","):
                 continue
@@ -63,13 +63,27 @@ def main():
             ws_p = ws.data_ptr() if ws_n else None
             row = []
             for c in cfgs:
-                L.hf_debug_set_dispatch(0 if up else c, c if up else 0)
+                L.hf_debug_set_dispatch(0 if (up or c >= 100) else c, c if up else 0)
                 try:
                     if up:
                         pitch = L.hf_modconv_up_pitch(r)
                         tmp = torch.empty(B, cout, 2 * r + 1, pitch, device=dev)
                         fn = lambda: L.hf_modconv3x3_up_f32(tmp.data_ptr(), x.data_ptr(), wt.data_ptr(), s.data_ptr(),
                                                             d.data_ptr(), B, cin, cout, r, r, pitch, ws_p, ws_n, stream())
+                    elif c >= 100:  # fp16 matrix cores (csrc/convh.hip): 1TT = plain f16, 3TT = split operands; TT = tile cfg (00 auto)
+                        if not M.modconv3x3_f16_supported(cin, cout, r, r):
+                            row.append("     -")
+                            continue
+                        hi, lo = M.split_weights_f16(L, stream(), wt)
+                        out = torch.empty(B, cout, r, r, device=dev)
+
+                        L.hf_debug_set_dispatch(c % 100, 0)
+
+                        def fn(nt=c // 100):
+                            code = L.hf_modconv3x3_f16_f32(out.data_ptr(), x.data_ptr(), hi.data_ptr(), lo.data_ptr(), nt,
+                                                           s.data_ptr(), d.data_ptr(), noise.data_ptr(), nw.data_ptr(), 0,
+                                                           bias.data_ptr(), B, cin, cout, r, r, 0.2, 1.4142135, stream())
+                            assert code == 0, code
                     else:
                         out = torch.empty(B, cout, r, r, device=dev)
                         fn = lambda: L.hf_modconv3x3_f32(out.data_ptr(), x.data_ptr(), wt.data_ptr(), s.data_ptr(),
