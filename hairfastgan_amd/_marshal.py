@@ -199,19 +199,33 @@ def modconv3x3_f16(lib, st, x, wt_hi, wt_lo, nterms, s, d, noise, noise_w, bias,
     return out
 
 
-def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha=0.2, scale=SQRT2):
-    """conv_transpose(stride 2) -> [B,cout,2h+1,2w+1] scratch -> blur+noise+bias+act -> [B,cout,2h,2w]."""
+def modconv3x3_up_f16_supported(cin, cout, h, w):
+    """Shapes hf_modconv3x3_up_f16_f32 takes (include/hairfast_hip.h)."""
+    return cin % 16 == 0 and cout % 32 == 0 and h * w >= (256 if cout % 64 == 0 else 512) and min(h, w) >= 2
+
+
+def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha=0.2, scale=SQRT2, f16=None):
+    """conv_transpose(stride 2) -> [B,cout,2h+1,2w+1] scratch -> blur+noise+bias+act -> [B,cout,2h,2w].
+    f16 = (wt_hi, wt_lo, nterms): part 1 on the fp16 matrix cores (hf_modconv3x3_up_f16_f32)."""
     x = _c(x)
     b, cin, h, w = x.shape
     cout = wt.shape[2]
     pitch = lib.hf_modconv_up_pitch(w)  # rows padded to a multiple of 4 floats (aligned 16 B loads in the blur)
     tmp = x.new_empty((b, cout, 2 * h + 1, pitch))
-    ws, ws_n = _workspace(lib, x, b, cin, cout, h, w, True)
-    code = _launch_profiled(
-        lib, 2.0 * cin * cout * 9 * h * w * b,
-        lambda: lib.hf_modconv3x3_up_f32(_p(tmp), _p(x), _p(wt), _p(s), _p(d), b, cin, cout, h, w, pitch, _p(ws), ws_n,
-                                         st))
-    check(lib, code, "hf_modconv3x3_up_f32")
+    if f16 is not None:
+        hi, lo, nterms = f16
+        code = _launch_profiled(
+            lib, 2.0 * cin * cout * 9 * h * w * b,
+            lambda: lib.hf_modconv3x3_up_f16_f32(_p(tmp), _p(x), _p(hi), _p(lo), nterms, _p(s), _p(d), b, cin, cout, h, w,
+                                                 pitch, st))
+        check(lib, code, "hf_modconv3x3_up_f16_f32")
+    else:
+        ws, ws_n = _workspace(lib, x, b, cin, cout, h, w, True)
+        code = _launch_profiled(
+            lib, 2.0 * cin * cout * 9 * h * w * b,
+            lambda: lib.hf_modconv3x3_up_f32(_p(tmp), _p(x), _p(wt), _p(s), _p(d), b, cin, cout, h, w, pitch, _p(ws),
+                                             ws_n, st))
+        check(lib, code, "hf_modconv3x3_up_f32")
     noise, nbs = _noise_args(noise, b, 4 * h * w)
     out = x.new_empty((b, cout, 2 * h, 2 * w))
     check(lib, lib.hf_blur_noise_bias_act_f32(_p(out), _p(tmp), _p(_c(blur_kernel)), _p(noise), _p(_c(noise_w)),

@@ -200,11 +200,12 @@ inline int geom_xs(const TileGeom &g, int stride, int ext) {
 }
 
 
-// convh.hip: 3x3 stride-1 same-resolution convolution on v_mfma_f32_32x32x16_f16.
+// convh.hip: 3x3 stride-1 same-resolution convolution (up: the transposed stride-2 one, written
+// to the padded-pitch (2h+1)-row intermediate like hf_modconv3x3_up_f32) on v_mfma_f32_32x32x16_f16.
 // nterms 3: fp32 operands split into fp16 (hi, lo) pairs, hi*hi + hi*lo + lo*hi in fp32
 // accumulators (fp32-class accuracy, 5.3x the fp32 MFMA rate); nterms 1: plain fp16 operands.
 // Returns HF_E_INVALID when the shape does not qualify.
-int launch_conv_h(ConvParams &P, int nterms, const void *wt_hi, const void *wt_lo, hipStream_t st);
+int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wt_hi, const void *wt_lo, hipStream_t st);
 extern int g_force_h;            // hf_debug_set_dispatch same_cfg 51/52: force the convh.hip tile configuration
 void note_path(int path, int cfg);  // records what hf_debug_last_path reports
 

@@ -35,10 +35,8 @@ using namespace hf_detail;
 #define HF_H_VARIANT 0
 #endif
 #if HF_H_VARIANT & 1
-#define HF_H_GLDS hf_glds16
 #define HF_H_BARRIER() __syncthreads()
 #else
-#define HF_H_GLDS hf_glds16_raw
 #define HF_H_BARRIER() hf_barrier_keep_young<0>()
 #endif
 
@@ -47,15 +45,29 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KH = 16;  // input channels per stage = K of one MFMA
 
-template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool MOD>
+// Halo pixels the LDS activation tile is sized for: PT-pixel tiles of 32-pixel rows, and (UP)
+// the 2-row / 2-column rim tiles of make_geom(one_image).
+template <int PT, bool UP>
+constexpr int halo_pixels_max() {
+  constexpr int main_tile = (PT / 32 + (UP ? 1 : 2)) * (32 + (UP ? 1 : 2));
+  constexpr int rim_tile = 3 * (PT / 2 + 1);
+  return (UP && rim_tile > main_tile) ? rim_tile : main_tile;
+}
+
+// UP: the transposed (stride 2) conv of the upsampling StyledConv, as in modconv.hip: 4 output
+// phases (pr,pc) = (ky&1, kx&1) per input position (Y,X) of the (h+1)x(w+1) phase domain, each
+// tap feeding exactly one phase from x[Y - (ky==2), X - (kx==2)]; no zero-insertion flops.
+template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool MOD, bool UP>
 __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const ConvParams P,
                                                                           const _Float16 *__restrict__ wth,
                                                                           const _Float16 *__restrict__ wtl) {
   constexpr int NW = WAVES_CO * WAVES_PX;
   constexpr int NT = 64 * NW;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
-  constexpr int TH = PG * WAVES_PX;  // tile = TH rows x 32 columns
-  constexpr int HP = TH + 2, WP = 34, NPIX = HP * WP;
+  constexpr int PT = 32 * PG * WAVES_PX;  // pixels (UP: phase-domain positions) per tile
+  constexpr int NPH = UP ? 4 : 1;
+  constexpr int HALO = UP ? 1 : 2;
+  constexpr int NPIX = halo_pixels_max<PT, UP>();
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;          // hi (+ lo)
   constexpr int W_UNITS = 9 * 2 * CT;                   // 16-byte units of one weight part per stage
   constexpr int X_UNITS = 2 * NPIX;                     // 16-byte units of one activation part per stage
@@ -81,13 +93,18 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
   const int wave_pg = (wave % WAVES_PX) * PG;
   const int co0 = blockIdx.y * CT;
 
-  const TileGeom G = P.g[0];
-  int t = blockIdx.x;
+  int gi = 0;  // tile family (uniform): interior, or the rim row / column of the transposed conv
+  if (P.n_geom > 1 && (int)blockIdx.x >= P.g[1].first_block) gi = 1;
+  if (P.n_geom > 2 && (int)blockIdx.x >= P.g[2].first_block) gi = 2;
+  const TileGeom G = P.g[gi];
+  int t = blockIdx.x - G.first_block;
   const int tx = t % G.tiles_x;
   t /= G.tiles_x;
   const int ty = t % G.tiles_y;
-  const int b0 = t / G.tiles_y;
-  const int ty0 = ty * TH, tx0 = tx * 32;
+  const int b0 = t / G.tiles_y;  // one image per tile
+  const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
+  const int wp = tw + HALO, xs = (th + HALO) * wp;  // halo tile, first pixel (ty0-1, tx0-1)
+  const int ty0 = G.y0 + ty * th, tx0 = G.x0 + tx * tw;
   const long long plane = (long long)P.h * P.w;
   const float *xb = P.x + (long long)b0 * P.cin * plane;
 
@@ -101,23 +118,31 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
     const int i = tid + e * NT;
     e_src[e] = -2;  // -2: no item, -1: item outside the image (zero fill)
     e_kg[e] = 0;
-    if (i < X_UNITS) {
-      const int kg = i / NPIX, pix = i - kg * NPIX;
-      const int hy = pix / WP, hx = pix - hy * WP;
+    const int kg = i / NPIX, pix = i - kg * NPIX;
+    if (i < X_UNITS && pix < xs) {
+      const int hy = pix / wp, hx = pix - hy * wp;
       const int ys = ty0 + hy - 1, xc = tx0 + hx - 1;
       e_kg[e] = kg;
       e_src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? (int)((long long)ys * P.w + xc) : -1;
     }
   }
 
+  // weight stage of `chunk`: uniform base + per-lane byte offset ((tap*2+kg)*cout + co0 + col)*16
   auto dma_piece = [&](int i, int chunk, half8 *buf) {
     const int pc = wave + i * NW;
     if (pc < N_WPIECE) {
       const int part = pc / (W_UNITS / 64), q = pc % (W_UNITS / 64);
       const int u = q * 64 + lane;            // unit inside the part: (tap*2 + kg)*CT + co
       const int row = u / CT, col = u % CT;   // row = tap*2 + kg
-      const _Float16 *src = (part ? wtl : wth) + (((long long)chunk * 18 + row) * P.cout + co0 + col) * 8;
-      HF_H_GLDS(reinterpret_cast<const float *>(src), reinterpret_cast<float *>(buf + part * W_UNITS + q * 64));
+      int off = (row * P.cout + co0 + col) * 16;
+      HF_OPAQUE_I32(off);
+      const _Float16 *src = (part ? wtl : wth) + (long long)chunk * 18 * P.cout * 8;
+#if HF_H_VARIANT & 1
+      hf_glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + off),
+                reinterpret_cast<float *>(buf + part * W_UNITS + q * 64));
+#else
+      hf_glds16_raw_s(src, (unsigned)off, reinterpret_cast<float *>(buf + part * W_UNITS + q * 64));
+#endif
     }
   };
 
@@ -126,10 +151,12 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
   // chunk instead (unconditional loads: no branches in the pipeline) and are zeroed at conversion
   const int iplane = (int)plane;
   auto load_item = [&](int set, int e, int chunk) {
-    const float *xc = xb + (long long)chunk * KH * plane;
-    const int off = (e_src[e] >= 0) ? e_kg[e] * 8 * iplane + e_src[e] : 0;
+    const char *xc = reinterpret_cast<const char *>(xb + (long long)chunk * KH * plane);  // uniform
+    int off = (e_src[e] >= 0) ? e_kg[e] * 8 * iplane + e_src[e] : 0;
+    HF_OPAQUE_I32(off);  // addresses recomputed per chunk, not kept live as 8 hoisted 64-bit pairs
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xr[set][e][k] = xc[off + k * iplane];
+    for (int k = 0; k < 8; ++k)
+      xr[set][e][k] = *reinterpret_cast<const float *>(xc + (unsigned)((off + k * iplane) * 4));
   };
   auto convert_item = [&](int set, int e, int chunk, half8 *buf) {
     if (e_src[e] == -2) return;
@@ -151,17 +178,26 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
     if (NTERMS == 3) buf[OFF_XL + i] = lo;
   };
 
-  int pixoff[PG];
+  // halo-tile unit of the lane's pixel of group g, per tap row (ky*wp; UP: rows 1 and 0)
+  constexpr int NROW = UP ? 2 : 3;
+  int pixrow[PG][NROW];
 #pragma unroll
-  for (int g = 0; g < PG; ++g) pixoff[g] = (wave_pg + g) * WP + li;  // one 32-pixel row per group
+  for (int g = 0; g < PG; ++g) {
+    const int p = (wave_pg + g) * 32 + li;
+    const int po = ((p >> G.lg_tw) & (th - 1)) * wp + (p & (tw - 1));
+#pragma unroll
+    for (int r = 0; r < NROW; ++r) pixrow[g][r] = po + r * wp;
+  }
 
-  f32x16 acc[1][CT_TILES][PG];
+  f32x16 acc[NPH][CT_TILES][PG];
 #pragma unroll
-  for (int ct = 0; ct < CT_TILES; ++ct)
+  for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
-    for (int g = 0; g < PG; ++g)
+    for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][ct][g][r] = 0.0f;
+      for (int g = 0; g < PG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ph][ct][g][r] = 0.0f;
 
   const int nchunks = P.cin / KH;
   __syncthreads();  // sl visible
@@ -184,9 +220,11 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
     const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT + ct*32
     const half8 *b_hi = buf + OFF_XH + lh * NPIX;      // + pixoff + toff
     // fragments of tap+1 are fetched from LDS while the MFMAs of tap run
-    half8 ah[2][CT_TILES], al[2][CT_TILES], bh[2][PG], bl[2][PG];
+    constexpr int NSLOT = UP ? 1 : 2;  // UP: 128 accumulator registers leave no room for a second set
+    half8 ah[NSLOT][CT_TILES], al[NSLOT][CT_TILES], bh[NSLOT][PG], bl[NSLOT][PG];
     auto fetch = [&](int slot, int tap) {
-      const int toff = (tap / 3) * WP + tap % 3;
+      const int ky = tap / 3, kx = tap % 3;
+      const int brow = UP ? (ky == 2 ? 0 : 1) : ky, bcol = UP ? (kx == 2 ? 0 : 1) : kx;
 #pragma unroll
       for (int ct = 0; ct < CT_TILES; ++ct) {
         ah[slot][ct] = a_hi[tap * 2 * CT + ct * 32];
@@ -194,19 +232,19 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
       }
 #pragma unroll
       for (int g = 0; g < PG; ++g) {
-        bh[slot][g] = b_hi[pixoff[g] + toff];
-        if (NTERMS == 3) bl[slot][g] = b_hi[X_UNITS + pixoff[g] + toff];
+        bh[slot][g] = b_hi[pixrow[g][brow] + bcol];
+        if (NTERMS == 3) bl[slot][g] = b_hi[X_UNITS + pixrow[g][brow] + bcol];
       }
     };
     fetch(0, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int sl_ = tap & 1;
-#if HF_H_VARIANT & 2
-      fetch(sl_, tap);
-#else
-      if (tap + 1 < 9) fetch(sl_ ^ 1, tap + 1);
-#endif
+      const int sl_ = UP ? 0 : (tap & 1);
+      if (UP) {
+        if (tap > 0) fetch(0, tap);
+      } else if (tap + 1 < 9) {
+        fetch(sl_ ^ 1, tap + 1);
+      }
       // ---- side work of this step ----
       if (more1) {
 #pragma unroll
@@ -219,22 +257,23 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
       }
       if (more1 && tap >= 9 - XE) convert_item(0, tap - (9 - XE), c + 1, nbuf);
       __builtin_amdgcn_sched_barrier(0);
+      const int ph = UP ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) : 0;
 #pragma unroll
       for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
         for (int g = 0; g < PG; ++g)
-          acc[0][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl_][ct], bh[sl_][g], acc[0][ct][g], 0, 0, 0);
+          acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl_][ct], bh[sl_][g], acc[ph][ct][g], 0, 0, 0);
       if (NTERMS == 3) {
 #pragma unroll
         for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
           for (int g = 0; g < PG; ++g)
-            acc[0][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl_][ct], bl[sl_][g], acc[0][ct][g], 0, 0, 0);
+            acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl_][ct], bl[sl_][g], acc[ph][ct][g], 0, 0, 0);
 #pragma unroll
         for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
           for (int g = 0; g < PG; ++g)
-            acc[0][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl_][ct], bh[sl_][g], acc[0][ct][g], 0, 0, 0);
+            acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl_][ct], bh[sl_][g], acc[ph][ct][g], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -242,7 +281,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
     HF_H_BARRIER();
   }
 
-  store_tile<CT_TILES, PG, false>(P, G, GroupOfs{0, 0, 0, 0, 0}, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+  store_tile<CT_TILES, PG, UP>(P, G, GroupOfs{0, 0, 0, 0, 0}, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
 // fp32 prepared weights wt[tap][ci][co] -> hi / lo halves in [chunk16][tap][kg][co][8]
@@ -262,30 +301,41 @@ __global__ __launch_bounds__(256) void split_weights(_Float16 *__restrict__ wth,
   }
 }
 
-template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX>
+template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP>
 int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_t st) {
   constexpr int NT = 64 * WAVES_CO * WAVES_PX;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
-  constexpr int TH = PG * WAVES_PX, HP = TH + 2;
+  constexpr int PT = 32 * PG * WAVES_PX;
+  constexpr int NPIX = halo_pixels_max<PT, UP>();
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;
   if (P.cin % KH || P.cout % CT || P.stride != 1 || P.t || P.groups > 1) return HF_E_INVALID;
-  if (P.w < 32 || P.h < TH) return HF_E_INVALID;
   if ((long long)P.cin * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
   P.splits = 1;
   P.n_geom = 1;
-  TileGeom g{};
-  g.y0 = 0; g.x0 = 0; g.dh = P.h; g.dw = P.w;
-  g.lg_tw = 5; g.lg_th = ilog2(TH); g.lg_nb = 0;
-  g.tiles_x = hf_cdiv(P.w, 32); g.tiles_y = hf_cdiv(P.h, TH); g.tiles_b = P.batch; g.first_block = 0;
-  P.g[0] = g;
-  const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * HP * 34) * 16 + (P.s ? P.cin * sizeof(float) : 0);
+  P.g[0] = make_geom(0, 0, P.h, P.w, P.batch, PT, 0);
+  int nblocks = geom_blocks(P.g[0]);
+  if (UP) {  // + the Y = h row (incl. corner) and the X = w column of the (h+1)x(w+1) phase domain
+    P.n_geom = 3;
+    P.g[1] = make_geom(P.h, 0, 1, P.w + 1, P.batch, PT, nblocks, true);
+    nblocks += geom_blocks(P.g[1]);
+    P.g[2] = make_geom(0, P.w, P.h, 1, P.batch, PT, nblocks, true);
+    nblocks += geom_blocks(P.g[2]);
+  }
+  for (int i = 0; i < P.n_geom; ++i) {
+    // one image per tile, whole PT-pixel tiles, halo within the LDS tile
+    if (P.g[i].lg_nb != 0 || (1 << (P.g[i].lg_tw + P.g[i].lg_th)) != PT) return HF_E_INVALID;
+    if (geom_xs(P.g[i], 1, UP ? 1 : 2) > NPIX) return HF_E_INVALID;
+  }
+  const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + (P.s ? P.cin * sizeof(float) : 0);
   if (lds > 160 * 1024) return HF_E_INVALID;
-  dim3 grid(geom_blocks(g), P.cout / CT);
+  dim3 grid(nblocks, P.cout / CT);
   if (grid.y > 65535) return HF_E_INVALID;
   if (P.s)
-    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, true>), grid, dim3(NT), lds, st, P, wth, wtl);
+    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, true, UP>), grid, dim3(NT), lds, st, P, wth,
+                       wtl);
   else
-    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, false>), grid, dim3(NT), lds, st, P, wth, wtl);
+    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, false, UP>), grid, dim3(NT), lds, st, P, wth,
+                       wtl);
   return hf_launch_status();
 }
 
@@ -295,24 +345,32 @@ namespace hf_detail {
 
 int g_force_h = 0;
 
-int launch_conv_h(ConvParams &P, int nterms, const void *wth, const void *wtl, hipStream_t st) {
+int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const void *wtl, hipStream_t st) {
   const _Float16 *h = static_cast<const _Float16 *>(wth), *l = static_cast<const _Float16 *>(wtl);
   if (!h || (nterms == 3 && !l)) return HF_E_INVALID;
+  int cfg, rc;
+  if (up) {
+    // 61: 64 co x 256 positions x 4 phases, 2 co-waves x 4 pixel-waves, 1x2 MFMA tiles per phase
+    // 63: 32 co x 512 positions x 4 phases, 8 pixel-waves (cout % 64 != 0: the 1024^2 layer)
+    cfg = (P.cout % 64) ? 63 : 61;
+    if (cfg == 63) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, true>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, true>(P, h, l, st);
+    else rc = (nterms == 3) ? launch_h<3, 1, 2, 2, 4, true>(P, h, l, st) : launch_h<1, 1, 2, 2, 4, true>(P, h, l, st);
+    if (rc == HF_OK) note_path(5, cfg);
+    return rc;
+  }
   // 51: 64 co x 256 px (8 rows), 2 co-waves x 4 pixel-waves, 1x2 MFMA tiles per wave
   // 52: 64 co x 512 px (16 rows), 8 pixel-waves, 2x2 MFMA tiles per wave: 0.67 LDS fragment
   //     reads per MFMA instead of 2 (fewer issue slots beside the MFMAs), needs >= 256 such blocks
   // 53: 32 co x 512 px (16 rows), 8 pixel-waves, 1x2 tiles: layers with cout % 64 != 0 (1024^2: 32)
-  int cfg = g_force_h;
+  cfg = g_force_h;
   if (cfg == 0) {
     const long long blocks52 = (long long)P.batch * hf_cdiv(P.h, 16) * hf_cdiv(P.w, 32) * (P.cout / 64);
     if (P.cout % 64) cfg = 53;
-    else cfg = (P.h >= 16 && blocks52 >= 256) ? 52 : 51;
+    else cfg = (P.h * P.w >= 512 && blocks52 >= 256) ? 52 : 51;
   }
-  if ((cfg == 52 || cfg == 53) && P.h < 16) cfg = 51;
-  int rc;
-  if (cfg == 53) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8>(P, h, l, st) : launch_h<1, 1, 2, 1, 8>(P, h, l, st);
-  else if (cfg == 52) rc = (nterms == 3) ? launch_h<3, 2, 2, 1, 8>(P, h, l, st) : launch_h<1, 2, 2, 1, 8>(P, h, l, st);
-  else rc = (nterms == 3) ? launch_h<3, 1, 2, 2, 4>(P, h, l, st) : launch_h<1, 1, 2, 2, 4>(P, h, l, st);
+  if (cfg == 53) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false>(P, h, l, st);
+  else if (cfg == 52) rc = (nterms == 3) ? launch_h<3, 2, 2, 1, 8, false>(P, h, l, st) : launch_h<1, 2, 2, 1, 8, false>(P, h, l, st);
+  else rc = (nterms == 3) ? launch_h<3, 1, 2, 2, 4, false>(P, h, l, st) : launch_h<1, 1, 2, 2, 4, false>(P, h, l, st);
   if (rc == HF_OK) note_path(5, cfg);
   return rc;
 }
@@ -345,5 +403,21 @@ extern "C" int hf_modconv3x3_f16_f32(float *out, const float *x, const void *wt_
   P.stride = 1;
   P.act = bias ? ACT_LRELU : ACT_NONE;
   P.alpha = alpha; P.scale = scale;
-  return launch_conv_h(P, nterms, wt_hi, wt_lo, (hipStream_t)stream);
+  return launch_conv_h(P, nterms, false, wt_hi, wt_lo, (hipStream_t)stream);
+}
+
+extern "C" int hf_modconv3x3_up_f16_f32(float *tmp, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
+                                        const float *s, const float *d, int batch, int cin, int cout, int h, int w,
+                                        int tmp_pitch, void *stream) {
+  if (!tmp || !x || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || tmp_pitch < 2 * w + 1 ||
+      (nterms != 1 && nterms != 3))
+    return HF_E_INVALID;
+  ConvParams P{};
+  P.out = tmp; P.x = x; P.s = s; P.d = d;
+  P.s_bstride = cin; P.d_bstride = cout;
+  P.groups = 1;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = 2 * h + 1; P.out_w = tmp_pitch;
+  P.out_wv = 2 * w + 1;
+  P.stride = 1;
+  return launch_conv_h(P, nterms, true, wt_hi, wt_lo, (hipStream_t)stream);
 }

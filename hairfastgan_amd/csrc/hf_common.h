@@ -18,6 +18,9 @@
 // conversion (v_fma_mixlo_f16 rounds the UNROUNDED product).
 #ifndef HF_OPAQUE_F32
 #define HF_OPAQUE_F32(v) asm volatile("" : "+v"(v))
+// same for an int: recomputed where it is used instead of being hoisted out of the loop
+// into a register that stays live (address arithmetic of software-pipelined loads)
+#define HF_OPAQUE_I32(v) asm volatile("" : "+v"(v))
 #endif
 
 // Hand-scheduled LDS-DMA pipeline primitives.  hipcc models global_load_lds as a FLAT access
@@ -38,6 +41,20 @@ __device__ __forceinline__ void hf_glds16_raw(const float *gsrc_lane, float *lds
   const unsigned base = __builtin_amdgcn_readfirstlane(
       (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)lds_wave_base);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(gsrc_lane) : "memory");
+}
+// wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: one VGPR of address
+__device__ __forceinline__ void hf_glds16_raw_s(const void *gsrc_uniform, unsigned lane_byte_offset,
+                                                float *lds_wave_base) {
+  const unsigned base = __builtin_amdgcn_readfirstlane(
+      (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)lds_wave_base);
+  // readfirstlane: the pointer is wave-uniform by contract, but the compiler may hold it in
+  // VGPRs (e.g. selected by a wave index) - an "s" operand needs a provably scalar value
+  const unsigned long long g = (unsigned long long)gsrc_uniform;
+  const unsigned g_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(g >> 32));
+  const unsigned g_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)g);  // unsigned: no sign extension
+  const unsigned long long gs = ((unsigned long long)g_hi << 32) | g_lo;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(base), "v"(lane_byte_offset), "s"(gs)
+               : "memory");
 }
 template <int NYOUNG>
 __device__ __forceinline__ void hf_barrier_keep_young() {

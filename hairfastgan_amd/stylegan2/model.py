@@ -162,6 +162,17 @@ class ModulatedConv2d(nn.Module):  # :183-279
                                     noise_w, bias, alpha, scale)
         return M.modconv3x3(lib(), stream(), input, wt, s, d, noise, noise_w, bias, alpha, scale)
 
+    def conv_up(self, input, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=math.sqrt(2)):
+        """Transposed 3x3 conv + blur (+ fused noise/bias/lrelu), matrix cores per the mode."""
+        mode = conv_precision()
+        _, cin, h, w = input.shape
+        f16 = None
+        if mode != "f32" and M.modconv3x3_up_f16_supported(cin, self.out_channel, h, w):
+            hi, lo = self.prepared_f16()
+            f16 = (hi, lo, 3 if mode == "f16x3" else 1)
+        return M.modconv3x3_up(lib(), stream(), input, wt, s, d, self.blur.kernel, noise, noise_w, bias, alpha, scale,
+                               f16=f16)
+
     def style_coefficients(self, style):
         """s[b,ci] (EqualLinear :241) and d[b,co] (:244-246; None when demodulate=False)."""
         wt, wsq = self.prepared()
@@ -177,7 +188,7 @@ class ModulatedConv2d(nn.Module):  # :183-279
         if self.upsample:
             if tuple(self.blur.pad) != (1, 1) or tuple(self.blur.kernel.shape) != (4, 4):
                 raise NotImplementedError("fused upsampling path expects the [1,3,3,1] blur with pad (1,1)")
-            return M.modconv3x3_up(lib(), stream(), input, wt, s, d, self.blur.kernel, None, None, None)
+            return self.conv_up(input, wt, s, d, None, None, None)
         return self.conv_same_res(input, wt, s, d, None, None, None)
 
 
@@ -224,8 +235,8 @@ class StyledConv(nn.Module):  # :309-343
             noise = input.new_empty(b, 1, oh, ow).normal_()
         act = self.activate
         if conv.upsample:
-            return M.modconv3x3_up(lib(), stream(), input, wt, s, d, conv.blur.kernel, noise,
-                                   self.noise.weight.detach(), act.bias.detach(), act.negative_slope, act.scale)
+            return conv.conv_up(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
+                                act.negative_slope, act.scale)
         return conv.conv_same_res(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
                                   act.negative_slope, act.scale)
 

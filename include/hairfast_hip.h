@@ -123,6 +123,13 @@ int hf_modconv3x3_f16_f32(float *out, const float *x, const void *wt_hi, const v
                           const float *s, const float *d, const float *noise, const float *noise_w,
                           long long noise_bstride, const float *bias, int batch, int cin, int cout, int h,
                           int w, float alpha, float scale, void *stream);
+/* Part 1 of the upsampling StyledConv (hf_modconv3x3_up_f32) on the fp16 matrix cores: same
+ * intermediate [batch, cout, 2h+1, tmp_pitch], same weights as hf_modconv3x3_f16_f32 (the
+ * transposed conv's tap flip is in the phase mapping, not in the layout).  Shapes:
+ * cin % 16 == 0, cout % 32 == 0, h*w >= 256 (cout % 64 == 0) or >= 512; otherwise HF_E_INVALID. */
+int hf_modconv3x3_up_f16_f32(float *tmp, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
+                             const float *s, const float *d, int batch, int cin, int cout, int h, int w,
+                             int tmp_pitch, void *stream);
 
 /* Scratch (in floats) the two modulated-conv entry points need for this shape: the
  * small-plane layers (4x4 .. 16x16) run split-K over the input channels and reduce the
@@ -243,7 +250,8 @@ int hf_add_bcast_f32(float *out, const float *a, const float *b, long long n, lo
 int hf_debug_set_dispatch(int same_cfg, int up_cfg);
 /* Which kernel the last modulated-conv call used: 100 * family + tile configuration id,
  * family 1 = general, 2 = pipelined (double-buffered DMA), 3 = split-K (id 0), 5 = fp16 matrix
- * cores (hf_modconv3x3_f16_f32; ids 51/52, forced through same_cfg).  Tests use
+ * cores (hf_modconv3x3_f16_f32: ids 51-53, 51/52 can be forced through same_cfg;
+ * hf_modconv3x3_up_f16_f32: ids 61/63).  Tests use
  * it to make sure a shape exercises the path it is meant to; bench.py to label launches. */
 int hf_debug_last_path(void);
 

@@ -77,9 +77,13 @@ inline void hf_glds16_if(bool a, const float *g, float *l) { ::hipsim::glds_mask
 inline void hf_glds4_if(bool a, const float *g, float *l) { ::hipsim::glds_masked(a, 4, g, l); }
 
 #define HF_OPAQUE_F32(v) ((void)0)
+#define HF_OPAQUE_I32(v) ((void)0)
 #define HF_BARRIER_KEEP_DEFINED
 template <int NYOUNG> inline void hf_barrier_keep_young() { ::hipsim::syncthreads(); }
 inline void hf_glds16_raw(const float *gsrc_lane, float *lds_wave_base) { ::hipsim::glds16(gsrc_lane, lds_wave_base); }
+inline void hf_glds16_raw_s(const void *g, unsigned off, float *l) {
+  ::hipsim::glds16(reinterpret_cast<const float *>(static_cast<const char *>(g) + off), l);
+}
 
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) ::hipsim::mfma32x32x2((a), (b), (c))

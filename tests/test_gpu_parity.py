@@ -321,3 +321,38 @@ def test_modconv_f16_matrix_cores(nterms, tol, shape):
         full = O.fused_leaky_relu(O.modulated_conv2d(x.cpu(), sty.cpu(), wgt.cpu(), mw.cpu(), mb.cpu(), True, False)
                                   + nw.cpu() * nz.cpu(), bias.cpu())
         assert float((y.cpu() - full).abs().max()) < (1e-5 if nterms == 3 else tol) * scale
+
+
+@pytest.mark.parametrize("nterms,tol", [(3, 5e-6), (1, 4e-3)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 16, 16), (1, 48, 128, 20, 70), (2, 512, 256, 64, 64), (1, 64, 32, 40, 64)])
+def test_modconv_up_f16_matrix_cores(nterms, tol, shape):
+    """Transposed conv of csrc/convh.hip (interior + rim tile families) + blur epilogue against
+    the exact-fp32 MFMA path and (small shapes) the oracle."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib as _lib_fn, stream
+
+    B, cin, cout, H, W = shape
+    torch.manual_seed(11)
+    dev = _dev()
+    lib = _lib_fn()
+    x = torch.randn(B, cin, H, W, device=dev)
+    wgt = torch.randn(1, cout, cin, 3, 3, device=dev)
+    mw, mb, sty = torch.randn(cin, 16, device=dev), torch.randn(cin, device=dev), torch.randn(B, 16, device=dev)
+    nz, nw, bias = torch.randn(B, 1, 2 * H, 2 * W, device=dev), torch.tensor([0.3], device=dev), torch.randn(cout, device=dev)
+    st = stream()
+    wt, wsq = M.prepare_weights(lib, st, wgt)
+    s = M.modulation(lib, st, sty, mw, mb)
+    dm = M.demod(lib, st, s, wsq)
+    hi, lo = M.split_weights_f16(lib, st, wt)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0).to(dev)
+    assert M.modconv3x3_up_f16_supported(cin, cout, H, W)
+    ref = M.modconv3x3_up(lib, st, x, wt, s, dm, k4, nz, nw, bias)
+    y = M.modconv3x3_up(lib, st, x, wt, s, dm, k4, nz, nw, bias, f16=(hi, lo, nterms))
+    assert lib.hf_debug_last_path() in (561, 563)
+    torch.cuda.synchronize()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((y - ref).abs().max()) < tol * scale
+    if cin <= 64:
+        full = O.fused_leaky_relu(O.modulated_conv2d(x.cpu(), sty.cpu(), wgt.cpu(), mw.cpu(), mb.cpu(), True, True)
+                                  + nw.cpu() * nz.cpu(), bias.cpu())
+        assert float((y.cpu() - full).abs().max()) < (1e-5 if nterms == 3 else tol) * scale

@@ -201,3 +201,30 @@ def test_modconv_f16_matrix_cores(simlib, nterms, tol, cfg, shape):
     if nterms == 3:
         full = O.fused_leaky_relu(O.modulated_conv2d(x, sty, wgt, mw, mb, True, False) + nw * nz, bias)
         assert maxdiff(y, full) < TOL * max(1.0, float(full.abs().max()))
+
+
+@pytest.mark.parametrize("nterms,tol", [(3, 5e-6), (1, 4e-3)])
+@pytest.mark.parametrize("cfg,shape", [(61, (1, 32, 64, 16, 16)), (61, (2, 16, 64, 9, 40)), (63, (1, 16, 32, 16, 32))])
+def test_modconv_up_f16_matrix_cores(simlib, nterms, tol, cfg, shape):
+    """Transposed conv on the fp16 matrix cores: interior tiles plus the rim row / column
+    families, against the fp32 MFMA kernel and the oracle (incl. blur + noise + bias + lrelu)."""
+    B, cin, cout, H, W = shape
+    torch.manual_seed(11)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+    nz, nw, bias = torch.randn(B, 1, 2 * H, 2 * W), torch.tensor([0.3]), torch.randn(cout)
+    wt, wsq = M.prepare_weights(simlib, None, wgt)
+    s = M.modulation(simlib, None, sty, mw, mb)
+    dm = M.demod(simlib, None, s, wsq)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0)
+    assert M.modconv3x3_up_f16_supported(cin, cout, H, W)
+    ref = M.modconv3x3_up(simlib, None, x, wt, s, dm, k4, nz, nw, bias)
+    y = M.modconv3x3_up(simlib, None, x, wt, s, dm, k4, nz, nw, bias, f16=(hi, lo, nterms))
+    assert simlib.hf_debug_last_path() == 500 + cfg
+    assert y.shape == ref.shape
+    assert maxdiff(y, ref) < tol * max(1.0, float(ref.abs().max()))
+    if nterms == 3:
+        full = O.fused_leaky_relu(O.modulated_conv2d(x, sty, wgt, mw, mb, True, True) + nw * nz, bias)
+        assert maxdiff(y, full) < TOL * max(1.0, float(full.abs().max()))

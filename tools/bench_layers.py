@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--same", default="0,351,352,151,152")
-    ap.add_argument("--up", default="0,21,22,23,24,25")
+    ap.add_argument("--up", default="0,300,100")
     ap.add_argument("--only", default="", help="restrict to e.g. 'same:64,up:128' (kind:input resolution)")
     ap.add_argument("--no-streaming", action="store_true")
     args = ap.parse_args()
@@ -63,9 +63,21 @@ def main():
             ws_p = ws.data_ptr() if ws_n else None
             row = []
             for c in cfgs:
-                L.hf_debug_set_dispatch(0 if (up or c >= 100) else c, c if up else 0)
+                L.hf_debug_set_dispatch(0 if (up or c >= 100) else c, c if (up and c < 100) else 0)
                 try:
-                    if up:
+                    if up and c >= 100:  # fp16 matrix cores: 100 = plain f16, 300 = split operands
+                        if not M.modconv3x3_up_f16_supported(cin, cout, r, r):
+                            row.append("     -")
+                            continue
+                        hi, lo = M.split_weights_f16(L, stream(), wt)
+                        pitch = L.hf_modconv_up_pitch(r)
+                        tmp = torch.empty(B, cout, 2 * r + 1, pitch, device=dev)
+
+                        def fn(nt=c // 100):
+                            code = L.hf_modconv3x3_up_f16_f32(tmp.data_ptr(), x.data_ptr(), hi.data_ptr(), lo.data_ptr(), nt,
+                                                              s.data_ptr(), d.data_ptr(), B, cin, cout, r, r, pitch, stream())
+                            assert code == 0, code
+                    elif up:
                         pitch = L.hf_modconv_up_pitch(r)
                         tmp = torch.empty(B, cout, 2 * r + 1, pitch, device=dev)
                         fn = lambda: L.hf_modconv3x3_up_f32(tmp.data_ptr(), x.data_ptr(), wt.data_ptr(), s.data_ptr(),
