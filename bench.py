@@ -9,10 +9,13 @@ already resident in HBM; noise is drawn fresh per layer like HairFast's callers 
 fill of oracle/synth.py (no checkpoints / network on the box); timing is weight-independent.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel = the fp32-MFMA modulated-conv instantiation with the largest share
-                of the step (per-launch labels come from hf_debug_last_path): algorithmic FLOPs of its launches /
-                their HIP-event durations, measured during the timed steps on the launch
-                stream, against the 157.3 TFLOP/s fp32 MFMA peak.
+  roofline      dominant kernel = the modulated-conv instantiation with the largest share of the
+                step (per-launch labels come from hf_debug_last_path): ALGORITHMIC FLOPs of its
+                launches / their HIP-event durations, measured during the timed steps on the launch
+                stream.  peak: 157.3 TFLOP/s for the fp32-MFMA kernels; for the split-operand
+                fp16 kernels (3 fp16 MFMAs per fp32-class product) the fp16 dense peak / 3.
+  exact_f32     the same forward with every conv on the fp32 MFMA (HAIRFAST_CONV_PRECISION=f32),
+                timed after the headline run, for comparison.
   cpu_baseline  the CPU oracle (bit-identical restatement of the reference's PyTorch CPU
                 path) timed on this host: batch-1 forwards, all host cores (rank 0, N=1 only).
 For N>1 (torchrun, one rank per GPU over RCCL) every rank runs the same per-GPU batch
@@ -31,6 +34,12 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_f16: 32768 FLOP / 32 cycles / SIMD, 1024 SIMDs x 2.4 GHz
+DTYPES = {
+    "f16x3": "f32 tensors + f32 accumulate; conv products as 3 fp16 MFMAs on (hi,lo)-split operands (fp32-class)",
+    "f32": "f32 (fp32 MFMA)",
+    "f16": "f32 tensors + f32 accumulate; conv operands rounded to fp16 (fp16 MFMA)",
+}
 GFLOP_PER_IMAGE = 148.52       # modulated-conv FLOPs of one 0->8 forward
 
 
@@ -134,13 +143,19 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--precision", choices=("f16x3", "f32", "f16"), default=None,
+                    help="matrix-core mode of the 3x3 convs (default: HAIRFAST_CONV_PRECISION or f16x3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--swap-triples", type=int, default=4,
                     help="triples per GPU for the secondary hair-swap hot-path schedule measurement (0 = skip)")
     args = ap.parse_args()
 
-    from hairfastgan_amd import _marshal, parallel
+    from hairfastgan_amd import _marshal, _runtime, parallel
+
+    if args.precision:
+        _runtime.set_conv_precision(args.precision)
+    precision = _runtime.conv_precision()
 
     rank, world, local = parallel.init_from_env()
     if world != args.gpus and rank == 0:
@@ -201,6 +216,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # comparison run (outside the timed region): every conv on the exact-fp32 MFMA
+    exact_f32 = None
+    if precision != "f32" and world == 1:
+        prev = _runtime.set_conv_precision("f32")
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        e32 = time.perf_counter() - t1
+        _runtime.set_conv_precision(prev)
+        exact_f32 = {"value": round(B * args.steps / e32, 3), "unit": "images/s", "ms_per_step": round(e32 / args.steps * 1e3, 4),
+                     "note": "same forward, HAIRFAST_CONV_PRECISION=f32 (v_mfma_f32_32x32x2_f32 only)"}
+
     # Secondary measurement (outside the timed region above): the hot-path call schedule of
     # one HairFast swap (BASELINE.json configs[2]/[3]), triples sharded
     # over ranks, no collective in the path.
@@ -235,12 +266,12 @@ def main():
             "metric": "stylegan2_generator_fwd_1024_images_per_sec", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "ms_per_image": round(ms_step / B, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPES[precision], "data": "synthetic",
             "config": {"workload": "StyleGAN2 1024^2 generator forward (range 0->8), random W+, fresh noise per layer, "
                                    "HIP modulated-conv + upfirdn2d kernels (BASELINE.json configs[1])",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"replica x{world}",
-                       "weights": "synthetic closed-form (oracle/synth.py)"},
-            "mfma_fraction_whole_forward": round(value * GFLOP_PER_IMAGE / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4),
+                       "weights": "synthetic closed-form (oracle/synth.py)", "conv_precision": precision},
+            "algorithmic_tflops_whole_forward": round(value * GFLOP_PER_IMAGE / 1e3 / world, 2),
         }
         if gather_note:
             out["config"]["gather"] = gather_note
@@ -258,14 +289,23 @@ def main():
             dom = max(agg, key=lambda k: agg[k][1])
             d = agg[dom]
             ach = d[0] / d[1] / 1e12
+            if dom.startswith("conv_mfma_h"):
+                terms = 3 if precision == "f16x3" else 1
+                peak = PEAK_F16_MFMA_TFLOPS / terms
+                peak_note = (f"fp16 dense MFMA peak {PEAK_F16_MFMA_TFLOPS} TFLOP/s / {terms} MFMA per product; "
+                             f"MFMA FLOPs issued = {terms} x algorithmic = {round(ach * terms, 1)} TFLOP/s")
+            else:
+                peak, peak_note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA peak"
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
-                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                               "peak": round(peak, 1), "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom),
                                "avg_launch_ms": round(d[1] / d[2] * 1e3, 4), "launches": d[2],
-                               "flops_per_launch_avg": d[0] / d[2]}
+                               "flops_per_launch_avg": d[0] / d[2], "peak_note": peak_note}
             out["kernels"] = fams
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
+        if exact_f32 is not None:
+            out["exact_f32"] = exact_f32
         if swap_info is not None:
             out["swap_schedule"] = swap_info
         print(json.dumps(out), flush=True)
