@@ -47,6 +47,7 @@ SIGNATURES = {
     "hf_add_bcast_f32": [_f, _f, _f, _ll, _ll, _st],
     "hf_debug_set_dispatch": [_i, _i],
     "hf_debug_last_path": [],
+    "hf_debug_set_persistent_blocks": [_i],
 }
 
 

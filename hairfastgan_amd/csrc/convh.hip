@@ -31,14 +31,7 @@
 
 using namespace hf_detail;
 
-#ifndef HF_H_VARIANT
-#define HF_H_VARIANT 0
-#endif
-#if HF_H_VARIANT & 1
-#define HF_H_BARRIER() __syncthreads()
-#else
 #define HF_H_BARRIER() hf_barrier_keep_young<0>()
-#endif
 
 namespace {
 
@@ -80,7 +73,6 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
 
   HF_DYN_LDS;
   half8 *lds = reinterpret_cast<half8 *>(hf_dyn_lds);               // [2][BUF_UNITS] 16-byte units
-  float *sl = reinterpret_cast<float *>(lds + 2 * BUF_UNITS);       // s[cin]
   // buffer layout (units): [W hi][W lo][X hi][X lo]
   constexpr int OFF_WL = W_UNITS, OFF_XH = NPART * W_UNITS, OFF_XL = NPART * W_UNITS + X_UNITS;
 
@@ -93,42 +85,76 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
   const int wave_pg = (wave % WAVES_PX) * PG;
   const int co0 = blockIdx.y * CT;
 
-  int gi = 0;  // tile family (uniform): interior, or the rim row / column of the transposed conv
-  if (P.n_geom > 1 && (int)blockIdx.x >= P.g[1].first_block) gi = 1;
-  if (P.n_geom > 2 && (int)blockIdx.x >= P.g[2].first_block) gi = 2;
-  const TileGeom G = P.g[gi];
-  int t = blockIdx.x - G.first_block;
-  const int tx = t % G.tiles_x;
-  t /= G.tiles_x;
-  const int ty = t % G.tiles_y;
-  const int b0 = t / G.tiles_y;  // one image per tile
-  const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
-  const int wp = tw + HALO, xs = (th + HALO) * wp;  // halo tile, first pixel (ty0-1, tx0-1)
-  const int ty0 = G.y0 + ty * th, tx0 = G.x0 + tx * tw;
   const long long plane = (long long)P.h * P.w;
-  const float *xb = P.x + (long long)b0 * P.cin * plane;
+  const int iplane = (int)plane;
+  const int nchunks = P.cin / KH;
+  float *sl_base = reinterpret_cast<float *>(lds + 2 * BUF_UNITS);  // [2][cin]: s of the current / next image
 
-  if (MOD)
-    for (int i = tid; i < P.cin; i += NT) sl[i] = P.s[(long long)b0 * P.s_bstride + i];
-
-  // staging items of this thread: (pixel, kgroup) -> plane offset (-1: zero) and LDS unit
-  int e_src[XE], e_kg[XE];
+  // ---- tiles: the block walks tiles blockIdx.x, +gridDim.x, ... of its cout tile as ONE
+  // pipeline - the first stage of the next tile is prefetched during the last stage of the
+  // current one and the epilogue stores drain under the next tile's first stage ----
+  struct Tile {
+    int gi, b0, ty0, tx0;
+  };
+  // constant indices only: a runtime index into the by-value kernel argument would make the
+  // compiler copy the whole struct to scratch memory
+  const TileGeom G0 = P.g[0], G1 = P.g[1], G2 = P.g[2];
+  auto geom = [&](int gi) {
+    TileGeom G;
+#define HF_PICK(f) G.f = gi == 0 ? G0.f : (gi == 1 ? G1.f : G2.f)
+    HF_PICK(y0); HF_PICK(x0); HF_PICK(dh); HF_PICK(dw); HF_PICK(lg_tw); HF_PICK(lg_th); HF_PICK(lg_nb);
+    HF_PICK(tiles_x); HF_PICK(tiles_y); HF_PICK(tiles_b); HF_PICK(first_block);
+#undef HF_PICK
+    return G;
+  };
+  auto locate = [&](int t) {  // flat tile index -> family, image, first pixel
+    Tile T;
+    T.gi = 0;
+    if (P.n_geom > 1 && t >= G1.first_block) T.gi = 1;
+    if (P.n_geom > 2 && t >= G2.first_block) T.gi = 2;
+    const TileGeom G = geom(T.gi);
+    int r = t - G.first_block;
+    const int tx = r % G.tiles_x;
+    r /= G.tiles_x;
+    const int ty = r % G.tiles_y;
+    T.b0 = r / G.tiles_y;  // one image per tile
+    T.ty0 = G.y0 + (ty << G.lg_th);
+    T.tx0 = G.x0 + (tx << G.lg_tw);
+    return T;
+  };
+  // staging items of this thread: (halo pixel, kgroup) -> offset inside a channel plane
+  // (-1: outside the image, zero fill; -2: no item); the halo tile starts at (ty0-1, tx0-1)
+  constexpr int NSRC = XE;
+  auto locate_items = [&](const Tile &T, int (&src)[NSRC]) {
+    const TileGeom G = geom(T.gi);
+    const int wp = (1 << G.lg_tw) + HALO, xs = ((1 << G.lg_th) + HALO) * wp;
 #pragma unroll
-  for (int e = 0; e < XE; ++e) {
-    const int i = tid + e * NT;
-    e_src[e] = -2;  // -2: no item, -1: item outside the image (zero fill)
-    e_kg[e] = 0;
-    const int kg = i / NPIX, pix = i - kg * NPIX;
-    if (i < X_UNITS && pix < xs) {
-      const int hy = pix / wp, hx = pix - hy * wp;
-      const int ys = ty0 + hy - 1, xc = tx0 + hx - 1;
-      e_kg[e] = kg;
-      e_src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? (int)((long long)ys * P.w + xc) : -1;
+    for (int e = 0; e < XE; ++e) {
+      const int i = tid + e * NT;
+      const int kg = i / NPIX, pix = i - kg * NPIX;
+      src[e] = -2;
+      if (i < X_UNITS && pix < xs) {
+        const int hy = pix / wp, hx = pix - hy * wp;
+        const int ys = T.ty0 + hy - 1, xc = T.tx0 + hx - 1;
+        src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
+      }
     }
-  }
+  };
+  auto load_s = [&](int b, float *dst) {
+    if (MOD)
+      for (int i = tid; i < P.cin; i += NT) dst[i] = P.s[(long long)b * P.s_bstride + i];
+  };
+
+  // prefetch source (tile whose stage is being staged): items, image base, s
+  int e_src[XE];
+  const float *xb;
+  int sl_off;  // offset of the prefetch source's s inside sl_base (an index, not a pointer: LDS
+               // pointers that get selected at run time turn into generic pointers + aperture checks)
+  int sl_slot = 0;
 
   // weight stage of `chunk`: uniform base + per-lane byte offset ((tap*2+kg)*cout + co0 + col)*16
-  auto dma_piece = [&](int i, int chunk, half8 *buf) {
+  const unsigned lds_addr0 = hf_lds_addr(lds);
+  auto dma_piece = [&](int i, int chunk, int bufsel) {
     const int pc = wave + i * NW;
     if (pc < N_WPIECE) {
       const int part = pc / (W_UNITS / 64), q = pc % (W_UNITS / 64);
@@ -137,35 +163,30 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
       int off = (row * P.cout + co0 + col) * 16;
       HF_OPAQUE_I32(off);
       const _Float16 *src = (part ? wtl : wth) + (long long)chunk * 18 * P.cout * 8;
-#if HF_H_VARIANT & 1
-      hf_glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + off),
-                reinterpret_cast<float *>(buf + part * W_UNITS + q * 64));
-#else
-      hf_glds16_raw_s(src, (unsigned)off, reinterpret_cast<float *>(buf + part * W_UNITS + q * 64));
-#endif
+      hf_glds16_raw_s(src, (unsigned)off, lds_addr0 + (unsigned)(bufsel * BUF_UNITS + part * W_UNITS + q * 64) * 16u);
     }
   };
 
-  float xr[1][XE][8];  // raw activations of the next stage, in flight for one whole chunk
+  float xr[XE][8];  // raw activations of the next stage, in flight for most of a chunk
   // uniform chunk base + per-lane offset; halo items outside the image load element 0 of the
   // chunk instead (unconditional loads: no branches in the pipeline) and are zeroed at conversion
-  const int iplane = (int)plane;
-  auto load_item = [&](int set, int e, int chunk) {
+  auto load_item = [&](int e, int chunk) {
     const char *xc = reinterpret_cast<const char *>(xb + (long long)chunk * KH * plane);  // uniform
-    int off = (e_src[e] >= 0) ? e_kg[e] * 8 * iplane + e_src[e] : 0;
+    const int kg = (tid + e * NT) / NPIX;
+    int off = (e_src[e] >= 0) ? kg * 8 * iplane + e_src[e] : 0;
     HF_OPAQUE_I32(off);  // addresses recomputed per chunk, not kept live as 8 hoisted 64-bit pairs
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      xr[set][e][k] = *reinterpret_cast<const float *>(xc + (unsigned)((off + k * iplane) * 4));
+    for (int k = 0; k < 8; ++k) xr[e][k] = *reinterpret_cast<const float *>(xc + (unsigned)((off + k * iplane) * 4));
   };
-  auto convert_item = [&](int set, int e, int chunk, half8 *buf) {
+  auto convert_item = [&](int e, int chunk, half8 *buf) {
     if (e_src[e] == -2) return;
     const int i = tid + e * NT;
+    const int kg = i / NPIX;
     half8 hi, lo;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float v = (e_src[e] >= 0) ? xr[set][e][k] : 0.0f;
-      if (MOD) v *= sl[chunk * KH + e_kg[e] * 8 + k];
+      float v = (e_src[e] >= 0) ? xr[e][k] : 0.0f;
+      if (MOD) v *= sl_base[sl_off + chunk * KH + kg * 8 + k];
       // hi and lo must both derive from the fp32-ROUNDED product: left alone, hipcc stores
       // hi = fp16(fp32(x*s)) but subtracts v_fma_mixlo_f16's fp16(x*s unrounded); at an fp16
       // rounding tie of the fp32 product the two differ by one fp16 ulp (seen on hardware).
@@ -178,110 +199,157 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
     if (NTERMS == 3) buf[OFF_XL + i] = lo;
   };
 
-  // halo-tile unit of the lane's pixel of group g, per tap row (ky*wp; UP: rows 1 and 0)
-  constexpr int NROW = UP ? 2 : 3;
-  int pixrow[PG][NROW];
-#pragma unroll
-  for (int g = 0; g < PG; ++g) {
-    const int p = (wave_pg + g) * 32 + li;
-    const int po = ((p >> G.lg_tw) & (th - 1)) * wp + (p & (tw - 1));
-#pragma unroll
-    for (int r = 0; r < NROW; ++r) pixrow[g][r] = po + r * wp;
-  }
-
   f32x16 acc[NPH][CT_TILES][PG];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int ph = 0; ph < NPH; ++ph)
-#pragma unroll
-    for (int ct = 0; ct < CT_TILES; ++ct)
-#pragma unroll
-      for (int g = 0; g < PG; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ph][ct][g][r] = 0.0f;
-
-  const int nchunks = P.cin / KH;
-  __syncthreads();  // sl visible
-  // prologue: stage 0 resident, activations of stage 1 in flight
-#pragma unroll
-  for (int i = 0; i < ND; ++i) dma_piece(i, 0, lds);
-#pragma unroll
-  for (int e = 0; e < XE; ++e) load_item(0, e, 0);
-#pragma unroll
-  for (int e = 0; e < XE; ++e) convert_item(0, e, 0, lds);
-  HF_H_BARRIER();
-
-  // one chunk = 9 tap-steps; side work spread over the steps: step 0 issues the activation
-  // loads of chunk c+1 into registers, steps 0-2 its weight DMAs, the last steps convert the
-  // activations (6+ steps of MFMA time after their loads) into the other buffer
-  for (int c = 0; c < nchunks; ++c) {
-    const int cur = c & 1;
-    half8 *buf = lds + cur * BUF_UNITS, *nbuf = lds + (cur ^ 1) * BUF_UNITS;
-    const bool more1 = c + 1 < nchunks;
-    const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT + ct*32
-    const half8 *b_hi = buf + OFF_XH + lh * NPIX;      // + pixoff + toff
-    // fragments of tap+1 are fetched from LDS while the MFMAs of tap run
-    constexpr int NSLOT = UP ? 1 : 2;  // UP: 128 accumulator registers leave no room for a second set
-    half8 ah[NSLOT][CT_TILES], al[NSLOT][CT_TILES], bh[NSLOT][PG], bl[NSLOT][PG];
-    auto fetch = [&](int slot, int tap) {
-      const int ky = tap / 3, kx = tap % 3;
-      const int brow = UP ? (ky == 2 ? 0 : 1) : ky, bcol = UP ? (kx == 2 ? 0 : 1) : kx;
-#pragma unroll
-      for (int ct = 0; ct < CT_TILES; ++ct) {
-        ah[slot][ct] = a_hi[tap * 2 * CT + ct * 32];
-        if (NTERMS == 3) al[slot][ct] = a_hi[OFF_WL + tap * 2 * CT + ct * 32];
-      }
-#pragma unroll
-      for (int g = 0; g < PG; ++g) {
-        bh[slot][g] = b_hi[pixrow[g][brow] + bcol];
-        if (NTERMS == 3) bl[slot][g] = b_hi[X_UNITS + pixrow[g][brow] + bcol];
-      }
-    };
-    fetch(0, 0);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int sl_ = UP ? 0 : (tap & 1);
-      if (UP) {
-        if (tap > 0) fetch(0, tap);
-      } else if (tap + 1 < 9) {
-        fetch(sl_ ^ 1, tap + 1);
-      }
-      // ---- side work of this step ----
-      if (more1) {
-#pragma unroll
-        for (int i = 0; i < ND; ++i)
-          if (i / DMA_PER_STEP == tap) dma_piece(i, c + 1, nbuf);
-      }
-      if (more1 && tap == 0) {
-#pragma unroll
-        for (int e = 0; e < XE; ++e) load_item(0, e, c + 1);
-      }
-      if (more1 && tap >= 9 - XE) convert_item(0, tap - (9 - XE), c + 1, nbuf);
-      __builtin_amdgcn_sched_barrier(0);
-      const int ph = UP ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) : 0;
+    for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
       for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
         for (int g = 0; g < PG; ++g)
-          acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl_][ct], bh[sl_][g], acc[ph][ct][g], 0, 0, 0);
-      if (NTERMS == 3) {
 #pragma unroll
-        for (int ct = 0; ct < CT_TILES; ++ct)
-#pragma unroll
-          for (int g = 0; g < PG; ++g)
-            acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl_][ct], bl[sl_][g], acc[ph][ct][g], 0, 0, 0);
-#pragma unroll
-        for (int ct = 0; ct < CT_TILES; ++ct)
-#pragma unroll
-          for (int g = 0; g < PG; ++g)
-            acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl_][ct], bh[sl_][g], acc[ph][ct][g], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // next stage complete (DMA landed, conversions written), current one free
-    HF_H_BARRIER();
-  }
+          for (int r = 0; r < 16; ++r) acc[ph][ct][g][r] = 0.0f;
+  };
+  zero_acc();
 
-  store_tile<CT_TILES, PG, UP>(P, G, GroupOfs{0, 0, 0, 0, 0}, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+  int t_cur = blockIdx.x;
+  Tile cur = locate(t_cur);
+  locate_items(cur, e_src);
+  xb = P.x + (long long)cur.b0 * P.cin * plane;
+  sl_off = 0;
+  load_s(cur.b0, sl_base);
+  __syncthreads();  // s visible
+  // prologue: stage 0 of the first tile
+#pragma unroll
+  for (int i = 0; i < ND; ++i) dma_piece(i, 0, 0);
+#pragma unroll
+  for (int e = 0; e < XE; ++e) load_item(e, 0);
+#pragma unroll
+  for (int e = 0; e < XE; ++e) convert_item(e, 0, lds);
+  HF_H_BARRIER();
+
+  int stage = 0;  // LDS buffer = stage & 1, running across tiles
+  while (true) {
+    const TileGeom G = geom(cur.gi);
+    const int tw = 1 << G.lg_tw, th = 1 << G.lg_th, wp = tw + HALO;
+    // halo-tile unit of the lane's pixel of group g, per tap row (ky*wp; UP: rows 1 and 0)
+    constexpr int NROW = UP ? 2 : 3;
+    int pixrow[PG][NROW];
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+      const int p = (wave_pg + g) * 32 + li;
+      const int po = ((p >> G.lg_tw) & (th - 1)) * wp + (p & (tw - 1));
+#pragma unroll
+      for (int r = 0; r < NROW; ++r) pixrow[g][r] = po + r * wp;
+    }
+    // the block's next tile, and its image's s into the other slot (read only after
+    // the barriers of this tile's first nchunks-1 stages; nchunks >= 2)
+    const int t_next = t_cur + gridDim.x;
+    const bool has_next = t_next < P.n_tiles;
+    Tile nxt = cur;
+    int nxt_sl_off = sl_off;
+    if (has_next) {
+      nxt = locate(t_next);
+      if (nxt.b0 != cur.b0) {
+        sl_slot ^= 1;
+        nxt_sl_off = sl_slot * P.cin;
+        load_s(nxt.b0, sl_base + nxt_sl_off);
+      }
+    }
+
+    // one chunk = 9 tap-steps; side work spread over the steps: step 0 issues the activation
+    // loads of the next stage into registers, steps 0-2 its weight DMAs, the last steps convert
+    // the activations (6+ steps of MFMA time after their loads) into the other buffer
+    for (int c = 0; c < nchunks; ++c, ++stage) {
+      const int cb = stage & 1;
+      half8 *buf = lds + cb * BUF_UNITS, *nbuf = lds + (cb ^ 1) * BUF_UNITS;
+      const bool last = c + 1 == nchunks;
+      const bool more1 = !last || has_next;
+      const int cpf = last ? 0 : c + 1;  // chunk being staged (of this tile, or chunk 0 of the next)
+      if (last && has_next) {  // switch the prefetch source to the next tile
+        locate_items(nxt, e_src);
+        xb = P.x + (long long)nxt.b0 * P.cin * plane;
+        sl_off = nxt_sl_off;
+      }
+      const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT + ct*32
+      const half8 *b_hi = buf + OFF_XH + lh * NPIX;      // + pixrow + tap column
+      // fragments of tap+1 are fetched from LDS while the MFMAs of tap run
+      constexpr int NSLOT = UP ? 1 : 2;  // UP: 128 accumulator registers leave no room for a second set
+      half8 ah[NSLOT][CT_TILES], al[NSLOT][CT_TILES], bh[NSLOT][PG], bl[NSLOT][PG];
+      auto fetch = [&](int slot, int tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const int brow = UP ? (ky == 2 ? 0 : 1) : ky, bcol = UP ? (kx == 2 ? 0 : 1) : kx;
+#pragma unroll
+        for (int ct = 0; ct < CT_TILES; ++ct) {
+          ah[slot][ct] = a_hi[tap * 2 * CT + ct * 32];
+          if (NTERMS == 3) al[slot][ct] = a_hi[OFF_WL + tap * 2 * CT + ct * 32];
+        }
+#pragma unroll
+        for (int g = 0; g < PG; ++g) {
+          bh[slot][g] = b_hi[pixrow[g][brow] + bcol];
+          if (NTERMS == 3) bl[slot][g] = b_hi[X_UNITS + pixrow[g][brow] + bcol];
+        }
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int sl_ = UP ? 0 : (tap & 1);
+        if (UP) {
+          if (tap > 0) fetch(0, tap);
+        } else if (tap + 1 < 9) {
+          fetch(sl_ ^ 1, tap + 1);
+        }
+        // ---- side work of this step ----
+        if (more1) {
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+            if (i / DMA_PER_STEP == tap) dma_piece(i, cpf, cb ^ 1);
+        }
+        if (more1 && tap == 0) {
+#pragma unroll
+          for (int e = 0; e < XE; ++e) load_item(e, cpf);
+        }
+        if (more1 && tap >= 9 - XE) convert_item(tap - (9 - XE), cpf, nbuf);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ph = UP ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) : 0;
+#pragma unroll
+        for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+          for (int g = 0; g < PG; ++g)
+            acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl_][ct], bh[sl_][g], acc[ph][ct][g], 0, 0, 0);
+        if (NTERMS == 3) {
+#pragma unroll
+          for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+            for (int g = 0; g < PG; ++g)
+              acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl_][ct], bl[sl_][g], acc[ph][ct][g], 0, 0, 0);
+#pragma unroll
+          for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+            for (int g = 0; g < PG; ++g)
+              acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl_][ct], bh[sl_][g], acc[ph][ct][g], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // next stage complete (DMA landed, conversions written), current one free
+      HF_H_BARRIER();
+    }
+
+    {
+      // opaque per tile: otherwise the epilogue's per-register channel offsets (64-bit, one per
+      // accumulator register) are hoisted out of the tile loop and live - spilled - through it
+      int co_w = co0 + wave_co, li_o = li, lh_o = lh;
+      HF_OPAQUE_I32(co_w);
+      HF_OPAQUE_I32(li_o);
+      HF_OPAQUE_I32(lh_o);
+      store_tile<CT_TILES, PG, UP>(P, G, GroupOfs{0, 0, 0, 0, 0}, acc, co_w, wave_pg, li_o, lh_o, cur.ty0, cur.tx0,
+                                   cur.b0);
+    }
+    if (!has_next) break;
+    zero_acc();
+    cur = nxt;
+    t_cur = t_next;
+  }
 }
 
 // fp32 prepared weights wt[tap][ci][co] -> hi / lo halves in [chunk16][tap][kg][co][8]
@@ -326,9 +394,16 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
     if (P.g[i].lg_nb != 0 || (1 << (P.g[i].lg_tw + P.g[i].lg_th)) != PT) return HF_E_INVALID;
     if (geom_xs(P.g[i], 1, UP ? 1 : 2) > NPIX) return HF_E_INVALID;
   }
-  const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + (P.s ? P.cin * sizeof(float) : 0);
+  const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + (P.s ? 2 * P.cin * sizeof(float) : 0);
   if (lds > 160 * 1024) return HF_E_INVALID;
-  dim3 grid(nblocks, P.cout / CT);
+  P.n_tiles = nblocks;
+  // LDS allows one block per CU: size the grid to the chip and let each block walk its share
+  // of the tiles as one pipeline (the tile-to-tile hand-over needs >= 2 stages per tile)
+  const int co_tiles = P.cout / CT;
+  int resident = (g_h_blocks > 0 ? g_h_blocks : 256) / co_tiles;
+  if (resident < 1) resident = 1;
+  const int gx = (P.cin / KH >= 2 && nblocks > resident) ? resident : nblocks;
+  dim3 grid(gx, co_tiles);
   if (grid.y > 65535) return HF_E_INVALID;
   if (P.s)
     hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, true, UP>), grid, dim3(NT), lds, st, P, wth,
@@ -344,6 +419,7 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
 namespace hf_detail {
 
 int g_force_h = 0;
+int g_h_blocks = 0;
 
 int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const void *wtl, hipStream_t st) {
   const _Float16 *h = static_cast<const _Float16 *>(wth), *l = static_cast<const _Float16 *>(wtl);
@@ -420,4 +496,9 @@ extern "C" int hf_modconv3x3_up_f16_f32(float *tmp, const float *x, const void *
   P.out_wv = 2 * w + 1;
   P.stride = 1;
   return launch_conv_h(P, nterms, true, wt_hi, wt_lo, (hipStream_t)stream);
+}
+
+extern "C" int hf_debug_set_persistent_blocks(int blocks) {
+  hf_detail::g_h_blocks = blocks;
+  return HF_OK;
 }

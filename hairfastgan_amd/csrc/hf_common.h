@@ -42,11 +42,16 @@ __device__ __forceinline__ void hf_glds16_raw(const float *gsrc_lane, float *lds
       (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)lds_wave_base);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(gsrc_lane) : "memory");
 }
-// wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: one VGPR of address
+// LDS byte address of a pointer into the dynamic LDS region (what M0 takes)
+__device__ __forceinline__ unsigned hf_lds_addr(const void *lds_ptr) {
+  return (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const void *)lds_ptr;
+}
+// wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: one VGPR of address.
+// The LDS destination is an integer byte address (hf_lds_addr of the region base + offset):
+// LDS *pointers* selected at run time degrade to generic pointers with aperture checks.
 __device__ __forceinline__ void hf_glds16_raw_s(const void *gsrc_uniform, unsigned lane_byte_offset,
-                                                float *lds_wave_base) {
-  const unsigned base = __builtin_amdgcn_readfirstlane(
-      (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)lds_wave_base);
+                                                unsigned lds_wave_addr) {
+  const unsigned base = __builtin_amdgcn_readfirstlane(lds_wave_addr);
   // readfirstlane: the pointer is wave-uniform by contract, but the compiler may hold it in
   // VGPRs (e.g. selected by a wave index) - an "s" operand needs a provably scalar value
   const unsigned long long g = (unsigned long long)gsrc_uniform;

@@ -254,6 +254,10 @@ int hf_debug_set_dispatch(int same_cfg, int up_cfg);
  * hf_modconv3x3_up_f16_f32: ids 61/63).  Tests use
  * it to make sure a shape exercises the path it is meant to; bench.py to label launches. */
 int hf_debug_last_path(void);
+/* The fp16 matrix-core kernels launch one resident block per CU and let it walk several tiles
+ * as one software pipeline; `blocks` overrides the resident-block count the grid is sized for
+ * (0 = the MI355X's 256 CUs).  Tests use small values to exercise the tile hand-over. */
+int hf_debug_set_persistent_blocks(int blocks);
 
 #ifdef __cplusplus
 }

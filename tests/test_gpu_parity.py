@@ -356,3 +356,43 @@ def test_modconv_up_f16_matrix_cores(nterms, tol, shape):
         full = O.fused_leaky_relu(O.modulated_conv2d(x.cpu(), sty.cpu(), wgt.cpu(), mw.cpu(), mb.cpu(), True, True)
                                   + nw.cpu() * nz.cpu(), bias.cpu())
         assert float((y.cpu() - full).abs().max()) < (1e-5 if nterms == 3 else tol) * scale
+
+
+@pytest.mark.parametrize("up", [False, True])
+@pytest.mark.parametrize("blocks", [0, 7, 64])
+def test_modconv_f16_persistent_tile_walk(up, blocks):
+    """Resident blocks walking many tiles (csrc/convh.hip): same result for any block count,
+    equal to the exact-fp32 MFMA path; B=3 crosses images, the transposed conv crosses families."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib as _lib_fn, stream
+
+    B, cin, cout, H, W = (3, 64, 64, 64, 96)
+    torch.manual_seed(5)
+    dev = _dev()
+    lib = _lib_fn()
+    st = stream()
+    x = torch.randn(B, cin, H, W, device=dev)
+    wgt = torch.randn(1, cout, cin, 3, 3, device=dev)
+    mw, mb, sty = torch.randn(cin, 16, device=dev), torch.randn(cin, device=dev), torch.randn(B, 16, device=dev)
+    oh, ow = (2 * H, 2 * W) if up else (H, W)
+    nz, nw, bias = torch.randn(B, 1, oh, ow, device=dev), torch.tensor([0.3], device=dev), torch.randn(cout, device=dev)
+    wt, wsq = M.prepare_weights(lib, st, wgt)
+    s = M.modulation(lib, st, sty, mw, mb)
+    dm = M.demod(lib, st, s, wsq)
+    hi, lo = M.split_weights_f16(lib, st, wt)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0).to(dev)
+    if up:
+        ref = M.modconv3x3_up(lib, st, x, wt, s, dm, k4, nz, nw, bias)
+    else:
+        ref = M.modconv3x3(lib, st, x, wt, s, dm, nz, nw, bias)
+    try:
+        lib.hf_debug_set_persistent_blocks(blocks)
+        for _ in range(2):  # twice: stale LDS / workspace state from the first launch must not matter
+            if up:
+                y = M.modconv3x3_up(lib, st, x, wt, s, dm, k4, nz, nw, bias, f16=(hi, lo, 3))
+            else:
+                y = M.modconv3x3_f16(lib, st, x, hi, lo, 3, s, dm, nz, nw, bias)
+            torch.cuda.synchronize()
+            assert float((y - ref).abs().max()) < 5e-6 * max(1.0, float(ref.abs().max()))
+    finally:
+        lib.hf_debug_set_persistent_blocks(0)

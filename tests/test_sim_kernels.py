@@ -228,3 +228,33 @@ def test_modconv_up_f16_matrix_cores(simlib, nterms, tol, cfg, shape):
     if nterms == 3:
         full = O.fused_leaky_relu(O.modulated_conv2d(x, sty, wgt, mw, mb, True, True) + nw * nz, bias)
         assert maxdiff(y, full) < TOL * max(1.0, float(full.abs().max()))
+
+
+@pytest.mark.parametrize("up", [False, True])
+@pytest.mark.parametrize("blocks", [1, 3, 5])
+def test_modconv_f16_persistent_tile_walk(simlib, up, blocks):
+    """One resident block walks several tiles as one pipeline (csrc/convh.hip): tile-to-tile
+    hand-over across rows, images (the second s slot) and - transposed conv - rim families,
+    with a block count that does not divide the tile count."""
+    B, cin, cout, H, W = (3, 32, 64, 16, 32) if not up else (2, 32, 64, 16, 32)
+    torch.manual_seed(5)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+    oh, ow = (2 * H, 2 * W) if up else (H, W)
+    nz, nw, bias = torch.randn(B, 1, oh, ow), torch.tensor([0.3]), torch.randn(cout)
+    wt, wsq = M.prepare_weights(simlib, None, wgt)
+    s = M.modulation(simlib, None, sty, mw, mb)
+    dm = M.demod(simlib, None, s, wsq)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0)
+    try:
+        simlib.hf_debug_set_persistent_blocks(blocks)
+        if up:
+            y = M.modconv3x3_up(simlib, None, x, wt, s, dm, k4, nz, nw, bias, f16=(hi, lo, 3))
+        else:
+            y = M.modconv3x3_f16(simlib, None, x, hi, lo, 3, s, dm, nz, nw, bias)
+    finally:
+        simlib.hf_debug_set_persistent_blocks(0)
+    full = O.fused_leaky_relu(O.modulated_conv2d(x, sty, wgt, mw, mb, True, up) + nw * nz, bias)
+    assert maxdiff(y, full) < TOL * max(1.0, float(full.abs().max()))
