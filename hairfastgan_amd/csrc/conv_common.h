@@ -3,6 +3,14 @@
 #pragma once
 #include "hf_common.h"
 
+#ifndef HF_STORE_OUT
+#ifdef HF_NT_STORES
+#define HF_STORE_OUT(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define HF_STORE_OUT(p, v) (*(p) = (v))
+#endif
+#endif
+
 namespace hf_detail {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -153,7 +161,7 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
             v = apply_act(v + nz + bsv[r], P.act, P.alpha, P.scale, slv[r]);
             if (P.residual) v += P.residual[go.o + obofs + pofs];
           }
-          ob[pofs] = v;
+          HF_STORE_OUT(&ob[pofs], v);
         }
       }
     }
@@ -171,7 +179,7 @@ inline int pow2_ceil(int v) { return (v & (v - 1)) ? (pow2_floor(v) << 1) : v; }
 // Tiles of `pt` pixels over a dh x dw OUTPUT domain (per image) of `batch` images.
 // Prefers full 32-pixel rows; small planes put several images in one tile.
 inline TileGeom make_geom(int y0, int x0, int dh, int dw, int batch, int pt, int first_block,
-                          bool one_image = false) {
+                          bool one_image = false, int rim = 2) {
   TileGeom g;
   g.y0 = y0; g.x0 = x0; g.dh = dh; g.dw = dw;
   int tw = pow2_ceil(dw);
@@ -181,8 +189,8 @@ inline TileGeom make_geom(int y0, int x0, int dh, int dw, int batch, int pt, int
   if (th > pt / tw) th = pt / tw;
   if (one_image) {  // rim families of the pipelined kernel: stretch the tile instead of batching
     // images; two rows (columns) so that the halo tile stays within the staging budget
-    if (dh == 1) { th = 2; tw = pt / 2; }
-    else { tw = 2; th = pt / 2; }
+    if (dh == 1) { th = rim; tw = pt / rim; }
+    else { tw = rim; th = pt / rim; }
   }
   int nb = pt / (tw * th);
   if (nb > pow2_ceil(batch)) nb = pow2_ceil(batch);  // never stage images that do not exist

@@ -32,26 +32,50 @@
 using namespace hf_detail;
 
 #define HF_H_BARRIER() hf_barrier_keep_young<0>()
+#ifndef HF_H_ABLATE
+#define HF_H_ABLATE 0  // timing experiments only: 1 no activation loads, 2 no epilogue stores, 4 no weight DMA
+#endif
+
+#ifdef HF_H_TRACE
+// kernel-development build only: wave-level timeline of block 0 (s_memtime at pipeline points)
+__device__ unsigned long long hf_trace_buf[8 * 512];
+#define HF_TRACE_POINT(id)                                                                    \
+  do {                                                                                         \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && trace_n < 510) {                    \
+      hf_trace_buf[wave * 512 + trace_n++] = ((unsigned long long)(id) << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffULL); \
+    }                                                                                          \
+  } while (0)
+extern "C" int hf_debug_read_trace(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hf_trace_buf), sizeof(unsigned long long) * n);
+}
+#else
+#define HF_TRACE_POINT(id) ((void)0)
+#endif
 
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KH = 16;  // input channels per stage = K of one MFMA
 
-// Halo pixels the LDS activation tile is sized for: PT-pixel tiles of 32-pixel rows, and (UP)
-// the 2-row / 2-column rim tiles of make_geom(one_image).
-template <int PT, bool UP>
+// Halo pixels the LDS activation tile is sized for: PT-pixel tiles of 32..TWMAX-pixel rows, and
+// (UP) the 2-row / 2-column rim tiles of make_geom(one_image).  Wide tiles (TWMAX 128) turn the
+// 128-byte row segments of a 32-pixel-wide tile into 512-byte ones: the high-resolution layers
+// are HBM-bound and DRAM row locality decides their bandwidth.
+template <int PT, bool UP, int TWMAX>
 constexpr int halo_pixels_max() {
-  constexpr int main_tile = (PT / 32 + (UP ? 1 : 2)) * (32 + (UP ? 1 : 2));
-  constexpr int rim_tile = 3 * (PT / 2 + 1);
+  constexpr int h = UP ? 1 : 2;
+  constexpr int narrow = (PT / 32 + h) * (32 + h), wide = (PT / TWMAX + h) * (TWMAX + h);
+  constexpr int main_tile = wide > narrow ? wide : narrow;
+  constexpr int rim = PT >= 512 ? 4 : 2;  // rows (columns) of a rim tile: keeps its halo below the main tile's
+  constexpr int rim_tile = (rim + 1) * (PT / rim + 1);
   return (UP && rim_tile > main_tile) ? rim_tile : main_tile;
 }
 
 // UP: the transposed (stride 2) conv of the upsampling StyledConv, as in modconv.hip: 4 output
 // phases (pr,pc) = (ky&1, kx&1) per input position (Y,X) of the (h+1)x(w+1) phase domain, each
 // tap feeding exactly one phase from x[Y - (ky==2), X - (kx==2)]; no zero-insertion flops.
-template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool MOD, bool UP>
-__global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const ConvParams P,
+template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool MOD, bool UP, int TWMAX>
+__global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const ConvParams P,
                                                                           const _Float16 *__restrict__ wth,
                                                                           const _Float16 *__restrict__ wtl) {
   constexpr int NW = WAVES_CO * WAVES_PX;
@@ -60,7 +84,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
   constexpr int PT = 32 * PG * WAVES_PX;  // pixels (UP: phase-domain positions) per tile
   constexpr int NPH = UP ? 4 : 1;
   constexpr int HALO = UP ? 1 : 2;
-  constexpr int NPIX = halo_pixels_max<PT, UP>();
+  constexpr int NPIX = halo_pixels_max<PT, UP, TWMAX>();
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;          // hi (+ lo)
   constexpr int W_UNITS = 9 * 2 * CT;                   // 16-byte units of one weight part per stage
   constexpr int X_UNITS = 2 * NPIX;                     // 16-byte units of one activation part per stage
@@ -89,6 +113,11 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
   const int iplane = (int)plane;
   const int nchunks = P.cin / KH;
   float *sl_base = reinterpret_cast<float *>(lds + 2 * BUF_UNITS);  // [2][cin]: s of the current / next image
+  // epilogue parameters of the block's CT output channels, per image slot: [2][2][CT] = d, bias.
+  // In LDS so that the epilogue issues NO vector-memory loads: on gfx9 loads and stores share
+  // vmcnt, every load that follows a store waits for that store's acknowledgement (measured:
+  // the epilogue's second pixel group waited ~12k cycles behind the first group's stores).
+  float *ep_base = sl_base + 2 * ((P.cin + 3) & ~3);
 
   // ---- tiles: the block walks tiles blockIdx.x, +gridDim.x, ... of its cout tile as ONE
   // pipeline - the first stage of the next tile is prefetched during the last stage of the
@@ -140,9 +169,15 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
       }
     }
   };
-  auto load_s = [&](int b, float *dst) {
+  auto load_s = [&](int b, int slot) {
+    float *dst = sl_base + slot * P.cin;
     if (MOD)
       for (int i = tid; i < P.cin; i += NT) dst[i] = P.s[(long long)b * P.s_bstride + i];
+    float *ep = ep_base + slot * 2 * CT;
+    for (int i = tid; i < CT; i += NT) {
+      ep[i] = P.d ? P.d[(long long)b * P.d_bstride + co0 + i] : 1.0f;
+      ep[CT + i] = P.bias ? P.bias[co0 + i] : 0.0f;
+    }
   };
 
   // prefetch source (tile whose stage is being staged): items, image base, s
@@ -156,7 +191,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
   const unsigned lds_addr0 = hf_lds_addr(lds);
   auto dma_piece = [&](int i, int chunk, int bufsel) {
     const int pc = wave + i * NW;
-    if (pc < N_WPIECE) {
+    if (pc < N_WPIECE && !(HF_H_ABLATE & 4)) {
       const int part = pc / (W_UNITS / 64), q = pc % (W_UNITS / 64);
       const int u = q * 64 + lane;            // unit inside the part: (tap*2 + kg)*CT + co
       const int row = u / CT, col = u % CT;   // row = tap*2 + kg
@@ -176,7 +211,8 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
     int off = (e_src[e] >= 0) ? kg * 8 * iplane + e_src[e] : 0;
     HF_OPAQUE_I32(off);  // addresses recomputed per chunk, not kept live as 8 hoisted 64-bit pairs
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xr[e][k] = *reinterpret_cast<const float *>(xc + (unsigned)((off + k * iplane) * 4));
+    for (int k = 0; k < 8; ++k)
+      xr[e][k] = (HF_H_ABLATE & 1) ? 1.0f : *reinterpret_cast<const float *>(xc + (unsigned)((off + k * iplane) * 4));
   };
   auto convert_item = [&](int e, int chunk, half8 *buf) {
     if (e_src[e] == -2) return;
@@ -212,12 +248,17 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
   };
   zero_acc();
 
+#ifdef HF_H_STAGGER
+  // break the chip-wide lockstep (every CU loading, then computing, then storing at once)
+  for (int i = 0; i < (int)(blockIdx.x & 7); ++i) __builtin_amdgcn_s_sleep(HF_H_STAGGER);
+#endif
   int t_cur = blockIdx.x;
   Tile cur = locate(t_cur);
   locate_items(cur, e_src);
   xb = P.x + (long long)cur.b0 * P.cin * plane;
   sl_off = 0;
-  load_s(cur.b0, sl_base);
+  load_s(cur.b0, 0);
+  int ep_slot = 0;  // slot of the tile being computed (its epilogue)
   __syncthreads();  // s visible
   // prologue: stage 0 of the first tile
 #pragma unroll
@@ -228,8 +269,72 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
   for (int e = 0; e < XE; ++e) convert_item(e, 0, lds);
   HF_H_BARRIER();
 
+  // Epilogue of one tile.  MFMA D layout: row (= co) = (r&3) + 8*(r>>2) + 4*lh, col (= pixel) = li:
+  // the lane's 4 channels of register group q = r>>2 are consecutive -> one ds_read_b128 each of
+  // d and bias.  Same-res: v = lrelu(acc*d + noise_w*noise + bias)*scale (bias NULL: v = acc*d);
+  // UP: v = acc*d of the 4 phases into the (2h+1) x pitch intermediate, phases (pr,0),(pr,1) as
+  // one 8-byte store.  Nothing but stores goes to vector memory here.
+  const float nw_ = (!UP && P.noise) ? P.noise_w[0] : 0.0f;
+  auto epilogue = [&](const TileGeom &G, const Tile &T, int slot, const float (&nz)[PG]) {
+    // opaque per tile: otherwise the per-register channel offsets (64-bit, one per accumulator
+    // register) are hoisted out of the tile loop and live - spilled - through it
+    int co_w = wave_co, li_o = li, lh_o = lh;
+    HF_OPAQUE_I32(co_w);
+    HF_OPAQUE_I32(li_o);
+    HF_OPAQUE_I32(lh_o);
+    const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
+    const long long oplane = (long long)P.out_h * P.out_w;
+    const float *ep = ep_base + slot * 2 * CT;
+    float *ob0 = P.out + ((long long)T.b0 * P.cout + co0) * oplane;
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+      const int p = (wave_pg + g) * 32 + li_o;
+      const int Y = T.ty0 + ((p >> G.lg_tw) & (th - 1)), X = T.tx0 + (p & (tw - 1));
+      if (!((Y < G.y0 + G.dh) && (X < G.x0 + G.dw))) continue;
+      const float nzv = nw_ * nz[g];
+#pragma unroll
+      for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c4 = co_w + ct * 32 + 8 * q + 4 * lh_o;  // first of the lane's 4 channels (tile-relative)
+          const float4 dm = *reinterpret_cast<const float4 *>(ep + c4);
+          const float4 bs = *reinterpret_cast<const float4 *>(ep + CT + c4);
+          const float dmv[4] = {dm.x, dm.y, dm.z, dm.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = 4 * q + k;
+            float *ob = ob0 + (long long)(c4 + k) * oplane;
+            if (UP) {
+#pragma unroll
+              for (int pr = 0; pr < 2; ++pr) {
+                const int ro = 2 * Y + pr, cc = 2 * X;
+                if (ro >= P.out_h) continue;
+                float *qo = ob + (long long)ro * P.out_w + cc;
+                const float v0 = acc[2 * pr][ct][g][r] * dmv[k], v1 = acc[(UP ? 2 * pr + 1 : 0)][ct][g][r] * dmv[k];
+                if (cc + 1 < P.out_wv) {
+                  f32x2u pair;
+                  pair.x = v0;
+                  pair.y = v1;
+                  *reinterpret_cast<f32x2u *>(qo) = pair;
+                } else {
+                  qo[0] = v0;
+                }
+              }
+            } else {
+              float v = acc[0][ct][g][r] * dmv[k];
+              if (P.bias) v = apply_act(v + nzv + bsv[k], P.act, P.alpha, P.scale, 0.0f);
+              ob[(long long)Y * P.out_w + X] = v;
+            }
+          }
+        }
+    }
+  };
+
   int stage = 0;  // LDS buffer = stage & 1, running across tiles
+  int trace_n = 0;
+  (void)trace_n;
   while (true) {
+    HF_TRACE_POINT(1);  // tile start
     const TileGeom G = geom(cur.gi);
     const int tw = 1 << G.lg_tw, th = 1 << G.lg_th, wp = tw + HALO;
     // halo-tile unit of the lane's pixel of group g, per tap row (ky*wp; UP: rows 1 and 0)
@@ -242,6 +347,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
 #pragma unroll
       for (int r = 0; r < NROW; ++r) pixrow[g][r] = po + r * wp;
     }
+    float nzr[PG];
+#pragma unroll
+    for (int g = 0; g < PG; ++g) nzr[g] = 0.0f;
     // the block's next tile, and its image's s into the other slot (read only after
     // the barriers of this tile's first nchunks-1 stages; nchunks >= 2)
     const int t_next = t_cur + gridDim.x;
@@ -253,7 +361,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
       if (nxt.b0 != cur.b0) {
         sl_slot ^= 1;
         nxt_sl_off = sl_slot * P.cin;
-        load_s(nxt.b0, sl_base + nxt_sl_off);
+        load_s(nxt.b0, sl_slot);
       }
     }
 
@@ -270,6 +378,14 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
         locate_items(nxt, e_src);
         xb = P.x + (long long)nxt.b0 * P.cin * plane;
         sl_off = nxt_sl_off;
+      }
+      if (last && !UP && P.noise) {  // this tile's noise, in registers before the epilogue (no loads there)
+#pragma unroll
+        for (int g = 0; g < PG; ++g) {
+          const int p = (wave_pg + g) * 32 + li;
+          const int Y = min(cur.ty0 + ((p >> G.lg_tw) & (th - 1)), P.h - 1), X = min(cur.tx0 + (p & (tw - 1)), P.w - 1);
+          nzr[g] = P.noise[(long long)cur.b0 * P.noise_bstride + (long long)Y * P.out_w + X];
+        }
       }
       const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT + ct*32
       const half8 *b_hi = buf + OFF_XH + lh * NPIX;      // + pixrow + tap column
@@ -309,7 +425,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
 #pragma unroll
           for (int e = 0; e < XE; ++e) load_item(e, cpf);
         }
-        if (more1 && tap >= 9 - XE) convert_item(tap - (9 - XE), cpf, nbuf);
+        if (more1 && tap == 9 - XE) HF_TRACE_POINT(5);  // before the first conversion (waits for the loads)
+      if (more1 && tap >= 9 - XE) convert_item(tap - (9 - XE), cpf, nbuf);
+      if (more1 && tap == 8) HF_TRACE_POINT(6);  // conversions done
         __builtin_amdgcn_sched_barrier(0);
         const int ph = UP ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) : 0;
 #pragma unroll
@@ -331,22 +449,17 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_h(const Co
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      HF_TRACE_POINT(2);  // chunk MFMAs issued, before the barrier
       // next stage complete (DMA landed, conversions written), current one free
       HF_H_BARRIER();
+      HF_TRACE_POINT(3);  // after the barrier
     }
 
-    {
-      // opaque per tile: otherwise the epilogue's per-register channel offsets (64-bit, one per
-      // accumulator register) are hoisted out of the tile loop and live - spilled - through it
-      int co_w = co0 + wave_co, li_o = li, lh_o = lh;
-      HF_OPAQUE_I32(co_w);
-      HF_OPAQUE_I32(li_o);
-      HF_OPAQUE_I32(lh_o);
-      store_tile<CT_TILES, PG, UP>(P, G, GroupOfs{0, 0, 0, 0, 0}, acc, co_w, wave_pg, li_o, lh_o, cur.ty0, cur.tx0,
-                                   cur.b0);
-    }
+    epilogue(G, cur, ep_slot, nzr);
+    HF_TRACE_POINT(4);  // epilogue issued
     if (!has_next) break;
     zero_acc();
+    if (nxt.b0 != cur.b0) ep_slot ^= 1;
     cur = nxt;
     t_cur = t_next;
   }
@@ -369,24 +482,33 @@ __global__ __launch_bounds__(256) void split_weights(_Float16 *__restrict__ wth,
   }
 }
 
-template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP>
+template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int TWMAX = 32>
 int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_t st) {
   constexpr int NT = 64 * WAVES_CO * WAVES_PX;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
   constexpr int PT = 32 * PG * WAVES_PX;
-  constexpr int NPIX = halo_pixels_max<PT, UP>();
+  constexpr int NPIX = halo_pixels_max<PT, UP, TWMAX>();
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;
-  if (P.cin % KH || P.cout % CT || P.stride != 1 || P.t || P.groups > 1) return HF_E_INVALID;
+  if (P.cin % KH || P.cout % CT || P.stride != 1 || P.t || P.groups > 1 || P.residual || P.act == ACT_PRELU)
+    return HF_E_INVALID;
   if ((long long)P.cin * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
   P.splits = 1;
   P.n_geom = 1;
   P.g[0] = make_geom(0, 0, P.h, P.w, P.batch, PT, 0);
+  if (TWMAX > 32 && P.w >= 64 && P.g[0].lg_nb == 0) {  // wider tiles: longer contiguous row segments
+    const int tw = min(TWMAX, pow2_floor(P.w)), th = PT / tw;
+    if (th >= 1 && P.h >= th) {
+      P.g[0].lg_tw = ilog2(tw); P.g[0].lg_th = ilog2(th);
+      P.g[0].tiles_x = hf_cdiv(P.w, tw); P.g[0].tiles_y = hf_cdiv(P.h, th);
+    }
+  }
   int nblocks = geom_blocks(P.g[0]);
   if (UP) {  // + the Y = h row (incl. corner) and the X = w column of the (h+1)x(w+1) phase domain
     P.n_geom = 3;
-    P.g[1] = make_geom(P.h, 0, 1, P.w + 1, P.batch, PT, nblocks, true);
+    constexpr int RIM = PT >= 512 ? 4 : 2;
+    P.g[1] = make_geom(P.h, 0, 1, P.w + 1, P.batch, PT, nblocks, true, RIM);
     nblocks += geom_blocks(P.g[1]);
-    P.g[2] = make_geom(0, P.w, P.h, 1, P.batch, PT, nblocks, true);
+    P.g[2] = make_geom(0, P.w, P.h, 1, P.batch, PT, nblocks, true, RIM);
     nblocks += geom_blocks(P.g[2]);
   }
   for (int i = 0; i < P.n_geom; ++i) {
@@ -394,22 +516,24 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
     if (P.g[i].lg_nb != 0 || (1 << (P.g[i].lg_tw + P.g[i].lg_th)) != PT) return HF_E_INVALID;
     if (geom_xs(P.g[i], 1, UP ? 1 : 2) > NPIX) return HF_E_INVALID;
   }
-  const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + (P.s ? 2 * P.cin * sizeof(float) : 0);
+  const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float) +
+                     2 * 2 * CT * sizeof(float);  // stages + s[2][cin] + epilogue d/bias [2][2][CT]
   if (lds > 160 * 1024) return HF_E_INVALID;
   P.n_tiles = nblocks;
   // LDS allows one block per CU: size the grid to the chip and let each block walk its share
   // of the tiles as one pipeline (the tile-to-tile hand-over needs >= 2 stages per tile)
   const int co_tiles = P.cout / CT;
-  int resident = (g_h_blocks > 0 ? g_h_blocks : 256) / co_tiles;
+  const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
+  int resident = (g_h_blocks > 0 ? g_h_blocks : 256 * per_cu) / co_tiles;
   if (resident < 1) resident = 1;
   const int gx = (P.cin / KH >= 2 && nblocks > resident) ? resident : nblocks;
   dim3 grid(gx, co_tiles);
   if (grid.y > 65535) return HF_E_INVALID;
   if (P.s)
-    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, true, UP>), grid, dim3(NT), lds, st, P, wth,
+    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, true, UP, TWMAX>), grid, dim3(NT), lds, st, P, wth,
                        wtl);
   else
-    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, false, UP>), grid, dim3(NT), lds, st, P, wth,
+    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, false, UP, TWMAX>), grid, dim3(NT), lds, st, P, wth,
                        wtl);
   return hf_launch_status();
 }
@@ -438,13 +562,19 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
   // 52: 64 co x 512 px (16 rows), 8 pixel-waves, 2x2 MFMA tiles per wave: 0.67 LDS fragment
   //     reads per MFMA instead of 2 (fewer issue slots beside the MFMAs), needs >= 256 such blocks
   // 53: 32 co x 512 px (16 rows), 8 pixel-waves, 1x2 tiles: layers with cout % 64 != 0 (1024^2: 32)
+  // 54: 32 co x 256 px, 4 pixel-waves (256 threads), 80 KB of LDS: TWO resident blocks per CU, so
+  //     one block's barrier drains (activation loads, epilogue stores) hide under the other's
+  //     MFMAs - the HBM-bound high-resolution layers (few chunks per tile)
   cfg = g_force_h;
   if (cfg == 0) {
     const long long blocks52 = (long long)P.batch * hf_cdiv(P.h, 16) * hf_cdiv(P.w, 32) * (P.cout / 64);
     if (P.cout % 64) cfg = 53;
     else cfg = (P.h * P.w >= 512 && blocks52 >= 256) ? 52 : 51;
   }
-  if (cfg == 53) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false>(P, h, l, st);
+  if (cfg == 55) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 128>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 128>(P, h, l, st);
+  else if (cfg == 56) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 64>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 64>(P, h, l, st);
+  else if (cfg == 54) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 4, false>(P, h, l, st) : launch_h<1, 1, 2, 1, 4, false>(P, h, l, st);
+  else if (cfg == 53) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false>(P, h, l, st);
   else if (cfg == 52) rc = (nterms == 3) ? launch_h<3, 2, 2, 1, 8, false>(P, h, l, st) : launch_h<1, 2, 2, 1, 8, false>(P, h, l, st);
   else rc = (nterms == 3) ? launch_h<3, 1, 2, 2, 4, false>(P, h, l, st) : launch_h<1, 1, 2, 2, 4, false>(P, h, l, st);
   if (rc == HF_OK) note_path(5, cfg);

@@ -30,7 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--same", default="0,351,352,151,152")
+    ap.add_argument("--same", default="0,300,354")
     ap.add_argument("--up", default="0,300,100")
     ap.add_argument("--only", default="", help="restrict to e.g. 'same:64,up:128' (kind:input resolution)")
     ap.add_argument("--no-streaming", action="store_true")
