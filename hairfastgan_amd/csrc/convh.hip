@@ -283,15 +283,18 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     HF_OPAQUE_I32(li_o);
     HF_OPAQUE_I32(lh_o);
     const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
-    const long long oplane = (long long)P.out_h * P.out_w;
     const float *ep = ep_base + slot * 2 * CT;
-    float *ob0 = P.out + ((long long)T.b0 * P.cout + co0) * oplane;
+    // uniform base of the block's CT output planes of this image + 32-bit per-lane byte offsets
+    // (the launcher checks CT * plane bytes < 4 GiB): one add per store instead of 64-bit math
+    const unsigned oplane4 = (unsigned)(P.out_h * P.out_w) * 4u;
+    char *ob0 = reinterpret_cast<char *>(P.out + ((long long)T.b0 * P.cout + co0) * ((long long)P.out_h * P.out_w));
 #pragma unroll
     for (int g = 0; g < PG; ++g) {
       const int p = (wave_pg + g) * 32 + li_o;
       const int Y = T.ty0 + ((p >> G.lg_tw) & (th - 1)), X = T.tx0 + (p & (tw - 1));
       if (!((Y < G.y0 + G.dh) && (X < G.x0 + G.dw))) continue;
       const float nzv = nw_ * nz[g];
+      const unsigned pix4 = UP ? (unsigned)(2 * Y * P.out_w + 2 * X) * 4u : (unsigned)(Y * P.out_w + X) * 4u;
 #pragma unroll
       for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
@@ -300,18 +303,17 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
           const float4 dm = *reinterpret_cast<const float4 *>(ep + c4);
           const float4 bs = *reinterpret_cast<const float4 *>(ep + CT + c4);
           const float dmv[4] = {dm.x, dm.y, dm.z, dm.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+          unsigned off = (unsigned)c4 * oplane4 + pix4;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < 4; ++k, off += oplane4) {
             const int r = 4 * q + k;
-            float *ob = ob0 + (long long)(c4 + k) * oplane;
             if (UP) {
 #pragma unroll
               for (int pr = 0; pr < 2; ++pr) {
-                const int ro = 2 * Y + pr, cc = 2 * X;
-                if (ro >= P.out_h) continue;
-                float *qo = ob + (long long)ro * P.out_w + cc;
+                if (2 * Y + pr >= P.out_h) continue;
+                float *qo = reinterpret_cast<float *>(ob0 + (off + (unsigned)(pr * P.out_w) * 4u));
                 const float v0 = acc[2 * pr][ct][g][r] * dmv[k], v1 = acc[(UP ? 2 * pr + 1 : 0)][ct][g][r] * dmv[k];
-                if (cc + 1 < P.out_wv) {
+                if (2 * X + 1 < P.out_wv) {
                   f32x2u pair;
                   pair.x = v0;
                   pair.y = v1;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
             } else {
               float v = acc[0][ct][g][r] * dmv[k];
               if (P.bias) v = apply_act(v + nzv + bsv[k], P.act, P.alpha, P.scale, 0.0f);
-              ob[(long long)Y * P.out_w + X] = v;
+              *reinterpret_cast<float *>(ob0 + off) = v;
             }
           }
         }
@@ -425,9 +427,11 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
 #pragma unroll
           for (int e = 0; e < XE; ++e) load_item(e, cpf);
         }
+        // (staggering the conversions over the two waves of a SIMD - early half in taps 3-5 - was
+        // measured 5-15 % slower: the early half then waits on its loads)
         if (more1 && tap == 9 - XE) HF_TRACE_POINT(5);  // before the first conversion (waits for the loads)
-      if (more1 && tap >= 9 - XE) convert_item(tap - (9 - XE), cpf, nbuf);
-      if (more1 && tap == 8) HF_TRACE_POINT(6);  // conversions done
+        if (more1 && tap >= 9 - XE) convert_item(tap - (9 - XE), cpf, nbuf);
+        if (more1 && tap == 8) HF_TRACE_POINT(6);  // conversions done
         __builtin_amdgcn_sched_barrier(0);
         const int ph = UP ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) : 0;
 #pragma unroll
@@ -492,6 +496,7 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
   if (P.cin % KH || P.cout % CT || P.stride != 1 || P.t || P.groups > 1 || P.residual || P.act == ACT_PRELU)
     return HF_E_INVALID;
   if ((long long)P.cin * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
+  if ((long long)CT * P.out_h * P.out_w * 4 >= (1LL << 32)) return HF_E_INVALID;  // 32-bit epilogue offsets
   P.splits = 1;
   P.n_geom = 1;
   P.g[0] = make_geom(0, 0, P.h, P.w, P.batch, PT, 0);
@@ -562,13 +567,15 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
   // 52: 64 co x 512 px (16 rows), 8 pixel-waves, 2x2 MFMA tiles per wave: 0.67 LDS fragment
   //     reads per MFMA instead of 2 (fewer issue slots beside the MFMAs), needs >= 256 such blocks
   // 53: 32 co x 512 px (16 rows), 8 pixel-waves, 1x2 tiles: layers with cout % 64 != 0 (1024^2: 32)
+  // 55/56: 53 with tiles of 128 / 64-pixel rows (4 / 8 rows): longer contiguous row segments for the
+  //     HBM-bound 1024^2 layer (+9 % measured)
   // 54: 32 co x 256 px, 4 pixel-waves (256 threads), 80 KB of LDS: TWO resident blocks per CU, so
   //     one block's barrier drains (activation loads, epilogue stores) hide under the other's
   //     MFMAs - the HBM-bound high-resolution layers (few chunks per tile)
   cfg = g_force_h;
   if (cfg == 0) {
     const long long blocks52 = (long long)P.batch * hf_cdiv(P.h, 16) * hf_cdiv(P.w, 32) * (P.cout / 64);
-    if (P.cout % 64) cfg = 53;
+    if (P.cout % 64) cfg = (P.w >= 128) ? 55 : 53;
     else cfg = (P.h * P.w >= 512 && blocks52 >= 256) ? 52 : 51;
   }
   if (cfg == 55) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 128>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 128>(P, h, l, st);

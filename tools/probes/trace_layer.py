@@ -5,14 +5,17 @@ from hairfastgan_amd import _marshal as M
 from hairfastgan_amd._runtime import lib, stream
 cin, cout, r = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+up = len(sys.argv) > 5 and sys.argv[5] == 'up'
 L = lib(); st = stream(); dev = torch.device("cuda:0")
 x = torch.randn(B, cin, r, r, device=dev)
 wt, wsq = M.prepare_weights(L, st, torch.randn(1, cout, cin, 3, 3, device=dev))
 hi, lo = M.split_weights_f16(L, st, wt)
 s = torch.rand(B, cin, device=dev) + 0.5; d = torch.rand(B, cout, device=dev) + 0.5
-nz = torch.randn(1, 1, r, r, device=dev); nw = torch.tensor([0.1], device=dev); bias = torch.randn(cout, device=dev)
+oh = 2 * r if up else r
+nz = torch.randn(1, 1, oh, oh, device=dev)
+k4 = torch.tensor([1., 3., 3., 1.], device=dev); k4 = k4[None] * k4[:, None] / 16; nw = torch.tensor([0.1], device=dev); bias = torch.randn(cout, device=dev)
 for _ in range(2):
-    y = M.modconv3x3_f16(L, st, x, hi, lo, 3, s, d, nz, nw, bias)
+    y = M.modconv3x3_up(L, st, x, wt, s, d, k4, nz, nw, bias, f16=(hi, lo, 3)) if up else M.modconv3x3_f16(L, st, x, hi, lo, 3, s, d, nz, nw, bias)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (8 * 512))()
 L.hf_debug_read_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
