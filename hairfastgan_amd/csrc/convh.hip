@@ -361,6 +361,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     if (has_next) {
       nxt = locate(t_next);
       if (nxt.b0 != cur.b0) {
+        // the slot about to be overwritten held the image before this one: another wave may still
+        // be in that tile's epilogue (reading its d / bias) when images change on every tile
+        hf_barrier_lds();
         sl_slot ^= 1;
         nxt_sl_off = sl_slot * P.cin;
         load_s(nxt.b0, sl_slot);

@@ -61,6 +61,8 @@ __device__ __forceinline__ void hf_glds16_raw_s(const void *gsrc_uniform, unsign
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(base), "v"(lane_byte_offset), "s"(gs)
                : "memory");
 }
+// workgroup barrier that only orders LDS traffic (vector-memory operations stay in flight)
+__device__ __forceinline__ void hf_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int NYOUNG>
 __device__ __forceinline__ void hf_barrier_keep_young() {
   static_assert(NYOUNG >= 0 && NYOUNG < 64, "vmcnt is a 6-bit counter");

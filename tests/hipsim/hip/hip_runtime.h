@@ -80,6 +80,7 @@ inline void hf_glds4_if(bool a, const float *g, float *l) { ::hipsim::glds_maske
 #define HF_OPAQUE_I32(v) ((void)0)
 #define HF_BARRIER_KEEP_DEFINED
 template <int NYOUNG> inline void hf_barrier_keep_young() { ::hipsim::syncthreads(); }
+inline void hf_barrier_lds() { ::hipsim::syncthreads(); }
 inline void hf_glds16_raw(const float *gsrc_lane, float *lds_wave_base) { ::hipsim::glds16(gsrc_lane, lds_wave_base); }
 inline unsigned hf_lds_addr(const void *p) { return (unsigned)(static_cast<const unsigned char *>(p) - ::hipsim::dyn_lds()); }
 inline void hf_glds16_raw_s(const void *g, unsigned off, unsigned lds_addr) {

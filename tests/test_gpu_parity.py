@@ -359,14 +359,15 @@ def test_modconv_up_f16_matrix_cores(nterms, tol, shape):
 
 
 @pytest.mark.parametrize("up", [False, True])
-@pytest.mark.parametrize("blocks", [0, 7, 64])
-def test_modconv_f16_persistent_tile_walk(up, blocks):
+@pytest.mark.parametrize("blocks,shape", [(0, (3, 64, 64, 64, 96)), (7, (3, 64, 64, 64, 96)), (64, (3, 64, 64, 64, 96)),
+                                          (4, (9, 32, 64, 16, 32))])  # last: a new image on every tile step
+def test_modconv_f16_persistent_tile_walk(up, blocks, shape):
     """Resident blocks walking many tiles (csrc/convh.hip): same result for any block count,
     equal to the exact-fp32 MFMA path; B=3 crosses images, the transposed conv crosses families."""
     from hairfastgan_amd import _marshal as M
     from hairfastgan_amd._runtime import lib as _lib_fn, stream
 
-    B, cin, cout, H, W = (3, 64, 64, 64, 96)
+    B, cin, cout, H, W = shape
     torch.manual_seed(5)
     dev = _dev()
     lib = _lib_fn()
@@ -387,12 +388,15 @@ def test_modconv_f16_persistent_tile_walk(up, blocks):
         ref = M.modconv3x3(lib, st, x, wt, s, dm, nz, nw, bias)
     try:
         lib.hf_debug_set_persistent_blocks(blocks)
-        for _ in range(2):  # twice: stale LDS / workspace state from the first launch must not matter
+        first = None
+        for _ in range(4):  # repeated: bit-identical results (no LDS slot races between waves)
             if up:
                 y = M.modconv3x3_up(lib, st, x, wt, s, dm, k4, nz, nw, bias, f16=(hi, lo, 3))
             else:
                 y = M.modconv3x3_f16(lib, st, x, hi, lo, 3, s, dm, nz, nw, bias)
             torch.cuda.synchronize()
             assert float((y - ref).abs().max()) < 5e-6 * max(1.0, float(ref.abs().max()))
+            first = y.clone() if first is None else first
+            assert torch.equal(y, first)
     finally:
         lib.hf_debug_set_persistent_blocks(0)
