@@ -98,6 +98,15 @@ def pmc_traffic(kernel):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             k = json.load(f)["kernels"].get(kernel)
         return None if k is None else round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def pmc_mfma_busy(kernel):
+    """MFMA-busy fraction of `kernel` at the clock it actually ran at (same committed PMC passes), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["kernels"].get(kernel, {}).get("mfma_busy")
     except (OSError, ValueError, KeyError):
         return None
 
@@ -146,6 +155,7 @@ def main():
     ap.add_argument("--precision", choices=("f16x3", "f32", "f16"), default=None,
                     help="matrix-core mode of the 3x3 convs (default: HAIRFAST_CONV_PRECISION or f16x3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-f32", action="store_true", help="skip the fp32-MFMA comparison run (profiling)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--swap-triples", type=int, default=4,
                     help="triples per GPU for the secondary hair-swap hot-path schedule measurement (0 = skip)")
@@ -218,7 +228,7 @@ def main():
 
     # comparison run (outside the timed region): every conv on the exact-fp32 MFMA
     exact_f32 = None
-    if precision != "f32" and world == 1:
+    if precision != "f32" and world == 1 and not args.no_exact_f32:
         prev = _runtime.set_conv_precision("f32")
         for _ in range(2):
             step()
@@ -300,7 +310,8 @@ def main():
                                "peak": round(peak, 1), "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom),
                                "avg_launch_ms": round(d[1] / d[2] * 1e3, 4), "launches": d[2],
-                               "flops_per_launch_avg": d[0] / d[2], "peak_note": peak_note}
+                               "flops_per_launch_avg": d[0] / d[2], "peak_note": peak_note,
+                               "mfma_busy_pmc": pmc_mfma_busy(dom)}
             out["kernels"] = fams
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)

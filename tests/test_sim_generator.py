@@ -92,3 +92,33 @@ def test_modules_standalone(sim_backend):
     conv.weight.data.mul_(2.0)
     ref = O.modulated_conv2d(x, w, conv.weight, conv.modulation.weight, conv.modulation.bias)
     assert float((conv(x, w) - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("mode,tol", [("f16x3", 2e-5), ("f32", 2e-5), ("f16", 5e-3)])
+def test_styled_conv_precision_modes(sim_backend, simlib, mode, tol):
+    """StyledConv through the module API in each matrix-core mode (_runtime.set_conv_precision):
+    same-resolution and upsampling layers at a shape the fp16 kernels take, asserting which
+    kernel family ran (hf_debug_last_path: 5xx = csrc/convh.hip)."""
+    from hairfastgan_amd import _runtime
+
+    m = sim_backend
+    torch.manual_seed(4)
+    x = torch.randn(1, 32, 16, 32)
+    w = torch.randn(1, 24)
+    prev = _runtime.set_conv_precision(mode)
+    try:
+        for up in (False, True):
+            sc = m.StyledConv(32, 64, 3, 24, upsample=up).eval()
+            sc.noise.weight.data.fill_(0.3)
+            sc.activate.bias.data.normal_()
+            oh, ow = (32, 64) if up else (16, 32)
+            nz = torch.randn(1, 1, oh, ow)
+            with torch.inference_mode():
+                y = sc(x, w, noise=nz)
+            fam = simlib.hf_debug_last_path() // 100
+            assert (fam == 5) == (mode != "f32"), (mode, up, simlib.hf_debug_last_path())
+            P = {f"L.{k}": v.detach() for k, v in sc.state_dict().items()}
+            ref = O.styled_conv(P, "L", x, w, nz, up)
+            assert float((y - ref).abs().max()) < tol * max(1.0, float(ref.abs().max())), (mode, up)
+    finally:
+        _runtime.set_conv_precision(prev)

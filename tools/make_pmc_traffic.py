@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from whole-bench rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and
+optionally SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE), averaged per launch and keyed by the
+kernel labels bench.py uses.  usage: make_pmc_traffic.py <fetch_dir> <write_dir> [<mfma_dir>]"""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+
+def label(name):
+    m = re.search(r"conv_mfma_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d+)E", name)
+    if m:
+        nt, ct, pg, wc, wp, mod, up, tw = (int(v) for v in m.groups())
+        return f"conv_mfma_h<{ct},{pg},{wc},{wp}{',up' if up else ''}{',tw%d' % tw if tw > 32 else ''}>"
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    m = re.match(r"(conv_mfma\w*)<(.*)>", name)
+    if not m:
+        return name
+    fam, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
+    if fam == "conv_mfma_dma":
+        return f"conv_mfma_dma<{','.join(args[:4])}>"
+    if fam == "conv_mfma_pipe":
+        tag = ",up" if args[4] == "true" else (",stride2" if len(args) > 6 and args[6] == "2" else "")
+        return f"conv_mfma_pipe<{','.join(args[:4])}{tag}>"
+    return f"{fam}<{','.join(args)}>"
+
+
+def agg(d, counter):
+    acc = collections.defaultdict(lambda: [0.0, set()])
+    for r in csv.DictReader(open(os.path.join(d, "bench_counter_collection.csv"))):
+        if r["Counter_Name"] == counter:
+            a = acc[label(r["Kernel_Name"])]
+            a[0] += float(r["Counter_Value"])
+            a[1].add(r["Dispatch_Id"])
+    return acc
+
+
+def main():
+    f, w = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
+    busy = gui = None
+    if len(sys.argv) > 3:
+        busy, gui = agg(sys.argv[3], "SQ_VALU_MFMA_BUSY_CYCLES"), agg(sys.argv[3], "GRBM_GUI_ACTIVE")
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE (separate passes), "
+                     "python bench.py --steps 1 --warmup 1 --no-exact-f32; KiB*1024; FETCH_SIZE not doubled (uncalibrated for "
+                     "dword halo loads, MI355X_MICROARCH.md HBM section); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
+                     "(GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs), i.e. relative to the clock the kernel actually ran at",
+           "kernels": {}}
+    for k in f:
+        n = max(1, len(f[k][1]))
+        if f[k][0] / n < 1000 and not k.startswith("conv_mfma"):
+            continue
+        e = {"fetch_bytes_per_launch": f[k][0] / n * 1024, "write_bytes_per_launch": w[k][0] / max(1, len(w[k][1])) * 1024,
+             "launches": n}
+        if busy and gui and gui[k][0] > 0:
+            e["mfma_busy"] = round(busy[k][0] / (gui[k][0] / 8 * 1024), 4)
+        out["kernels"][k] = e
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

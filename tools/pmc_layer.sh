@@ -1,17 +1,18 @@
 #!/bin/bash
 # PMC passes over one conv layer (tools/probes/one_layer.py); run on the GPU box from the repo root:
 #   tools/pmc_layer.sh <tag> <cin> <cout> <res> [batch] [up]
-# Counters go in separate runs (slots per block are limited); outputs under gpurun_out/pmc_<tag>/.
+# Counters go in separate runs (slots per block are limited), each under its own timeout (a
+# TA_*_sum pass once hung for the whole gpurun limit); outputs under gpurun_out/pmc_<tag>/.
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/pmc_$tag
 cd /tmp && export TMPDIR=/tmp
 i=0
-for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
-           "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_ACTIVE_INST_ANY" \
-           "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum GRBM_GUI_ACTIVE" \
-           "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
-           "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"; do
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY" \
+           "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "FETCH_SIZE" \
+           "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag/p$i -o l -- python $R/tools/probes/one_layer.py "$@" > $R/gpurun_out/pmc_$tag/p$i.log 2>&1
+  timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag/p$i -o l -- python $R/tools/probes/one_layer.py "$@" > $R/gpurun_out/pmc_$tag/p$i.log 2>&1
+  echo "pass $i rc=$?"
 done
-ls $R/gpurun_out/pmc_$tag
