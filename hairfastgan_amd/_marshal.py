@@ -185,15 +185,32 @@ def modconv3x3_f16_supported(cin, cout, h, w):
     return cin % 16 == 0 and w >= 32 and (h >= 8 if cout % 64 == 0 else (cout % 32 == 0 and h >= 16))
 
 
-def modconv3x3_f16(lib, st, x, wt_hi, wt_lo, nterms, s, d, noise, noise_w, bias, alpha=0.2, scale=SQRT2):
+def torgb_fusable(cin, cout, h, w):
+    """Layers whose ToRGB hf_modconv3x3_f16_rgb_f32 computes in the conv epilogue."""
+    return cout in (32, 64) and modconv3x3_f16_supported(cin, cout, h, w) and h * w >= 512
+
+
+def modconv3x3_f16(lib, st, x, wt_hi, wt_lo, nterms, s, d, noise, noise_w, bias, alpha=0.2, scale=SQRT2, rgb=None):
     """hf_modconv3x3_f32 on the fp16 matrix cores (nterms 3: split operands, fp32-class
-    accuracy; nterms 1: fp16 operands); fp32 tensors and accumulation."""
+    accuracy; nterms 1: fp16 operands); fp32 tensors and accumulation.
+    rgb = (rgb_wt [1,cout,3], rgb_s [B,cout]): also returns ToRGB's raw 1x1 modulated conv of the
+    output, computed in the epilogue (hf_modconv3x3_f16_rgb_f32)."""
     x = _c(x)
     b, cin, h, w = x.shape
     cout = wt_hi.shape[3]
     noise, nbs = _noise_args(noise, b, h * w)
     out = x.new_empty((b, cout, h, w))
     noise_w, bias = _c(noise_w), _c(bias)
+    if rgb is not None:
+        rgb_wt, rgb_s = _c(rgb[0]), _c(rgb[1])
+        raw = x.new_empty((b, 3, h, w))
+        code = _launch_profiled(
+            lib, 2.0 * cin * cout * 9 * h * w * b,
+            lambda: lib.hf_modconv3x3_f16_rgb_f32(_p(out), _p(x), _p(wt_hi), _p(wt_lo), nterms, _p(s), _p(d), _p(noise),
+                                                  _p(noise_w), nbs, _p(bias), b, cin, cout, h, w, alpha, scale,
+                                                  _p(raw), _p(rgb_wt), _p(rgb_s), st))
+        check(lib, code, "hf_modconv3x3_f16_rgb_f32")
+        return out, raw
     code = _launch_profiled(
         lib, 2.0 * cin * cout * 9 * h * w * b,
         lambda: lib.hf_modconv3x3_f16_f32(_p(out), _p(x), _p(wt_hi), _p(wt_lo), nterms, _p(s), _p(d), _p(noise),

@@ -60,6 +60,10 @@ struct ConvParams {
   int splits;                  // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps); 1 = off
   int chunks_per_split;
   float *partial;              // splits > 1: raw accumulators go to partial[z][b][co][oh][ow]
+  // convh.hip, fused ToRGB: raw 1x1 modulated conv of the epilogue's output values,
+  // rgb_out[b][c][Y][X] = sum_co rgb_w[co*3+c] * rgb_s[b*cout+co] * y[b][co][Y][X]  (null = off)
+  const float *rgb_w, *rgb_s;
+  float *rgb_out;
   int n_tiles;                 // convh.hip: tiles over all families; a block walks blockIdx.x + k*gridDim.x
   TileGeom g[3];
 };

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   // vmcnt, every load that follows a store waits for that store's acknowledgement (measured:
   // the epilogue's second pixel group waited ~12k cycles behind the first group's stores).
   float *ep_base = sl_base + 2 * ((P.cin + 3) & ~3);
+  float *rgbw_base = ep_base + 2 * 2 * CT;  // fused ToRGB: [2 slots][3][CT] = rgb_w[co][c] * rgb_s[b][co]
 
   // ---- tiles: the block walks tiles blockIdx.x, +gridDim.x, ... of its cout tile as ONE
   // pipeline - the first stage of the next tile is prefetched during the last stage of the
@@ -177,6 +178,14 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     for (int i = tid; i < CT; i += NT) {
       ep[i] = P.d ? P.d[(long long)b * P.d_bstride + co0 + i] : 1.0f;
       ep[CT + i] = P.bias ? P.bias[co0 + i] : 0.0f;
+    }
+    if (!UP && P.rgb_out) {
+      float *rw = rgbw_base + slot * 3 * CT;
+      for (int i = tid; i < CT; i += NT) {
+        const float sv = P.rgb_s[(long long)b * P.cout + co0 + i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rw[c * CT + i] = P.rgb_w[(co0 + i) * 3 + c] * sv;
+      }
     }
   };
 
@@ -292,8 +301,10 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     for (int g = 0; g < PG; ++g) {
       const int p = (wave_pg + g) * 32 + li_o;
       const int Y = T.ty0 + ((p >> G.lg_tw) & (th - 1)), X = T.tx0 + (p & (tw - 1));
-      if (!((Y < G.y0 + G.dh) && (X < G.x0 + G.dw))) continue;
+      const bool pv = (Y < G.y0 + G.dh) && (X < G.x0 + G.dw);
       const float nzv = nw_ * nz[g];
+      float rgb[3] = {0.0f, 0.0f, 0.0f};
+      if (pv) {
       const unsigned pix4 = UP ? (unsigned)(2 * Y * P.out_w + 2 * X) * 4u : (unsigned)(Y * P.out_w + X) * 4u;
 #pragma unroll
       for (int ct = 0; ct < CT_TILES; ++ct)
@@ -326,9 +337,40 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
               float v = acc[0][ct][g][r] * dmv[k];
               if (P.bias) v = apply_act(v + nzv + bsv[k], P.act, P.alpha, P.scale, 0.0f);
               *reinterpret_cast<float *>(ob0 + off) = v;
+              acc[0][ct][g][r] = v;  // kept for the fused ToRGB below
             }
           }
         }
+      }  // pv
+      if (!UP && P.rgb_out) {
+        // fused ToRGB (model.py:356-362 without bias / skip): the wave holds all CT = cout channels
+        // of its pixels (WAVES_CO == 1, one cout tile): 3 dot products over the lane's 16*CT_TILES
+        // values, then the two half-waves (channels +4) are added and the low half stores.
+        // The shuffle runs for every lane (pixels outside the image contribute to nothing).
+        const float *rw = rgbw_base + slot * 3 * CT;
+        if (pv) {
+#pragma unroll
+          for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int c4 = co_w + ct * 32 + 8 * q + 4 * lh_o;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const float4 wv = *reinterpret_cast<const float4 *>(rw + c * CT + c4);
+                rgb[c] = fmaf(acc[0][ct][g][4 * q + 0], wv.x, rgb[c]);
+                rgb[c] = fmaf(acc[0][ct][g][4 * q + 1], wv.y, rgb[c]);
+                rgb[c] = fmaf(acc[0][ct][g][4 * q + 2], wv.z, rgb[c]);
+                rgb[c] = fmaf(acc[0][ct][g][4 * q + 3], wv.w, rgb[c]);
+              }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          rgb[c] += __shfl_xor(rgb[c], 32, 64);
+          if (pv && lh_o == 0)
+            P.rgb_out[((long long)T.b0 * 3 + c) * ((long long)P.out_h * P.out_w) + (long long)Y * P.out_w + X] = rgb[c];
+        }
+      }
     }
   };
 
@@ -525,7 +567,9 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
     if (geom_xs(P.g[i], 1, UP ? 1 : 2) > NPIX) return HF_E_INVALID;
   }
   const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float) +
-                     2 * 2 * CT * sizeof(float);  // stages + s[2][cin] + epilogue d/bias [2][2][CT]
+                     2 * 2 * CT * sizeof(float) + (P.rgb_out ? 2 * 3 * CT * sizeof(float) : 0);
+  // stages + s[2][cin] + epilogue d/bias [2][2][CT] (+ fused ToRGB weights [2][3][CT])
+  if (P.rgb_out && (UP || WAVES_CO != 1 || P.cout != CT || !P.rgb_w || !P.rgb_s)) return HF_E_INVALID;
   if (lds > 160 * 1024) return HF_E_INVALID;
   P.n_tiles = nblocks;
   // LDS allows one block per CU: size the grid to the chip and let each block walk its share
@@ -581,6 +625,7 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
     if (P.cout % 64) cfg = (P.w >= 128) ? 55 : 53;
     else cfg = (P.h * P.w >= 512 && blocks52 >= 256) ? 52 : 51;
   }
+  if (P.rgb_out && cfg == 51) cfg = 52;  // fused ToRGB needs all cout channels in one wave
   if (cfg == 55) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 128>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 128>(P, h, l, st);
   else if (cfg == 56) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 64>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 64>(P, h, l, st);
   else if (cfg == 54) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 4, false>(P, h, l, st) : launch_h<1, 1, 2, 1, 4, false>(P, h, l, st);
@@ -641,4 +686,25 @@ extern "C" int hf_modconv3x3_up_f16_f32(float *tmp, const float *x, const void *
 extern "C" int hf_debug_set_persistent_blocks(int blocks) {
   hf_detail::g_h_blocks = blocks;
   return HF_OK;
+}
+
+extern "C" int hf_modconv3x3_f16_rgb_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
+                                         const float *s, const float *d, const float *noise, const float *noise_w,
+                                         long long noise_bstride, const float *bias, int batch, int cin, int cout,
+                                         int h, int w, float alpha, float scale, float *rgb_raw, const float *rgb_wt,
+                                         const float *rgb_s, void *stream) {
+  if (!out || !x || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (noise && !noise_w) ||
+      (nterms != 1 && nterms != 3) || !rgb_raw || !rgb_wt || !rgb_s || (cout != 32 && cout != 64))
+    return HF_E_INVALID;
+  ConvParams P{};
+  P.out = out; P.x = x; P.s = s; P.d = d; P.noise = noise; P.noise_w = noise_w; P.bias = bias;
+  P.s_bstride = cin; P.d_bstride = cout;
+  P.groups = 1;
+  P.noise_bstride = noise_bstride;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = h; P.out_w = w; P.out_wv = w;
+  P.stride = 1;
+  P.act = bias ? ACT_LRELU : ACT_NONE;
+  P.alpha = alpha; P.scale = scale;
+  P.rgb_out = rgb_raw; P.rgb_w = rgb_wt; P.rgb_s = rgb_s;
+  return launch_conv_h(P, nterms, false, wt_hi, wt_lo, (hipStream_t)stream);
 }

@@ -151,16 +151,24 @@ class ModulatedConv2d(nn.Module):  # :183-279
             self._prep_f16 = (key, hi, lo)
         return self._prep_f16[1], self._prep_f16[2]
 
-    def conv_same_res(self, input, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=math.sqrt(2)):
+    def conv_same_res(self, input, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=math.sqrt(2), rgb=None):
         """3x3 same-resolution modulated conv (+ fused noise/bias/lrelu epilogue) on the matrix
-        cores the process-wide mode selects (_runtime.conv_precision)."""
+        cores the process-wide mode selects (_runtime.conv_precision).  rgb: see fuses_torgb."""
         mode = conv_precision()
         _, cin, h, w = input.shape
         if mode != "f32" and M.modconv3x3_f16_supported(cin, self.out_channel, h, w):
             hi, lo = self.prepared_f16()
             return M.modconv3x3_f16(lib(), stream(), input, hi, lo, 3 if mode == "f16x3" else 1, s, d, noise,
-                                    noise_w, bias, alpha, scale)
+                                    noise_w, bias, alpha, scale, rgb=rgb)
+        assert rgb is None
         return M.modconv3x3(lib(), stream(), input, wt, s, d, noise, noise_w, bias, alpha, scale)
+
+    def fuses_torgb(self, input):
+        """True when the layer's ToRGB can be computed in this conv's epilogue (fp16-core modes,
+        32/64 output channels: one wave holds every channel of its pixels)."""
+        _, cin, h, w = input.shape
+        return (conv_precision() != "f32" and not self.upsample and self.kernel_size == 3
+                and M.torgb_fusable(cin, self.out_channel, h, w))
 
     def conv_up(self, input, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=math.sqrt(2)):
         """Transposed 3x3 conv + blur (+ fused noise/bias/lrelu), matrix cores per the mode."""
@@ -223,9 +231,14 @@ class StyledConv(nn.Module):  # :309-343
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None):
+    def forward(self, input, style, noise=None, rgb=None):
         """conv -> +noise -> bias -> leaky-ReLU*sqrt2 with the last three fused into the
-        producing kernel's epilogue (same-res) or into the blur pass (upsample)."""
+        producing kernel's epilogue (same-res) or into the blur pass (upsample).
+        rgb = ToRGB.coefficients(style) of the layer's ToRGB (only when conv.fuses_torgb(input)):
+        ToRGB's 1x1 modulated conv is computed in the same epilogue and travels with the returned
+        tensor (attribute _hf_fused_rgb); that ToRGB's forward picks it up instead of re-reading
+        the feature map.  The return value stays a plain Tensor (module hooks see what they
+        always saw)."""
         require_gpu(input, style, noise)
         conv = self.conv
         wt, s, d = conv.style_coefficients(style)
@@ -237,8 +250,14 @@ class StyledConv(nn.Module):  # :309-343
         if conv.upsample:
             return conv.conv_up(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
                                 act.negative_slope, act.scale)
-        return conv.conv_same_res(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
-                                  act.negative_slope, act.scale)
+        if rgb is None:
+            return conv.conv_same_res(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
+                                      act.negative_slope, act.scale)
+        key, rgb_wt, rgb_s = rgb
+        out, raw = conv.conv_same_res(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
+                                      act.negative_slope, act.scale, rgb=(rgb_wt, rgb_s))
+        out._hf_fused_rgb = (key, raw)
+        return out
 
 
 class ToRGB(nn.Module):  # :346-365
@@ -249,15 +268,38 @@ class ToRGB(nn.Module):  # :346-365
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
+    def _skip_kernel(self, skip):
+        if skip is None:
+            return None
+        kern = self.upsample.kernel
+        if tuple(kern.shape) != (4, 4) or self.upsample.factor != 2 or tuple(self.upsample.pad) != (2, 1):
+            raise NotImplementedError("fused skip path expects the [1,3,3,1] x2 upsampler")
+        return kern
+
     def forward(self, input, style, skip=None):
         require_gpu(input, style, skip)
+        fused = getattr(input, "_hf_fused_rgb", None)
+        if fused is not None and fused[0] == self._fusion_key(style):
+            return self._finish(fused[1], skip)
         wt, s, _ = self.conv.style_coefficients(style)
-        kern = None
-        if skip is not None:
-            kern = self.upsample.kernel
-            if tuple(kern.shape) != (4, 4) or self.upsample.factor != 2 or tuple(self.upsample.pad) != (2, 1):
-                raise NotImplementedError("fused skip path expects the [1,3,3,1] x2 upsampler")
-        return M.torgb(lib(), stream(), input, wt, s, self.bias.detach(), skip, kern)
+        return M.torgb(lib(), stream(), input, wt, s, self.bias.detach(), skip, self._skip_kernel(skip))
+
+    def _fusion_key(self, style):
+        return (id(self), style.data_ptr(), tuple(style.shape), tuple(style.stride()))
+
+    def coefficients(self, style):
+        """(key, wt [1,cin,3], s [B,cin]) for the producer that fuses the 1x1 conv (StyledConv rgb=)."""
+        wt, s, _ = self.conv.style_coefficients(style)
+        return self._fusion_key(style), wt, s
+
+    def _finish(self, raw, skip=None):
+        """bias + upsampled skip on top of the raw 1x1 conv the producer computed: the same kernel
+        with a 3-channel input and identity weights."""
+        require_gpu(raw, skip)
+        eye = getattr(self, "_eye", None)
+        if eye is None or eye.device != raw.device:
+            eye = self._eye = torch.eye(3, device=raw.device, dtype=raw.dtype).reshape(1, 3, 3)
+        return M.torgb(lib(), stream(), raw, eye, None, self.bias.detach(), skip, self._skip_kernel(skip))
 
 
 class Generator(nn.Module):  # :368-565
@@ -348,8 +390,12 @@ class Generator(nn.Module):  # :368-565
             else:
                 src = layer_in if block == start_layer else out
                 out = conv_up(src, latent[:, i], noise=noise[2 * block - 1])
-                out = conv_same(out, latent[:, i + 1], noise=noise[2 * block])
-                skip = to_rgb(out, latent[:, i + 2], skip)
+                rgb_style = latent[:, i + 2]
+                if conv_same.conv.fuses_torgb(out):  # ToRGB's 1x1 conv in conv_same's epilogue
+                    out = conv_same(out, latent[:, i + 1], noise=noise[2 * block], rgb=to_rgb.coefficients(rgb_style))
+                else:
+                    out = conv_same(out, latent[:, i + 1], noise=noise[2 * block])
+                skip = to_rgb(out, rgb_style, skip)
             i += 2
         image = skip
         return (image, latent) if return_latents else (image, None)

@@ -123,6 +123,18 @@ int hf_modconv3x3_f16_f32(float *out, const float *x, const void *wt_hi, const v
                           const float *s, const float *d, const float *noise, const float *noise_w,
                           long long noise_bstride, const float *bias, int batch, int cin, int cout, int h,
                           int w, float alpha, float scale, void *stream);
+/* hf_modconv3x3_f16_f32 with ToRGB's 1x1 modulated conv fused into the epilogue (layers whose
+ * cout is 32 or 64: a wave holds every channel of its pixels):
+ *   rgb_raw[b,c,Y,X] = sum_co rgb_wt[co*3+c] * rgb_s[b*cout+co] * out[b,co,Y,X]
+ * i.e. ToRGB.forward (models/stylegan2/model.py:356-362) before its bias and upsampled skip;
+ * finish with hf_torgb_f32(out_rgb, rgb_raw, identity3x3, NULL, bias, skip, k4, batch, 3, h, w).
+ * rgb_wt: ToRGB's prepared 1x1 weight ([cout][3], from hf_modconv_prepare_f32), rgb_s: its
+ * modulation (hf_modulation_f32).  Saves re-reading the layer's output (4*cout*H*W bytes). */
+int hf_modconv3x3_f16_rgb_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
+                              const float *s, const float *d, const float *noise, const float *noise_w,
+                              long long noise_bstride, const float *bias, int batch, int cin, int cout, int h,
+                              int w, float alpha, float scale, float *rgb_raw, const float *rgb_wt,
+                              const float *rgb_s, void *stream);
 /* Part 1 of the upsampling StyledConv (hf_modconv3x3_up_f32) on the fp16 matrix cores: same
  * intermediate [batch, cout, 2h+1, tmp_pitch], same weights as hf_modconv3x3_f16_f32 (the
  * transposed conv's tap flip is in the phase mapping, not in the layout).  Shapes:

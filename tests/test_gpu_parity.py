@@ -400,3 +400,75 @@ def test_modconv_f16_persistent_tile_walk(up, blocks, shape):
             assert torch.equal(y, first)
     finally:
         lib.hf_debug_set_persistent_blocks(0)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 64, 64), (1, 32, 32, 96, 128)])
+def test_modconv_f16_fused_torgb(shape):
+    """Fused ToRGB epilogue (hf_modconv3x3_f16_rgb_f32) + finishing pass == conv followed by the
+    stand-alone ToRGB kernel; the conv output itself is unchanged bit for bit."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib as _lib_fn, stream
+
+    B, cin, cout, H, W = shape
+    torch.manual_seed(9)
+    dev = _dev()
+    lib, st = _lib_fn(), stream()
+    r = lambda *sz: torch.randn(*sz, device=dev)  # noqa: E731
+    x, wgt = r(B, cin, H, W), r(1, cout, cin, 3, 3)
+    mw, mb, sty = r(cin, 16), r(cin), r(B, 16)
+    nz, nw, bias = r(B, 1, H, W), torch.tensor([0.3], device=dev), r(cout)
+    wrgb, mwr, mbr, styr = r(1, 3, cout, 1, 1), r(cout, 16), r(cout), r(B, 16)
+    brgb, skip = r(3), r(B, 3, H // 2, W // 2)
+    wt, wsq = M.prepare_weights(lib, st, wgt)
+    s = M.modulation(lib, st, sty, mw, mb)
+    dm = M.demod(lib, st, s, wsq)
+    hi, lo = M.split_weights_f16(lib, st, wt)
+    wtr, _ = M.prepare_weights(lib, st, wrgb)
+    sr = M.modulation(lib, st, styr, mwr, mbr)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0).to(dev)
+    assert M.torgb_fusable(cin, cout, H, W)
+    y, raw = M.modconv3x3_f16(lib, st, x, hi, lo, 3, s, dm, nz, nw, bias, rgb=(wtr, sr))
+    y_plain = M.modconv3x3_f16(lib, st, x, hi, lo, 3, s, dm, nz, nw, bias)
+    rgb = M.torgb(lib, st, raw, torch.eye(3, device=dev).reshape(1, 3, 3), None, brgb, skip, k4)
+    ref = M.torgb(lib, st, y, wtr, sr, brgb, skip, k4)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_plain)
+    assert float((rgb - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
+    """The 512^2 (64 ch) and 1024^2 (32 ch) ToRGBs ride in their producer's epilogue in the
+    default mode - and only when the ToRGB is called with the style it was fused for."""
+    from hairfastgan_amd import _marshal as M
+
+    dev = _dev()
+    g, shapes, size, _, _ = _gpu_generator("g1024", dev)
+    lat, nz, _ = C.generator_inputs(size, 1, 0)
+    lat, nz = lat.to(dev), [n.to(dev) for n in nz]
+    fused, plain_rgb = [], []
+    real_conv, real_rgb = M.modconv3x3_f16, M.torgb
+
+    def conv(*a, **k):
+        if k.get("rgb") is not None:
+            fused.append(a[2].shape[2])
+        return real_conv(*a, **k)
+
+    def rgb(lib, st, x, *a):
+        plain_rgb.append(x.shape[1])
+        return real_rgb(lib, st, x, *a)
+
+    monkeypatch.setattr(M, "modconv3x3_f16", conv)
+    monkeypatch.setattr(M, "torgb", rgb)
+    with torch.inference_mode():
+        y, _ = g([lat], input_is_latent=True, noise=nz)
+        assert fused == [512, 1024]
+        assert plain_rgb.count(3) == 2 and len(plain_rgb) == 9  # two finishing passes on 3-channel input
+        # a ToRGB asked for a different style must not use the stashed product
+        out = g.convs[15](torch.randn(1, 32, 1024, 1024, device=dev), lat[:, 16], noise=nz[16],
+                          rgb=g.to_rgbs[7].coefficients(lat[:, 17]))
+        other = lat[:, 3].contiguous()
+        a = g.to_rgbs[7](out, other)
+        delattr(out, "_hf_fused_rgb")
+        b = g.to_rgbs[7](out, other)
+        assert torch.equal(a, b)
+    assert y.shape == (1, 3, 1024, 1024)

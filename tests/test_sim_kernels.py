@@ -258,3 +258,31 @@ def test_modconv_f16_persistent_tile_walk(simlib, up, blocks):
         simlib.hf_debug_set_persistent_blocks(0)
     full = O.fused_leaky_relu(O.modulated_conv2d(x, sty, wgt, mw, mb, True, up) + nw * nz, bias)
     assert maxdiff(y, full) < TOL * max(1.0, float(full.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 16, 32), (1, 16, 32, 20, 40)])
+def test_modconv_f16_fused_torgb(simlib, golden, shape):
+    """ToRGB's 1x1 modulated conv in the conv epilogue (hf_modconv3x3_f16_rgb_f32) + the finishing
+    pass (bias + upsampled skip through hf_torgb_f32 with identity weights) == conv then ToRGB."""
+    B, cin, cout, H, W = shape
+    torch.manual_seed(9)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+    nz, nw, bias = torch.randn(B, 1, H, W), torch.tensor([0.3]), torch.randn(cout)
+    wrgb, mwr, mbr, styr = torch.randn(1, 3, cout, 1, 1), torch.randn(cout, 16), torch.randn(cout), torch.randn(B, 16)
+    brgb, skip = torch.randn(3), torch.randn(B, 3, H // 2, W // 2)
+    wt, wsq = M.prepare_weights(simlib, None, wgt)
+    s = M.modulation(simlib, None, sty, mw, mb)
+    dm = M.demod(simlib, None, s, wsq)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    wtr, _ = M.prepare_weights(simlib, None, wrgb)
+    sr = M.modulation(simlib, None, styr, mwr, mbr)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0)
+    assert M.torgb_fusable(cin, cout, H, W)
+    y, raw = M.modconv3x3_f16(simlib, None, x, hi, lo, 3, s, dm, nz, nw, bias, rgb=(wtr, sr))
+    y_plain = M.modconv3x3_f16(simlib, None, x, hi, lo, 3, s, dm, nz, nw, bias)
+    assert torch.equal(y, y_plain)
+    rgb = M.torgb(simlib, None, raw, torch.eye(3).reshape(1, 3, 3), None, brgb, skip, k4)
+    ref = M.torgb(simlib, None, y, wtr, sr, brgb, skip, k4)
+    assert maxdiff(rgb, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
