@@ -226,21 +226,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # comparison run (outside the timed region): every conv on the exact-fp32 MFMA
-    exact_f32 = None
-    if precision != "f32" and world == 1 and not args.no_exact_f32:
-        prev = _runtime.set_conv_precision("f32")
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        e32 = time.perf_counter() - t1
-        _runtime.set_conv_precision(prev)
-        exact_f32 = {"value": round(B * args.steps / e32, 3), "unit": "images/s", "ms_per_step": round(e32 / args.steps * 1e3, 4),
-                     "note": "same forward, HAIRFAST_CONV_PRECISION=f32 (v_mfma_f32_32x32x2_f32 only)"}
+    # comparison runs (outside the timed region): the same forward with every conv on the exact-fp32
+    # MFMA, and BASELINE.json configs[4] (fp16 operands, batch 16)
+    def alt_run(mode, batch):
+        prev = _runtime.set_conv_precision(mode)
+        lat = torch.randn(batch, 18, 512, device=dev)
+        try:
+            with torch.inference_mode():
+                for _ in range(2):
+                    g([lat], input_is_latent=True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    g([lat], input_is_latent=True)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t1
+        finally:
+            _runtime.set_conv_precision(prev)
+
+    exact_f32 = f16_mode = None
+    if world == 1 and not args.no_exact_f32:
+        if precision != "f32":
+            e32 = alt_run("f32", B)
+            exact_f32 = {"value": round(B * args.steps / e32, 3), "unit": "images/s", "ms_per_step": round(e32 / args.steps * 1e3, 4),
+                         "note": "same forward, HAIRFAST_CONV_PRECISION=f32 (v_mfma_f32_32x32x2_f32 only)"}
+        e16 = alt_run("f16", 16)
+        f16_mode = {"value": round(16 * args.steps / e16, 3), "unit": "images/s", "ms_per_step": round(e16 / args.steps * 1e3, 4),
+                    "batch": 16, "note": "BASELINE.json configs[4]: fp16 conv operands (HAIRFAST_CONV_PRECISION=f16), fp32 tensors, "
+                                         "accumulation and demodulation; pixel MSE vs the reference 2e-6 (tests/test_gpu_parity.py)"}
 
     # Secondary measurement (outside the timed region above): the hot-path call schedule of
     # one HairFast swap (BASELINE.json configs[2]/[3]), triples sharded
@@ -317,6 +330,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd)
         if exact_f32 is not None:
             out["exact_f32"] = exact_f32
+        if f16_mode is not None:
+            out["f16_mode"] = f16_mode
         if swap_info is not None:
             out["swap_schedule"] = swap_info
         print(json.dumps(out), flush=True)

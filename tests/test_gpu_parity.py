@@ -472,3 +472,31 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
         b = g.to_rgbs[7](out, other)
         assert torch.equal(a, b)
     assert y.shape == (1, 3, 1024, 1024)
+
+
+@pytest.mark.parametrize("mode,bar", [("f16", 1e-4), ("f32", 1e-8)])
+def test_generator1024_other_precision_modes(golden, mode, bar):
+    """BASELINE.json configs[4] (fp16 operands, fp32 accumulate / demodulation) and the exact-fp32
+    mode against the reference's golden 1024^2 output: pixel MSE below north_star's 1e-4 bar for
+    fp16, below the fp32 bar for f32 (the default f16x3 mode is what every other test runs in)."""
+    from hairfastgan_amd import _runtime
+
+    dev = _dev()
+    g, shapes, size, batches, _ = _gpu_generator("g1024", dev)
+    G = golden("generator_1024.npz")
+    B = batches[0]
+    prev = _runtime.set_conv_precision(mode)
+    try:
+        y, _ = _run_range(g, shapes, size, B, 0, 8, dev)
+    finally:
+        _runtime.set_conv_precision(prev)
+    key = f"g1024_B{B}_r0to8"
+    ref = torch.from_numpy(np.asarray(G[f"{key}_crop"])).double()
+    c0 = y.shape[-1] // 2 - 32
+    got = y[:, :, c0:c0 + 64, c0:c0 + 64].cpu().double()
+    mse = float(((got - ref) ** 2).mean())
+    assert mse < bar * max(1.0, float(ref.var())), (mode, mse)
+    smp = torch.from_numpy(np.asarray(G[f"{key}_samples"])).double()
+    mse_s = float(((_strided(y).cpu().double() - smp) ** 2).mean())
+    assert mse_s < bar * max(1.0, float(smp.var())), (mode, mse_s)
+    print(f"{mode}: crop mse {mse:.3e}, strided-sample mse {mse_s:.3e}")
