@@ -34,6 +34,7 @@ SIGNATURES = {
     "hf_modconv3x3_up_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _ll, _st],
     "hf_modconv_up_pitch": [_i],
     "hf_blur_noise_bias_act_f32": [_f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _st],
+    "hf_blur_noise_bias_act_split_f16": [_f, _f, _f, _f, _f, _f, _ll, _f, _f, _i, _i, _i, _i, _i, _fl, _fl, _st],
     "hf_torgb_f32": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st],
     "hf_conv_prepare_f32": [_f, _f, _i, _i, _i, _fl, _st],
     "hf_bn_fold_f32": [_f, _f, _f, _f, _f, _f, _f, _fl, _i, _st],

@@ -224,9 +224,22 @@ def modconv3x3_up_f16_supported(cin, cout, h, w):
     return cin % 16 == 0 and cout % 32 == 0 and h * w >= (256 if cout % 64 == 0 else 512) and min(h, w) >= 2
 
 
-def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha=0.2, scale=SQRT2, f16=None):
+class SplitActivation:
+    """An activation handed from a producer to a 3x3 conv on the fp16 matrix cores without an fp32
+    round trip: s_next * y split into fp16 (hi, lo) and K-blocked [B, C/8, H, W, 8] (csrc/convh.hip)."""
+
+    def __init__(self, hi, lo, key):
+        self.hi, self.lo, self.key = hi, lo, key
+        b, cb, h, w, _ = hi.shape
+        self.shape = (b, cb * 8, h, w)
+
+
+def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha=0.2, scale=SQRT2, f16=None,
+                  split_for=None):
     """conv_transpose(stride 2) -> [B,cout,2h+1,2w+1] scratch -> blur+noise+bias+act -> [B,cout,2h,2w].
-    f16 = (wt_hi, wt_lo, nterms): part 1 on the fp16 matrix cores (hf_modconv3x3_up_f16_f32)."""
+    f16 = (wt_hi, wt_lo, nterms): part 1 on the fp16 matrix cores (hf_modconv3x3_up_f16_f32).
+    split_for = (key, s_next [B,cout]): part 2 writes a SplitActivation for the conv whose modulation
+    is s_next instead of the fp32 tensor (hf_blur_noise_bias_act_split_f16)."""
     x = _c(x)
     b, cin, h, w = x.shape
     cout = wt.shape[2]
@@ -247,6 +260,15 @@ def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha
                                              ws_n, st))
         check(lib, code, "hf_modconv3x3_up_f32")
     noise, nbs = _noise_args(noise, b, 4 * h * w)
+    if split_for is not None:
+        key, s_next = split_for
+        hi = torch.empty((b, cout // 8, 2 * h, 2 * w, 8), dtype=torch.float16, device=x.device)
+        lo = torch.empty_like(hi)
+        check(lib, lib.hf_blur_noise_bias_act_split_f16(_p(hi), _p(lo), _p(tmp), _p(_c(blur_kernel)), _p(noise),
+                                                        _p(_c(noise_w)), nbs, _p(_c(bias)), _p(_c(s_next)), b, cout,
+                                                        2 * h + 1, 2 * w + 1, pitch, alpha, scale, st),
+              "hf_blur_noise_bias_act_split_f16")
+        return SplitActivation(hi, lo, key)
     out = x.new_empty((b, cout, 2 * h, 2 * w))
     check(lib, lib.hf_blur_noise_bias_act_f32(_p(out), _p(tmp), _p(_c(blur_kernel)), _p(noise), _p(_c(noise_w)),
                                               nbs, _p(_c(bias)), b, cout, 2 * h + 1, 2 * w + 1, pitch, alpha, scale,

@@ -259,6 +259,122 @@ extern "C" int hf_upfirdn2d_f32(float *out, const float *in, const float *kernel
   return hf_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// Blur + noise + bias + lrelu whose result feeds a 3x3 conv on the fp16 matrix cores directly:
+// instead of the fp32 NCHW activation it writes s_next[b,c] * y already SPLIT into fp16 (hi, lo)
+// pairs and K-BLOCKED, hi/lo[b][c/8][y][x][8 halves] - the exact units csrc/convh.hip stages into
+// LDS, so that kernel fetches them by LDS-DMA with no per-element loads or conversion.  Values
+// are bit-identical to what convh's own staging derives from the fp32 activation (same tap
+// order, fp32 product with s, hi = fp16(v), lo = fp16(v - hi)).
+// A thread owns one output column and 8 channels and walks down the rows; per input row and
+// channel one unaligned 16-byte load (columns x-1..x+2; neighbouring lanes overlap in L1) feeds
+// four rotating accumulators (the output rows the input row contributes to).  Reads are 256-byte
+// row segments per channel, writes are 1 KiB per wave (64 pixels x 16 B) for hi and for lo.
+typedef _Float16 hf_half8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void blur4x4_split8(hf_half8 *__restrict__ hi, hf_half8 *__restrict__ lo,
+                                                      const float *__restrict__ in,
+                                                      const float *__restrict__ kernel4x4,
+                                                      const float *__restrict__ noise,
+                                                      const float *__restrict__ noise_w, long long noise_bstride,
+                                                      const float *__restrict__ bias,
+                                                      const float *__restrict__ s_next, int channels, int in_h,
+                                                      int in_w, int in_pitch, float alpha, float scale,
+                                                      int rows_per_thread) {
+  const int out_h = in_h - 1, out_w = in_w - 1;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const int oy0 = blockIdx.y * rows_per_thread;
+  const int cblocks = channels >> 3;
+  const int b = blockIdx.z / cblocks, cb = blockIdx.z - b * cblocks;
+  if (ox >= out_w || oy0 >= out_h) return;
+
+  float kf[4][4];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) kf[ky][kx] = kernel4x4[(3 - ky) * 4 + (3 - kx)];
+  float bc[8], sv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    bc[k] = bias ? bias[cb * 8 + k] : 0.0f;
+    sv[k] = s_next ? s_next[(long long)b * channels + cb * 8 + k] : 1.0f;
+  }
+  const float nw = noise ? noise_w[0] : 0.0f;
+  const float *nz = noise ? noise + (long long)b * noise_bstride : nullptr;
+  const long long iplane = (long long)in_h * in_pitch;
+  const float *src = in + ((long long)b * channels + cb * 8) * iplane + (ox - 1);
+  const bool interior = ox >= 1 && ox + 2 < in_w;
+  bool cv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cv[j] = (ox - 1 + j) >= 0 && (ox - 1 + j) < in_w;
+  hf_half8 *hp = hi + ((long long)b * cblocks + cb) * out_h * out_w + ox;
+  hf_half8 *lp = lo + ((long long)b * cblocks + cb) * out_h * out_w + ox;
+
+  const int oy_end = min(oy0 + rows_per_thread, out_h);
+  float acc[8][4];  // acc[k][slot]: output row oy with (oy - oy0) % 4 == slot, channel k
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[k][t] = 0.0f;
+
+  // input rows iy = oy0 - 1 + n, n = 0 .. (oy_end - oy0) + 2; unrolled by 4 so slots are static
+  const int n_end = (oy_end - oy0) + 3;
+  for (int n0 = 0; n0 < n_end; n0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + u;
+      if (n >= n_end) break;
+      const int iy = oy0 - 1 + n;
+      const bool rv = iy >= 0 && iy < in_h;
+      float row[8][4];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float *p = src + k * iplane + (long long)iy * in_pitch;
+        if (rv && interior) {
+          const f32x4u v = *reinterpret_cast<const f32x4u *>(p);
+          row[k][0] = v.x; row[k][1] = v.y; row[k][2] = v.z; row[k][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) row[k][j] = (rv && cv[j]) ? p[j] : 0.0f;
+        }
+      }
+      // kernel row r of output row oy = oy0 + n - r (r ascending per output row, columns inner:
+      // the accumulation order of blur4x4_noise_bias_act)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int slot = (u - r) & 3;
+        if (n - r < 0) continue;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float a = (r == 0) ? 0.0f : acc[k][slot];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a = fmaf(row[k][j], kf[r][j], a);
+          acc[k][slot] = a;
+        }
+      }
+      // the output row whose last kernel row just arrived
+      const int oy = oy0 + n - 3;
+      if (n >= 3 && oy < oy_end) {
+        const int slot = (u - 3) & 3;
+        hf_half8 h8, l8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float v = acc[k][slot];
+          if (nz) v = fmaf(nw, nz[(long long)oy * out_w + ox], v);
+          if (bias) v = hf_lrelu(v + bc[k], alpha, scale);
+          v *= sv[k];
+          HF_OPAQUE_F32(v);  // hi and lo from the same fp32-rounded product (see convh.hip)
+          const _Float16 hv = (_Float16)v;
+          h8[k] = hv;
+          l8[k] = (_Float16)(v - (float)hv);
+        }
+        hp[(long long)oy * out_w] = h8;
+        lp[(long long)oy * out_w] = l8;
+      }
+    }
+  }
+}
+
 extern "C" int hf_blur_noise_bias_act_f32(float *out, const float *in, const float *kernel4x4,
                                           const float *noise, const float *noise_w,
                                           long long noise_bstride, const float *bias, int batch,
@@ -285,5 +401,27 @@ extern "C" int hf_blur_noise_bias_act_f32(float *out, const float *in, const flo
   dim3 grid(hf_cdiv(out_w, kBlurCols), hf_cdiv(out_h, kBlurSegs * kRowsPerThread), (unsigned)planes);
   hipLaunchKernelGGL(blur4x4_noise_bias_act, grid, dim3(kBlurCols, kBlurSegs), 0, (hipStream_t)stream, out,
                      in, kernel4x4, noise, noise_w, noise_bstride, bias, channels, in_h, in_w, in_pitch, alpha, scale);
+  return hf_launch_status();
+}
+
+extern "C" int hf_blur_noise_bias_act_split_f16(void *out_hi, void *out_lo, const float *in, const float *kernel4x4,
+                                                const float *noise, const float *noise_w, long long noise_bstride,
+                                                const float *bias, const float *s_next, int batch, int channels,
+                                                int in_h, int in_w, int in_pitch, float alpha, float scale,
+                                                void *stream) {
+  if (!out_hi || !out_lo || !in || !kernel4x4 || batch <= 0 || channels <= 0 || (channels & 7) || in_h < 2 || in_w < 2 ||
+      in_pitch < in_w || (noise && !noise_w))
+    return HF_E_INVALID;
+  const long long zs = (long long)batch * (channels >> 3);
+  if (zs > 65535) return HF_E_INVALID;
+  const int out_h = in_h - 1, out_w = in_w - 1;
+  int tx = 256;
+  while (tx > 64 && tx >= 2 * out_w) tx >>= 1;
+  int rpt = 64;  // rows per thread: 3 warm-up rows per strip
+  while (rpt > 8 && (long long)hf_cdiv(out_w, tx) * hf_cdiv(out_h, rpt) * zs < 2048) rpt >>= 1;
+  dim3 grid(hf_cdiv(out_w, tx), hf_cdiv(out_h, rpt), (unsigned)zs);
+  hipLaunchKernelGGL(blur4x4_split8, grid, dim3(tx), 0, (hipStream_t)stream, static_cast<hf_half8 *>(out_hi),
+                     static_cast<hf_half8 *>(out_lo), in, kernel4x4, noise, noise_w, noise_bstride, bias, s_next, channels,
+                     in_h, in_w, in_pitch, alpha, scale, rpt);
   return hf_launch_status();
 }

@@ -174,6 +174,18 @@ int hf_blur_noise_bias_act_f32(float *out, const float *in, const float *kernel4
                                int batch, int channels, int in_h, int in_w, int in_pitch, float alpha,
                                float scale, void *stream);
 
+/* hf_blur_noise_bias_act_f32 for a consumer on the fp16 matrix cores: writes
+ *   s_next[b,c] * y[b,c,Y,X]   (y = the fp32 result above; s_next NULL = 1)
+ * split into fp16 pairs hi = fp16(v), lo = fp16(v - hi) and K-blocked,
+ *   out_hi / out_lo [batch][channels/8][out_h][out_w][8]      (channels % 8 == 0),
+ * the layout hf_modconv3x3_f16_pre_f32 stages by LDS-DMA.  s_next is the NEXT conv's modulation
+ * (hf_modulation_f32 of that layer): the product with the activation has to happen in fp32 before
+ * the split.  Bit-identical to splitting the fp32 activation inside the conv kernel. */
+int hf_blur_noise_bias_act_split_f16(void *out_hi, void *out_lo, const float *in, const float *kernel4x4,
+                                     const float *noise, const float *noise_w, long long noise_bstride,
+                                     const float *bias, const float *s_next, int batch, int channels, int in_h,
+                                     int in_w, int in_pitch, float alpha, float scale, void *stream);
+
 /* ---------------------------------------------------------------------------
  * ToRGB: 1x1 modulated conv WITHOUT demodulation + bias + upsampled skip:
  *   y[b,c] = sum_ci wt[ci,c] * s[b,ci] * x[b,ci] + bias[c] + upfirdn2d(skip, k4, up=2, pad=(2,1))[b,c]

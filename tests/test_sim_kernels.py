@@ -286,3 +286,29 @@ def test_modconv_f16_fused_torgb(simlib, golden, shape):
     rgb = M.torgb(simlib, None, raw, torch.eye(3).reshape(1, 3, 3), None, brgb, skip, k4)
     ref = M.torgb(simlib, None, y, wtr, sr, brgb, skip, k4)
     assert maxdiff(rgb, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 6, 5), (1, 8, 9, 40), (1, 24, 33, 70)])
+def test_blur_split_output_is_the_split_of_the_fp32_blur(simlib, shape):
+    """hf_blur_noise_bias_act_split_f16 == hf_blur_noise_bias_act_f32 followed by *s, fp16 (hi, lo)
+    split and K-blocking, bit for bit (odd sizes, edges, strips shorter than the plane)."""
+    B, C, h, w = shape
+    torch.manual_seed(13)
+    pitch = simlib.hf_modconv_up_pitch(w)
+    tmp = torch.randn(B, C, 2 * h + 1, pitch)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0)
+    nz, nw, bias, s_next = torch.randn(B, 1, 2 * h, 2 * w), torch.tensor([0.3]), torch.randn(C), torch.rand(B, C) + 0.5
+    out = torch.empty(B, C, 2 * h, 2 * w)
+    M.check(simlib, simlib.hf_blur_noise_bias_act_f32(M._p(out), M._p(tmp), M._p(k4), M._p(nz), M._p(nw), 4 * h * w, M._p(bias),
+                                                      B, C, 2 * h + 1, 2 * w + 1, pitch, 0.2, 2 ** 0.5, None), "blur")
+    hi = torch.empty(B, C // 8, 2 * h, 2 * w, 8, dtype=torch.float16)
+    lo = torch.empty_like(hi)
+    M.check(simlib, simlib.hf_blur_noise_bias_act_split_f16(M._p(hi), M._p(lo), M._p(tmp), M._p(k4), M._p(nz), M._p(nw), 4 * h * w,
+                                                            M._p(bias), M._p(s_next), B, C, 2 * h + 1, 2 * w + 1, pitch, 0.2,
+                                                            2 ** 0.5, None), "blur split")
+    v = out * s_next[:, :, None, None]
+    eh = v.half()
+    el = (v - eh.float()).half()
+    blocked = lambda t: t.reshape(B, C // 8, 8, 2 * h, 2 * w).permute(0, 1, 3, 4, 2).contiguous()  # noqa: E731
+    assert torch.equal(hi, blocked(eh))
+    assert torch.equal(lo, blocked(el))
