@@ -27,6 +27,7 @@ KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modc
     221: "conv_mfma_pipe<1,2,2,2,up>", 222: "conv_mfma_pipe<1,2,1,4,up>", 223: "conv_mfma_pipe<1,1,2,2,up>",
     224: "conv_mfma_pipe<1,2,2,4,up>", 225: "conv_mfma_pipe<1,1,1,4,up>", 300: "conv_mfma<1,1,2,2> split-K",
     # csrc/convh.hip (fp16 matrix cores; <CT_TILES,PG,WAVES_CO,WAVES_PX>)
+    571: "conv_mfma_h<1,2,2,4,pre>", 572: "conv_mfma_h<2,2,1,8,pre>", 573: "conv_mfma_h<1,2,1,8,pre>", 575: "conv_mfma_h<1,2,1,8,tw128,pre>",
     551: "conv_mfma_h<1,2,2,4>", 552: "conv_mfma_h<2,2,1,8>", 553: "conv_mfma_h<1,2,1,8>", 555: "conv_mfma_h<1,2,1,8,tw128>",
     561: "conv_mfma_h<1,2,2,4,up>", 563: "conv_mfma_h<1,2,1,8,up>",
 }
@@ -217,6 +218,37 @@ def modconv3x3_f16(lib, st, x, wt_hi, wt_lo, nterms, s, d, noise, noise_w, bias,
                                           _p(noise_w), nbs, _p(bias), b, cin, cout, h, w, alpha, scale, st))
     check(lib, code, "hf_modconv3x3_f16_f32")
     return out
+
+
+def split_activation_reference(x, s):
+    """torch statement of the producer-side split (tests / tools): s*x -> (hi, lo) K-blocked."""
+    b, c, h, w = x.shape
+    v = x if s is None else x * s[:, :, None, None]
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    blk = lambda t: t.reshape(b, c // 8, 8, h, w).permute(0, 1, 3, 4, 2).contiguous()  # noqa: E731
+    return blk(hi), blk(lo)
+
+
+def modconv3x3_f16_pre(lib, st, act, wt_hi, wt_lo, nterms, d, noise, noise_w, bias, alpha=0.2, scale=SQRT2, rgb=None):
+    """hf_modconv3x3_f16_pre_f32: same-resolution 3x3 conv on the fp16 matrix cores whose input is a
+    SplitActivation (modulation already applied by the producer).  rgb as in modconv3x3_f16."""
+    b, cin, h, w = act.shape
+    cout = wt_hi.shape[3]
+    noise, nbs = _noise_args(noise, b, h * w)
+    out = torch.empty((b, cout, h, w), dtype=torch.float32, device=act.hi.device)
+    noise_w, bias = _c(noise_w), _c(bias)
+    raw = rgb_wt = rgb_s = None
+    if rgb is not None:
+        rgb_wt, rgb_s = _c(rgb[0]), _c(rgb[1])
+        raw = torch.empty((b, 3, h, w), dtype=torch.float32, device=act.hi.device)
+    code = _launch_profiled(
+        lib, 2.0 * cin * cout * 9 * h * w * b,
+        lambda: lib.hf_modconv3x3_f16_pre_f32(_p(out), _p(act.hi), _p(act.lo), _p(wt_hi), _p(wt_lo), nterms, _p(d), _p(noise),
+                                              _p(noise_w), nbs, _p(bias), b, cin, cout, h, w, alpha, scale, _p(raw),
+                                              _p(rgb_wt), _p(rgb_s), st))
+    check(lib, code, "hf_modconv3x3_f16_pre_f32")
+    return out if rgb is None else (out, raw)
 
 
 def modconv3x3_up_f16_supported(cin, cout, h, w):

@@ -64,6 +64,9 @@ struct ConvParams {
   // rgb_out[b][c][Y][X] = sum_co rgb_w[co*3+c] * rgb_s[b*cout+co] * y[b][co][Y][X]  (null = off)
   const float *rgb_w, *rgb_s;
   float *rgb_out;
+  // convh.hip, pre-split input: s*x already split into fp16 (hi, lo) and K-blocked
+  // [batch][cin/8][h][w][8] by the producer (hf_blur_noise_bias_act_split_f16); x and s unused
+  const void *xh, *xl;
   int n_tiles;                 // convh.hip: tiles over all families; a block walks blockIdx.x + k*gridDim.x
   TileGeom g[3];
 };

@@ -74,7 +74,9 @@ constexpr int halo_pixels_max() {
 // UP: the transposed (stride 2) conv of the upsampling StyledConv, as in modconv.hip: 4 output
 // phases (pr,pc) = (ky&1, kx&1) per input position (Y,X) of the (h+1)x(w+1) phase domain, each
 // tap feeding exactly one phase from x[Y - (ky==2), X - (kx==2)]; no zero-insertion flops.
-template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool MOD, bool UP, int TWMAX>
+// PRE: the activations arrive pre-split and K-blocked (ConvParams::xh/xl): the stage's halo tile
+// is fetched by LDS-DMA like the weights - no per-element loads, no conversion, no s.
+template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool MOD, bool UP, int TWMAX, bool PRE>
 __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const ConvParams P,
                                                                           const _Float16 *__restrict__ wth,
                                                                           const _Float16 *__restrict__ wtl) {
@@ -211,6 +213,29 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     }
   };
 
+  // PRE: one (halo pixel, kgroup) unit per lane and item straight into LDS; halo pixels outside
+  // the image are masked out of the DMA and zero-filled by the same lane
+  const char *xh_b = nullptr, *xl_b = nullptr;  // image base of the pre-split tensors (uniform)
+  auto dma_x = [&](int e, int chunk, int bufsel) {
+    const int i = tid + e * NT;
+    const int kg = i / NPIX;
+    const bool inside = e_src[e] >= 0;
+    int off = inside ? (kg * iplane + e_src[e]) * 16 : 0;
+    HF_OPAQUE_I32(off);
+    const long long cofs = (long long)chunk * 2 * plane * 16;  // 2 channel blocks per stage
+    const unsigned dst = lds_addr0 + (unsigned)(bufsel * BUF_UNITS + OFF_XH + (i - lane)) * 16u;
+    hf_glds16_raw_s_if(inside, xh_b + cofs, (unsigned)off, dst);
+    if (NTERMS == 3) hf_glds16_raw_s_if(inside, xl_b + cofs, (unsigned)off, dst + (unsigned)X_UNITS * 16u);
+    if (e_src[e] == -1) {
+      half8 z;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.0f;
+      half8 *buf = lds + bufsel * BUF_UNITS;
+      buf[OFF_XH + i] = z;
+      if (NTERMS == 3) buf[OFF_XL + i] = z;
+    }
+  };
+
   float xr[XE][8];  // raw activations of the next stage, in flight for most of a chunk
   // uniform chunk base + per-lane offset; halo items outside the image load element 0 of the
   // chunk instead (unconditional loads: no branches in the pipeline) and are zeroed at conversion
@@ -265,6 +290,10 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   Tile cur = locate(t_cur);
   locate_items(cur, e_src);
   xb = P.x + (long long)cur.b0 * P.cin * plane;
+  if (PRE) {
+    xh_b = static_cast<const char *>(P.xh) + (long long)cur.b0 * (P.cin / 8) * plane * 16;
+    xl_b = static_cast<const char *>(P.xl) + (long long)cur.b0 * (P.cin / 8) * plane * 16;
+  }
   sl_off = 0;
   load_s(cur.b0, 0);
   int ep_slot = 0;  // slot of the tile being computed (its epilogue)
@@ -272,10 +301,15 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   // prologue: stage 0 of the first tile
 #pragma unroll
   for (int i = 0; i < ND; ++i) dma_piece(i, 0, 0);
+  if (PRE) {
 #pragma unroll
-  for (int e = 0; e < XE; ++e) load_item(e, 0);
+    for (int e = 0; e < XE; ++e) dma_x(e, 0, 0);
+  } else {
 #pragma unroll
-  for (int e = 0; e < XE; ++e) convert_item(e, 0, lds);
+    for (int e = 0; e < XE; ++e) load_item(e, 0);
+#pragma unroll
+    for (int e = 0; e < XE; ++e) convert_item(e, 0, lds);
+  }
   HF_H_BARRIER();
 
   // Epilogue of one tile.  MFMA D layout: row (= co) = (r&3) + 8*(r>>2) + 4*lh, col (= pixel) = li:
@@ -424,6 +458,10 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       if (last && has_next) {  // switch the prefetch source to the next tile
         locate_items(nxt, e_src);
         xb = P.x + (long long)nxt.b0 * P.cin * plane;
+        if (PRE) {
+          xh_b = static_cast<const char *>(P.xh) + (long long)nxt.b0 * (P.cin / 8) * plane * 16;
+          xl_b = static_cast<const char *>(P.xl) + (long long)nxt.b0 * (P.cin / 8) * plane * 16;
+        }
         sl_off = nxt_sl_off;
       }
       if (last && !UP && P.noise) {  // this tile's noise, in registers before the epilogue (no loads there)
@@ -469,13 +507,18 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
             if (i / DMA_PER_STEP == tap) dma_piece(i, cpf, cb ^ 1);
         }
         if (more1 && tap == 0) {
+          if (PRE) {
 #pragma unroll
-          for (int e = 0; e < XE; ++e) load_item(e, cpf);
+            for (int e = 0; e < XE; ++e) dma_x(e, cpf, cb ^ 1);
+          } else {
+#pragma unroll
+            for (int e = 0; e < XE; ++e) load_item(e, cpf);
+          }
         }
         // (staggering the conversions over the two waves of a SIMD - early half in taps 3-5 - was
         // measured 5-15 % slower: the early half then waits on its loads)
         if (more1 && tap == 9 - XE) HF_TRACE_POINT(5);  // before the first conversion (waits for the loads)
-        if (more1 && tap >= 9 - XE) convert_item(tap - (9 - XE), cpf, nbuf);
+        if (!PRE && more1 && tap >= 9 - XE) convert_item(tap - (9 - XE), cpf, nbuf);
         if (more1 && tap == 8) HF_TRACE_POINT(6);  // conversions done
         __builtin_amdgcn_sched_barrier(0);
         const int ph = UP ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) : 0;
@@ -531,7 +574,7 @@ __global__ __launch_bounds__(256) void split_weights(_Float16 *__restrict__ wth,
   }
 }
 
-template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int TWMAX = 32>
+template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int TWMAX = 32, bool PRE = false>
 int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_t st) {
   constexpr int NT = 64 * WAVES_CO * WAVES_PX;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
@@ -581,12 +624,18 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
   const int gx = (P.cin / KH >= 2 && nblocks > resident) ? resident : nblocks;
   dim3 grid(gx, co_tiles);
   if (grid.y > 65535) return HF_E_INVALID;
-  if (P.s)
-    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, true, UP, TWMAX>), grid, dim3(NT), lds, st, P, wth,
-                       wtl);
-  else
-    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, false, UP, TWMAX>), grid, dim3(NT), lds, st, P, wth,
-                       wtl);
+  if (PRE) {
+    if (!P.xh || (NTERMS == 3 && !P.xl) || P.s || (P.cin & 15)) return HF_E_INVALID;
+    if ((long long)2 * P.h * P.w * 16 >= (1LL << 31)) return HF_E_INVALID;  // 32-bit offsets inside a stage
+    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, false, UP, TWMAX, PRE>), grid, dim3(NT), lds, st, P,
+                       wth, wtl);
+  } else if (P.s) {
+    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, true, UP, TWMAX, false>), grid, dim3(NT), lds, st, P,
+                       wth, wtl);
+  } else {
+    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, false, UP, TWMAX, false>), grid, dim3(NT), lds, st, P,
+                       wth, wtl);
+  }
   return hf_launch_status();
 }
 
@@ -626,6 +675,15 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
     else cfg = (P.h * P.w >= 512 && blocks52 >= 256) ? 52 : 51;
   }
   if (P.rgb_out && cfg == 51) cfg = 52;  // fused ToRGB needs all cout channels in one wave
+  if (P.xh) {  // pre-split activations (ids 7x = the 5x tile shapes with DMA-staged activations)
+    if (cfg == 55) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 128, true>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 128, true>(P, h, l, st);
+    else if (cfg == 53) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 32, true>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 32, true>(P, h, l, st);
+    else if (cfg == 52) rc = (nterms == 3) ? launch_h<3, 2, 2, 1, 8, false, 32, true>(P, h, l, st) : launch_h<1, 2, 2, 1, 8, false, 32, true>(P, h, l, st);
+    else if (cfg == 51) rc = (nterms == 3) ? launch_h<3, 1, 2, 2, 4, false, 32, true>(P, h, l, st) : launch_h<1, 1, 2, 2, 4, false, 32, true>(P, h, l, st);
+    else return HF_E_INVALID;
+    if (rc == HF_OK) note_path(5, cfg + 20);
+    return rc;
+  }
   if (cfg == 55) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 128>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 128>(P, h, l, st);
   else if (cfg == 56) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 64>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 64>(P, h, l, st);
   else if (cfg == 54) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 4, false>(P, h, l, st) : launch_h<1, 1, 2, 1, 4, false>(P, h, l, st);
@@ -698,6 +756,28 @@ extern "C" int hf_modconv3x3_f16_rgb_f32(float *out, const float *x, const void 
     return HF_E_INVALID;
   ConvParams P{};
   P.out = out; P.x = x; P.s = s; P.d = d; P.noise = noise; P.noise_w = noise_w; P.bias = bias;
+  P.s_bstride = cin; P.d_bstride = cout;
+  P.groups = 1;
+  P.noise_bstride = noise_bstride;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = h; P.out_w = w; P.out_wv = w;
+  P.stride = 1;
+  P.act = bias ? ACT_LRELU : ACT_NONE;
+  P.alpha = alpha; P.scale = scale;
+  P.rgb_out = rgb_raw; P.rgb_w = rgb_wt; P.rgb_s = rgb_s;
+  return launch_conv_h(P, nterms, false, wt_hi, wt_lo, (hipStream_t)stream);
+}
+
+extern "C" int hf_modconv3x3_f16_pre_f32(float *out, const void *x_hi, const void *x_lo, const void *wt_hi,
+                                         const void *wt_lo, int nterms, const float *d, const float *noise,
+                                         const float *noise_w, long long noise_bstride, const float *bias, int batch,
+                                         int cin, int cout, int h, int w, float alpha, float scale, float *rgb_raw,
+                                         const float *rgb_wt, const float *rgb_s, void *stream) {
+  if (!out || !x_hi || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (noise && !noise_w) ||
+      (nterms != 1 && nterms != 3) || (nterms == 3 && !x_lo))
+    return HF_E_INVALID;
+  if (rgb_raw && (!rgb_wt || !rgb_s || (cout != 32 && cout != 64))) return HF_E_INVALID;
+  ConvParams P{};
+  P.out = out; P.xh = x_hi; P.xl = x_lo; P.d = d; P.noise = noise; P.noise_w = noise_w; P.bias = bias;
   P.s_bstride = cin; P.d_bstride = cout;
   P.groups = 1;
   P.noise_bstride = noise_bstride;

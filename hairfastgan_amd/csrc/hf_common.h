@@ -61,6 +61,11 @@ __device__ __forceinline__ void hf_glds16_raw_s(const void *gsrc_uniform, unsign
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(base), "v"(lane_byte_offset), "s"(gs)
                : "memory");
 }
+// lane-masked form: lanes with `active` false copy nothing (their LDS slots keep their contents)
+__device__ __forceinline__ void hf_glds16_raw_s_if(bool active, const void *gsrc_uniform, unsigned lane_byte_offset,
+                                                   unsigned lds_wave_addr) {
+  if (active) hf_glds16_raw_s(gsrc_uniform, lane_byte_offset, lds_wave_addr);
+}
 // workgroup barrier that only orders LDS traffic (vector-memory operations stay in flight)
 __device__ __forceinline__ void hf_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int NYOUNG>

@@ -266,10 +266,12 @@ extern "C" int hf_upfirdn2d_f32(float *out, const float *in, const float *kernel
 // LDS, so that kernel fetches them by LDS-DMA with no per-element loads or conversion.  Values
 // are bit-identical to what convh's own staging derives from the fp32 activation (same tap
 // order, fp32 product with s, hi = fp16(v), lo = fp16(v - hi)).
-// A thread owns one output column and 8 channels and walks down the rows; per input row and
-// channel one unaligned 16-byte load (columns x-1..x+2; neighbouring lanes overlap in L1) feeds
-// four rotating accumulators (the output rows the input row contributes to).  Reads are 256-byte
-// row segments per channel, writes are 1 KiB per wave (64 pixels x 16 B) for hi and for lo.
+// A lane owns one INPUT column (x-1 of its output column) and 8 channels and walks down the rows:
+// per input row and channel one coalesced dword load; the three further columns of the 4-tap
+// window come from the next lanes' registers (wave shuffles), so a wave of 64 input columns
+// produces 61 output columns and every input byte is requested once.  Four rotating accumulators
+// per channel hold the output rows an input row contributes to.  Writes are 16 B per lane for hi
+// and for lo (up to 1 KiB contiguous per wave).
 typedef _Float16 hf_half8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void blur4x4_split8(hf_half8 *__restrict__ hi, hf_half8 *__restrict__ lo,
@@ -282,11 +284,17 @@ __global__ __launch_bounds__(256) void blur4x4_split8(hf_half8 *__restrict__ hi,
                                                       int in_w, int in_pitch, float alpha, float scale,
                                                       int rows_per_thread) {
   const int out_h = in_h - 1, out_w = in_w - 1;
-  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  // waves tile the columns with a stride of 61: lane l of wave wv holds input column
+  // ix = 61*wv + l - 1 and produces output column ox = ix + 1 (lanes 61..63 only feed neighbours)
+  const int lane = threadIdx.x & 63;
+  const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int ix = 61 * wv + lane - 1;
+  const int ox = ix + 1;
   const int oy0 = blockIdx.y * rows_per_thread;
   const int cblocks = channels >> 3;
   const int b = blockIdx.z / cblocks, cb = blockIdx.z - b * cblocks;
-  if (ox >= out_w || oy0 >= out_h) return;
+  if (61 * wv >= out_w || oy0 >= out_h) return;  // whole wave out of range (uniform)
+  const bool produces = lane < 61 && ox < out_w;
 
   float kf[4][4];
 #pragma unroll
@@ -302,13 +310,11 @@ __global__ __launch_bounds__(256) void blur4x4_split8(hf_half8 *__restrict__ hi,
   const float nw = noise ? noise_w[0] : 0.0f;
   const float *nz = noise ? noise + (long long)b * noise_bstride : nullptr;
   const long long iplane = (long long)in_h * in_pitch;
-  const float *src = in + ((long long)b * channels + cb * 8) * iplane + (ox - 1);
-  const bool interior = ox >= 1 && ox + 2 < in_w;
-  bool cv[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) cv[j] = (ox - 1 + j) >= 0 && (ox - 1 + j) < in_w;
-  hf_half8 *hp = hi + ((long long)b * cblocks + cb) * out_h * out_w + ox;
-  hf_half8 *lp = lo + ((long long)b * cblocks + cb) * out_h * out_w + ox;
+  const bool colv = ix >= 0 && ix < in_w;
+  const float *src = in + ((long long)b * channels + cb * 8) * iplane + (colv ? ix : 0);
+  const int oxc = min(ox, out_w - 1);
+  hf_half8 *hp = hi + ((long long)b * cblocks + cb) * out_h * out_w + oxc;
+  hf_half8 *lp = lo + ((long long)b * cblocks + cb) * out_h * out_w + oxc;
 
   const int oy_end = min(oy0 + rows_per_thread, out_h);
   float acc[8][4];  // acc[k][slot]: output row oy with (oy - oy0) % 4 == slot, channel k
@@ -317,59 +323,67 @@ __global__ __launch_bounds__(256) void blur4x4_split8(hf_half8 *__restrict__ hi,
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[k][t] = 0.0f;
 
-  // input rows iy = oy0 - 1 + n, n = 0 .. (oy_end - oy0) + 2; unrolled by 4 so slots are static
+  // input rows iy = oy0 - 1 + n, n = 0 .. (oy_end - oy0) + 2, four per iteration: the 32 row loads
+  // of an iteration are issued before the first use, and the slots of the rotating accumulators
+  // are compile-time constants
   const int n_end = (oy_end - oy0) + 3;
   for (int n0 = 0; n0 < n_end; n0 += 4) {
+    float own[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int iy = oy0 - 1 + n0 + u;
+      const bool rv = colv && iy >= 0 && iy < in_h && (n0 + u) < n_end;
+      const long long ro = (long long)min(max(iy, 0), in_h - 1) * in_pitch;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = src[k * iplane + ro];  // unconditional, clamped address
+        own[u][k] = rv ? v : 0.0f;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int n = n0 + u;
-      if (n >= n_end) break;
-      const int iy = oy0 - 1 + n;
-      const bool rv = iy >= 0 && iy < in_h;
-      float row[8][4];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float *p = src + k * iplane + (long long)iy * in_pitch;
-        if (rv && interior) {
-          const f32x4u v = *reinterpret_cast<const f32x4u *>(p);
-          row[k][0] = v.x; row[k][1] = v.y; row[k][2] = v.z; row[k][3] = v.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) row[k][j] = (rv && cv[j]) ? p[j] : 0.0f;
-        }
-      }
-      // kernel row r of output row oy = oy0 + n - r (r ascending per output row, columns inner:
-      // the accumulation order of blur4x4_noise_bias_act)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int slot = (u - r) & 3;
-        if (n - r < 0) continue;
+      if (n < n_end) {  // uniform
+        // kernel row r of output row oy = oy0 + n - r (r ascending per output row, columns inner:
+        // the accumulation order of blur4x4_noise_bias_act); window = own column and the next three
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          float a = (r == 0) ? 0.0f : acc[k][slot];
+          float win[4];
+          win[0] = own[u][k];
+          win[1] = __shfl_down(own[u][k], 1, 64);
+          win[2] = __shfl_down(own[u][k], 2, 64);
+          win[3] = __shfl_down(own[u][k], 3, 64);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) a = fmaf(row[k][j], kf[r][j], a);
-          acc[k][slot] = a;
-        }
-      }
-      // the output row whose last kernel row just arrived
-      const int oy = oy0 + n - 3;
-      if (n >= 3 && oy < oy_end) {
-        const int slot = (u - 3) & 3;
-        hf_half8 h8, l8;
+          for (int r = 0; r < 4; ++r) {
+            const int slot = (u - r) & 3;
+            if (n - r >= 0) {
+              float a = (r == 0) ? 0.0f : acc[k][slot];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          float v = acc[k][slot];
-          if (nz) v = fmaf(nw, nz[(long long)oy * out_w + ox], v);
-          if (bias) v = hf_lrelu(v + bc[k], alpha, scale);
-          v *= sv[k];
-          HF_OPAQUE_F32(v);  // hi and lo from the same fp32-rounded product (see convh.hip)
-          const _Float16 hv = (_Float16)v;
-          h8[k] = hv;
-          l8[k] = (_Float16)(v - (float)hv);
+              for (int j = 0; j < 4; ++j) a = fmaf(win[j], kf[r][j], a);
+              acc[k][slot] = a;
+            }
+          }
         }
-        hp[(long long)oy * out_w] = h8;
-        lp[(long long)oy * out_w] = l8;
+        // the output row whose last kernel row just arrived
+        const int oy = oy0 + n - 3;
+        if (n >= 3 && oy < oy_end && produces) {
+          const int slot = (u - 3) & 3;
+          const float nzr = nz ? nz[(long long)oy * out_w + ox] : 0.0f;
+          hf_half8 h8, l8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float v = acc[k][slot];
+            if (nz) v = fmaf(nw, nzr, v);
+            if (bias) v = hf_lrelu(v + bc[k], alpha, scale);
+            v *= sv[k];
+            HF_OPAQUE_F32(v);  // hi and lo from the same fp32-rounded product (see convh.hip)
+            const _Float16 hv = (_Float16)v;
+            h8[k] = hv;
+            l8[k] = (_Float16)(v - (float)hv);
+          }
+          hp[(long long)oy * out_w] = h8;
+          lp[(long long)oy * out_w] = l8;
+        }
       }
     }
   }
@@ -415,11 +429,12 @@ extern "C" int hf_blur_noise_bias_act_split_f16(void *out_hi, void *out_lo, cons
   const long long zs = (long long)batch * (channels >> 3);
   if (zs > 65535) return HF_E_INVALID;
   const int out_h = in_h - 1, out_w = in_w - 1;
+  const int waves = hf_cdiv(out_w, 61);  // 61 output columns per wave
   int tx = 256;
-  while (tx > 64 && tx >= 2 * out_w) tx >>= 1;
+  while (tx > 64 && (tx >> 6) >= 2 * waves) tx >>= 1;
   int rpt = 64;  // rows per thread: 3 warm-up rows per strip
-  while (rpt > 8 && (long long)hf_cdiv(out_w, tx) * hf_cdiv(out_h, rpt) * zs < 2048) rpt >>= 1;
-  dim3 grid(hf_cdiv(out_w, tx), hf_cdiv(out_h, rpt), (unsigned)zs);
+  while (rpt > 8 && (long long)hf_cdiv(waves, tx >> 6) * hf_cdiv(out_h, rpt) * zs < 2048) rpt >>= 1;
+  dim3 grid(hf_cdiv(waves, tx >> 6), hf_cdiv(out_h, rpt), (unsigned)zs);
   hipLaunchKernelGGL(blur4x4_split8, grid, dim3(tx), 0, (hipStream_t)stream, static_cast<hf_half8 *>(out_hi),
                      static_cast<hf_half8 *>(out_lo), in, kernel4x4, noise, noise_w, noise_bstride, bias, s_next, channels,
                      in_h, in_w, in_pitch, alpha, scale, rpt);

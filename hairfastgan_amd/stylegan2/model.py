@@ -170,8 +170,9 @@ class ModulatedConv2d(nn.Module):  # :183-279
         return (conv_precision() != "f32" and not self.upsample and self.kernel_size == 3
                 and M.torgb_fusable(cin, self.out_channel, h, w))
 
-    def conv_up(self, input, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=math.sqrt(2)):
-        """Transposed 3x3 conv + blur (+ fused noise/bias/lrelu), matrix cores per the mode."""
+    def conv_up(self, input, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=math.sqrt(2), split_for=None):
+        """Transposed 3x3 conv + blur (+ fused noise/bias/lrelu), matrix cores per the mode.
+        split_for=(key, s_next): the blur pass writes a SplitActivation for the next conv."""
         mode = conv_precision()
         _, cin, h, w = input.shape
         f16 = None
@@ -179,7 +180,7 @@ class ModulatedConv2d(nn.Module):  # :183-279
             hi, lo = self.prepared_f16()
             f16 = (hi, lo, 3 if mode == "f16x3" else 1)
         return M.modconv3x3_up(lib(), stream(), input, wt, s, d, self.blur.kernel, noise, noise_w, bias, alpha, scale,
-                               f16=f16)
+                               f16=f16, split_for=split_for)
 
     def style_coefficients(self, style):
         """s[b,ci] (EqualLinear :241) and d[b,co] (:244-246; None when demodulate=False)."""
@@ -258,6 +259,54 @@ class StyledConv(nn.Module):  # :309-343
                                       act.negative_slope, act.scale, rgb=(rgb_wt, rgb_s))
         out._hf_fused_rgb = (key, raw)
         return out
+
+    # -- producer -> consumer hand-over without an fp32 round trip (Generator's fast path) --------
+    def forward_split(self, input, style, noise, s_next):
+        """The upsampling StyledConv whose only consumer is the next same-resolution StyledConv:
+        returns s_next * output already split into fp16 (hi, lo) and K-blocked (M.SplitActivation)
+        instead of the fp32 tensor; same arithmetic as forward()."""
+        require_gpu(input, style, noise)
+        conv = self.conv
+        assert conv.upsample
+        wt, s, d = conv.style_coefficients(style)
+        b, _, h, w = input.shape
+        if noise is None:
+            noise = input.new_empty(b, 1, 2 * h, 2 * w).normal_()
+        act = self.activate
+        return conv.conv_up(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
+                            act.negative_slope, act.scale, split_for=(None, s_next))
+
+    def forward_from_split(self, split, coeffs, noise=None, rgb=None):
+        """Same-resolution StyledConv on a SplitActivation produced for it (coeffs = this layer's
+        conv.style_coefficients(style), whose s went into the split).  Returns what forward() does."""
+        conv = self.conv
+        assert not conv.upsample
+        _, s, d = coeffs
+        b, _, h, w = split.shape
+        if noise is None:
+            noise = split.hi.new_empty(b, 1, h, w, dtype=torch.float32).normal_()
+        require_gpu(noise)
+        act = self.activate
+        hi, lo = conv.prepared_f16()
+        nterms = 3 if conv_precision() == "f16x3" else 1
+        if rgb is None:
+            return M.modconv3x3_f16_pre(lib(), stream(), split, hi, lo, nterms, d, noise, self.noise.weight.detach(),
+                                        act.bias.detach(), act.negative_slope, act.scale)
+        key, rgb_wt, rgb_s = rgb
+        out, raw = M.modconv3x3_f16_pre(lib(), stream(), split, hi, lo, nterms, d, noise, self.noise.weight.detach(),
+                                        act.bias.detach(), act.negative_slope, act.scale, rgb=(rgb_wt, rgb_s))
+        out._hf_fused_rgb = (key, raw)
+        return out
+
+
+def _observed(*modules):
+    """True when someone registered hooks on these modules or their children: the fused fast
+    paths then step aside so that every module is called and sees / returns plain tensors."""
+    for m in modules:
+        for sub in m.modules():
+            if sub._forward_hooks or sub._forward_pre_hooks:
+                return True
+    return False
 
 
 class ToRGB(nn.Module):  # :346-365
@@ -389,12 +438,23 @@ class Generator(nn.Module):  # :368-565
                 return out, skip
             else:
                 src = layer_in if block == start_layer else out
-                out = conv_up(src, latent[:, i], noise=noise[2 * block - 1])
                 rgb_style = latent[:, i + 2]
-                if conv_same.conv.fuses_torgb(out):  # ToRGB's 1x1 conv in conv_same's epilogue
-                    out = conv_same(out, latent[:, i + 1], noise=noise[2 * block], rgb=to_rgb.coefficients(rgb_style))
+                _, cmid, h2, w2 = src.shape[0], conv_up.conv.out_channel, 2 * src.shape[2], 2 * src.shape[3]
+                if (conv_precision() != "f32" and cmid % 16 == 0
+                        and M.modconv3x3_f16_supported(cmid, conv_same.conv.out_channel, h2, w2)
+                        and not _observed(conv_up, conv_same)):
+                    # fast path: conv_up's blur pass hands conv_same its input pre-modulated, split into
+                    # fp16 pairs and K-blocked - no fp32 activation is written or read in between
+                    coeffs = conv_same.conv.style_coefficients(latent[:, i + 1])
+                    split = conv_up.forward_split(src, latent[:, i], noise[2 * block - 1], coeffs[1])
+                    rgb = to_rgb.coefficients(rgb_style) if M.torgb_fusable(cmid, conv_same.conv.out_channel, h2, w2) else None
+                    out = conv_same.forward_from_split(split, coeffs, noise[2 * block], rgb=rgb)
                 else:
-                    out = conv_same(out, latent[:, i + 1], noise=noise[2 * block])
+                    out = conv_up(src, latent[:, i], noise=noise[2 * block - 1])
+                    if conv_same.conv.fuses_torgb(out):  # ToRGB's 1x1 conv in conv_same's epilogue
+                        out = conv_same(out, latent[:, i + 1], noise=noise[2 * block], rgb=to_rgb.coefficients(rgb_style))
+                    else:
+                        out = conv_same(out, latent[:, i + 1], noise=noise[2 * block])
                 skip = to_rgb(out, rgb_style, skip)
             i += 2
         image = skip

@@ -135,6 +135,16 @@ int hf_modconv3x3_f16_rgb_f32(float *out, const float *x, const void *wt_hi, con
                               long long noise_bstride, const float *bias, int batch, int cin, int cout, int h,
                               int w, float alpha, float scale, float *rgb_raw, const float *rgb_wt,
                               const float *rgb_s, void *stream);
+/* hf_modconv3x3_f16_f32 whose input arrives pre-split from its producer
+ * (hf_blur_noise_bias_act_split_f16: x_hi / x_lo = fp16 (hi, lo) of s*x, [batch][cin/8][h][w][8]):
+ * the kernel stages weights AND activations by LDS-DMA - no per-element loads, no conversion, and
+ * no s argument (already applied).  rgb_raw / rgb_wt / rgb_s as in hf_modconv3x3_f16_rgb_f32, all
+ * NULL = no fused ToRGB.  x_lo may be NULL for nterms 1.  Same shapes as hf_modconv3x3_f16_f32. */
+int hf_modconv3x3_f16_pre_f32(float *out, const void *x_hi, const void *x_lo, const void *wt_hi, const void *wt_lo,
+                              int nterms, const float *d, const float *noise, const float *noise_w,
+                              long long noise_bstride, const float *bias, int batch, int cin, int cout, int h, int w,
+                              float alpha, float scale, float *rgb_raw, const float *rgb_wt, const float *rgb_s,
+                              void *stream);
 /* Part 1 of the upsampling StyledConv (hf_modconv3x3_up_f32) on the fp16 matrix cores: same
  * intermediate [batch, cout, 2h+1, tmp_pitch], same weights as hf_modconv3x3_f16_f32 (the
  * transposed conv's tap flip is in the phase mapping, not in the layout).  Shapes:
@@ -274,7 +284,7 @@ int hf_add_bcast_f32(float *out, const float *a, const float *b, long long n, lo
 int hf_debug_set_dispatch(int same_cfg, int up_cfg);
 /* Which kernel the last modulated-conv call used: 100 * family + tile configuration id,
  * family 1 = general, 2 = pipelined (double-buffered DMA), 3 = split-K (id 0), 5 = fp16 matrix
- * cores (hf_modconv3x3_f16_f32: ids 51-53, 51/52 can be forced through same_cfg;
+ * cores (hf_modconv3x3_f16_f32: ids 51-56, 51/52 can be forced through same_cfg; +20 = pre-split input;
  * hf_modconv3x3_up_f16_f32: ids 61/63).  Tests use
  * it to make sure a shape exercises the path it is meant to; bench.py to label launches. */
 int hf_debug_last_path(void);

@@ -82,6 +82,10 @@ inline void hf_glds4_if(bool a, const float *g, float *l) { ::hipsim::glds_maske
 template <int NYOUNG> inline void hf_barrier_keep_young() { ::hipsim::syncthreads(); }
 inline void hf_barrier_lds() { ::hipsim::syncthreads(); }
 inline void hf_glds16_raw(const float *gsrc_lane, float *lds_wave_base) { ::hipsim::glds16(gsrc_lane, lds_wave_base); }
+inline void hf_glds16_raw_s_if(bool active, const void *g, unsigned off, unsigned lds_addr) {
+  ::hipsim::glds_masked(active, 16, reinterpret_cast<const float *>(static_cast<const char *>(g) + off),
+                        reinterpret_cast<float *>(::hipsim::dyn_lds() + lds_addr));
+}
 inline unsigned hf_lds_addr(const void *p) { return (unsigned)(static_cast<const unsigned char *>(p) - ::hipsim::dyn_lds()); }
 inline void hf_glds16_raw_s(const void *g, unsigned off, unsigned lds_addr) {
   ::hipsim::glds16(reinterpret_cast<const float *>(static_cast<const char *>(g) + off),

@@ -445,13 +445,21 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
     g, shapes, size, _, _ = _gpu_generator("g1024", dev)
     lat, nz, _ = C.generator_inputs(size, 1, 0)
     lat, nz = lat.to(dev), [n.to(dev) for n in nz]
-    fused, plain_rgb = [], []
-    real_conv, real_rgb = M.modconv3x3_f16, M.torgb
+    fused, plain_rgb, presplit = [], [], []
+    real_conv, real_rgb, real_pre = M.modconv3x3_f16, M.torgb, M.modconv3x3_f16_pre
 
     def conv(*a, **k):
         if k.get("rgb") is not None:
             fused.append(a[2].shape[2])
         return real_conv(*a, **k)
+
+    def pre(*a, **k):
+        presplit.append(a[2].shape[2])
+        if k.get("rgb") is not None:
+            fused.append(a[2].shape[2])
+        return real_pre(*a, **k)
+
+    monkeypatch.setattr(M, "modconv3x3_f16_pre", pre)
 
     def rgb(lib, st, x, *a):
         plain_rgb.append(x.shape[1])
@@ -462,6 +470,7 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
     with torch.inference_mode():
         y, _ = g([lat], input_is_latent=True, noise=nz)
         assert fused == [512, 1024]
+        assert presplit == [32, 64, 128, 256, 512, 1024]  # blur -> conv hand-over without an fp32 activation
         assert plain_rgb.count(3) == 2 and len(plain_rgb) == 9  # two finishing passes on 3-channel input
         # a ToRGB asked for a different style must not use the stashed product
         out = g.convs[15](torch.randn(1, 32, 1024, 1024, device=dev), lat[:, 16], noise=nz[16],
@@ -500,3 +509,65 @@ def test_generator1024_other_precision_modes(golden, mode, bar):
     mse_s = float(((_strided(y).cpu().double() - smp) ** 2).mean())
     assert mse_s < bar * max(1.0, float(smp.var())), (mode, mse_s)
     print(f"{mode}: crop mse {mse:.3e}, strided-sample mse {mse_s:.3e}")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 48, 128, 20, 70), (2, 512, 512, 64, 64), (1, 32, 32, 100, 128),
+                                   (9, 32, 64, 16, 32)])
+def test_modconv_f16_presplit_pipeline(shape):
+    """Producer-side split: hf_blur_noise_bias_act_split_f16 -> hf_modconv3x3_f16_pre_f32 equals
+    hf_blur_noise_bias_act_f32 -> hf_modconv3x3_f16_f32 bit for bit (activations by LDS-DMA instead of
+    per-element loads + in-kernel split), repeated launches identical."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib as _lib_fn, stream
+
+    B, cin, cout, H, W = shape  # H, W: resolution of the same-res conv = output of the blur
+    torch.manual_seed(21)
+    dev = _dev()
+    lib, st = _lib_fn(), stream()
+    r = lambda *sz: torch.randn(*sz, device=dev)  # noqa: E731
+    h2, w2 = H // 2, W // 2
+    pitch = lib.hf_modconv_up_pitch(w2)
+    tmp = r(B, cin, 2 * h2 + 1, pitch)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0).to(dev)
+    nz1, nw1, b1 = r(B, 1, 2 * h2, 2 * w2), torch.tensor([0.2], device=dev), r(cin)
+    wgt = r(1, cout, cin, 3, 3)
+    s, dm = torch.rand(B, cin, device=dev) + 0.5, torch.rand(B, cout, device=dev) + 0.5
+    nz2, nw2, b2 = r(B, 1, 2 * h2, 2 * w2), torch.tensor([0.3], device=dev), r(cout)
+    wt, _ = M.prepare_weights(lib, st, wgt)
+    hi, lo = M.split_weights_f16(lib, st, wt)
+    x = torch.empty(B, cin, 2 * h2, 2 * w2, device=dev)
+    M.check(lib, lib.hf_blur_noise_bias_act_f32(x.data_ptr(), tmp.data_ptr(), k4.data_ptr(), nz1.data_ptr(), nw1.data_ptr(),
+                                                4 * h2 * w2, b1.data_ptr(), B, cin, 2 * h2 + 1, 2 * w2 + 1, pitch, 0.2, 2 ** 0.5, st),
+            "blur")
+    xh = torch.empty(B, cin // 8, 2 * h2, 2 * w2, 8, dtype=torch.float16, device=dev)
+    xl = torch.empty_like(xh)
+    M.check(lib, lib.hf_blur_noise_bias_act_split_f16(xh.data_ptr(), xl.data_ptr(), tmp.data_ptr(), k4.data_ptr(), nz1.data_ptr(),
+                                                      nw1.data_ptr(), 4 * h2 * w2, b1.data_ptr(), s.data_ptr(), B, cin, 2 * h2 + 1,
+                                                      2 * w2 + 1, pitch, 0.2, 2 ** 0.5, st), "blur split")
+    eh, el = M.split_activation_reference(x, s)
+    torch.cuda.synchronize()
+    assert torch.equal(xh, eh) and torch.equal(xl, el)
+    ref = M.modconv3x3_f16(lib, st, x, hi, lo, 3, s, dm, nz2, nw2, b2)
+    for _ in range(3):
+        y = M.modconv3x3_f16_pre(lib, st, M.SplitActivation(xh, xl, None), hi, lo, 3, dm, nz2, nw2, b2)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+
+
+def test_generator1024_fast_paths_equal_the_module_by_module_path():
+    """Generator's fused hand-overs (pre-split blur output, ToRGB in the conv epilogue) against the
+    same forward with a forward hook registered (which makes every module run on plain tensors):
+    the conv inputs are bit-identical by construction, so the images are too."""
+    dev = _dev()
+    g, shapes, size, _, _ = _gpu_generator("g1024", dev)
+    lat, nz, _ = C.generator_inputs(size, 2, 0)
+    lat, nz = lat.to(dev), [n.to(dev) for n in nz]
+    with torch.inference_mode():
+        fast, _ = g([lat], input_is_latent=True, noise=nz)
+        seen = []
+        hooks = [m.register_forward_hook(lambda _m, _i, o: seen.append(type(o))) for m in g.convs]
+        slow, _ = g([lat], input_is_latent=True, noise=nz)
+        for h in hooks:
+            h.remove()
+    assert len(seen) == 16 and all(t is torch.Tensor for t in seen)
+    assert torch.equal(fast, slow)

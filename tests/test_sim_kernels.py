@@ -312,3 +312,30 @@ def test_blur_split_output_is_the_split_of_the_fp32_blur(simlib, shape):
     blocked = lambda t: t.reshape(B, C // 8, 8, 2 * h, 2 * w).permute(0, 1, 3, 4, 2).contiguous()  # noqa: E731
     assert torch.equal(hi, blocked(eh))
     assert torch.equal(lo, blocked(el))
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
+@pytest.mark.parametrize("cfg,shape", [(51, (2, 32, 64, 8, 32)), (51, (1, 48, 128, 20, 70)), (52, (1, 48, 64, 20, 40)),
+                                       (53, (1, 16, 32, 16, 64))])
+def test_modconv_f16_presplit_input(simlib, nterms, cfg, shape):
+    """Pre-split, K-blocked activations staged by LDS-DMA (hf_modconv3x3_f16_pre_f32) give the
+    bit-identical result of the kernel that loads fp32 activations and splits them itself:
+    ragged planes (zero-filled halo), odd chunk counts, every tile shape."""
+    B, cin, cout, H, W = shape
+    torch.manual_seed(17)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    s, dm = torch.rand(B, cin) + 0.5, torch.rand(B, cout) + 0.5
+    nz, nw, bias = torch.randn(B, 1, H, W), torch.tensor([0.3]), torch.randn(cout)
+    wt, _ = M.prepare_weights(simlib, None, wgt)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    xh, xl = M.split_activation_reference(x, s)
+    act = M.SplitActivation(xh, xl, None)
+    try:
+        simlib.hf_debug_set_dispatch(cfg if cfg in (51, 52) else 0, 0)
+        ref = M.modconv3x3_f16(simlib, None, x, hi, lo, nterms, s, dm, nz, nw, bias)
+        y = M.modconv3x3_f16_pre(simlib, None, act, hi, lo, nterms, dm, nz, nw, bias)
+        assert simlib.hf_debug_last_path() == 520 + cfg
+    finally:
+        simlib.hf_debug_set_dispatch(0, 0)
+    assert torch.equal(y, ref)

@@ -82,6 +82,20 @@ def main():
                         tmp = torch.empty(B, cout, 2 * r + 1, pitch, device=dev)
                         fn = lambda: L.hf_modconv3x3_up_f32(tmp.data_ptr(), x.data_ptr(), wt.data_ptr(), s.data_ptr(),
                                                             d.data_ptr(), B, cin, cout, r, r, pitch, ws_p, ws_n, stream())
+                    elif c == 400:  # fp16 matrix cores, pre-split K-blocked input (hf_modconv3x3_f16_pre_f32)
+                        if not M.modconv3x3_f16_supported(cin, cout, r, r):
+                            row.append("     -")
+                            continue
+                        hi, lo = M.split_weights_f16(L, stream(), wt)
+                        xh, xl = M.split_activation_reference(x, s)
+                        out = torch.empty(B, cout, r, r, device=dev)
+
+                        def fn():
+                            code = L.hf_modconv3x3_f16_pre_f32(out.data_ptr(), xh.data_ptr(), xl.data_ptr(), hi.data_ptr(),
+                                                               lo.data_ptr(), 3, d.data_ptr(), noise.data_ptr(), nw.data_ptr(), 0,
+                                                               bias.data_ptr(), B, cin, cout, r, r, 0.2, 1.4142135, None, None,
+                                                               None, stream())
+                            assert code == 0, code
                     elif c >= 100:  # fp16 matrix cores (csrc/convh.hip): 1TT = plain f16, 3TT = split operands; TT = tile cfg (00 auto)
                         if not M.modconv3x3_f16_supported(cin, cout, r, r):
                             row.append("     -")
@@ -127,6 +141,13 @@ def main():
                                                 stream()), args.iters) if (out_b := torch.empty(B, c, r, r, device=dev)) is not None else 0
         byts = 4.0 * B * c * ((r + 1) ** 2 + r * r)
         print(f"  blur+noise+act  c={c:4d} out={r:5d}: {t * 1e6:8.1f} us  {byts / t / 1e9:7.0f} GB/s")
+        xh = torch.empty(B, c // 8, r, r, 8, dtype=torch.float16, device=dev)
+        xl = torch.empty_like(xh)
+        sn = torch.rand(B, c, device=dev)
+        t = timeit(lambda: L.hf_blur_noise_bias_act_split_f16(xh.data_ptr(), xl.data_ptr(), tmp.data_ptr(), k4.data_ptr(),
+                                                              noise.data_ptr(), nw.data_ptr(), 0, bias.data_ptr(), sn.data_ptr(),
+                                                              B, c, r + 1, r + 1, pitch, 0.2, 1.4142, stream()), args.iters)
+        print(f"  blur -> split16 c={c:4d} out={r:5d}: {t * 1e6:8.1f} us  {byts / t / 1e9:7.0f} GB/s")
         x = torch.randn(B, c, r, r, device=dev)
         wrgb = torch.randn(1, c, 3, device=dev)
         s = torch.rand(B, c, device=dev)
