@@ -230,13 +230,17 @@ def split_activation_reference(x, s):
     return blk(hi), blk(lo)
 
 
-def modconv3x3_f16_pre(lib, st, act, wt_hi, wt_lo, nterms, d, noise, noise_w, bias, alpha=0.2, scale=SQRT2, rgb=None):
+def modconv3x3_f16_pre(lib, st, act, wt_hi, wt_lo, nterms, d, noise, noise_w, bias, alpha=0.2, scale=SQRT2, rgb=None,
+                       want_out=True):
     """hf_modconv3x3_f16_pre_f32: same-resolution 3x3 conv on the fp16 matrix cores whose input is a
-    SplitActivation (modulation already applied by the producer).  rgb as in modconv3x3_f16."""
+    SplitActivation (modulation already applied by the producer).  rgb as in modconv3x3_f16;
+    want_out=False (with rgb): the activation itself is not written (returns (None, raw))."""
     b, cin, h, w = act.shape
     cout = wt_hi.shape[3]
     noise, nbs = _noise_args(noise, b, h * w)
-    out = torch.empty((b, cout, h, w), dtype=torch.float32, device=act.hi.device)
+    if not want_out and rgb is None:
+        raise ValueError("want_out=False needs the fused ToRGB (rgb=...)")
+    out = torch.empty((b, cout, h, w), dtype=torch.float32, device=act.hi.device) if want_out else None
     noise_w, bias = _c(noise_w), _c(bias)
     raw = rgb_wt = rgb_s = None
     if rgb is not None:

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
             } else {
               float v = acc[0][ct][g][r] * dmv[k];
               if (P.bias) v = apply_act(v + nzv + bsv[k], P.act, P.alpha, P.scale, 0.0f);
-              *reinterpret_cast<float *>(ob0 + off) = v;
+              if (P.out) *reinterpret_cast<float *>(ob0 + off) = v;  // null: only the fused ToRGB consumes it
               acc[0][ct][g][r] = v;  // kept for the fused ToRGB below
             }
           }
@@ -772,8 +772,8 @@ extern "C" int hf_modconv3x3_f16_pre_f32(float *out, const void *x_hi, const voi
                                          const float *noise_w, long long noise_bstride, const float *bias, int batch,
                                          int cin, int cout, int h, int w, float alpha, float scale, float *rgb_raw,
                                          const float *rgb_wt, const float *rgb_s, void *stream) {
-  if (!out || !x_hi || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (noise && !noise_w) ||
-      (nterms != 1 && nterms != 3) || (nterms == 3 && !x_lo))
+  if ((!out && !rgb_raw) || !x_hi || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 ||
+      (noise && !noise_w) || (nterms != 1 && nterms != 3) || (nterms == 3 && !x_lo))
     return HF_E_INVALID;
   if (rgb_raw && (!rgb_wt || !rgb_s || (cout != 32 && cout != 64))) return HF_E_INVALID;
   ConvParams P{};

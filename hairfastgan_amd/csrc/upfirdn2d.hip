@@ -274,7 +274,7 @@ extern "C" int hf_upfirdn2d_f32(float *out, const float *in, const float *kernel
 // and for lo (up to 1 KiB contiguous per wave).
 typedef _Float16 hf_half8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256) void blur4x4_split8(hf_half8 *__restrict__ hi, hf_half8 *__restrict__ lo,
+__global__ __launch_bounds__(512) void blur4x4_split8(hf_half8 *__restrict__ hi, hf_half8 *__restrict__ lo,
                                                       const float *__restrict__ in,
                                                       const float *__restrict__ kernel4x4,
                                                       const float *__restrict__ noise,
@@ -430,11 +430,15 @@ extern "C" int hf_blur_noise_bias_act_split_f16(void *out_hi, void *out_lo, cons
   if (zs > 65535) return HF_E_INVALID;
   const int out_h = in_h - 1, out_w = in_w - 1;
   const int waves = hf_cdiv(out_w, 61);  // 61 output columns per wave
-  int tx = 256;
-  while (tx > 64 && (tx >> 6) >= 2 * waves) tx >>= 1;
+  int wpb = 1, waste = 1 << 30;  // waves per block (<= 8) leaving the fewest idle wave slots
+  for (int k = 8; k >= 1; --k) {
+    const int ws = hf_cdiv(waves, k) * k - waves;
+    if (ws < waste) { waste = ws; wpb = k; }
+  }
+  const int tx = 64 * wpb;
   int rpt = 64;  // rows per thread: 3 warm-up rows per strip
-  while (rpt > 8 && (long long)hf_cdiv(waves, tx >> 6) * hf_cdiv(out_h, rpt) * zs < 2048) rpt >>= 1;
-  dim3 grid(hf_cdiv(waves, tx >> 6), hf_cdiv(out_h, rpt), (unsigned)zs);
+  while (rpt > 8 && (long long)hf_cdiv(waves, wpb) * hf_cdiv(out_h, rpt) * zs * wpb < 8192) rpt >>= 1;
+  dim3 grid(hf_cdiv(waves, wpb), hf_cdiv(out_h, rpt), (unsigned)zs);
   hipLaunchKernelGGL(blur4x4_split8, grid, dim3(tx), 0, (hipStream_t)stream, static_cast<hf_half8 *>(out_hi),
                      static_cast<hf_half8 *>(out_lo), in, kernel4x4, noise, noise_w, noise_bstride, bias, s_next, channels,
                      in_h, in_w, in_pitch, alpha, scale, rpt);

@@ -276,9 +276,11 @@ class StyledConv(nn.Module):  # :309-343
         return conv.conv_up(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
                             act.negative_slope, act.scale, split_for=(None, s_next))
 
-    def forward_from_split(self, split, coeffs, noise=None, rgb=None):
+    def forward_from_split(self, split, coeffs, noise=None, rgb=None, want_out=True):
         """Same-resolution StyledConv on a SplitActivation produced for it (coeffs = this layer's
-        conv.style_coefficients(style), whose s went into the split).  Returns what forward() does."""
+        conv.style_coefficients(style), whose s went into the split).  Returns what forward() does;
+        want_out=False (needs rgb): the activation is not materialised, only its fused ToRGB - the
+        returned tensor is an empty placeholder carrying _hf_fused_rgb."""
         conv = self.conv
         assert not conv.upsample
         _, s, d = coeffs
@@ -294,7 +296,10 @@ class StyledConv(nn.Module):  # :309-343
                                         act.bias.detach(), act.negative_slope, act.scale)
         key, rgb_wt, rgb_s = rgb
         out, raw = M.modconv3x3_f16_pre(lib(), stream(), split, hi, lo, nterms, d, noise, self.noise.weight.detach(),
-                                        act.bias.detach(), act.negative_slope, act.scale, rgb=(rgb_wt, rgb_s))
+                                        act.bias.detach(), act.negative_slope, act.scale, rgb=(rgb_wt, rgb_s),
+                                        want_out=want_out)
+        if out is None:
+            out = raw.new_empty(0)
         out._hf_fused_rgb = (key, raw)
         return out
 
@@ -448,7 +453,9 @@ class Generator(nn.Module):  # :368-565
                     coeffs = conv_same.conv.style_coefficients(latent[:, i + 1])
                     split = conv_up.forward_split(src, latent[:, i], noise[2 * block - 1], coeffs[1])
                     rgb = to_rgb.coefficients(rgb_style) if M.torgb_fusable(cmid, conv_same.conv.out_channel, h2, w2) else None
-                    out = conv_same.forward_from_split(split, coeffs, noise[2 * block], rgb=rgb)
+                    # the last block's activation has no reader besides its (fused) ToRGB: not written
+                    last = block == self.log_size - 2 and rgb is not None and not _observed(to_rgb)
+                    out = conv_same.forward_from_split(split, coeffs, noise[2 * block], rgb=rgb, want_out=not last)
                 else:
                     out = conv_up(src, latent[:, i], noise=noise[2 * block - 1])
                     if conv_same.conv.fuses_torgb(out):  # ToRGB's 1x1 conv in conv_same's epilogue

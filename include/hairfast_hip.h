@@ -139,7 +139,9 @@ int hf_modconv3x3_f16_rgb_f32(float *out, const float *x, const void *wt_hi, con
  * (hf_blur_noise_bias_act_split_f16: x_hi / x_lo = fp16 (hi, lo) of s*x, [batch][cin/8][h][w][8]):
  * the kernel stages weights AND activations by LDS-DMA - no per-element loads, no conversion, and
  * no s argument (already applied).  rgb_raw / rgb_wt / rgb_s as in hf_modconv3x3_f16_rgb_f32, all
- * NULL = no fused ToRGB.  x_lo may be NULL for nterms 1.  Same shapes as hf_modconv3x3_f16_f32. */
+ * NULL = no fused ToRGB.  x_lo may be NULL for nterms 1.  out may be NULL when rgb_raw is given (the
+ * generator's last layer: nothing but its ToRGB reads the activation - 4*cout*H*W bytes not written).
+ * Same shapes as hf_modconv3x3_f16_f32. */
 int hf_modconv3x3_f16_pre_f32(float *out, const void *x_hi, const void *x_lo, const void *wt_hi, const void *wt_lo,
                               int nterms, const float *d, const float *noise, const float *noise_w,
                               long long noise_bstride, const float *bias, int batch, int cin, int cout, int h, int w,
