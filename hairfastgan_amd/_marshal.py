@@ -27,6 +27,7 @@ KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modc
     221: "conv_mfma_pipe<1,2,2,2,up>", 222: "conv_mfma_pipe<1,2,1,4,up>", 223: "conv_mfma_pipe<1,1,2,2,up>",
     224: "conv_mfma_pipe<1,2,2,4,up>", 225: "conv_mfma_pipe<1,1,1,4,up>", 300: "conv_mfma<1,1,2,2> split-K",
     # csrc/convh.hip (fp16 matrix cores; <CT_TILES,PG,WAVES_CO,WAVES_PX>)
+    581: "conv_mfma_h<1,2,2,4,up,pre>", 583: "conv_mfma_h<1,2,1,8,up,pre>",
     571: "conv_mfma_h<1,2,2,4,pre>", 572: "conv_mfma_h<2,2,1,8,pre>", 573: "conv_mfma_h<1,2,1,8,pre>", 575: "conv_mfma_h<1,2,1,8,tw128,pre>",
     551: "conv_mfma_h<1,2,2,4>", 552: "conv_mfma_h<2,2,1,8>", 553: "conv_mfma_h<1,2,1,8>", 555: "conv_mfma_h<1,2,1,8,tw128>",
     561: "conv_mfma_h<1,2,2,4,up>", 563: "conv_mfma_h<1,2,1,8,up>",
@@ -231,28 +232,41 @@ def split_activation_reference(x, s):
 
 
 def modconv3x3_f16_pre(lib, st, act, wt_hi, wt_lo, nterms, d, noise, noise_w, bias, alpha=0.2, scale=SQRT2, rgb=None,
-                       want_out=True):
+                       want_out=True, split_for=None):
     """hf_modconv3x3_f16_pre_f32: same-resolution 3x3 conv on the fp16 matrix cores whose input is a
-    SplitActivation (modulation already applied by the producer).  rgb as in modconv3x3_f16;
-    want_out=False (with rgb): the activation itself is not written (returns (None, raw))."""
+    SplitActivation (modulation already applied by the producer).
+    rgb = (rgb_wt, rgb_s): fused ToRGB raw product (see modconv3x3_f16);
+    split_for = s_next [B,cout]: the epilogue also writes a SplitActivation of s_next*out for the next
+    layer's transposed conv; want_out=False: the fp32 activation itself is not written.
+    Returns out, or (out, raw), (out, split), (out, raw, split) in that order of optional parts."""
     b, cin, h, w = act.shape
     cout = wt_hi.shape[3]
+    dev = act.hi.device
     noise, nbs = _noise_args(noise, b, h * w)
-    if not want_out and rgb is None:
-        raise ValueError("want_out=False needs the fused ToRGB (rgb=...)")
-    out = torch.empty((b, cout, h, w), dtype=torch.float32, device=act.hi.device) if want_out else None
+    if not want_out and rgb is None and split_for is None:
+        raise ValueError("want_out=False needs another consumer (rgb= or split_for=)")
+    out = torch.empty((b, cout, h, w), dtype=torch.float32, device=dev) if want_out else None
     noise_w, bias = _c(noise_w), _c(bias)
-    raw = rgb_wt = rgb_s = None
+    raw = rgb_wt = rgb_s = sh = sl = s_next = None
     if rgb is not None:
         rgb_wt, rgb_s = _c(rgb[0]), _c(rgb[1])
-        raw = torch.empty((b, 3, h, w), dtype=torch.float32, device=act.hi.device)
+        raw = torch.empty((b, 3, h, w), dtype=torch.float32, device=dev)
+    if split_for is not None:
+        s_next = _c(split_for)
+        sh = torch.empty((b, cout // 8, h, w, 8), dtype=torch.float16, device=dev)
+        sl = torch.empty_like(sh)
     code = _launch_profiled(
         lib, 2.0 * cin * cout * 9 * h * w * b,
         lambda: lib.hf_modconv3x3_f16_pre_f32(_p(out), _p(act.hi), _p(act.lo), _p(wt_hi), _p(wt_lo), nterms, _p(d), _p(noise),
                                               _p(noise_w), nbs, _p(bias), b, cin, cout, h, w, alpha, scale, _p(raw),
-                                              _p(rgb_wt), _p(rgb_s), st))
+                                              _p(rgb_wt), _p(rgb_s), _p(sh), _p(sl), _p(s_next), st))
     check(lib, code, "hf_modconv3x3_f16_pre_f32")
-    return out if rgb is None else (out, raw)
+    res = [out]
+    if rgb is not None:
+        res.append(raw)
+    if split_for is not None:
+        res.append(SplitActivation(sh, sl, None))
+    return res[0] if len(res) == 1 else tuple(res)
 
 
 def modconv3x3_up_f16_supported(cin, cout, h, w):
@@ -276,12 +290,21 @@ def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha
     f16 = (wt_hi, wt_lo, nterms): part 1 on the fp16 matrix cores (hf_modconv3x3_up_f16_f32).
     split_for = (key, s_next [B,cout]): part 2 writes a SplitActivation for the conv whose modulation
     is s_next instead of the fp32 tensor (hf_blur_noise_bias_act_split_f16)."""
-    x = _c(x)
+    pre = isinstance(x, SplitActivation)
+    if not pre:
+        x = _c(x)
     b, cin, h, w = x.shape
     cout = wt.shape[2]
     pitch = lib.hf_modconv_up_pitch(w)  # rows padded to a multiple of 4 floats (aligned 16 B loads in the blur)
-    tmp = x.new_empty((b, cout, 2 * h + 1, pitch))
-    if f16 is not None:
+    tmp = torch.empty((b, cout, 2 * h + 1, pitch), dtype=torch.float32, device=(x.hi if pre else x).device)
+    if pre:  # pre-split input (modulation already applied by the producer): hf_modconv3x3_up_f16_pre_f32
+        hi, lo, nterms = f16
+        code = _launch_profiled(
+            lib, 2.0 * cin * cout * 9 * h * w * b,
+            lambda: lib.hf_modconv3x3_up_f16_pre_f32(_p(tmp), _p(x.hi), _p(x.lo), _p(hi), _p(lo), nterms, _p(d), b, cin, cout,
+                                                     h, w, pitch, st))
+        check(lib, code, "hf_modconv3x3_up_f16_pre_f32")
+    elif f16 is not None:
         hi, lo, nterms = f16
         code = _launch_profiled(
             lib, 2.0 * cin * cout * 9 * h * w * b,
@@ -298,14 +321,14 @@ def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha
     noise, nbs = _noise_args(noise, b, 4 * h * w)
     if split_for is not None:
         key, s_next = split_for
-        hi = torch.empty((b, cout // 8, 2 * h, 2 * w, 8), dtype=torch.float16, device=x.device)
+        hi = torch.empty((b, cout // 8, 2 * h, 2 * w, 8), dtype=torch.float16, device=tmp.device)
         lo = torch.empty_like(hi)
         check(lib, lib.hf_blur_noise_bias_act_split_f16(_p(hi), _p(lo), _p(tmp), _p(_c(blur_kernel)), _p(noise),
                                                         _p(_c(noise_w)), nbs, _p(_c(bias)), _p(_c(s_next)), b, cout,
                                                         2 * h + 1, 2 * w + 1, pitch, alpha, scale, st),
               "hf_blur_noise_bias_act_split_f16")
         return SplitActivation(hi, lo, key)
-    out = x.new_empty((b, cout, 2 * h, 2 * w))
+    out = tmp.new_empty((b, cout, 2 * h, 2 * w))
     check(lib, lib.hf_blur_noise_bias_act_f32(_p(out), _p(tmp), _p(_c(blur_kernel)), _p(noise), _p(_c(noise_w)),
                                               nbs, _p(_c(bias)), b, cout, 2 * h + 1, 2 * w + 1, pitch, alpha, scale,
                                               st), "hf_blur_noise_bias_act_f32")

@@ -67,6 +67,10 @@ struct ConvParams {
   // convh.hip, pre-split input: s*x already split into fp16 (hi, lo) and K-blocked
   // [batch][cin/8][h][w][8] by the producer (hf_blur_noise_bias_act_split_f16); x and s unused
   const void *xh, *xl;
+  // convh.hip, split output (same-resolution epilogue): s_next[b][co] * out also written as fp16
+  // (hi, lo), K-blocked [batch][cout/8][h][w][8], for a consumer that takes pre-split input
+  void *oh, *ol;
+  const float *s_next;
   int n_tiles;                 // convh.hip: tiles over all families; a block walks blockIdx.x + k*gridDim.x
   TileGeom g[3];
 };

@@ -115,12 +115,13 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   const int iplane = (int)plane;
   const int nchunks = P.cin / KH;
   float *sl_base = reinterpret_cast<float *>(lds + 2 * BUF_UNITS);  // [2][cin]: s of the current / next image
-  // epilogue parameters of the block's CT output channels, per image slot: [2][2][CT] = d, bias.
+  // epilogue parameters of the block's CT output channels, per image slot: [2][3][CT] = d, bias,
+  // s_next (modulation of the consumer, split output only).
   // In LDS so that the epilogue issues NO vector-memory loads: on gfx9 loads and stores share
   // vmcnt, every load that follows a store waits for that store's acknowledgement (measured:
   // the epilogue's second pixel group waited ~12k cycles behind the first group's stores).
   float *ep_base = sl_base + 2 * ((P.cin + 3) & ~3);
-  float *rgbw_base = ep_base + 2 * 2 * CT;  // fused ToRGB: [2 slots][3][CT] = rgb_w[co][c] * rgb_s[b][co]
+  float *rgbw_base = ep_base + 2 * 3 * CT;  // fused ToRGB: [2 slots][3][CT] = rgb_w[co][c] * rgb_s[b][co]
 
   // ---- tiles: the block walks tiles blockIdx.x, +gridDim.x, ... of its cout tile as ONE
   // pipeline - the first stage of the next tile is prefetched during the last stage of the
@@ -176,10 +177,11 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     float *dst = sl_base + slot * P.cin;
     if (MOD)
       for (int i = tid; i < P.cin; i += NT) dst[i] = P.s[(long long)b * P.s_bstride + i];
-    float *ep = ep_base + slot * 2 * CT;
+    float *ep = ep_base + slot * 3 * CT;
     for (int i = tid; i < CT; i += NT) {
       ep[i] = P.d ? P.d[(long long)b * P.d_bstride + co0 + i] : 1.0f;
       ep[CT + i] = P.bias ? P.bias[co0 + i] : 0.0f;
+      ep[2 * CT + i] = (!UP && P.oh && P.s_next) ? P.s_next[(long long)b * P.cout + co0 + i] : 1.0f;
     }
     if (!UP && P.rgb_out) {
       float *rw = rgbw_base + slot * 3 * CT;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     HF_OPAQUE_I32(li_o);
     HF_OPAQUE_I32(lh_o);
     const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
-    const float *ep = ep_base + slot * 2 * CT;
+    const float *ep = ep_base + slot * 3 * CT;
     // uniform base of the block's CT output planes of this image + 32-bit per-lane byte offsets
     // (the launcher checks CT * plane bytes < 4 GiB): one add per store instead of 64-bit math
     const unsigned oplane4 = (unsigned)(P.out_h * P.out_w) * 4u;
@@ -371,8 +373,28 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
               float v = acc[0][ct][g][r] * dmv[k];
               if (P.bias) v = apply_act(v + nzv + bsv[k], P.act, P.alpha, P.scale, 0.0f);
               if (P.out) *reinterpret_cast<float *>(ob0 + off) = v;  // null: only the fused ToRGB consumes it
-              acc[0][ct][g][r] = v;  // kept for the fused ToRGB below
+              acc[0][ct][g][r] = v;  // kept for the fused ToRGB / split output below
             }
+          }
+          if (!UP && P.oh) {
+            // split output for a pre-split consumer: the lane's 4 channels are one half (lh) of the
+            // 16-byte unit of pixel (Y, X), channel block (co0 + c4) / 8: two 8-byte stores; the two
+            // half-waves together write 512 contiguous bytes per 32 pixels
+            const float4 sn = *reinterpret_cast<const float4 *>(ep + 2 * CT + c4);
+            const float snv[4] = {sn.x, sn.y, sn.z, sn.w};
+            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+            half4 h4, l4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float v = acc[0][ct][g][4 * q + k] * snv[k];
+              HF_OPAQUE_F32(v);
+              const _Float16 hv = (_Float16)v;
+              h4[k] = hv;
+              l4[k] = (_Float16)(v - (float)hv);
+            }
+            const long long unit = (((long long)T.b0 * (P.cout >> 3) + ((co0 + c4) >> 3)) * P.out_h + Y) * P.out_w + X;
+            *reinterpret_cast<half4 *>(static_cast<char *>(P.oh) + unit * 16 + ((co0 + c4) & 4) * 2) = h4;
+            if (P.ol) *reinterpret_cast<half4 *>(static_cast<char *>(P.ol) + unit * 16 + ((co0 + c4) & 4) * 2) = l4;
           }
         }
       }  // pv
@@ -475,7 +497,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT + ct*32
       const half8 *b_hi = buf + OFF_XH + lh * NPIX;      // + pixrow + tap column
       // fragments of tap+1 are fetched from LDS while the MFMAs of tap run
-      constexpr int NSLOT = UP ? 1 : 2;  // UP: 128 accumulator registers leave no room for a second set
+      // UP with in-kernel staging: 128 accumulator registers + the staging registers leave no room
+      // for a second fragment set
+      constexpr int NSLOT = (UP && !PRE) ? 1 : 2;
       half8 ah[NSLOT][CT_TILES], al[NSLOT][CT_TILES], bh[NSLOT][PG], bl[NSLOT][PG];
       auto fetch = [&](int slot, int tap) {
         const int ky = tap / 3, kx = tap % 3;
@@ -494,8 +518,8 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       fetch(0, 0);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int sl_ = UP ? 0 : (tap & 1);
-        if (UP) {
+        const int sl_ = (NSLOT == 1) ? 0 : (tap & 1);
+        if (NSLOT == 1) {
           if (tap > 0) fetch(0, tap);
         } else if (tap + 1 < 9) {
           fetch(sl_ ^ 1, tap + 1);
@@ -610,8 +634,8 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
     if (geom_xs(P.g[i], 1, UP ? 1 : 2) > NPIX) return HF_E_INVALID;
   }
   const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float) +
-                     2 * 2 * CT * sizeof(float) + (P.rgb_out ? 2 * 3 * CT * sizeof(float) : 0);
-  // stages + s[2][cin] + epilogue d/bias [2][2][CT] (+ fused ToRGB weights [2][3][CT])
+                     2 * 3 * CT * sizeof(float) + (P.rgb_out ? 2 * 3 * CT * sizeof(float) : 0);
+  // stages + s[2][cin] + epilogue d/bias/s_next [2][3][CT] (+ fused ToRGB weights [2][3][CT])
   if (P.rgb_out && (UP || WAVES_CO != 1 || P.cout != CT || !P.rgb_w || !P.rgb_s)) return HF_E_INVALID;
   if (lds > 160 * 1024) return HF_E_INVALID;
   P.n_tiles = nblocks;
@@ -654,6 +678,12 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
     // 61: 64 co x 256 positions x 4 phases, 2 co-waves x 4 pixel-waves, 1x2 MFMA tiles per phase
     // 63: 32 co x 512 positions x 4 phases, 8 pixel-waves (cout % 64 != 0: the 1024^2 layer)
     cfg = (P.cout % 64) ? 63 : 61;
+    if (P.xh) {  // pre-split activations (ids 8x)
+      if (cfg == 63) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, true, 32, true>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, true, 32, true>(P, h, l, st);
+      else rc = (nterms == 3) ? launch_h<3, 1, 2, 2, 4, true, 32, true>(P, h, l, st) : launch_h<1, 1, 2, 2, 4, true, 32, true>(P, h, l, st);
+      if (rc == HF_OK) note_path(5, cfg + 20);
+      return rc;
+    }
     if (cfg == 63) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, true>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, true>(P, h, l, st);
     else rc = (nterms == 3) ? launch_h<3, 1, 2, 2, 4, true>(P, h, l, st) : launch_h<1, 1, 2, 2, 4, true>(P, h, l, st);
     if (rc == HF_OK) note_path(5, cfg);
@@ -771,8 +801,9 @@ extern "C" int hf_modconv3x3_f16_pre_f32(float *out, const void *x_hi, const voi
                                          const void *wt_lo, int nterms, const float *d, const float *noise,
                                          const float *noise_w, long long noise_bstride, const float *bias, int batch,
                                          int cin, int cout, int h, int w, float alpha, float scale, float *rgb_raw,
-                                         const float *rgb_wt, const float *rgb_s, void *stream) {
-  if ((!out && !rgb_raw) || !x_hi || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 ||
+                                         const float *rgb_wt, const float *rgb_s, void *split_hi, void *split_lo,
+                                         const float *s_next, void *stream) {
+  if ((!out && !rgb_raw && !split_hi) || !x_hi || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 ||
       (noise && !noise_w) || (nterms != 1 && nterms != 3) || (nterms == 3 && !x_lo))
     return HF_E_INVALID;
   if (rgb_raw && (!rgb_wt || !rgb_s || (cout != 32 && cout != 64))) return HF_E_INVALID;
@@ -786,5 +817,23 @@ extern "C" int hf_modconv3x3_f16_pre_f32(float *out, const void *x_hi, const voi
   P.act = bias ? ACT_LRELU : ACT_NONE;
   P.alpha = alpha; P.scale = scale;
   P.rgb_out = rgb_raw; P.rgb_w = rgb_wt; P.rgb_s = rgb_s;
+  P.oh = split_hi; P.ol = split_lo; P.s_next = s_next;
+  if (split_hi && ((cout & 7) || (nterms == 3 && !split_lo))) return HF_E_INVALID;
   return launch_conv_h(P, nterms, false, wt_hi, wt_lo, (hipStream_t)stream);
+}
+
+extern "C" int hf_modconv3x3_up_f16_pre_f32(float *tmp, const void *x_hi, const void *x_lo, const void *wt_hi,
+                                            const void *wt_lo, int nterms, const float *d, int batch, int cin, int cout,
+                                            int h, int w, int tmp_pitch, void *stream) {
+  if (!tmp || !x_hi || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || tmp_pitch < 2 * w + 1 ||
+      (nterms != 1 && nterms != 3) || (nterms == 3 && !x_lo))
+    return HF_E_INVALID;
+  ConvParams P{};
+  P.out = tmp; P.xh = x_hi; P.xl = x_lo; P.d = d;
+  P.s_bstride = cin; P.d_bstride = cout;
+  P.groups = 1;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = 2 * h + 1; P.out_w = tmp_pitch;
+  P.out_wv = 2 * w + 1;
+  P.stride = 1;
+  return launch_conv_h(P, nterms, true, wt_hi, wt_lo, (hipStream_t)stream);
 }

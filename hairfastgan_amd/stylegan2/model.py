@@ -265,22 +265,24 @@ class StyledConv(nn.Module):  # :309-343
         """The upsampling StyledConv whose only consumer is the next same-resolution StyledConv:
         returns s_next * output already split into fp16 (hi, lo) and K-blocked (M.SplitActivation)
         instead of the fp32 tensor; same arithmetic as forward()."""
-        require_gpu(input, style, noise)
+        pre = isinstance(input, M.SplitActivation)  # its own input may come pre-split from the layer below
+        require_gpu(None if pre else input, style, noise)
         conv = self.conv
         assert conv.upsample
         wt, s, d = conv.style_coefficients(style)
         b, _, h, w = input.shape
         if noise is None:
-            noise = input.new_empty(b, 1, 2 * h, 2 * w).normal_()
+            noise = style.new_empty(b, 1, 2 * h, 2 * w).normal_()
         act = self.activate
         return conv.conv_up(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
                             act.negative_slope, act.scale, split_for=(None, s_next))
 
-    def forward_from_split(self, split, coeffs, noise=None, rgb=None, want_out=True):
+    def forward_from_split(self, split, coeffs, noise=None, rgb=None, want_out=True, split_for=None):
         """Same-resolution StyledConv on a SplitActivation produced for it (coeffs = this layer's
-        conv.style_coefficients(style), whose s went into the split).  Returns what forward() does;
-        want_out=False (needs rgb): the activation is not materialised, only its fused ToRGB - the
-        returned tensor is an empty placeholder carrying _hf_fused_rgb."""
+        conv.style_coefficients(style), whose s went into the split).  Returns (out, next_split):
+        out is what forward() returns - or, with want_out=False, an empty placeholder carrying
+        _hf_fused_rgb when nobody reads the fp32 activation; next_split (split_for = the next
+        layer's modulation) is the SplitActivation for the transposed conv above, else None."""
         conv = self.conv
         assert not conv.upsample
         _, s, d = coeffs
@@ -291,17 +293,18 @@ class StyledConv(nn.Module):  # :309-343
         act = self.activate
         hi, lo = conv.prepared_f16()
         nterms = 3 if conv_precision() == "f16x3" else 1
-        if rgb is None:
-            return M.modconv3x3_f16_pre(lib(), stream(), split, hi, lo, nterms, d, noise, self.noise.weight.detach(),
-                                        act.bias.detach(), act.negative_slope, act.scale)
-        key, rgb_wt, rgb_s = rgb
-        out, raw = M.modconv3x3_f16_pre(lib(), stream(), split, hi, lo, nterms, d, noise, self.noise.weight.detach(),
-                                        act.bias.detach(), act.negative_slope, act.scale, rgb=(rgb_wt, rgb_s),
-                                        want_out=want_out)
+        res = M.modconv3x3_f16_pre(lib(), stream(), split, hi, lo, nterms, d, noise, self.noise.weight.detach(),
+                                   act.bias.detach(), act.negative_slope, act.scale,
+                                   rgb=None if rgb is None else (rgb[1], rgb[2]), want_out=want_out, split_for=split_for)
+        res = list(res) if isinstance(res, tuple) else [res]
+        out = res.pop(0)
+        raw = res.pop(0) if rgb is not None else None
+        nxt = res.pop(0) if split_for is not None else None
         if out is None:
-            out = raw.new_empty(0)
-        out._hf_fused_rgb = (key, raw)
-        return out
+            out = (raw if raw is not None else nxt.hi).new_empty(0, dtype=torch.float32)
+        if rgb is not None:
+            out._hf_fused_rgb = (rgb[0], raw)
+        return out, nxt
 
 
 def _observed(*modules):
@@ -435,6 +438,7 @@ class Generator(nn.Module):  # :368-565
         if end_layer == 0:
             return out, skip
         i = 1
+        split_in = None  # SplitActivation of `out` for the next block's transposed conv (fast path)
         for block in range(1, self.log_size - 1):
             conv_up, conv_same, to_rgb = self.convs[2 * block - 2], self.convs[2 * block - 1], self.to_rgbs[block - 1]
             if block < start_layer:
@@ -443,20 +447,40 @@ class Generator(nn.Module):  # :368-565
                 return out, skip
             else:
                 src = layer_in if block == start_layer else out
+                if split_in is not None and block != start_layer:
+                    src = split_in  # the fp32 `out` may not even exist (see want_out below)
                 rgb_style = latent[:, i + 2]
-                _, cmid, h2, w2 = src.shape[0], conv_up.conv.out_channel, 2 * src.shape[2], 2 * src.shape[3]
-                if (conv_precision() != "f32" and cmid % 16 == 0
-                        and M.modconv3x3_f16_supported(cmid, conv_same.conv.out_channel, h2, w2)
+                cmid, csame = conv_up.conv.out_channel, conv_same.conv.out_channel
+                h2, w2 = 2 * src.shape[2], 2 * src.shape[3]
+                fast_mode = conv_precision() != "f32"
+                if (fast_mode and cmid % 16 == 0 and M.modconv3x3_f16_supported(cmid, csame, h2, w2)
                         and not _observed(conv_up, conv_same)):
-                    # fast path: conv_up's blur pass hands conv_same its input pre-modulated, split into
-                    # fp16 pairs and K-blocked - no fp32 activation is written or read in between
+                    # fast path: activations travel between the convs pre-modulated, split into fp16
+                    # pairs and K-blocked (M.SplitActivation) - conv_up's blur pass writes conv_same's
+                    # input, conv_same's epilogue writes the next block's conv_up input; an fp32
+                    # activation is only materialised where something else reads it
                     coeffs = conv_same.conv.style_coefficients(latent[:, i + 1])
                     split = conv_up.forward_split(src, latent[:, i], noise[2 * block - 1], coeffs[1])
-                    rgb = to_rgb.coefficients(rgb_style) if M.torgb_fusable(cmid, conv_same.conv.out_channel, h2, w2) else None
-                    # the last block's activation has no reader besides its (fused) ToRGB: not written
-                    last = block == self.log_size - 2 and rgb is not None and not _observed(to_rgb)
-                    out = conv_same.forward_from_split(split, coeffs, noise[2 * block], rgb=rgb, want_out=not last)
+                    rgb = to_rgb.coefficients(rgb_style) if M.torgb_fusable(cmid, csame, h2, w2) else None
+                    nb = block + 1
+                    is_last = block == self.log_size - 2
+                    s_up = None
+                    if not is_last and nb <= end_layer:
+                        nup, nsame = self.convs[2 * nb - 2], self.convs[2 * nb - 1]
+                        if (csame % 16 == 0 and M.modconv3x3_up_f16_supported(csame, nup.conv.out_channel, h2, w2)
+                                and nup.conv.out_channel % 16 == 0
+                                and M.modconv3x3_f16_supported(nup.conv.out_channel, nsame.conv.out_channel, 2 * h2, 2 * w2)
+                                and not _observed(nup, nsame)):
+                            s_up = nup.conv.style_coefficients(latent[:, i + 2])[1]
+                    fused_rgb = rgb is not None and not _observed(to_rgb)
+                    # fp32 activation: read by a stand-alone ToRGB, returned on an early exit, or fed
+                    # to the next block as a plain tensor
+                    want_out = not fused_rgb or (not is_last and s_up is None)
+                    out, split_in = conv_same.forward_from_split(split, coeffs, noise[2 * block], rgb=rgb,
+                                                                 want_out=want_out, split_for=s_up)
                 else:
+                    assert not isinstance(src, M.SplitActivation)  # a split is only produced for a fast block
+                    split_in = None
                     out = conv_up(src, latent[:, i], noise=noise[2 * block - 1])
                     if conv_same.conv.fuses_torgb(out):  # ToRGB's 1x1 conv in conv_same's epilogue
                         out = conv_same(out, latent[:, i + 1], noise=noise[2 * block], rgb=to_rgb.coefficients(rgb_style))

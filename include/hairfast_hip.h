@@ -146,7 +146,15 @@ int hf_modconv3x3_f16_pre_f32(float *out, const void *x_hi, const void *x_lo, co
                               int nterms, const float *d, const float *noise, const float *noise_w,
                               long long noise_bstride, const float *bias, int batch, int cin, int cout, int h, int w,
                               float alpha, float scale, float *rgb_raw, const float *rgb_wt, const float *rgb_s,
-                              void *stream);
+                              void *split_hi, void *split_lo, const float *s_next, void *stream);
+/* split_hi / split_lo (NULL = off): the epilogue ALSO writes s_next[b,co] * out as fp16 (hi, lo) pairs,
+ * K-blocked [batch][cout/8][h][w][8] - the pre-split input of the next layer's transposed conv
+ * (hf_modconv3x3_up_f16_pre_f32); out may then be NULL too if nobody reads the fp32 activation.
+ *
+ * hf_modconv3x3_up_f16_f32 on pre-split input (x_hi / x_lo of s*x from the call above). */
+int hf_modconv3x3_up_f16_pre_f32(float *tmp, const void *x_hi, const void *x_lo, const void *wt_hi, const void *wt_lo,
+                                 int nterms, const float *d, int batch, int cin, int cout, int h, int w, int tmp_pitch,
+                                 void *stream);
 /* Part 1 of the upsampling StyledConv (hf_modconv3x3_up_f32) on the fp16 matrix cores: same
  * intermediate [batch, cout, 2h+1, tmp_pitch], same weights as hf_modconv3x3_f16_f32 (the
  * transposed conv's tap flip is in the phase mapping, not in the layout).  Shapes:
@@ -287,7 +295,7 @@ int hf_debug_set_dispatch(int same_cfg, int up_cfg);
 /* Which kernel the last modulated-conv call used: 100 * family + tile configuration id,
  * family 1 = general, 2 = pipelined (double-buffered DMA), 3 = split-K (id 0), 5 = fp16 matrix
  * cores (hf_modconv3x3_f16_f32: ids 51-56, 51/52 can be forced through same_cfg; +20 = pre-split input;
- * hf_modconv3x3_up_f16_f32: ids 61/63).  Tests use
+ * hf_modconv3x3_up_f16_f32: ids 61/63, +20 = pre-split input).  Tests use
  * it to make sure a shape exercises the path it is meant to; bench.py to label launches. */
 int hf_debug_last_path(void);
 /* The fp16 matrix-core kernels launch one resident block per CU and let it walk several tiles

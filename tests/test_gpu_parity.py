@@ -460,6 +460,14 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
         return real_pre(*a, **k)
 
     monkeypatch.setattr(M, "modconv3x3_f16_pre", pre)
+    up_pre, real_up = [], M.modconv3x3_up
+
+    def up(lib, st, x, *a, **k):
+        if isinstance(x, M.SplitActivation):
+            up_pre.append(x.shape[2])
+        return real_up(lib, st, x, *a, **k)
+
+    monkeypatch.setattr(M, "modconv3x3_up", up)
 
     def rgb(lib, st, x, *a):
         plain_rgb.append(x.shape[1])
@@ -471,6 +479,7 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
         y, _ = g([lat], input_is_latent=True, noise=nz)
         assert fused == [512, 1024]
         assert presplit == [32, 64, 128, 256, 512, 1024]  # blur -> conv hand-over without an fp32 activation
+        assert up_pre == [32, 64, 128, 256, 512]  # conv epilogue -> next block's transposed conv, pre-split
         assert plain_rgb.count(3) == 2 and len(plain_rgb) == 9  # two finishing passes on 3-channel input
         # a ToRGB asked for a different style must not use the stashed product
         out = g.convs[15](torch.randn(1, 32, 1024, 1024, device=dev), lat[:, 16], noise=nz[16],

@@ -339,3 +339,35 @@ def test_modconv_f16_presplit_input(simlib, nterms, cfg, shape):
     finally:
         simlib.hf_debug_set_dispatch(0, 0)
     assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 8, 32), (1, 32, 32, 16, 32), (2, 64, 32, 20, 40)])
+def test_presplit_chain_same_res_to_transposed(simlib, shape):
+    """Split output of the same-resolution epilogue (hf_modconv3x3_f16_pre_f32 split_hi/lo) is the
+    split of s_next * out bit for bit, and the transposed conv on it (hf_modconv3x3_up_f16_pre_f32,
+    incl. rim tiles) equals the transposed conv that loads the fp32 activation."""
+    B, cin, cup, H, W = shape
+    torch.manual_seed(23)
+    x = torch.randn(B, cin, H, W)
+    w1, w2 = torch.randn(1, cin, cin, 3, 3), torch.randn(1, cup, cin, 3, 3)
+    s1, d1 = torch.rand(B, cin) + 0.5, torch.rand(B, cin) + 0.5
+    s2, d2 = torch.rand(B, cin) + 0.5, torch.rand(B, cup) + 0.5
+    nz, nw, bias = torch.randn(B, 1, H, W), torch.tensor([0.3]), torch.randn(cin)
+    wt1, _ = M.prepare_weights(simlib, None, w1)
+    wt2, _ = M.prepare_weights(simlib, None, w2)
+    h1 = M.split_weights_f16(simlib, None, wt1)
+    h2 = M.split_weights_f16(simlib, None, wt2)
+    act = M.SplitActivation(*M.split_activation_reference(x, s1), None)
+    if not M.modconv3x3_f16_supported(cin, cin, H, W):
+        pytest.skip("shape not taken by the same-resolution fp16 kernel")
+    out, nxt = M.modconv3x3_f16_pre(simlib, None, act, h1[0], h1[1], 3, d1, nz, nw, bias, split_for=s2)
+    eh, el = M.split_activation_reference(out, s2)
+    assert torch.equal(nxt.hi, eh) and torch.equal(nxt.lo, el)
+    only_split = M.modconv3x3_f16_pre(simlib, None, act, h1[0], h1[1], 3, d1, nz, nw, bias, split_for=s2, want_out=False)
+    assert only_split[0] is None and torch.equal(only_split[1].hi, eh)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0)
+    nz2, b2 = torch.randn(B, 1, 2 * H, 2 * W), torch.randn(cup)
+    ref = M.modconv3x3_up(simlib, None, out, wt2, s2, d2, k4, nz2, nw, b2, f16=(h2[0], h2[1], 3))
+    y = M.modconv3x3_up(simlib, None, nxt, wt2, None, d2, k4, nz2, nw, b2, f16=(h2[0], h2[1], 3))
+    assert simlib.hf_debug_last_path() in (581, 583)
+    assert torch.equal(y, ref)
