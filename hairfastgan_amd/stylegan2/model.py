@@ -261,7 +261,7 @@ class StyledConv(nn.Module):  # :309-343
         return out
 
     # -- producer -> consumer hand-over without an fp32 round trip (Generator's fast path) --------
-    def forward_split(self, input, style, noise, s_next):
+    def forward_split(self, input, style, noise, s_next, coeffs=None):
         """The upsampling StyledConv whose only consumer is the next same-resolution StyledConv:
         returns s_next * output already split into fp16 (hi, lo) and K-blocked (M.SplitActivation)
         instead of the fp32 tensor; same arithmetic as forward()."""
@@ -269,7 +269,7 @@ class StyledConv(nn.Module):  # :309-343
         require_gpu(None if pre else input, style, noise)
         conv = self.conv
         assert conv.upsample
-        wt, s, d = conv.style_coefficients(style)
+        wt, s, d = conv.style_coefficients(style) if coeffs is None else coeffs  # coeffs: computed by the caller already
         b, _, h, w = input.shape
         if noise is None:
             noise = style.new_empty(b, 1, 2 * h, 2 * w).normal_()
@@ -438,7 +438,7 @@ class Generator(nn.Module):  # :368-565
         if end_layer == 0:
             return out, skip
         i = 1
-        split_in = None  # SplitActivation of `out` for the next block's transposed conv (fast path)
+        split_in = up_coeffs = None  # SplitActivation of `out` for the next block's transposed conv (fast path)
         for block in range(1, self.log_size - 1):
             conv_up, conv_same, to_rgb = self.convs[2 * block - 2], self.convs[2 * block - 1], self.to_rgbs[block - 1]
             if block < start_layer:
@@ -460,7 +460,8 @@ class Generator(nn.Module):  # :368-565
                     # input, conv_same's epilogue writes the next block's conv_up input; an fp32
                     # activation is only materialised where something else reads it
                     coeffs = conv_same.conv.style_coefficients(latent[:, i + 1])
-                    split = conv_up.forward_split(src, latent[:, i], noise[2 * block - 1], coeffs[1])
+                    split = conv_up.forward_split(src, latent[:, i], noise[2 * block - 1], coeffs[1],
+                                                  coeffs=up_coeffs if isinstance(src, M.SplitActivation) else None)
                     rgb = to_rgb.coefficients(rgb_style) if M.torgb_fusable(cmid, csame, h2, w2) else None
                     nb = block + 1
                     is_last = block == self.log_size - 2
@@ -471,7 +472,8 @@ class Generator(nn.Module):  # :368-565
                                 and nup.conv.out_channel % 16 == 0
                                 and M.modconv3x3_f16_supported(nup.conv.out_channel, nsame.conv.out_channel, 2 * h2, 2 * w2)
                                 and not _observed(nup, nsame)):
-                            s_up = nup.conv.style_coefficients(latent[:, i + 2])[1]
+                            up_coeffs = nup.conv.style_coefficients(latent[:, i + 2])
+                            s_up = up_coeffs[1]
                     fused_rgb = rgb is not None and not _observed(to_rgb)
                     # fp32 activation: read by a stand-alone ToRGB, returned on an early exit, or fed
                     # to the next block as a plain tensor

@@ -11,10 +11,13 @@ import sys
 
 
 def label(name):
-    m = re.search(r"conv_mfma_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d+)E", name)
+    m = re.search(r"conv_mfma_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d+)ELb(\d)E", name)
     if m:
-        nt, ct, pg, wc, wp, mod, up, tw = (int(v) for v in m.groups())
-        return f"conv_mfma_h<{ct},{pg},{wc},{wp}{',up' if up else ''}{',tw%d' % tw if tw > 32 else ''}>"
+        nt, ct, pg, wc, wp, mod, up, tw, pre = (int(v) for v in m.groups())
+        return (f"conv_mfma_h<{ct},{pg},{wc},{wp}{',tw%d' % tw if tw > 32 else ''}{',up' if up else ''}"
+                f"{',pre' if pre else ''}>")
+    if "blur4x4_split8" in name:
+        return "blur4x4_split8"
     name = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     m = re.match(r"(conv_mfma\w*)<(.*)>", name)
     if not m:

@@ -4,10 +4,20 @@ committed under profiles/.  Usage: tools/summarize_prof.py <tag> <stats_dir> [fe
 import collections
 import csv
 import os
+import re
 import sys
 
 
 def short(name):
+    m = re.search(r"conv_mfma_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d+)ELb(\d)E", name)
+    if m:  # anonymous-namespace templates come out mangled
+        nt, ct, pg, wc, wp, mod, up, tw, pre = (int(v) for v in m.groups())
+        return (f"conv_mfma_h<NTERMS={nt},{ct},{pg},{wc},{wp}{',tw%d' % tw if tw > 32 else ''}{',up' if up else ''}"
+                f"{',pre' if pre else ''}>")
+    if "blur4x4_split8" in name:
+        return "blur4x4_split8"
+    if "split_weights" in name:
+        return "split_weights"
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     return name.split("(")[0][:60]
 
