@@ -25,6 +25,7 @@ SIGNATURES = {
     "hf_noise_bias_act_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _ll, _fl, _fl, _st],
     "hf_modconv_prepare_f32": [_f, _f, _f, _i, _i, _i, _st],
     "hf_modulation_f32": [_f, _f, _ll, _f, _f, _i, _i, _i, _st],
+    "hf_style_batch_f32": [_f, _f, _ll, _ll, _f, _i, _i, _i, _i, _i, _st],
     "hf_demod_f32": [_f, _f, _f, _i, _i, _i, _st],
     "hf_modconv3x3_f32": [_f, _f, _f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _f, _ll, _st],
     "hf_conv_split_weights_f16": [_f, _f, _f, _i, _i, _st],

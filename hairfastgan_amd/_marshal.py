@@ -137,6 +137,44 @@ def modulation(lib, st, style, mod_w, mod_b):
     return s
 
 
+def style_job_table(convs, rows, batch, device):
+    """Device job table (hf_style_job records, 7 int64 = 56 bytes each) + output layout for hf_style_batch_f32.
+    convs: ModulatedConv2d-like objects with .modulation.weight/.bias, .in_channel, .out_channel,
+    .demodulate and .prepared(); rows: latent row of each.  Offsets depend on the batch size."""
+    recs, layout, ofs = [], [], 0
+    for conv, row in zip(convs, rows):
+        _, wsq = conv.prepared()
+        cin, cout = conv.in_channel, conv.out_channel
+        s_ofs = ofs
+        ofs += batch * cin
+        d_ofs = -1
+        if conv.demodulate:
+            d_ofs = ofs
+            ofs += batch * cout
+        mw, mb = conv.modulation.weight.detach(), conv.modulation.bias.detach()
+        recs.append([mw.data_ptr(), mb.data_ptr(), wsq.data_ptr() if conv.demodulate else 0, cin | (cout << 32), row,
+                     s_ofs, max(d_ofs, 0)])
+        layout.append((s_ofs, cin, d_ofs, cout))
+    table = torch.tensor(recs, dtype=torch.int64).to(device)
+    return table, layout, ofs
+
+
+def style_batch(lib, st, latent, table, layout, total, max_cin, max_cout):
+    """All (s, d) pairs of a forward in two launches; returns [(s, d|None)] views per job."""
+    if latent.dtype != torch.float32 or latent.stride(-1) != 1:
+        latent = latent.float().contiguous()
+    b, _, sd = latent.shape
+    out = latent.new_empty(total)
+    check(lib, lib.hf_style_batch_f32(_p(out), _p(latent), latent.stride(0), latent.stride(1), _p(table), len(layout), b, sd,
+                                      max_cin, max_cout, st), "hf_style_batch_f32")
+    res = []
+    for s_ofs, cin, d_ofs, cout in layout:
+        s = out[s_ofs:s_ofs + b * cin].view(b, cin)
+        d = out[d_ofs:d_ofs + b * cout].view(b, cout) if d_ofs >= 0 else None
+        res.append((s, d))
+    return res
+
+
 def demod(lib, st, s, wsq):
     b, cin = s.shape
     cout = wsq.shape[0]

@@ -82,7 +82,69 @@ __global__ __launch_bounds__(256) void demod_kernel(float *__restrict__ d, const
   if (lane == 0) d[(long long)b * cout + co] = rsqrtf(acc + 1e-8f);
 }
 
+// ---- all layers of a forward in two launches (hf_style_batch_f32) ----
+// blockIdx.z = job; same arithmetic per (job, b, channel) as modulation_kernel / demod_kernel
+__global__ __launch_bounds__(256) void modulation_batch_kernel(float *__restrict__ out,
+                                                               const float *__restrict__ latent,
+                                                               long long lat_bstride, long long lat_rstride,
+                                                               const hf_style_job *__restrict__ jobs, int style_dim,
+                                                               float scale) {
+  const hf_style_job J = jobs[blockIdx.z];
+  const int lane = threadIdx.x & 63;
+  const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (ci >= J.cin) return;
+  const float *wr = J.mod_w + (long long)ci * style_dim;
+  const float *lat = latent + (long long)b * lat_bstride + (long long)J.style_row * lat_rstride;
+  float wv[kMaxPerLane], lv[kMaxPerLane];
+#pragma unroll
+  for (int k = 0; k < kMaxPerLane; ++k) {
+    const int j = k * 64 + lane;
+    const bool ok = j < style_dim;
+    wv[k] = ok ? wr[j] : 0.0f;
+    lv[k] = ok ? lat[j] : 0.0f;
+  }
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kMaxPerLane; ++k) acc = fmaf(lv[k], wv[k] * scale, acc);
+  acc = hf_wave_sum(acc);
+  if (lane == 0) out[J.s_ofs + (long long)b * J.cin + ci] = acc + J.mod_b[ci];
+}
+
+__global__ __launch_bounds__(256) void demod_batch_kernel(float *__restrict__ out,
+                                                          const hf_style_job *__restrict__ jobs) {
+  const hf_style_job J = jobs[blockIdx.z];
+  const int lane = threadIdx.x & 63;
+  const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (!J.wsq || co >= J.cout) return;
+  const float *wr = J.wsq + (long long)co * J.cin;
+  const float *sr = out + J.s_ofs + (long long)b * J.cin;
+  float acc = 0.0f;
+  for (int j = lane; j < J.cin; j += 64) {
+    float sv = sr[j];
+    acc = fmaf(wr[j], sv * sv, acc);
+  }
+  acc = hf_wave_sum(acc);
+  if (lane == 0) out[J.d_ofs + (long long)b * J.cout + co] = rsqrtf(acc + 1e-8f);
+}
+
 }  // namespace
+
+extern "C" int hf_style_batch_f32(float *out, const float *latent, long long lat_bstride, long long lat_rstride,
+                                  const hf_style_job *jobs, int n_jobs, int batch, int style_dim, int max_cin,
+                                  int max_cout, void *stream) {
+  if (!out || !latent || !jobs || n_jobs <= 0 || n_jobs > 65535 || batch <= 0 || batch > 65535 || style_dim <= 0 ||
+      style_dim > 64 * kMaxPerLane || max_cin <= 0)
+    return HF_E_INVALID;
+  const float scale = 1.0f / sqrtf((float)style_dim);
+  hipLaunchKernelGGL(modulation_batch_kernel, dim3(hf_cdiv(max_cin, 4), batch, n_jobs), dim3(256), 0, (hipStream_t)stream,
+                     out, latent, lat_bstride, lat_rstride, jobs, style_dim, scale);
+  if (max_cout > 0)
+    hipLaunchKernelGGL(demod_batch_kernel, dim3(hf_cdiv(max_cout, 4), batch, n_jobs), dim3(256), 0, (hipStream_t)stream, out,
+                       jobs);
+  return hf_launch_status();
+}
 
 extern "C" int hf_modconv_prepare_f32(float *wt, float *wsq, const float *weight, int cout, int cin, int k,
                                       void *stream) {

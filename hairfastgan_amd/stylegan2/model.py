@@ -125,6 +125,7 @@ class ModulatedConv2d(nn.Module):  # :183-279
         self.demodulate = demodulate
         self._prep = None  # (key, wt [k*k,cin,cout], wsq [cout,cin]) - derived, not in the state dict
         self._prep_f16 = None  # (key, wt_hi, wt_lo) fp16 split of wt for the fp16 matrix-core path
+        self._coeffs = None  # ((style ptr, shape, stride), (wt, s, d)) set for the duration of one Generator.forward
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
@@ -184,6 +185,9 @@ class ModulatedConv2d(nn.Module):  # :183-279
 
     def style_coefficients(self, style):
         """s[b,ci] (EqualLinear :241) and d[b,co] (:244-246; None when demodulate=False)."""
+        pre = self._coeffs
+        if pre is not None and pre[0] == (style.data_ptr(), tuple(style.shape), tuple(style.stride())):
+            return pre[1]  # computed for this very row of W+ by Generator.forward's batched launch
         wt, wsq = self.prepared()
         s = M.modulation(lib(), stream(), style, self.modulation.weight.detach(), self.modulation.bias.detach())
         d = M.demod(lib(), stream(), s, wsq) if self.demodulate else None
@@ -431,6 +435,46 @@ class Generator(nn.Module):  # :368-565
             latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
 
+        styled = self._batch_styles(latent)
+        try:
+            return self._run_layers(latent, noise, layer_in, skip, start_layer, end_layer, return_latents)
+        finally:
+            for conv in styled:
+                conv._coeffs = None
+
+    def _batch_styles(self, latent):
+        """Modulation (and demodulation) coefficients of every layer from W+ in two launches
+        (hf_style_batch_f32) instead of one or two per layer; handed to the layers through
+        ModulatedConv2d._coeffs for the duration of this forward.  Rows as in :529-545."""
+        if latent.ndim != 3 or latent.shape[1] < self.n_latent or not latent.is_cuda:
+            return []
+        convs, rows = [self.conv1.conv, self.to_rgb1.conv], [0, 1]
+        for block in range(1, self.log_size - 1):
+            i = 2 * block - 1
+            convs += [self.convs[2 * block - 2].conv, self.convs[2 * block - 1].conv, self.to_rgbs[block - 1].conv]
+            rows += [i, i + 1, i + 2]
+        b = latent.shape[0]
+        for c in convs:
+            c.prepared()
+        key = (b, latent.device, tuple(c.modulation.weight.data_ptr() for c in convs), tuple(c._prep[1].data_ptr() for c in convs))
+        cache = self.__dict__.setdefault("_style_jobs", {})  # one table per (batch, parameter storage)
+        if key not in cache:
+            if torch.cuda.is_current_stream_capturing():
+                return []  # the table is uploaded from the host: never inside a graph capture (warm up first)
+            if len(cache) > 16:
+                cache.clear()
+            table, layout, total = M.style_job_table(convs, rows, b, latent.device)
+            cache[key] = (table, layout, total, max(c.in_channel for c in convs),
+                          max(c.out_channel for c in convs if c.demodulate))
+        table, layout, total, mci, mco = cache[key]
+        lat = latent if (latent.dtype == torch.float32 and latent.stride(-1) == 1) else latent.float().contiguous()
+        res = M.style_batch(lib(), stream(), lat, table, layout, total, mci, mco)
+        for conv, row, (sv, dv) in zip(convs, rows, res):
+            view = latent[:, row]
+            conv._coeffs = ((view.data_ptr(), tuple(view.shape), tuple(view.stride())), (conv.prepared()[0], sv, dv))
+        return convs
+
+    def _run_layers(self, latent, noise, layer_in, skip, start_layer, end_layer, return_latents):
         out = self.input(latent)
         if start_layer == 0:
             out = self.conv1(out, latent[:, 0], noise=noise[0])

@@ -104,6 +104,24 @@ int hf_modconv3x3_f32(float *out, const float *x, const float *wt, const float *
                       const float *bias, int batch, int cin, int cout, int h, int w, float alpha,
                       float scale, float *workspace, long long workspace_floats, void *stream);
 
+/* All style GEMVs of one generator forward in two launches: for every job (= one ModulatedConv2d)
+ *   s[b, ci] = hf_modulation_f32(latent[b, style_row, :], mod_w, mod_b)     -> out[s_ofs + b*cin + ci]
+ *   d[b, co] = hf_demod_f32(s, wsq)   (jobs with wsq != NULL)                -> out[d_ofs + b*cout + co]
+ * (EqualLinear of the 26 modulations + the 17 demodulations, models/stylegan2/model.py:241-246;
+ * SURVEY section 8 row a10).  jobs: device array; latent: [batch, n_latent, style_dim] with the
+ * given strides (floats).  Same arithmetic per element as the single-layer entry points. */
+typedef struct hf_style_job {
+  const float *mod_w;   /* [cin, style_dim] */
+  const float *mod_b;   /* [cin] */
+  const float *wsq;     /* [cout, cin] from hf_modconv_prepare_f32, NULL = no demodulation */
+  int cin, cout;
+  int style_row, reserved;
+  long long s_ofs, d_ofs; /* float offsets into out */
+} hf_style_job;
+int hf_style_batch_f32(float *out, const float *latent, long long lat_bstride, long long lat_rstride,
+                       const hf_style_job *jobs, int n_jobs, int batch, int style_dim, int max_cin, int max_cout,
+                       void *stream);
+
 /* ---------------------------------------------------------------------------
  * fp16-matrix-core variant of hf_modconv3x3_f32 (same contraction, same epilogue, fp32
  * tensors in HBM, fp32 accumulation; v_mfma_f32_32x32x16_f16).  Reference counterpart:

@@ -371,3 +371,32 @@ def test_presplit_chain_same_res_to_transposed(simlib, shape):
     y = M.modconv3x3_up(simlib, None, nxt, wt2, None, d2, k4, nz2, nw, b2, f16=(h2[0], h2[1], 3))
     assert simlib.hf_debug_last_path() in (581, 583)
     assert torch.equal(y, ref)
+
+
+def test_style_batch_equals_per_layer_launches(simlib):
+    """hf_style_batch_f32 (every layer's modulation + demodulation in two launches) against
+    hf_modulation_f32 / hf_demod_f32 per layer: identical values, strided W+ rows, a job without
+    demodulation (ToRGB), different channel counts per job."""
+    import types
+
+    torch.manual_seed(29)
+    B, sd = 3, 48
+    latent = torch.randn(B, 7, sd)
+    convs, rows = [], []
+    for cin, cout, demod, row in [(16, 24, True, 0), (40, 3, False, 5), (8, 8, True, 2)]:
+        w = torch.randn(1, cout, cin, 3 if demod else 1, 3 if demod else 1)
+        wt, wsq = M.prepare_weights(simlib, None, w)
+        c = types.SimpleNamespace(in_channel=cin, out_channel=cout, demodulate=demod,
+                                  modulation=types.SimpleNamespace(weight=torch.randn(cin, sd), bias=torch.randn(cin)),
+                                  prepared=lambda wt=wt, wsq=wsq: (wt, wsq))
+        convs.append(c)
+        rows.append(row)
+    table, layout, total = M.style_job_table(convs, rows, B, "cpu")
+    res = M.style_batch(simlib, None, latent, table, layout, total, 40, 24)
+    for c, row, (s, d) in zip(convs, rows, res):
+        s_ref = M.modulation(simlib, None, latent[:, row], c.modulation.weight, c.modulation.bias)
+        assert torch.equal(s, s_ref)
+        if c.demodulate:
+            assert torch.equal(d, M.demod(simlib, None, s_ref, c.prepared()[1]))
+        else:
+            assert d is None
