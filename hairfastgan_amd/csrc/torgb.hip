@@ -98,6 +98,78 @@ __global__ __launch_bounds__(256) void torgb_kernel(float *__restrict__ out, con
   }
 }
 
+// Small planes (<= 64^2): the streaming kernel above walks all cin channels in one thread - 64
+// dependent load batches, ~37 us even for a 4x4 plane.  Here a block is 64 pixels x GROUPS channel
+// groups; every group sums its cin/GROUPS channels, the partial sums meet in LDS (fixed order:
+// deterministic) and group 0 runs the same epilogue.
+template <int GROUPS>
+__global__ __launch_bounds__(64 * GROUPS) void torgb_small_kernel(float *__restrict__ out, const float *__restrict__ x,
+                                                                   const float *__restrict__ wt,
+                                                                   const float *__restrict__ s,
+                                                                   const float *__restrict__ bias,
+                                                                   const float *__restrict__ skip,
+                                                                   const float *__restrict__ kernel4x4, int cin, int h,
+                                                                   int w) {
+  HF_DYN_LDS;
+  float *wm = reinterpret_cast<float *>(hf_dyn_lds);  // wm[c*cin + ci] = wt[ci][c] * s[b][ci]
+  float *red = wm + 3 * cin;                           // [GROUPS][3][64]
+  const int b = blockIdx.y;
+  const int hw = h * w;
+  for (int i = threadIdx.x; i < cin; i += blockDim.x) {
+    const float sv = s ? s[(long long)b * cin + i] : 1.0f;
+    wm[i] = wt[i * 3 + 0] * sv;
+    wm[cin + i] = wt[i * 3 + 1] * sv;
+    wm[2 * cin + i] = wt[i * 3 + 2] * sv;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  const bool pv = p < hw;
+  const int per = (cin + GROUPS - 1) / GROUPS;
+  const int c_lo = grp * per, c_hi = min(cin, c_lo + per);
+  const float *xb = x + (long long)b * cin * hw + (pv ? p : 0);
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll 8
+  for (int ci = c_lo; ci < c_hi; ++ci) {
+    const float xv = xb[(long long)ci * hw];
+    a0 = fmaf(wm[ci], xv, a0);
+    a1 = fmaf(wm[cin + ci], xv, a1);
+    a2 = fmaf(wm[2 * cin + ci], xv, a2);
+  }
+  red[(grp * 3 + 0) * 64 + lane] = a0;
+  red[(grp * 3 + 1) * 64 + lane] = a1;
+  red[(grp * 3 + 2) * 64 + lane] = a2;
+  __syncthreads();
+  if (grp != 0 || !pv) return;
+  const int sh = h >> 1, sw = w >> 1;
+  const int y = p / w, xx = p - y * w;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float r = 0.0f;
+    for (int g = 0; g < GROUPS; ++g) r += red[(g * 3 + c) * 64 + lane];
+    r += bias ? bias[c] : 0.0f;
+    if (skip) {
+      const float *sp = skip + ((long long)b * 3 + c) * sh * sw;
+      float up = 0.0f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int ky = (y & 1) + 2 * a;
+        const int iy = (y + ky - 2) >> 1;
+        if (iy < 0 || iy >= sh) continue;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int kx = (xx & 1) + 2 * e;
+          const int ix = (xx + kx - 2) >> 1;
+          if (ix < 0 || ix >= sw) continue;
+          up = fmaf(sp[iy * sw + ix], kernel4x4[(3 - ky) * 4 + (3 - kx)], up);
+        }
+      }
+      r += up;
+    }
+    out[((long long)b * 3 + c) * hw + p] = r;
+  }
+}
+
 }  // namespace
 
 extern "C" int hf_torgb_f32(float *out, const float *x, const float *wt, const float *s, const float *bias,
@@ -109,6 +181,13 @@ extern "C" int hf_torgb_f32(float *out, const float *x, const float *wt, const f
   if (lds > 64 * 1024) return HF_E_INVALID;
   const int hw = h * w;
   hipStream_t st = (hipStream_t)stream;
+  if (hw <= 64 * 64 && cin >= 64) {  // small plane, long channel loop: split the channels over 16 waves
+    constexpr int GROUPS = 16;
+    dim3 grid(hf_cdiv(hw, 64), batch);
+    hipLaunchKernelGGL(torgb_small_kernel<GROUPS>, grid, dim3(64 * GROUPS), lds + GROUPS * 3 * 64 * sizeof(float), st, out, x,
+                       wt, s, bias, skip, kernel4x4, cin, h, w);
+    return hf_launch_status();
+  }
   const bool aligned = ((((size_t)out) | ((size_t)x)) & 15) == 0;
   if (hw % 4 == 0 && aligned) {
     dim3 grid(hf_cdiv(hw / 4, 256), batch);

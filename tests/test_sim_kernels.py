@@ -400,3 +400,19 @@ def test_style_batch_equals_per_layer_launches(simlib):
             assert torch.equal(d, M.demod(simlib, None, s_ref, c.prepared()[1]))
         else:
             assert d is None
+
+
+@pytest.mark.parametrize("shape,use_skip", [((2, 64, 4, 4), False), ((3, 136, 8, 12), True), ((1, 512, 16, 16), True)])
+def test_torgb_small_plane_kernel(simlib, shape, use_skip):
+    """hf_torgb_f32's small-plane kernel (channels split over 16 waves, LDS reduction) against a
+    direct torch statement of ToRGB (model.py:356-365): ragged pixel counts, cin not a multiple of 16."""
+    B, cin, H, W = shape
+    torch.manual_seed(31)
+    x, wt, s, bias = torch.randn(B, cin, H, W), torch.randn(1, cin, 3), torch.rand(B, cin) + 0.5, torch.randn(3)
+    skip = torch.randn(B, 3, H // 2, W // 2) if use_skip else None
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0)
+    y = M.torgb(simlib, None, x, wt, s, bias, skip, k4 if use_skip else None)
+    ref = torch.einsum("bihw,ic,bi->bchw", x, wt[0], s) + bias.view(1, 3, 1, 1)
+    if use_skip:
+        ref = ref + O.upfirdn2d(skip, k4, up=2, pad=(2, 1))
+    assert maxdiff(y, ref) < 1e-4 * max(1.0, float(ref.abs().max()))
