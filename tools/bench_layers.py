@@ -82,19 +82,20 @@ def main():
                         tmp = torch.empty(B, cout, 2 * r + 1, pitch, device=dev)
                         fn = lambda: L.hf_modconv3x3_up_f32(tmp.data_ptr(), x.data_ptr(), wt.data_ptr(), s.data_ptr(),
                                                             d.data_ptr(), B, cin, cout, r, r, pitch, ws_p, ws_n, stream())
-                    elif c == 400:  # fp16 matrix cores, pre-split K-blocked input (hf_modconv3x3_f16_pre_f32)
+                    elif c in (400, 451, 452):  # fp16 matrix cores, pre-split K-blocked input (hf_modconv3x3_f16_pre_f32); 45x = forced tile
                         if not M.modconv3x3_f16_supported(cin, cout, r, r):
                             row.append("     -")
                             continue
                         hi, lo = M.split_weights_f16(L, stream(), wt)
                         xh, xl = M.split_activation_reference(x, s)
                         out = torch.empty(B, cout, r, r, device=dev)
+                        L.hf_debug_set_dispatch(c - 400 if c != 400 else 0, 0)
 
                         def fn():
                             code = L.hf_modconv3x3_f16_pre_f32(out.data_ptr(), xh.data_ptr(), xl.data_ptr(), hi.data_ptr(),
                                                                lo.data_ptr(), 3, d.data_ptr(), noise.data_ptr(), nw.data_ptr(), 0,
                                                                bias.data_ptr(), B, cin, cout, r, r, 0.2, 1.4142135, None, None,
-                                                               None, stream())
+                                                               None, None, None, None, stream())
                             assert code == 0, code
                     elif c >= 100:  # fp16 matrix cores (csrc/convh.hip): 1TT = plain f16, 3TT = split operands; TT = tile cfg (00 auto)
                         if not M.modconv3x3_f16_supported(cin, cout, r, r):
