@@ -284,10 +284,6 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   };
   zero_acc();
 
-#ifdef HF_H_STAGGER
-  // break the chip-wide lockstep (every CU loading, then computing, then storing at once)
-  for (int i = 0; i < (int)(blockIdx.x & 7); ++i) __builtin_amdgcn_s_sleep(HF_H_STAGGER);
-#endif
   int t_cur = blockIdx.x;
   Tile cur = locate(t_cur);
   locate_items(cur, e_src);
