@@ -93,9 +93,13 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   constexpr int BUF_UNITS = NPART * (W_UNITS + X_UNITS);
   constexpr int N_WPIECE = NPART * W_UNITS / 64;        // 1 KiB DMA pieces per stage
   constexpr int ND = (N_WPIECE + NW - 1) / NW;          // per wave
-  constexpr int DMA_PER_STEP = (ND + 2) / 3;            // all weight DMAs in the first three tap-steps
+  // weight DMAs: all in the first three tap-steps when activations are staged through registers
+  // (their loads must be issued first thing); one per tap-step when everything is DMA (PRE) -
+  // spreading the arrivals over the chunk measured +1..3 %
+  constexpr int DMA_PER_STEP = PRE ? 1 : (ND + 2) / 3;
   constexpr int XE = (X_UNITS + NT - 1) / NT;           // (pixel, kgroup) items per thread per stage
   static_assert(W_UNITS % 64 == 0, "weight part must be whole 1 KiB pieces");
+  static_assert(!PRE || (ND <= 9 && 2 * XE <= 9), "PRE issue schedule: one weight DMA per tap-step, activations in odd steps");
 
   HF_DYN_LDS;
   half8 *lds = reinterpret_cast<half8 *>(hf_dyn_lds);               // [2][BUF_UNITS] 16-byte units
@@ -526,14 +530,14 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
           for (int i = 0; i < ND; ++i)
             if (i / DMA_PER_STEP == tap) dma_piece(i, cpf, cb ^ 1);
         }
-        if (more1 && tap == 0) {
-          if (PRE) {
+        if (PRE && more1) {  // activation DMAs in tap-steps 1, 3, 5, ...
 #pragma unroll
-            for (int e = 0; e < XE; ++e) dma_x(e, cpf, cb ^ 1);
-          } else {
+          for (int e = 0; e < XE; ++e)
+            if (tap == 1 + 2 * e) dma_x(e, cpf, cb ^ 1);
+        }
+        if (!PRE && more1 && tap == 0) {
 #pragma unroll
-            for (int e = 0; e < XE; ++e) load_item(e, cpf);
-          }
+          for (int e = 0; e < XE; ++e) load_item(e, cpf);
         }
         // (staggering the conversions over the two waves of a SIMD - early half in taps 3-5 - was
         // measured 5-15 % slower: the early half then waits on its loads)
