@@ -252,8 +252,9 @@ def main():
                          "note": "same forward, HAIRFAST_CONV_PRECISION=f32 (v_mfma_f32_32x32x2_f32 only)"}
         e16 = alt_run("f16", 16)
         f16_mode = {"value": round(16 * args.steps / e16, 3), "unit": "images/s", "ms_per_step": round(e16 / args.steps * 1e3, 4),
-                    "batch": 16, "note": "BASELINE.json configs[4]: fp16 conv operands (HAIRFAST_CONV_PRECISION=f16), fp32 tensors, "
-                                         "accumulation and demodulation; pixel MSE vs the reference 2e-6 (tests/test_gpu_parity.py)"}
+                    "batch": 16, "note": "BASELINE.json configs[4]: fp16 conv operands (HAIRFAST_CONV_PRECISION=f16; the hand-over "
+                                         "activations between convs are fp16, everything else fp32), fp32 accumulation and "
+                                         "demodulation; pixel MSE vs the reference 2e-6 (tests/test_gpu_parity.py)"}
 
     # Secondary measurement (outside the timed region above): the hot-path call schedule of
     # one HairFast swap (BASELINE.json configs[2]/[3]), triples sharded

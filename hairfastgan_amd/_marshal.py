@@ -292,7 +292,7 @@ def modconv3x3_f16_pre(lib, st, act, wt_hi, wt_lo, nterms, d, noise, noise_w, bi
     if split_for is not None:
         s_next = _c(split_for)
         sh = torch.empty((b, cout // 8, h, w, 8), dtype=torch.float16, device=dev)
-        sl = torch.empty_like(sh)
+        sl = torch.empty_like(sh) if nterms == 3 else None  # plain fp16 consumer: no lo part
     code = _launch_profiled(
         lib, 2.0 * cin * cout * 9 * h * w * b,
         lambda: lib.hf_modconv3x3_f16_pre_f32(_p(out), _p(act.hi), _p(act.lo), _p(wt_hi), _p(wt_lo), nterms, _p(d), _p(noise),
@@ -358,9 +358,10 @@ def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha
         check(lib, code, "hf_modconv3x3_up_f32")
     noise, nbs = _noise_args(noise, b, 4 * h * w)
     if split_for is not None:
-        key, s_next = split_for
+        key, s_next = split_for[0], split_for[1]
+        want_lo = split_for[2] if len(split_for) > 2 else True  # False: consumer with plain fp16 operands
         hi = torch.empty((b, cout // 8, 2 * h, 2 * w, 8), dtype=torch.float16, device=tmp.device)
-        lo = torch.empty_like(hi)
+        lo = torch.empty_like(hi) if want_lo else None
         check(lib, lib.hf_blur_noise_bias_act_split_f16(_p(hi), _p(lo), _p(tmp), _p(_c(blur_kernel)), _p(noise),
                                                         _p(_c(noise_w)), nbs, _p(_c(bias)), _p(_c(s_next)), b, cout,
                                                         2 * h + 1, 2 * w + 1, pitch, alpha, scale, st),

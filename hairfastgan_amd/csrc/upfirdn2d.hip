@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512) void blur4x4_split8(hf_half8 *__restrict__ hi,
             l8[k] = (_Float16)(v - (float)hv);
           }
           hp[(long long)oy * out_w] = h8;
-          lp[(long long)oy * out_w] = l8;
+          if (lo) lp[(long long)oy * out_w] = l8;  // lo == nullptr: plain fp16 consumer (nterms 1)
         }
       }
     }
@@ -423,7 +423,7 @@ extern "C" int hf_blur_noise_bias_act_split_f16(void *out_hi, void *out_lo, cons
                                                 const float *bias, const float *s_next, int batch, int channels,
                                                 int in_h, int in_w, int in_pitch, float alpha, float scale,
                                                 void *stream) {
-  if (!out_hi || !out_lo || !in || !kernel4x4 || batch <= 0 || channels <= 0 || (channels & 7) || in_h < 2 || in_w < 2 ||
+  if (!out_hi || !in || !kernel4x4 || batch <= 0 || channels <= 0 || (channels & 7) || in_h < 2 || in_w < 2 ||
       in_pitch < in_w || (noise && !noise_w))
     return HF_E_INVALID;
   const long long zs = (long long)batch * (channels >> 3);

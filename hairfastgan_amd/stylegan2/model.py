@@ -279,7 +279,7 @@ class StyledConv(nn.Module):  # :309-343
             noise = style.new_empty(b, 1, 2 * h, 2 * w).normal_()
         act = self.activate
         return conv.conv_up(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
-                            act.negative_slope, act.scale, split_for=(None, s_next))
+                            act.negative_slope, act.scale, split_for=(None, s_next, conv_precision() == "f16x3"))
 
     def forward_from_split(self, split, coeffs, noise=None, rgb=None, want_out=True, split_for=None):
         """Same-resolution StyledConv on a SplitActivation produced for it (coeffs = this layer's

@@ -218,7 +218,8 @@ int hf_blur_noise_bias_act_f32(float *out, const float *in, const float *kernel4
  *   out_hi / out_lo [batch][channels/8][out_h][out_w][8]      (channels % 8 == 0),
  * the layout hf_modconv3x3_f16_pre_f32 stages by LDS-DMA.  s_next is the NEXT conv's modulation
  * (hf_modulation_f32 of that layer): the product with the activation has to happen in fp32 before
- * the split.  Bit-identical to splitting the fp32 activation inside the conv kernel. */
+ * the split.  Bit-identical to splitting the fp32 activation inside the conv kernel.  out_lo may be
+ * NULL for a consumer that runs with nterms 1 (plain fp16 operands): half the bytes written. */
 int hf_blur_noise_bias_act_split_f16(void *out_hi, void *out_lo, const float *in, const float *kernel4x4,
                                      const float *noise, const float *noise_w, long long noise_bstride,
                                      const float *bias, const float *s_next, int batch, int channels, int in_h,
