@@ -27,6 +27,7 @@ SIGNATURES = {
     "hf_modulation_f32": [_f, _f, _ll, _f, _f, _i, _i, _i, _st],
     "hf_style_batch_f32": [_f, _f, _ll, _ll, _f, _i, _i, _i, _i, _i, _st],
     "hf_demod_f32": [_f, _f, _f, _i, _i, _i, _st],
+    "hf_style_normalize_f32": [_f, _f, _i, _i, _i, _st],
     "hf_modconv3x3_f32": [_f, _f, _f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _f, _ll, _st],
     "hf_conv_split_weights_f16": [_f, _f, _f, _i, _i, _st],
     "hf_modconv3x3_f16_f32": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _st],
@@ -49,6 +50,8 @@ SIGNATURES = {
     "hf_adaptive_avgpool_f32": [_f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _st],
     "hf_downscale2x_f32": [_f, _f, _i, _i, _i, _st],
     "hf_linear_f32": [_f, _f, _ll, _f, _f, _i, _i, _i, _fl, _st],
+    "hf_equal_linear_f32": [_f, _f, _ll, _f, _f, _i, _i, _i, _fl, _i, _fl, _fl, _st],
+    "hf_pixel_norm_f32": [_f, _f, _i, _i, _st],
     "hf_add_bcast_f32": [_f, _f, _f, _ll, _ll, _st],
     "hf_debug_set_dispatch": [_i, _i],
     "hf_debug_last_path": [],
@@ -75,6 +78,8 @@ def bind(cdll):
     cdll.hf_modconv_workspace_floats.restype = ctypes.c_longlong
     cdll.hf_conv2d_workspace_floats.argtypes = [_i, _i, _i, _i, _i, _i, _i, _i]
     cdll.hf_conv2d_workspace_floats.restype = ctypes.c_longlong
+    cdll.hf_f16_overflow_count.argtypes = [_i]
+    cdll.hf_f16_overflow_count.restype = ctypes.c_longlong
     cdll.hf_abi_version.argtypes = []
     cdll.hf_abi_version.restype = ctypes.c_int
     return cdll

@@ -183,6 +183,17 @@ def demod(lib, st, s, wsq):
     return d
 
 
+def style_normalize(lib, st, s, d):
+    """In-place power-of-two range normalisation of a layer's (s, d) pair (hf_style_normalize_f32)."""
+    b, cin = s.shape
+    check(lib, lib.hf_style_normalize_f32(_p(s), _p(d), b, cin, d.shape[1], st), "hf_style_normalize_f32")
+
+
+def f16_overflow_count(lib, reset=False):
+    """Elements the fp16 (hi, lo) split clamped since the last reset (synchronises the device)."""
+    return int(lib.hf_f16_overflow_count(1 if reset else 0))
+
+
 def _workspace(lib, like, b, cin, cout, h, w, up):
     """Split-K scratch for the small-plane layers (size dictated by the library)."""
     n = lib.hf_modconv_workspace_floats(b, cin, cout, h, w, 1 if up else 0)
@@ -214,10 +225,19 @@ def split_weights_f16(lib, st, wt):
     taps, cin, cout = wt.shape
     if taps != 9 or cin % 16:
         raise ValueError(f"f16 MFMA path needs 3x3 weights with cin % 16 == 0; got {tuple(wt.shape)}")
-    hi = torch.empty((cin // 16, 9, 2, cout, 8), dtype=torch.float16, device=wt.device)
-    lo = torch.empty_like(hi)
+    n = 9 * cin * cout
+    # wt_hi carries a 16-byte trailer behind its n halves (2^-k of the power-of-two pre-scale)
+    hi = torch.empty(n + 8, dtype=torch.float16, device=wt.device)[:n].view(cin // 16, 9, 2, cout, 8)
+    lo = torch.empty((cin // 16, 9, 2, cout, 8), dtype=torch.float16, device=wt.device)
     check(lib, lib.hf_conv_split_weights_f16(_p(hi), _p(lo), _p(wt), cin, cout, st), "hf_conv_split_weights_f16")
     return hi, lo
+
+
+def split_weights_unscale(wt_hi):
+    """The 2^-k of the power-of-two pre-scale, read from the trailer behind wt_hi's halves (tests)."""
+    n = wt_hi.numel()
+    flat = torch.empty(0, dtype=torch.float16, device=wt_hi.device).set_(wt_hi.untyped_storage(), wt_hi.storage_offset(), (n + 8,))
+    return float(flat[n:n + 2].view(torch.float32)[0])
 
 
 def modconv3x3_f16_supported(cin, cout, h, w):
@@ -506,6 +526,36 @@ def linear(lib, st, x, weight, bias, scale=1.0):
         nb = min(8, b - b0)
         check(lib, lib.hf_linear_f32(out[b0:].data_ptr(), x[b0:].data_ptr(), x.stride(0) if b > 1 else k, _p(weight),
                                      _p(_c(bias)), nb, k, n, float(scale), st), "hf_linear_f32")
+    return out
+
+
+def equal_linear(lib, st, x, weight, bias, lr_mul=1.0, fused_lrelu=False, alpha=0.2, act_scale=SQRT2):
+    """EqualLinear.forward (model.py:153-163) in one launch per <= 8 rows: x [..., in] -> [..., out]."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.dtype != torch.float32:
+        raise TypeError("hairfastgan_amd kernels are fp32")
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    b, k = x2.shape
+    weight = _c(weight)
+    n = weight.shape[0]
+    out = x2.new_empty((b, n))
+    for b0 in range(0, b, 8):
+        nb = min(8, b - b0)
+        check(lib, lib.hf_equal_linear_f32(out[b0:].data_ptr(), x2[b0:].data_ptr(), x2.stride(0) if b > 1 else k, _p(weight),
+                                           _p(_c(bias)), nb, k, n, float(lr_mul), 1 if fused_lrelu else 0, float(alpha),
+                                           float(act_scale), st), "hf_equal_linear_f32")
+    return out.reshape(*lead, n)
+
+
+def pixel_norm(lib, st, x):
+    """PixelNorm over dim 1 of [B, dim] (model.py:16-21)."""
+    x = _c(x)
+    if x.ndim != 2:
+        raise ValueError("pixel_norm expects [B, dim] (the mapping network's z)")
+    out = torch.empty_like(x)
+    check(lib, lib.hf_pixel_norm_f32(_p(out), _p(x), x.shape[0], x.shape[1], st), "hf_pixel_norm_f32")
     return out
 
 

@@ -11,11 +11,22 @@ def lib():
 
 
 def require_gpu(*tensors):
+    """Entry check of every public op: GPU tensors only, and no autograd - the kernels are forward
+    only (the reference's ops are differentiable, op/fused_act.py:19-70, op/upfirdn2d.py:19-142;
+    HairFast runs them frozen under inference_mode, models/Net.py:44-46), so a caller that expects
+    gradients is told instead of silently receiving detached outputs."""
+    grad = torch.is_grad_enabled()
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError(
                 "hairfastgan_amd ops run on the MI355X only (got a CPU tensor); there is no CPU fallback - "
                 "the CPU restatement lives in oracle/ and is test infrastructure")
+        if grad and t.requires_grad:
+            raise RuntimeError(
+                "hairfastgan_amd is inference only: an input requires grad while autograd is enabled; "
+                "wrap the call in torch.inference_mode() / torch.no_grad() or detach the input")
 
 
 def stream():

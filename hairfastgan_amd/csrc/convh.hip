@@ -27,6 +27,7 @@
 // through registers (loaded in the first tap-step, converted in the last ones); one barrier per
 // chunk.  LDS-DMA and register loads retire through different paths, so vmcnt cannot order one
 // against the other: everything is issued early in the chunk and drained at its barrier.
+#define HF_WANT_F16_SPLIT
 #include "conv_common.h"
 
 using namespace hf_detail;
@@ -177,13 +178,15 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       }
     }
   };
+  // 2^-k of the weights' power-of-two pre-scale (trailer of wt_hi, see split_weights): folded into d
+  const float w_unscale = *reinterpret_cast<const float *>(wth + 9LL * P.cin * P.cout);
   auto load_s = [&](int b, int slot) {
     float *dst = sl_base + slot * P.cin;
     if (MOD)
       for (int i = tid; i < P.cin; i += NT) dst[i] = P.s[(long long)b * P.s_bstride + i];
     float *ep = ep_base + slot * 3 * CT;
     for (int i = tid; i < CT; i += NT) {
-      ep[i] = P.d ? P.d[(long long)b * P.d_bstride + co0 + i] : 1.0f;
+      ep[i] = (P.d ? P.d[(long long)b * P.d_bstride + co0 + i] : 1.0f) * w_unscale;
       ep[CT + i] = P.bias ? P.bias[co0 + i] : 0.0f;
       ep[2 * CT + i] = (!UP && P.oh && P.s_next) ? P.s_next[(long long)b * P.cout + co0 + i] : 1.0f;
     }
@@ -259,18 +262,17 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     const int i = tid + e * NT;
     const int kg = i / NPIX;
     half8 hi, lo;
+    bool ovf = false;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float v = (e_src[e] >= 0) ? xr[e][k] : 0.0f;
       if (MOD) v *= sl_base[sl_off + chunk * KH + kg * 8 + k];
-      // hi and lo must both derive from the fp32-ROUNDED product: left alone, hipcc stores
-      // hi = fp16(fp32(x*s)) but subtracts v_fma_mixlo_f16's fp16(x*s unrounded); at an fp16
-      // rounding tie of the fp32 product the two differ by one fp16 ulp (seen on hardware).
-      HF_OPAQUE_F32(v);
-      const _Float16 hv = (_Float16)v;
+      _Float16 hv, lv;
+      hf_split_f16(v, hv, lv, ovf);  // saturating; see hf_common.h
       hi[k] = hv;
-      lo[k] = (_Float16)(v - (float)hv);
+      lo[k] = lv;
     }
+    hf_note_overflow(ovf);
     buf[OFF_XH + i] = hi;
     if (NTERMS == 3) buf[OFF_XL + i] = lo;
   };
@@ -384,14 +386,15 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
             const float snv[4] = {sn.x, sn.y, sn.z, sn.w};
             typedef _Float16 half4 __attribute__((ext_vector_type(4)));
             half4 h4, l4;
+            bool ovf = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              float v = acc[0][ct][g][4 * q + k] * snv[k];
-              HF_OPAQUE_F32(v);
-              const _Float16 hv = (_Float16)v;
+              _Float16 hv, lv;
+              hf_split_f16(acc[0][ct][g][4 * q + k] * snv[k], hv, lv, ovf);
               h4[k] = hv;
-              l4[k] = (_Float16)(v - (float)hv);
+              l4[k] = lv;
             }
+            hf_note_overflow(ovf);
             const long long unit = (((long long)T.b0 * (P.cout >> 3) + ((co0 + c4) >> 3)) * P.out_h + Y) * P.out_w + X;
             *reinterpret_cast<half4 *>(static_cast<char *>(P.oh) + unit * 16 + ((co0 + c4) & 4) * 2) = h4;
             if (P.ol) *reinterpret_cast<half4 *>(static_cast<char *>(P.ol) + unit * 16 + ((co0 + c4) & 4) * 2) = l4;
@@ -581,20 +584,49 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   }
 }
 
-// fp32 prepared weights wt[tap][ci][co] -> hi / lo halves in [chunk16][tap][kg][co][8]
+// fp32 prepared weights wt[tap][ci][co] -> hi / lo halves in [chunk16][tap][kg][co][8], PRE-SCALED
+// by a power of two 2^k chosen so that max|wt| * 2^k lies in [2^13, 2^14): prepared weights are
+// scale*W ~ 1e-2, whose lo parts would otherwise be fp16 subnormals (absolute error 2^-25 instead
+// of a relative 2^-22, see hf_split_f16).  With the pre-scale every weight within 2^-15 of the
+// largest keeps its full 22 bits.  The inverse 2^-k is stored in the 16-byte TRAILER that follows
+// the 9*cin*cout halves of wt_hi (float trailer[0]; trailer[1] = bit pattern of max|wt|) and is
+// folded into the epilogue's output scale by the conv kernels (exact: a power of two).
+__global__ __launch_bounds__(256) void split_weights_absmax(unsigned int *__restrict__ trailer,
+                                                            const float *__restrict__ wt, long long n) {
+  float m = 0.0f;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(wt[i]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(trailer + 1, __float_as_uint(m));  // non-negative floats order like their bits
+}
+__global__ void split_weights_clear(unsigned int *trailer) {
+  if (threadIdx.x < 4) trailer[threadIdx.x] = 0u;
+}
+__device__ __forceinline__ int weight_prescale_log2(unsigned int absmax_bits) {
+  const int e = (int)((absmax_bits >> 23) & 255u) - 127;  // floor(log2 max|wt|)
+  if (e <= -127 || e >= 128) return 0;                    // all zero / denormal / inf: leave alone
+  int k = 13 - e;
+  return k > 120 ? 120 : (k < -120 ? -120 : k);
+}
 __global__ __launch_bounds__(256) void split_weights(_Float16 *__restrict__ wth, _Float16 *__restrict__ wtl,
                                                      const float *__restrict__ wt, int cin, int cout) {
   const long long n = 9LL * cin * cout;
+  unsigned int *trailer = reinterpret_cast<unsigned int *>(wth + n);
+  const int k = weight_prescale_log2(trailer[1]);
+  const float up = __uint_as_float((unsigned int)(127 + k) << 23);
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float *>(trailer)[0] = __uint_as_float((unsigned int)(127 - k) << 23);
   const long long stride = (long long)gridDim.x * blockDim.x;
+  bool ovf = false;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int co = (int)(i % cout);
     const long long r = i / cout;
     const int ci = (int)(r % cin), tap = (int)(r / cin);
-    const float v = wt[i];
-    const _Float16 h = (_Float16)v;  // plain load: nothing to contract with
     const long long dst = ((((long long)(ci / 16) * 9 + tap) * 2 + (ci % 16) / 8) * cout + co) * 8 + (ci % 8);
+    _Float16 h, l;
+    hf_split_f16(wt[i] * up, h, l, ovf);
     wth[dst] = h;
-    wtl[dst] = (_Float16)(v - (float)h);
+    if (wtl) wtl[dst] = l;
   }
 }
 
@@ -731,14 +763,19 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
 }  // namespace hf_detail
 
 extern "C" int hf_conv_split_weights_f16(void *wt_hi, void *wt_lo, const float *wt, int cin, int cout, void *stream) {
-  if (!wt_hi || !wt_lo || !wt || cin <= 0 || cout <= 0 || (cin % 16)) return HF_E_INVALID;
+  if (!wt_hi || !wt || cin <= 0 || cout <= 0 || (cin % 16)) return HF_E_INVALID;
   long long n = 9LL * cin * cout;
   long long g = (n + 255) / 256;
   if (g > 4096) g = 4096;
+  unsigned int *trailer = reinterpret_cast<unsigned int *>(static_cast<_Float16 *>(wt_hi) + n);
+  hipLaunchKernelGGL(split_weights_clear, dim3(1), dim3(64), 0, (hipStream_t)stream, trailer);
+  hipLaunchKernelGGL(split_weights_absmax, dim3((int)g), dim3(256), 0, (hipStream_t)stream, trailer, wt, n);
   hipLaunchKernelGGL(split_weights, dim3((int)g), dim3(256), 0, (hipStream_t)stream, static_cast<_Float16 *>(wt_hi),
                      static_cast<_Float16 *>(wt_lo), wt, cin, cout);
   return hf_launch_status();
 }
+
+extern "C" unsigned long long hf_f16_overflow_count_convh(int reset) { return hf_f16_overflow_read_tu(reset); }
 
 extern "C" int hf_modconv3x3_f16_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
                                      const float *s, const float *d, const float *noise, const float *noise_w,

@@ -166,7 +166,8 @@ constexpr int kLinMaxBatch = 8;
 __global__ __launch_bounds__(256) void linear_kernel(float *__restrict__ out, const float *__restrict__ x,
                                                      long long x_stride, const float *__restrict__ w,
                                                      const float *__restrict__ bias, int batch, int in_f,
-                                                     int out_f, float scale) {
+                                                     int out_f, float scale, float bias_scale, int act, float alpha,
+                                                     float act_scale) {
   const int lane = threadIdx.x & 63;
   const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kLinRows;
   if (n0 >= out_f) return;
@@ -208,9 +209,26 @@ __global__ __launch_bounds__(256) void linear_kernel(float *__restrict__ out, co
 #pragma unroll
     for (int b = 0; b < kLinMaxBatch; ++b) {
       const float v = hf_wave_sum(acc[r][b]);
-      if (lane == 0 && b < batch && n0 + r < out_f)
-        out[(long long)b * out_f + n0 + r] = v * scale + (bias ? bias[n0 + r] : 0.0f);
+      if (lane == 0 && b < batch && n0 + r < out_f) {
+        float y = v * scale + (bias ? bias[n0 + r] * bias_scale : 0.0f);
+        if (act) y = hf_lrelu(y, alpha, act_scale);
+        out[(long long)b * out_f + n0 + r] = y;
+      }
     }
+}
+
+// PixelNorm (models/stylegan2/model.py:16-21): x * rsqrt(mean(x^2, dim 1) + 1e-8); one wave per row
+__global__ __launch_bounds__(256) void pixel_norm_rows(float *__restrict__ out, const float *__restrict__ x, int rows,
+                                                       int dim) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float *xr = x + (long long)r * dim;
+  float acc = 0.0f;
+  for (int k = lane; k < dim; k += 64) acc = fmaf(xr[k], xr[k], acc);
+  acc = hf_wave_sum(acc);
+  const float inv = rsqrtf(acc / (float)dim + 1e-8f);
+  for (int k = lane; k < dim; k += 64) out[(long long)r * dim + k] = xr[k] * inv;
 }
 
 __global__ __launch_bounds__(256) void add_bcast(float *__restrict__ out, const float *__restrict__ a,
@@ -304,7 +322,25 @@ extern "C" int hf_linear_f32(float *out, const float *x, long long x_stride, con
   if (!out || !x || !w || batch <= 0 || batch > kLinMaxBatch || in_features <= 0 || out_features <= 0)
     return HF_E_INVALID;
   hipLaunchKernelGGL(linear_kernel, dim3(hf_cdiv(out_features, 4 * kLinRows)), dim3(256), 0, (hipStream_t)stream,
-                     out, x, x_stride, w, bias, batch, in_features, out_features, scale);
+                     out, x, x_stride, w, bias, batch, in_features, out_features, scale, 1.0f, 0, 0.0f, 1.0f);
+  return hf_launch_status();
+}
+
+extern "C" int hf_equal_linear_f32(float *out, const float *x, long long x_stride, const float *w, const float *bias,
+                                   int batch, int in_features, int out_features, float lr_mul, int fused_lrelu,
+                                   float alpha, float act_scale, void *stream) {
+  if (!out || !x || !w || batch <= 0 || batch > kLinMaxBatch || in_features <= 0 || out_features <= 0)
+    return HF_E_INVALID;
+  const float scale = (1.0f / sqrtf((float)in_features)) * lr_mul;
+  hipLaunchKernelGGL(linear_kernel, dim3(hf_cdiv(out_features, 4 * kLinRows)), dim3(256), 0, (hipStream_t)stream,
+                     out, x, x_stride, w, bias, batch, in_features, out_features, scale, lr_mul, fused_lrelu ? 1 : 0,
+                     alpha, act_scale);
+  return hf_launch_status();
+}
+
+extern "C" int hf_pixel_norm_f32(float *out, const float *x, int rows, int dim, void *stream) {
+  if (!out || !x || rows <= 0 || dim <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(pixel_norm_rows, dim3(hf_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, out, x, rows, dim);
   return hf_launch_status();
 }
 

@@ -35,6 +35,10 @@
 //     order among themselves, but LDS-DMA copies retire through the LDS path and are not
 //     ordered against register loads (measured: stale DMA data with N = the number of younger
 //     register loads).  With DMA copies pending use N = 0.
+//   M0: the asm writes M0 without listing it as a clobber - the AMDGPU backend treats M0 as a
+//     RESERVED register (hipcc rejects the clobber with -Winline-asm "reserved registers: m0"): it
+//     never keeps a value live in M0 across statements, it re-materialises M0 immediately before
+//     each of its own instructions that read it.
 #ifndef HF_BARRIER_KEEP_DEFINED
 #define HF_BARRIER_KEEP_DEFINED
 __device__ __forceinline__ void hf_glds16_raw(const float *gsrc_lane, float *lds_wave_base) {
@@ -99,6 +103,42 @@ __device__ __forceinline__ void hf_glds4_if(bool active, const float *gsrc_lane,
   if (active) hf_glds4(gsrc_lane, lds_wave_base);
 }
 #endif
+
+// ---- fp32 -> fp16 (hi, lo) operand split of the f16x3 / f16 matrix-core modes ----
+// hi = fp16(v), lo = fp16(v - hi): 22 significant bits while lo stays a normal fp16 number, i.e.
+// for |v| >= 2^-3; below that the pair carries an ABSOLUTE error of at most 2^-25 (half the
+// fp16 subnormal step), which is why producers pre-scale by powers of two so that the large
+// operands of a dot product sit well inside [2^-2, 2^15] (weights: hf_conv_split_weights_f16;
+// modulation: hf_style_normalize_f32).  Range: both parts SATURATE at +-65504 instead of turning
+// into inf (inf - inf = NaN in the accumulator), so the pair is exact-ish up to 131008 and
+// clamps beyond; every clamped element is counted in hf_f16_overflow (hf_f16_overflow_count()),
+// so a caller can detect that a tensor left the representable range and re-run in f32 mode.
+// Translation units that split define HF_WANT_F16_SPLIT before including this header; each gets
+// its own counter (no relocatable device code), hf_f16_overflow_count() sums them.
+#ifdef HF_WANT_F16_SPLIT
+#define HF_F16_MAX 65504.0f
+static __device__ unsigned int hf_f16_overflow_dev;
+static inline unsigned int hf_f16_overflow_read_tu(int reset) {  // synchronous (diagnostics only)
+  unsigned int v = 0, z = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(hf_f16_overflow_dev), sizeof(v)) != hipSuccess) return 0xffffffffu;
+  if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(hf_f16_overflow_dev), &z, sizeof(z));
+  return v;
+}
+__device__ __forceinline__ void hf_split_f16(float v, _Float16 &hi, _Float16 &lo, bool &ovf) {
+  // hi and lo must both derive from the fp32-ROUNDED v: left alone, hipcc stores
+  // hi = fp16(fp32(x*s)) but subtracts v_fma_mixlo_f16's fp16(x*s unrounded); at an fp16
+  // rounding tie of the fp32 product the two differ by one fp16 ulp (seen on hardware).
+  HF_OPAQUE_F32(v);
+  ovf = ovf || !(fabsf(v) <= 2.0f * HF_F16_MAX);  // also true for NaN
+  const float vh = fminf(fmaxf(v, -HF_F16_MAX), HF_F16_MAX);
+  hi = (_Float16)vh;
+  const float r = v - (float)hi;
+  lo = (_Float16)fminf(fmaxf(r, -HF_F16_MAX), HF_F16_MAX);
+}
+__device__ __forceinline__ void hf_note_overflow(bool ovf) {
+  if (ovf) atomicAdd(&hf_f16_overflow_dev, 1u);
+}
+#endif  // HF_WANT_F16_SPLIT
 
 static inline int hf_launch_status() {
   return hipGetLastError() == hipSuccess ? HF_OK : HF_E_LAUNCH;

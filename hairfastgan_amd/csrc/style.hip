@@ -129,7 +129,50 @@ __global__ __launch_bounds__(256) void demod_batch_kernel(float *__restrict__ ou
   if (lane == 0) out[J.d_ofs + (long long)b * J.cout + co] = rsqrtf(acc + 1e-8f);
 }
 
+// ---- range normalisation of a (modulation, demodulation) pair (hf_style_normalize_f32) ----
+// One block per (job, b): e = floor(log2 max_ci |s[b,ci]|), then s[b,:] *= 2^-e and d[b,:] *= 2^e,
+// so that max|s| lies in [1, 2): |s*x| <= 2|x|, the split then overflows only where x itself would.  The demodulated conv is invariant under this rescaling
+// (y = d * sum w (s x)), and a power of two makes it exact in fp32 - every fp32 consumer computes
+// bit-identical results - while the fp16 (hi, lo) split of s*x in the matrix-core modes then
+// depends on the activation's magnitude only: it cannot overflow through a large trained style,
+// and small styles do not push s*x into the fp16 subnormals (hf_common.h, hf_split_f16).
+// (StyleGAN2-ADA's fp16 layers pre-normalise styles by their infinity norm for the same reason.)
+__device__ __forceinline__ void normalize_pair(float *__restrict__ s, float *__restrict__ d, int cin, int cout) {
+  HF_DYN_LDS;
+  float *red = reinterpret_cast<float *>(hf_dyn_lds);  // [4]
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < cin; i += blockDim.x) m = fmaxf(m, fabsf(s[i]));
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, HF_WAVE));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const int e = (int)((__float_as_uint(m) >> 23) & 255u) - 127;  // floor(log2 max|s|)
+  if (e <= -120 || e >= 120) return;                               // zero / denormal / huge: leave alone
+  const int k = e;
+  if (k == 0) return;
+  const float down = __uint_as_float((unsigned int)(127 - k) << 23), up = __uint_as_float((unsigned int)(127 + k) << 23);
+  for (int i = threadIdx.x; i < cin; i += blockDim.x) s[i] *= down;
+  for (int i = threadIdx.x; i < cout; i += blockDim.x) d[i] *= up;
+}
+__global__ __launch_bounds__(256) void normalize_batch_kernel(float *__restrict__ out, const hf_style_job *__restrict__ jobs) {
+  const hf_style_job J = jobs[blockIdx.y];
+  if (!J.wsq) return;  // no demodulation (ToRGB): nothing could absorb the factor
+  const int b = blockIdx.x;
+  normalize_pair(out + J.s_ofs + (long long)b * J.cin, out + J.d_ofs + (long long)b * J.cout, J.cin, J.cout);
+}
+__global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ s, float *__restrict__ d, int cin, int cout) {
+  const int b = blockIdx.x;
+  normalize_pair(s + (long long)b * cin, d + (long long)b * cout, cin, cout);
+}
+
 }  // namespace
+
+extern "C" int hf_style_normalize_f32(float *s, float *d, int batch, int cin, int cout, void *stream) {
+  if (!s || !d || batch <= 0 || batch > 65535 || cin <= 0 || cout <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(normalize_kernel, dim3(batch), dim3(256), 16, (hipStream_t)stream, s, d, cin, cout);
+  return hf_launch_status();
+}
 
 extern "C" int hf_style_batch_f32(float *out, const float *latent, long long lat_bstride, long long lat_rstride,
                                   const hf_style_job *jobs, int n_jobs, int batch, int style_dim, int max_cin,
@@ -141,8 +184,11 @@ extern "C" int hf_style_batch_f32(float *out, const float *latent, long long lat
   hipLaunchKernelGGL(modulation_batch_kernel, dim3(hf_cdiv(max_cin, 4), batch, n_jobs), dim3(256), 0, (hipStream_t)stream,
                      out, latent, lat_bstride, lat_rstride, jobs, style_dim, scale);
   if (max_cout > 0)
+  {
     hipLaunchKernelGGL(demod_batch_kernel, dim3(hf_cdiv(max_cout, 4), batch, n_jobs), dim3(256), 0, (hipStream_t)stream, out,
                        jobs);
+    hipLaunchKernelGGL(normalize_batch_kernel, dim3(batch, n_jobs), dim3(256), 16, (hipStream_t)stream, out, jobs);
+  }
   return hf_launch_status();
 }
 

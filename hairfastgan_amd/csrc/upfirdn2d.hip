@@ -12,6 +12,7 @@
 // global accesses are coalesced rows; the 4-row sliding window lives in
 // registers, so each input element is fetched from L1/L2 at most 4x by
 // neighbouring lanes and from HBM once.
+#define HF_WANT_F16_SPLIT
 #include "hf_common.h"
 
 namespace {
@@ -370,17 +371,19 @@ __global__ __launch_bounds__(512) void blur4x4_split8(hf_half8 *__restrict__ hi,
           const int slot = (u - 3) & 3;
           const float nzr = nz ? nz[(long long)oy * out_w + ox] : 0.0f;
           hf_half8 h8, l8;
+          bool ovf = false;
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             float v = acc[k][slot];
             if (nz) v = fmaf(nw, nzr, v);
             if (bias) v = hf_lrelu(v + bc[k], alpha, scale);
             v *= sv[k];
-            HF_OPAQUE_F32(v);  // hi and lo from the same fp32-rounded product (see convh.hip)
-            const _Float16 hv = (_Float16)v;
+            _Float16 hv, lv;
+            hf_split_f16(v, hv, lv, ovf);  // hi and lo from the same fp32-rounded product, saturating (hf_common.h)
             h8[k] = hv;
-            l8[k] = (_Float16)(v - (float)hv);
+            l8[k] = lv;
           }
+          hf_note_overflow(ovf);
           hp[(long long)oy * out_w] = h8;
           if (lo) lp[(long long)oy * out_w] = l8;  // lo == nullptr: plain fp16 consumer (nterms 1)
         }
@@ -388,6 +391,8 @@ __global__ __launch_bounds__(512) void blur4x4_split8(hf_half8 *__restrict__ hi,
     }
   }
 }
+
+extern "C" unsigned long long hf_f16_overflow_count_blur(int reset) { return hf_f16_overflow_read_tu(reset); }
 
 extern "C" int hf_blur_noise_bias_act_f32(float *out, const float *in, const float *kernel4x4,
                                           const float *noise, const float *noise_w,

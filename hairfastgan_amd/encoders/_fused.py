@@ -10,8 +10,15 @@ from .._runtime import lib, require_gpu, stream
 
 class FrozenPlanMixin:
     """Derived tensors (re-laid-out conv weights, folded BatchNorm) are cached per module
-    and dropped whenever the module is moved / cast / re-loaded.  Parameters are frozen
-    in HairFast (inference only); after an in-place edit call `invalidate()`."""
+    and dropped whenever the module is moved / cast / re-loaded - also when that happens through
+    a PARENT container: nn.Module.load_state_dict recurses through _load_from_state_dict, not
+    through the children's load_state_dict, but it does run every visited module's
+    load-state-dict post-hooks, so each planned module registers one.  Parameters are frozen
+    in HairFast (inference only); after an in-place edit of a parameter call `invalidate()`."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.register_load_state_dict_post_hook(lambda module, _incompatible: module.invalidate())
 
     def invalidate(self):
         for m in self.modules():
@@ -20,11 +27,6 @@ class FrozenPlanMixin:
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        self.invalidate()
-        return out
-
-    def load_state_dict(self, *a, **k):
-        out = super().load_state_dict(*a, **k)
         self.invalidate()
         return out
 

@@ -124,6 +124,13 @@ class FSEncoder(nn.Module):
         self.register_buffer("dlatent_avg", torch.zeros(n_styles, 512))
         self.scale = scale
         self.generator = generator
+        # False (default): the reference's discarded generator forward (trainer.py:295) is skipped.
+        # Besides 148.5 GFLOP per image it draws 17 noise maps from torch's device RNG, so with it
+        # skipped the RNG stream DIVERGES from the reference's: a seeded run whose later stages use
+        # randomize_noise / noise=None no longer reproduces the reference's random draws (outputs stay
+        # correct in distribution; HairFast's own later generator calls pass explicit layer ranges
+        # and the default noise=None, so only bit-reproduction of a seeded reference run is affected).
+        # Set True to keep the RNG stream - and the cost - identical to the reference.
         self.run_discarded_generator = run_discarded_generator
 
     @torch.inference_mode()

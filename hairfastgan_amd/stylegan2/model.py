@@ -30,7 +30,8 @@ from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 
 class PixelNorm(nn.Module):  # :16-21 (mapping network only; not on the HairFast hot path)
     def forward(self, input):
-        return input * torch.rsqrt(torch.mean(input ** 2, dim=1, keepdim=True) + 1e-8)
+        require_gpu(input)
+        return M.pixel_norm(lib(), stream(), input)
 
 
 def make_kernel(k):  # :24-32
@@ -87,13 +88,13 @@ class EqualLinear(nn.Module):  # :134-168
         self.lr_mul = lr_mul
 
     def forward(self, input):
-        # Only the z->w mapping network reaches this generic form (plain GEMM, not on
-        # HairFast's path: input_is_latent=True everywhere); the 26 modulation linears go
-        # through hf_modulation_f32 inside ModulatedConv2d.
-        if self.activation:
-            out = F.linear(input, self.weight * self.scale)
-            return fused_leaky_relu(out, self.bias * self.lr_mul)
-        return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+        # Only the z->w mapping network reaches this generic form (weight-streaming GEMV batch, one
+        # launch of hf_equal_linear_f32 per layer incl. bias*lr_mul and the fused leaky ReLU; not on
+        # HairFast's path: input_is_latent=True everywhere); the 26 modulation linears go through
+        # hf_modulation_f32 / hf_style_batch_f32 inside ModulatedConv2d.
+        require_gpu(input)
+        return M.equal_linear(lib(), stream(), input, self.weight.detach(),
+                              None if self.bias is None else self.bias.detach(), self.lr_mul, bool(self.activation))
 
 
 class ModulatedConv2d(nn.Module):  # :183-279
@@ -126,6 +127,12 @@ class ModulatedConv2d(nn.Module):  # :183-279
         self._prep = None  # (key, wt [k*k,cin,cout], wsq [cout,cin]) - derived, not in the state dict
         self._prep_f16 = None  # (key, wt_hi, wt_lo) fp16 split of wt for the fp16 matrix-core path
         self._coeffs = None  # ((style ptr, shape, stride), (wt, s, d)) set for the duration of one Generator.forward
+        # a (re)load - also through a parent container - drops the derived tensors: the cache key
+        # (data_ptr, version) cannot see an in-place copy into an inference tensor
+        self.register_load_state_dict_post_hook(lambda m, _ik: m.invalidate())
+
+    def invalidate(self):
+        self._prep = self._prep_f16 = self._coeffs = None
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
@@ -184,13 +191,19 @@ class ModulatedConv2d(nn.Module):  # :183-279
                                f16=f16, split_for=split_for)
 
     def style_coefficients(self, style):
-        """s[b,ci] (EqualLinear :241) and d[b,co] (:244-246; None when demodulate=False)."""
+        """s[b,ci] (EqualLinear :241) and d[b,co] (:244-246; None when demodulate=False).  With
+        demodulation the pair is returned range-normalised (s*2^-e, d*2^e per sample; exact)."""
         pre = self._coeffs
         if pre is not None and pre[0] == (style.data_ptr(), tuple(style.shape), tuple(style.stride())):
             return pre[1]  # computed for this very row of W+ by Generator.forward's batched launch
         wt, wsq = self.prepared()
         s = M.modulation(lib(), stream(), style, self.modulation.weight.detach(), self.modulation.bias.detach())
-        d = M.demod(lib(), stream(), s, wsq) if self.demodulate else None
+        d = None
+        if self.demodulate:
+            d = M.demod(lib(), stream(), s, wsq)
+            # exact power-of-two rescaling s*2^-e, d*2^e (the conv is invariant): keeps s*x inside the
+            # range of the fp16 (hi, lo) operand split whatever the trained style's magnitude
+            M.style_normalize(lib(), stream(), s, d)
         return wt, s, d
 
     def forward(self, input, style):
@@ -396,6 +409,7 @@ class Generator(nn.Module):  # :368-565
             self.to_rgbs.append(ToRGB(out_channel, style_dim))
             in_channel = out_channel
         self.n_latent = self.log_size * 2 - 2
+        self.register_load_state_dict_post_hook(lambda m, _ik: m.__dict__.pop("_style_jobs", None) and None)
 
     def make_noise(self):  # :455-464
         device = self.input.input.device

@@ -86,6 +86,16 @@ int hf_modulation_f32(float *s, const float *latent, long long lat_stride, const
  * per-sample weight is scale*W*s, so its squared norm factors through wsq). */
 int hf_demod_f32(float *d, const float *s, const float *wsq, int batch, int cin, int cout, void *stream);
 
+/* Range normalisation of one layer's (s, d) pair, IN PLACE: per sample b, with
+ * e = floor(log2 max_ci |s[b,ci]|):  s[b,:] *= 2^-e,  d[b,:] *= 2^e   (max|s| ends up in [1, 2)).
+ * The demodulated convolution y = d * sum w (s x) is invariant under it and a power of two is exact
+ * in fp32, so every fp32 consumer returns bit-identical results; the fp16 (hi, lo) operand split of
+ * s*x in the matrix-core modes (hf_modconv3x3_f16_* below) then cannot overflow through a large
+ * trained style and does not lose its lo part to fp16 subnormals through a small one.  No reference
+ * counterpart (the reference is fp32 throughout); call it after hf_demod_f32.  hf_style_batch_f32
+ * applies it to every job that has a demodulation. */
+int hf_style_normalize_f32(float *s, float *d, int batch, int cin, int cout, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Fused StyledConv, same resolution (3x3, pad 1):
  *   y[b,co] = act( d[b,co] * sum_{ci,tap} wt[tap,ci,co] * (s[b,ci]*x[b,ci] shifted by tap)
@@ -127,16 +137,33 @@ int hf_style_batch_f32(float *out, const float *latent, long long lat_bstride, l
  * tensors in HBM, fp32 accumulation; v_mfma_f32_32x32x16_f16).  Reference counterpart:
  * the fp16 autocast path the headline numbers of BASELINE.json configs[4] name; the
  * reference itself runs ModulatedConv2d in fp32 (models/stylegan2/model.py:238-277).
- *   nterms 3 ("f16x3"): operands split into fp16 (hi, lo) pairs, a*b = hi*hi + hi*lo + lo*hi
- *            -> fp32-class accuracy (rel. error ~5e-7 per product) at 3/16 of the fp32
- *            MFMA time; requires |s*x|, |w| < 65504.
- *   nterms 1 ("f16"): operands rounded to fp16 (rel. error ~5e-4 per product).
- * wt_hi / wt_lo: from hf_conv_split_weights_f16 (each 9*cin*cout fp16 values, layout
- * [cin/16][tap][2][cout][8]); wt_lo may be NULL for nterms 1.
+ *   nterms 3 ("f16x3"): operands split into fp16 (hi, lo) pairs, a*b = hi*hi + hi*lo + lo*hi,
+ *            each MFMA product exact in the fp32 accumulator, at 3/16 of the fp32 MFMA time.
+ *            Accuracy: an operand v is carried with relative error <= 2^-22 while |v| >= 2^-3 and
+ *            with ABSOLUTE error <= 2^-25 below that (lo becomes an fp16 subnormal); the dropped
+ *            lo*lo term is <= 2^-22 relative.  Weights are pre-scaled by a power of two so that
+ *            max|w| sits at 2^13 (every weight within 2^-15 of the largest keeps 22 bits), styles
+ *            are normalised to max|s| in [1,2) (hf_style_normalize_f32), so a dot product's large
+ *            terms are exact to ~2e-7 and its small terms to 3e-8 * |w| absolute: the same class
+ *            as an fp32 reassociation for activations of magnitude >= ~1e-2.
+ *            Range: full accuracy for |s*x| < 65504 (i.e. |x| < 32752 after the style normalisation);
+ *            both parts saturate at 65504 instead of becoming inf/NaN, so values up to 131008 are
+ *            still carried (to 2^-11 of their excess); larger ones clamp and are counted by
+ *            hf_f16_overflow_count().
+ *   nterms 1 ("f16"): operands rounded to fp16 (rel. error ~5e-4 per product), saturating at 65504.
+ * wt_hi / wt_lo: from hf_conv_split_weights_f16, layout [cin/16][tap][2][cout][8] fp16.
+ * wt_hi must hold 9*cin*cout fp16 values PLUS A 16-BYTE TRAILER (float 2^-k of the weights'
+ * power-of-two pre-scale, read by the conv kernels and folded into the output scale; 12 bytes
+ * reserved); wt_lo 9*cin*cout values, may be NULL for nterms 1.
  * Shapes: cin % 16 == 0, w >= 32 and (cout % 64 == 0, h >= 8) or (cout % 32 == 0, h >= 16);
  * anything else returns HF_E_INVALID and the caller uses hf_modconv3x3_f32.
  */
 int hf_conv_split_weights_f16(void *wt_hi, void *wt_lo, const float *wt, int cin, int cout, void *stream);
+/* Elements the fp16 split had to clamp (|v| > 131008 or NaN) since the last reset, summed over
+ * all kernels of the library.  SYNCHRONOUS (copies a device counter; do not call inside a stream
+ * capture).  A non-zero value means a tensor left the fp16-pair range: re-run with the exact
+ * fp32 kernels (hf_modconv3x3_f32 / hf_modconv3x3_up_f32).  reset != 0 clears the counter. */
+long long hf_f16_overflow_count(int reset);
 int hf_modconv3x3_f16_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
                           const float *s, const float *d, const float *noise, const float *noise_w,
                           long long noise_bstride, const float *bias, int batch, int cin, int cout, int h,
@@ -300,6 +327,16 @@ int hf_downscale2x_f32(float *out, const float *x, int planes, int h, int w, voi
  * 1/sqrt(in_features); psp_encoders.py:48, 53). */
 int hf_linear_f32(float *out, const float *x, long long x_stride, const float *w, const float *bias, int batch,
                   int in_features, int out_features, float scale, void *stream);
+/* EqualLinear.forward (models/stylegan2/model.py:153-163) as one launch:
+ *   out[b,n] = (sum_k x[b,k] * w[n,k]) * lr_mul/sqrt(in_features) + bias[n] * lr_mul
+ * and, with fused_lrelu != 0 (activation='fused_lrelu', :154-156), leaky_relu(., alpha) * act_scale on
+ * top - one layer of the z -> w mapping network (:384-393: lr_mul 0.01, alpha 0.2, act_scale sqrt 2).
+ * bias may be NULL; batch <= 8 per launch. */
+int hf_equal_linear_f32(float *out, const float *x, long long x_stride, const float *w, const float *bias, int batch,
+                        int in_features, int out_features, float lr_mul, int fused_lrelu, float alpha, float act_scale,
+                        void *stream);
+/* PixelNorm.forward (models/stylegan2/model.py:16-21) on [rows, dim]: x * rsqrt(mean_k x^2 + 1e-8). */
+int hf_pixel_norm_f32(float *out, const float *x, int rows, int dim, void *stream);
 /* out[i] = a[i] + b[i % b_period] */
 int hf_add_bcast_f32(float *out, const float *a, const float *b, long long n, long long b_period, void *stream);
 

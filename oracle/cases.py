@@ -114,6 +114,20 @@ def generator_inputs(size, B, start_layer, cin_of_block=None):
     return lat, noise, layer_in
 
 
+def edge_crops(size, c=32):
+    """Crops of a [.., size, size] image away from its centre: the four corners and the middle of
+    each edge (tile-edge coverage the centre crop does not give).  name -> (slice_y, slice_x)."""
+    m = size // 2 - c // 2
+    lo, hi, mid = slice(0, c), slice(size - c, size), slice(m, m + c)
+    return {"tl": (lo, lo), "tr": (lo, hi), "bl": (hi, lo), "br": (hi, hi),
+            "top": (lo, mid), "bottom": (hi, mid), "left": (mid, lo), "right": (mid, hi)}
+
+
+def mapping_inputs(B=3, dim=512):
+    """z for the mapping network (Generator.style / input_is_latent=False)."""
+    return t(synth.pseudo_normal(f"mapping/z/{B}", (B, dim)))
+
+
 # ------------------------------------------------------------------------------------
 # encoders (oracle/ref_encoders.py)
 # ------------------------------------------------------------------------------------

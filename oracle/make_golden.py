@@ -180,6 +180,9 @@ def main():
                 elif y.shape[1] == 3:
                     c0 = y.shape[-1] // 2 - 32
                     out[f"{key}_crop"] = y[:, :, c0:c0 + 64, c0:c0 + 64].numpy().copy()
+                    out[f"{key}_edges"] = np.array([1])
+                    for nm, (sy, sx) in C.edge_crops(y.shape[-1]).items():
+                        out[f"{key}_edges_{nm}"] = y[:, :, sy, sx].numpy().copy()
                 else:  # feature map early exit: every 16th channel, full spatial
                     out[f"{key}_chan16"] = y[:, ::16].numpy().copy()
                 if sk is not None:
@@ -188,6 +191,18 @@ def main():
                 for nm, v in inter.items():
                     out[f"{key}_inter_{nm}"] = v
                 print("done", key, report[f"gen/{key}"], flush=True)
+        # mapping network: z -> w, and one forward entered through z
+        z = C.mapping_inputs(3)
+        w = gen.style(z)
+        report[f"gen/{tag}_mapping"] = maxdiff(w, O.mapping_network(P, z, n_mlp=n_mlp))
+        out[f"{tag}_mapping_w"] = w.numpy()
+        if size <= 64:
+            lat, nz, _ = C.generator_inputs(size, 3, 0)
+            y, _ = gen([z], input_is_latent=False, noise=nz)
+            yo, _ = O.generator_forward(P, O.mapping_network(P, z, n_mlp=n_mlp).unsqueeze(1).repeat(1, 2 * log_size - 2, 1),
+                                        nz, log_size=log_size)
+            report[f"gen/{tag}_from_z"] = maxdiff(y, yo)
+            out[f"{tag}_from_z_full"] = y.numpy()
         return out
 
     g = run_generator("g64")
@@ -260,6 +275,11 @@ def main():
             g[f"e4e_{nm}_stats"] = stats(tap)
             g[f"e4e_{nm}_samples"] = strided_samples(tap, 256)
         print("done e4e", report["enc/e4e"], flush=True)
+        x3, _ = C.e4e_inputs(3)  # the batch HairFast embeds with (Embedding.py:71)
+        w3 = e4e(x3) + latent_avg.repeat(3, 1, 1)
+        report["enc/e4e_B3"] = maxdiff(w3, E.e4e_forward(P, x3, latent_avg=latent_avg))
+        g["e4e_w_B3"] = w3.numpy()
+        print("done e4e B3", report["enc/e4e_B3"], flush=True)
 
         from nets.feature_style_encoder import fs_encoder_v2
 
@@ -286,6 +306,18 @@ def main():
         g["fs_content_stats"] = stats(content)
         g["fs_x256_samples"] = strided_samples(x256, 256)
         print("done fs", report["enc/fs_s"], report["enc/fs_content"], flush=True)
+        img3, _ = C.fs_inputs(3)
+        x3 = img3
+        for _ in range(2):
+            x3 = torch.nn.functional.interpolate(x3, scale_factor=0.5, mode="bilinear")
+        s3, c3 = fs(x3)
+        s3 = s3 + dlat
+        so3, co3 = E.fs_encoder_test(P, img3, dlat)
+        report["enc/fs_s_B3"] = maxdiff(s3, so3)
+        report["enc/fs_content_B3"] = maxdiff(c3, co3)
+        g["fs_s_B3"] = s3.numpy()
+        g["fs_content_chan16_B3"] = c3[:, ::16].numpy().copy()
+        print("done fs B3", report["enc/fs_s_B3"], report["enc/fs_content_B3"], flush=True)
         np.savez_compressed(os.path.join(args.out, "encoders.npz"), **g)
 
     worst = max(report.values())

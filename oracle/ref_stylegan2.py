@@ -188,6 +188,18 @@ def generator_forward(P, latent, noise, layer_in=None, skip=None, start_layer=0,
     return skip, None
 
 
+def mapping_network(P, z, n_mlp=8, lr_mlp=0.01):
+    """z -> w: PixelNorm (model.py:16-21) then n_mlp x EqualLinear(lr_mul=lr_mlp, 'fused_lrelu')
+    (model.py:384-393; EqualLinear.forward :153-163 with activation: F.linear(x, W*scale) then
+    fused_leaky_relu(out, bias*lr_mul), scale = lr_mul/sqrt(in_dim))."""
+    x = z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8)
+    for i in range(1, n_mlp + 1):
+        w, b = P[f"style.{i}.weight"], P[f"style.{i}.bias"]
+        scale = (1 / math.sqrt(w.shape[1])) * lr_mlp
+        x = fused_leaky_relu(F.linear(x, w * scale), b * lr_mlp)
+    return x
+
+
 def generator_param_shapes(size=1024, style_dim=512, n_mlp=8, channel_multiplier=2):
     """State-dict key -> shape for Generator(size, style_dim, n_mlp, cm)
     (layout from model.py:368-452); 171 entries for the 1024 config."""

@@ -67,6 +67,14 @@ inline float __shfl_xor(float v, int mask, int /*width*/ = 64) { return ::hipsim
 inline float __shfl_up(float v, int d, int /*width*/ = 64) { return ::hipsim::shfl_rel(v, -d); }
 inline float __shfl_down(float v, int d, int /*width*/ = 64) { return ::hipsim::shfl_rel(v, d); }
 inline float rsqrtf(float v) { return 1.0f / sqrtf(v); }
+// single OS thread, fibers only switch at rendezvous points: plain read-modify-write is atomic
+inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
+inline unsigned int atomicMax(unsigned int *p, unsigned int v) { unsigned int o = *p; if (v > o) *p = v; return o; }
+inline unsigned int __float_as_uint(float f) { unsigned int u; __builtin_memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned int u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+#define HIP_SYMBOL(x) (&(x))
+inline hipError_t hipMemcpyFromSymbol(void *dst, const void *sym, size_t n) { __builtin_memcpy(dst, sym, n); return hipSuccess; }
+inline hipError_t hipMemcpyToSymbol(void *sym, const void *src, size_t n) { __builtin_memcpy(sym, src, n); return hipSuccess; }
 template <class T> inline T min(T a, T b) { return a < b ? a : b; }
 template <class T> inline T max(T a, T b) { return a > b ? a : b; }
 

@@ -100,8 +100,10 @@ def test_e4e_vs_reference_golden(golden):
     with torch.inference_mode():
         w = get_latents(net, x.to(dev))
         w2 = get_latents(net, x.to(dev))
+        w3 = get_latents(net, C.e4e_inputs(3)[0].to(dev))  # the batch HairFast embeds with (Embedding.py:71)
     assert torch.equal(w, w2)
     close(w, G["e4e_w"])
+    close(w3, G["e4e_w_B3"])
 
 
 def test_fs_encoder_vs_reference_golden(golden):
@@ -120,3 +122,6 @@ def test_fs_encoder_vs_reference_golden(golden):
     assert out[1] is None and out[0].shape == (2, 3, 1024, 1024)
     close(s, G["fs_s"])
     close(fea[:, ::16], G["fs_content_chan16"])
+    out3 = fs.test(img=C.fs_inputs(3)[0].to(dev), return_latent=True)  # batch 3: Embedding.py:74
+    close(out3[2], G["fs_s_B3"])
+    close(out3[3][:, ::16], G["fs_content_chan16_B3"])

@@ -35,9 +35,10 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 12
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
-    assert set(_lib.SIGNATURES) | {"hf_strerror", "hf_abi_version", "hf_modconv_workspace_floats", "hf_conv2d_workspace_floats"} == declared
+    assert set(_lib.SIGNATURES) | {"hf_strerror", "hf_abi_version", "hf_modconv_workspace_floats", "hf_conv2d_workspace_floats",
+                                    "hf_f16_overflow_count"} == declared
     bound = _lib.bind(lib)
-    assert bound.hf_abi_version() == 6
+    assert bound.hf_abi_version() == 7
     assert bound.hf_strerror(-1) == b"invalid argument"
 
 
@@ -126,3 +127,30 @@ def test_kernels_use_no_scratch_memory():
         sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
         assert sizes, f"{f}: no kernel resource remarks"
         assert max(sizes) == 0, f"{f}: scratch {max(sizes)} bytes/lane"
+
+
+def test_cached_plans_drop_when_loaded_through_a_parent():
+    """Advisor (round 1): derived tensors cached on a module (folded BN, re-laid-out weights) must
+    not survive a load_state_dict issued on a PARENT container - nn.Module.load_state_dict does not
+    call the children's load_state_dict, only their post-hooks."""
+    import argparse
+
+    from hairfastgan_amd.encoders import Encoder4Editing
+    from hairfastgan_amd.encoders.fs_encoder import FSEncoder
+    from hairfastgan_amd.stylegan2.model import Generator
+
+    holder = torch.nn.Module()
+    holder.e4e = Encoder4Editing(50, "ir_se", argparse.Namespace(stylegan_size=1024))
+    holder.fs = FSEncoder()
+    holder.g = Generator(16, 512, 1)
+    unit, head, blk = holder.e4e.body[3], holder.e4e.styles[2], holder.fs.enc.block_2[1]
+    conv = holder.g.convs[0].conv
+    for m in (holder.e4e, unit, head, blk, holder.fs.enc):
+        m._plan = "stale"
+    conv._prep, conv._prep_f16 = ("k", 1, 2), ("k", 1, 2)
+    holder.g.__dict__["_style_jobs"] = {"x": 1}
+    holder.load_state_dict(holder.state_dict())
+    for m in (holder.e4e, unit, head, blk, holder.fs.enc):
+        assert m._plan is None
+    assert conv._prep is None and conv._prep_f16 is None
+    assert "_style_jobs" not in holder.g.__dict__

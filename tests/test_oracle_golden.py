@@ -74,3 +74,17 @@ def test_generator1024_partial_range(golden):
     # 0->3 is 8 GFLOP: cheap enough for the CPU suite; the full 0->8 forward is exercised
     # by make_golden.py itself and by bench.py's cpu_baseline leg.
     _check_generator(golden, "g1024", "generator_1024.npz", ranges=[(0, 3), (3, 3)])
+
+
+def test_mapping_network(golden):
+    """Row a11: oracle z -> w against the reference's Generator.style, and a 64^2 forward entered
+    through z (input_is_latent=False)."""
+    for tag, fname in (("g64", "generator_64.npz"), ("g1024", "generator_1024.npz")):
+        size, cm, n_mlp, _, _ = C.GENERATOR_CASES[tag]
+        P = C.generator_params(O.generator_param_shapes(size, 512, n_mlp, cm))
+        w = O.mapping_network(P, C.mapping_inputs(3), n_mlp=n_mlp)
+        assert np.array_equal(w.numpy(), golden(fname)[f"{tag}_mapping_w"])
+        if tag == "g64":
+            _, nz, _ = C.generator_inputs(size, 3, 0)
+            y, _ = O.generator_forward(P, w.unsqueeze(1).repeat(1, 10, 1), nz, log_size=6)
+            assert np.array_equal(y.numpy(), golden(fname)["g64_from_z_full"])

@@ -2,6 +2,8 @@
 golden vectors produced by the real reference.  They validate index arithmetic, LDS
 layouts, the MFMA fragment maps and tile geometry before any GPU time is spent; the
 numerical parity proper is re-established on the GPU by the -m gpu tests."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -186,9 +188,14 @@ def test_modconv_f16_matrix_cores(simlib, nterms, tol, cfg, shape):
     s = M.modulation(simlib, None, sty, mw, mb)
     dm = M.demod(simlib, None, s, wsq)
     hi, lo = M.split_weights_f16(simlib, None, wt)
-    # hi + lo carries the weight to 2^-22 relative
-    back = (hi.float() + lo.float()).permute(1, 0, 2, 4, 3).reshape(9, cin, cout)
+    # hi + lo carries 2^k * weight (k: power-of-two pre-scale putting max|w| at 2^13) to 2^-22 relative
+    # of the LARGEST weight - and, because of the pre-scale, of every weight above 2^-15 of it
+    unscale = M.split_weights_unscale(hi)
+    assert 2 ** 13 <= float(wt.abs().max()) / unscale < 2 ** 14 and math.log2(unscale) == round(math.log2(unscale))
+    back = (hi.float() + lo.float()).permute(1, 0, 2, 4, 3).reshape(9, cin, cout) * unscale
     assert maxdiff(back, wt) < 3e-7 * float(wt.abs().max())
+    rel = ((back.double() - wt.double()).abs() / wt.double().abs().clamp_min(1e-30))[wt.abs() > 2.0 ** -14 * wt.abs().max()]
+    assert float(rel.max()) < 2.0 ** -21
     ref = M.modconv3x3(simlib, None, x, wt, s, dm, nz, nw, bias)
     try:
         simlib.hf_debug_set_dispatch(cfg, 0)
@@ -395,11 +402,53 @@ def test_style_batch_equals_per_layer_launches(simlib):
     res = M.style_batch(simlib, None, latent, table, layout, total, 40, 24)
     for c, row, (s, d) in zip(convs, rows, res):
         s_ref = M.modulation(simlib, None, latent[:, row], c.modulation.weight, c.modulation.bias)
-        assert torch.equal(s, s_ref)
         if c.demodulate:
-            assert torch.equal(d, M.demod(simlib, None, s_ref, c.prepared()[1]))
+            d_ref = M.demod(simlib, None, s_ref, c.prepared()[1])
+            # the batch applies hf_style_normalize_f32: per sample s * 2^-e, d * 2^e (exact), max|s| in [1, 2)
+            e = torch.floor(torch.log2(s_ref.abs().amax(1, keepdim=True)))
+            assert torch.equal(s, s_ref * torch.exp2(-e)) and torch.equal(d, d_ref * torch.exp2(e))
+            assert float(s.abs().amax(1).min()) >= 1.0 and float(s.abs().amax(1).max()) < 2.0
+            M.style_normalize(simlib, None, s_ref, d_ref)  # the per-layer entry point does the same, in place
+            assert torch.equal(s, s_ref) and torch.equal(d, d_ref)
         else:
+            assert torch.equal(s, s_ref)  # no demodulation (ToRGB): nothing could absorb the factor
             assert d is None
+
+
+def test_f16_split_range(simlib):
+    """The fp16 (hi, lo) operand split is range-safe: a style 1e5 times larger than usual (normalised
+    away, exactly), activations beyond the fp16 range (both parts saturate: representable up to
+    131008, no inf/NaN) and a clamp counter for what lies beyond; tiny activations keep fp32-class
+    accuracy because weights and styles are pre-scaled into the normal fp16 range."""
+    B, cin, cout, H, W = 1, 32, 64, 8, 32
+    torch.manual_seed(3)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+    wt, wsq = M.prepare_weights(simlib, None, wgt)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    x = torch.randn(B, cin, H, W)
+    for sty_scale, x_scale in [(1e5, 1.0), (1e-5, 1.0), (1.0, 5e3), (1.0, 1e-2), (1.0, 1e-4), (1e4, 5e3)]:
+        simlib.hf_f16_overflow_count(1)
+        s = M.modulation(simlib, None, sty * sty_scale, mw * 1.0, mb * sty_scale)
+        dm = M.demod(simlib, None, s, wsq)
+        M.style_normalize(simlib, None, s, dm)
+        xs = x * x_scale
+        ref = M.modconv3x3(simlib, None, xs, wt, s, dm, None, None, None)
+        y = M.modconv3x3_f16(simlib, None, xs, hi, lo, 3, s, dm, None, None, None)
+        assert torch.isfinite(y).all()
+        # error model (include/hairfast_hip.h): 2^-22 relative per operand while |s*x| >= 2^-3, an absolute
+        # 2^-25 below that - i.e. relative to the output ~3e-8 / rms(s*x) once the activations are tiny
+        tol = 5e-6 + 6e-8 / min(1.0, x_scale)
+        assert maxdiff(y, ref) < tol * float(ref.abs().max()), (sty_scale, x_scale)
+        assert M.f16_overflow_count(simlib) == 0
+    # beyond 2 * 65504 after normalisation (max|s| in [1, 2), |x| up to ~4 * 4e4): clamped, finite, counted
+    s = M.modulation(simlib, None, sty, mw, mb)
+    dm = M.demod(simlib, None, s, wsq)
+    M.style_normalize(simlib, None, s, dm)
+    y = M.modconv3x3_f16(simlib, None, x * 4e4, hi, lo, 3, s, dm, None, None, None)
+    assert torch.isfinite(y).all()
+    assert M.f16_overflow_count(simlib, reset=True) > 0
+    assert M.f16_overflow_count(simlib) == 0
 
 
 @pytest.mark.parametrize("shape,use_skip", [((2, 64, 4, 4), False), ((3, 136, 8, 12), True), ((1, 512, 16, 16), True)])
@@ -416,3 +465,24 @@ def test_torgb_small_plane_kernel(simlib, shape, use_skip):
     if use_skip:
         ref = ref + O.upfirdn2d(skip, k4, up=2, pad=(2, 1))
     assert maxdiff(y, ref) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_mapping_network_kernels(simlib, golden):
+    """Row a11: PixelNorm + 8 x EqualLinear(lr_mul 0.01, fused_lrelu) through hf_pixel_norm_f32 /
+    hf_equal_linear_f32 against the reference's golden w (and the oracle), 3 and 11 rows (> 8: two launches)."""
+    size, cm, n_mlp, _, _ = C.GENERATOR_CASES["g64"]
+    P = C.generator_params(O.generator_param_shapes(size, 512, n_mlp, cm))
+    for B in (3, 11):
+        z = C.mapping_inputs(B)
+        x = M.pixel_norm(simlib, None, z)
+        for i in range(1, n_mlp + 1):
+            x = M.equal_linear(simlib, None, x, P[f"style.{i}.weight"], P[f"style.{i}.bias"], 0.01, True)
+        ref = O.mapping_network(P, z, n_mlp=n_mlp)
+        assert maxdiff(x, ref) < 1e-5 * max(1.0, float(ref.abs().max()))
+        if B == 3:
+            assert maxdiff(x, torch.from_numpy(golden("generator_64.npz")["g64_mapping_w"])) < 1e-5
+    # no activation, no bias, strided input rows
+    xx = torch.randn(5, 40)[:, :24]
+    w = torch.randn(7, 24)
+    y = M.equal_linear(simlib, None, xx, w, None, 1.0, False)
+    assert maxdiff(y, xx @ w.t() / 24 ** 0.5) < 1e-5
