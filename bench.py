@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py - StyleGAN2 1024^2 generator forward on MI355X (BASELINE.json configs[1]).
+"""bench.py - MI355X measurements of the HairFastGAN hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8] [--workload generator|swap256]
 
-A "step" is one full generator forward (range 0->8) of one batch of W+ latents that are
-already resident in HBM; noise is drawn fresh per layer like HairFast's callers do
-(noise=None, models/stylegan2/model.py:289-291).  Weights are the closed-form synthetic
-fill of oracle/synth.py (no checkpoints / network on the box); timing is weight-independent.
+--workload generator (default; BASELINE.json configs[1], the configuration the headline metric
+  is quoted on): a "step" is one full StyleGAN2 1024^2 generator forward (range 0->8) of one batch
+  of W+ latents that are already resident in HBM; noise is drawn fresh per layer like HairFast's
+  callers do (noise=None, models/stylegan2/model.py:289-291).  value = images/s.
+--workload swap256 (BASELINE.json configs[3]): `--triples` (default 256) synthetic 1024^2 triples,
+  block-partitioned over the ranks; every triple goes host uint8 -> H2D -> HairFast.swap (the complete
+  call schedule of hair_swap.py:38-61 with SyntheticStages standing in for the out-of-scope networks)
+  -> uint8 -> chunked RCCL all-gather; wall clock from the first H2D to the completion of the last
+  gather.  value = triples/s (strong scaling: total work fixed).  --steps / --warmup count triples
+  per rank are ignored: the workload is the whole set; --warmup triples are run untimed first.
 
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel = the modulated-conv instantiation with the largest share of the
-                step (per-launch labels come from hf_debug_last_path): ALGORITHMIC FLOPs of its
-                launches / their HIP-event durations, measured during the timed steps on the launch
-                stream.  peak: 157.3 TFLOP/s for the fp32-MFMA kernels; for the split-operand
-                fp16 kernels (3 fp16 MFMAs per fp32-class product) the fp16 dense peak / 3.
-  exact_f32     the same forward with every conv on the fp32 MFMA (HAIRFAST_CONV_PRECISION=f32),
-                timed after the headline run, for comparison.
-  cpu_baseline  the CPU oracle (bit-identical restatement of the reference's PyTorch CPU
-                path) timed on this host: batch-1 forwards, all host cores (rank 0, N=1 only).
-For N>1 (torchrun, one rank per GPU over RCCL) every rank runs the same per-GPU batch
-(weak scaling) and the uint8 result images of each step are all-gathered (async, overlapped
-with the next step's compute).
+Weights are the closed-form synthetic fill of oracle/synth.py (no checkpoints / network on the box);
+timing is weight-independent.  Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant MFMA kernel = the conv instantiation with the largest share of the timed
+                region (labels from hf_debug_last_path): ALGORITHMIC FLOPs of its launches / their
+                HIP-event durations, measured in this run on the launch stream.  peak: 157.3 TFLOP/s
+                for the fp32-MFMA kernels; for the split-operand fp16 kernels (3 fp16 MFMAs per
+                fp32-class product) the fp16 dense peak / 3.  `traffic` (HBM bytes per launch, PMC)
+                cannot be collected inside a timing run: it is replayed from the committed rocprofv3
+                --pmc pass named in `traffic_source` (null when that pass does not list the kernel).
+  roofline_hbm  the same for the dominant HBM-bound (streaming) kernel: algorithmic bytes / duration
+                against 8 TB/s.
+  exact_f32     the generator workload with every conv on the fp32 MFMA, timed after the headline run.
+  cpu_baseline  the CPU oracle (bit-identical restatement of the reference's PyTorch CPU path) timed
+                on this host: batch-1 forwards with the best thread count (value) and with ONE thread
+                (per_core), host core count stated (rank 0, N=1 only).
+For N>1 (torchrun, one rank per GPU over RCCL) the generator workload weak-scales (same per-GPU batch,
+uint8 result images all-gathered asynchronously per step).
 """
 import argparse
 import json
@@ -35,19 +45,31 @@ import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_f16: 32768 FLOP / 32 cycles / SIMD, 1024 SIMDs x 2.4 GHz
+PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (~6.3 TB/s achievable)
 DTYPES = {
     "f16x3": "f32 tensors + f32 accumulate; conv products as 3 fp16 MFMAs on (hi,lo)-split operands (fp32-class)",
     "f32": "f32 (fp32 MFMA)",
     "f16": "f32 tensors + f32 accumulate; conv operands rounded to fp16 (fp16 MFMA)",
 }
 GFLOP_PER_IMAGE = 148.52       # modulated-conv FLOPs of one 0->8 forward
+GFLOP_PER_TRIPLE = 1545.0      # hot-path FLOPs of one swap (encoders + generator calls)
+PMC_PROFILE = os.path.join("profiles", "pmc_traffic.json")
+
+
+def synth_state(prefix, shapes):
+    import numpy as np
+
+    from oracle import synth  # closed-form parameter fill only (data, not compute)
+
+    return {k: torch.from_numpy(np.ascontiguousarray(synth.fill_value(f"{prefix}.{k}" if prefix else k, tuple(s))))
+            for k, s in shapes.items()}
 
 
 def build_generator(dev):
     import numpy as np
 
     from hairfastgan_amd.stylegan2.model import Generator
-    from oracle import synth  # closed-form parameter fill only (data, not compute)
+    from oracle import synth
 
     g = Generator(1024, 512, 8, channel_multiplier=2).eval()
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in
@@ -56,10 +78,21 @@ def build_generator(dev):
     return g.to(dev), sd
 
 
+def build_hairfast(sd, dev):
+    """HairFast(args) on synthetic weights with SyntheticStages for the out-of-scope networks."""
+    from hairfastgan_amd.hair_swap import HairFast, SyntheticStages, get_parser
+    from oracle import ref_encoders as E
+
+    args = get_parser().parse_args([])
+    args.device = dev
+    return HairFast(args, stages=SyntheticStages(), generator_state={"g_ema": sd, "latent_avg": torch.zeros(512)},
+                    e4e_state=synth_state("e4e", E.e4e_param_shapes()), fs_state=synth_state("fs", E.fs_param_shapes()))
+
+
 def cpu_baseline(sd, budget_s=30.0):
-    """Oracle forward (generator 0->8, batch 1, explicit noise) timed on this host with all
-    cores and, because very wide hosts oversubscribe ATen's grouped convs, with 32 threads;
-    the faster setting is reported with the thread count it used."""
+    """Oracle forward (generator 0->8, batch 1, explicit noise) timed on this host: with all cores
+    (only up to 64: very wide hosts oversubscribe ATen's grouped convs) and with 32 threads - the
+    faster is `value` - and with ONE thread (`per_core`, a single forward: ~10-20 s)."""
     from oracle import cases as C
     from oracle import ref_stylegan2 as O
 
@@ -67,8 +100,6 @@ def cpu_baseline(sd, budget_s=30.0):
     lat, nz, _ = C.generator_inputs(1024, 1, 0)
     tried = {}
     t_start = time.time()
-    # very wide hosts (256 hardware threads) take ~40 s per forward with all threads: only try
-    # the full count up to 64 cores, otherwise 32 threads
     counts = {min(ncpu, 32)} | ({ncpu} if ncpu <= 64 else set())
     for threads in sorted(counts, reverse=True):
         torch.set_num_threads(threads)
@@ -83,49 +114,47 @@ def cpu_baseline(sd, budget_s=30.0):
         tried[threads] = (times[len(times) // 2], len(times))
     cores = min(tried, key=lambda k: tried[k][0])
     med, n = tried[cores]
-    return {"value": round(1.0 / med, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "ms_per_image": round(med * 1e3, 1),
+    per_core = None
+    if med * cores < 90.0:  # predicted single-thread time: keep the default run within minutes
+        torch.set_num_threads(1)
+        with torch.inference_mode():
+            t0 = time.time()
+            O.generator_forward(sd, lat, nz)
+            t1 = time.time() - t0
+        per_core = {"value": round(1.0 / t1, 5), "unit": "images/s", "cores": 1, "ms_per_image": round(t1 * 1e3, 1),
+                    "sample": "one timed forward, torch.set_num_threads(1), no warm-up"}
+    torch.set_num_threads(min(ncpu, 32))
+    return {"value": round(1.0 / med, 4), "unit": "images/s", "cores": cores, "host_cores": ncpu, "kind": "port",
+            "ms_per_image": round(med * 1e3, 1), "per_core": per_core,
             "sample": f"oracle (CPU restatement, bit-identical to the reference's PyTorch CPU path) generator "
                       f"0->8, batch 1, explicit noise; median of {n} timed forwards after 1 warm-up, torch "
                       f"{torch.__version__}; thread counts tried: "
                       + ", ".join(f"{k}T={v[0] * 1e3:.0f}ms" for k, v in sorted(tried.items()))}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json:
-    FETCH_SIZE + WRITE_SIZE collected in separate rocprofv3 --pmc runs of this bench), or None."""
+def pmc_profile(kernel):
+    """(bytes per launch, MFMA-busy fraction, tag) of `kernel` from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate runs of this bench), or Nones."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            k = json.load(f)["kernels"].get(kernel)
-        return None if k is None else round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
+        with open(os.path.join(ROOT, PMC_PROFILE)) as f:
+            doc = json.load(f)
+        k = doc["kernels"].get(kernel)
+        if k is None:
+            return None, None, doc.get("tag", "r01h")
+        return round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]), k.get("mfma_busy"), doc.get("tag", "r01h")
     except (OSError, KeyError, ValueError):
-        return None
-
-
-def pmc_mfma_busy(kernel):
-    """MFMA-busy fraction of `kernel` at the clock it actually ran at (same committed PMC passes), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["kernels"].get(kernel, {}).get("mfma_busy")
-    except (OSError, ValueError, KeyError):
-        return None
+        return None, None, None
 
 
 def swap_schedule_bench(g, sd, dev, n_triples):
     """Seconds for `n_triples` replays of the per-triple hot-path schedule (after one warm-up)."""
-    import numpy as np
-
     from hairfastgan_amd.hair_swap import HairFastHotPath, get_parser
     from oracle import ref_encoders as E
-    from oracle import synth
-
-    def fill(prefix, shapes):
-        return {k: torch.from_numpy(np.ascontiguousarray(synth.fill_value(f"{prefix}.{k}", tuple(s)))) for k, s in shapes.items()}
 
     args = get_parser().parse_args([])
     args.device = dev
-    hp = HairFastHotPath(args, {"g_ema": sd, "latent_avg": torch.zeros(512)}, fill("e4e", E.e4e_param_shapes()),
-                         fill("fs", E.fs_param_shapes()))
+    hp = HairFastHotPath(args, {"g_ema": sd, "latent_avg": torch.zeros(512)}, synth_state("e4e", E.e4e_param_shapes()),
+                         synth_state("fs", E.fs_param_shapes()))
     torch.manual_seed(3407)
     z = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
     inputs = (z(3, 3, 1024, 1024) * 0.5, z(3, 3, 256, 256) * 0.5, z(2, 3, 256, 256) * 0.5, z(1, 512, 32, 32),
@@ -146,19 +175,88 @@ def swap_schedule_bench(g, sd, dev, n_triples):
     return res
 
 
+def make_triple_loader(n_pool=8):
+    """Host-side synthetic triples: uint8 [3,1024,1024] images in pinned memory, seeded per image
+    (seeds 3i, 3i+1, 3i+2 of triple i; a pool of n_pool distinct triples is cycled so that the host
+    holds 75 MB instead of 2.4 GB - every triple still crosses PCIe)."""
+    pool = []
+    for t in range(n_pool):
+        imgs = []
+        for k in range(3):
+            gen = torch.Generator().manual_seed(3 * t + k)
+            im = torch.randint(0, 256, (3, 1024, 1024), dtype=torch.uint8, generator=gen)
+            imgs.append(im.pin_memory() if torch.cuda.is_available() else im)
+        pool.append(tuple(imgs))
+    return lambda i: pool[i % n_pool]
+
+
+def kernel_report(prof, elapsed, precision):
+    """Aggregate the HIP-event brackets of the timed region: per-kernel table + the two rooflines."""
+    agg = {}
+    for label, flops, e0, e1, nbytes in prof:
+        a = agg.setdefault(label, [0.0, 0.0, 0, 0.0])
+        a[0] += flops
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+        a[3] += nbytes
+    fams = {}
+    for k, v in agg.items():
+        row = {"avg_launch_ms": round(v[1] / v[2] * 1e3, 4), "launches": v[2], "share_of_timed_region": round(v[1] / elapsed, 4)}
+        if v[0] > 0:
+            row["tflops"] = round(v[0] / v[1] / 1e12, 2)
+        if v[3] > 0:
+            row["hbm_gbps_algorithmic"] = round(v[3] / v[1] / 1e9, 1)
+        fams[k] = row
+    out = {"kernels": fams}
+    mfma = {k: v for k, v in agg.items() if v[0] > 0}
+    if mfma:
+        dom = max(mfma, key=lambda k: mfma[k][1])
+        d = mfma[dom]
+        ach = d[0] / d[1] / 1e12
+        if dom.startswith("conv_mfma_h"):
+            terms = 3 if precision == "f16x3" else 1
+            peak = PEAK_F16_MFMA_TFLOPS / terms
+            peak_note = (f"fp16 dense MFMA peak {PEAK_F16_MFMA_TFLOPS} TFLOP/s / {terms} MFMA per product; "
+                         f"MFMA FLOPs issued = {terms} x algorithmic = {round(ach * terms, 1)} TFLOP/s")
+        else:
+            peak, peak_note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA peak"
+        traffic, busy, tag = pmc_profile(dom)
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1),
+                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                           "traffic_source": (f"{PMC_PROFILE} (tag {tag}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                              f"bench, replayed - NOT measured in this run") if traffic is not None else None,
+                           "avg_launch_ms": round(d[1] / d[2] * 1e3, 4), "launches": d[2],
+                           "flops_per_launch_avg": d[0] / d[2], "peak_note": peak_note,
+                           "mfma_busy_pmc": busy, "mfma_busy_pmc_source": f"{PMC_PROFILE} (tag {tag})" if busy is not None else None}
+    hbm = {k: v for k, v in agg.items() if v[3] > 0 and v[0] == 0}
+    if hbm:
+        dom = max(hbm, key=lambda k: hbm[k][1])
+        d = hbm[dom]
+        ach = d[3] / d[1] / 1e9
+        traffic, _, tag = pmc_profile(dom)
+        out["roofline_hbm"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                               "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": traffic,
+                               "traffic_source": f"{PMC_PROFILE} (tag {tag}), replayed" if traffic is not None else None,
+                               "avg_launch_ms": round(d[1] / d[2] * 1e3, 4), "launches": d[2],
+                               "bytes_per_launch_avg": d[3] / d[2]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (generator workload)")
+    ap.add_argument("--workload", choices=("generator", "swap256"), default="generator")
+    ap.add_argument("--triples", type=int, default=256, help="swap256: triples of the whole job")
     ap.add_argument("--precision", choices=("f16x3", "f32", "f16"), default=None,
                     help="matrix-core mode of the 3x3 convs (default: HAIRFAST_CONV_PRECISION or f16x3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the fp32-MFMA comparison run (profiling)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--swap-triples", type=int, default=4,
-                    help="triples per GPU for the secondary hair-swap hot-path schedule measurement (0 = skip)")
+                    help="generator workload: triples per GPU for the secondary hair-swap measurements (0 = skip)")
     args = ap.parse_args()
 
     from hairfastgan_amd import _marshal, _runtime, parallel
@@ -174,17 +272,69 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    import torch.distributed as dist
+
+    use_dist = world > 1 or os.environ.get("HF_FORCE_DIST", "0") == "1"
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(sec):
+        if not use_dist:
+            return sec
+        t = torch.tensor([sec], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     g, sd = build_generator(dev)
+
+    # =========================== workload swap256 (BASELINE.json configs[3]) ===========================
+    if args.workload == "swap256":
+        hf = build_hairfast(sd, dev)
+        load = make_triple_loader()
+        with torch.inference_mode():
+            for i in range(max(1, args.warmup)):
+                hf.swap(*[t.to(dev) for t in load(i)])
+        barrier()
+        prof = None if args.no_kernel_events else []
+        _marshal.PROFILE = prof
+        t0 = time.perf_counter()
+        images, n_local = parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), args.triples, load, device=dev)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        _marshal.PROFILE = None
+        assert images.shape == (args.triples, 3, 1024, 1024) and images.dtype == torch.uint8
+        if rank == 0:
+            out = {"metric": "hair_swap_triples_per_sec", "value": round(args.triples / elapsed, 3), "unit": "triples/s",
+                   "n_gpus": world, "steps": args.triples, "warmup": max(1, args.warmup),
+                   "ms_per_step": round(elapsed / args.triples * 1e3 * world, 4), "ms_per_triple_per_gpu": round(elapsed / max(n_local, 1) * 1e3, 3),
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPES[precision],
+                   "data": "synthetic",
+                   "config": {"workload": f"{args.triples} synthetic 1024^2 triples sharded over {world} GPU(s): host uint8 -> H2D -> "
+                                          "HairFast.swap (e4e B=3, FS-encoder B=3, gen 3->3 B=3, gen 0->3 B=3, gen 0->8 B=2 [both "
+                                          "Alignment rotations batched], e4e B=2, gen 0->3 B=2, gen 4->8 B=1, gen 4->4 B=1 "
+                                          "[PostProcess stand-in], gen 5->8 B=1; out-of-scope networks = SyntheticStages) -> uint8 -> "
+                                          "chunked RCCL all-gather; wall from first H2D to last gather (BASELINE.json configs[3])",
+                              "triples": args.triples, "triples_per_gpu": n_local, "parallelism": f"replica x{world}, block-partitioned triples",
+                              "weights": "synthetic closed-form (oracle/synth.py)", "conv_precision": precision,
+                              "gather": "RCCL all_gather_into_tensor of uint8 images per 8 local triples (async)" if use_dist else "single process: no collective"},
+                   "algorithmic_tflops_hot_path": round(args.triples * GFLOP_PER_TRIPLE / elapsed / 1e3, 2)}
+            if prof:
+                out.update(kernel_report(prof, elapsed, precision))
+            print(json.dumps(out), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # =========================== workload generator (BASELINE.json configs[1]) ===========================
     B = args.batch
     torch.manual_seed(3407 + rank)  # the reference's default seed (utils/seed.py:19)
     latent = torch.randn(B, 18, 512, device=dev)
-
-    import torch.distributed as dist
-
     gather_note = None
     pending = None
-
-    use_dist = world > 1 or os.environ.get("HF_FORCE_DIST", "0") == "1"
 
     def step():
         nonlocal pending, gather_note
@@ -200,11 +350,6 @@ def main():
                     gather_note = f"all_gather failed: {type(e).__name__}: {e}"
         return img
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
     if pending is not None:
@@ -218,13 +363,9 @@ def main():
     if pending is not None:
         pending[1].wait()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     _marshal.PROFILE = None
-
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    overflow = _marshal.f16_overflow_count(_runtime.lib())
 
     # comparison runs (outside the timed region): the same forward with every conv on the exact-fp32
     # MFMA, and BASELINE.json configs[4] (fp16 operands, batch 16)
@@ -254,22 +395,15 @@ def main():
         f16_mode = {"value": round(16 * args.steps / e16, 3), "unit": "images/s", "ms_per_step": round(e16 / args.steps * 1e3, 4),
                     "batch": 16, "note": "BASELINE.json configs[4]: fp16 conv operands (HAIRFAST_CONV_PRECISION=f16; the hand-over "
                                          "activations between convs are fp16, everything else fp32), fp32 accumulation and "
-                                         "demodulation; pixel MSE vs the reference 2e-6 (tests/test_gpu_parity.py)"}
+                                         "demodulation; batch-16 rows checked against the reference goldens in tests/test_gpu_parity.py"}
 
-    # Secondary measurement (outside the timed region above): the hot-path call schedule of
-    # one HairFast swap (BASELINE.json configs[2]/[3]), triples sharded
-    # over ranks, no collective in the path.
-    swap_info = None
+    # Secondary measurements (outside the timed region above) of BASELINE.json configs[2]/[3] on a bounded
+    # sample: (a) the hot-path kernels of one swap replayed on resident tensors (eager / hipGraph),
+    # (b) the complete HairFast.swap pipeline incl. H2D, the stages in between and the uint8 gather path.
+    swap_info = pipeline_info = None
     if args.swap_triples > 0:
         swap_res = swap_schedule_bench(g, sd, dev, args.swap_triples)
-        times = {}
-        for mode in ("eager", "hipgraph"):
-            tsec = swap_res.get(mode)
-            if tsec is not None and use_dist:
-                t = torch.tensor([tsec], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                tsec = float(t.item())
-            times[mode] = tsec
+        times = {m: (None if swap_res.get(m) is None else max_over_ranks(swap_res[m])) for m in ("eager", "hipgraph")}
         best = min((v for v in times.values() if v is not None), default=None)
         swap_info = {"metric": "hair_swap_hot_path_triples_per_sec",
                      "value": None if best is None else round(args.swap_triples * world / best, 3),
@@ -277,11 +411,27 @@ def main():
                      "ms_per_triple": {m: (None if v is None else round(v / args.swap_triples * 1e3, 2)) for m, v in times.items()},
                      "errors": {k: v for k, v in swap_res.items() if k.endswith("_error")},
                      "triples_per_gpu": args.swap_triples,
-                     "workload": "per triple: e4e B=3, FS-encoder B=3, gen 3->3 B=3, gen 0->3 B=3, gen 0->8 B=1, e4e B=2, "
-                                 "gen 0->3 B=2, gen 0->8 B=1, gen 4->8 B=1, gen 5->8 B=1 (1545 GFLOP; the reference's "
-                                 "discarded FS-encoder generator forward is not run); BiSeNet/SEAN/CLIP/PostProcess "
-                                 "stages are out of scope and replaced by resident synthetic tensors",
-                     "gflop_per_triple": 1545}
+                     "workload": "per triple: e4e B=3, FS-encoder B=3, gen 3->3 B=3, gen 0->3 B=3, gen 0->8 B=2 (the two Alignment.py:63 "
+                                 "forwards batched), e4e B=2, gen 0->3 B=2, gen 4->8 B=1, gen 5->8 B=1 (1545 GFLOP; the reference's "
+                                 "discarded FS-encoder generator forward is not run); resident synthetic tensors between the calls",
+                     "gflop_per_triple": GFLOP_PER_TRIPLE}
+        try:
+            hf = build_hairfast(sd, dev)
+            load = make_triple_loader(2)
+            with torch.inference_mode():
+                hf.swap(*[t.to(dev) for t in load(0)])
+            barrier()
+            n_pipe = 2 * args.swap_triples * world
+            t0 = time.perf_counter()
+            parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), n_pipe, load, device=dev)
+            barrier()
+            tp = max_over_ranks(time.perf_counter() - t0)
+            pipeline_info = {"metric": "hair_swap_triples_per_sec", "value": round(n_pipe / tp, 3), "unit": "triples/s",
+                             "ms_per_triple_per_gpu": round(tp / (n_pipe / world) * 1e3, 2), "triples": n_pipe,
+                             "workload": "python bench.py --workload swap256 on a bounded sample: host uint8 -> H2D -> HairFast.swap "
+                                         "(SyntheticStages between the hot-path calls) -> uint8 -> gather (BASELINE.json configs[3])"}
+        except Exception as e:
+            pipeline_info = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -296,37 +446,14 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"replica x{world}",
                        "weights": "synthetic closed-form (oracle/synth.py)", "conv_precision": precision},
             "algorithmic_tflops_whole_forward": round(value * GFLOP_PER_IMAGE / 1e3 / world, 2),
+            "f16_split_clamped_elements": overflow,
         }
         if gather_note:
             out["config"]["gather"] = gather_note
         elif use_dist:
             out["config"]["gather"] = "async RCCL all_gather_into_tensor of uint8 images, one per step"
         if prof:
-            agg = {}
-            for label, flops, e0, e1 in prof:
-                a = agg.setdefault(label, [0.0, 0.0, 0])
-                a[0] += flops
-                a[1] += e0.elapsed_time(e1) * 1e-3
-                a[2] += 1
-            fams = {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "avg_launch_ms": round(v[1] / v[2] * 1e3, 4),
-                        "launches": v[2], "share_of_step": round(v[1] / elapsed, 4)} for k, v in agg.items()}
-            dom = max(agg, key=lambda k: agg[k][1])
-            d = agg[dom]
-            ach = d[0] / d[1] / 1e12
-            if dom.startswith("conv_mfma_h"):
-                terms = 3 if precision == "f16x3" else 1
-                peak = PEAK_F16_MFMA_TFLOPS / terms
-                peak_note = (f"fp16 dense MFMA peak {PEAK_F16_MFMA_TFLOPS} TFLOP/s / {terms} MFMA per product; "
-                             f"MFMA FLOPs issued = {terms} x algorithmic = {round(ach * terms, 1)} TFLOP/s")
-            else:
-                peak, peak_note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA peak"
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
-                               "peak": round(peak, 1), "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom),
-                               "avg_launch_ms": round(d[1] / d[2] * 1e3, 4), "launches": d[2],
-                               "flops_per_launch_avg": d[0] / d[2], "peak_note": peak_note,
-                               "mfma_busy_pmc": pmc_mfma_busy(dom)}
-            out["kernels"] = fams
+            out.update(kernel_report(prof, elapsed, precision))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         if exact_f32 is not None:
@@ -335,6 +462,8 @@ def main():
             out["f16_mode"] = f16_mode
         if swap_info is not None:
             out["swap_schedule"] = swap_info
+        if pipeline_info is not None:
+            out["swap_pipeline"] = pipeline_info
         print(json.dumps(out), flush=True)
 
     if use_dist:

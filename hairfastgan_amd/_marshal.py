@@ -34,7 +34,10 @@ KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modc
 }
 
 
-def _launch_profiled(lib, flops, fn):
+def _launch_profiled(lib, flops, fn, label=None, nbytes=0.0):
+    """bench.py only: brackets one launch with HIP events on the launch stream.  Entries are
+    (kernel label, algorithmic flops, start, end, algorithmic bytes); `label` None = a modulated /
+    plain conv whose instantiation hf_debug_last_path reports."""
     if PROFILE is None:
         return fn()
     e0 = torch.cuda.Event(enable_timing=True)
@@ -42,8 +45,10 @@ def _launch_profiled(lib, flops, fn):
     e0.record()
     r = fn()
     e1.record()
-    code = lib.hf_debug_last_path()
-    PROFILE.append((KERNEL_NAMES.get(code, f"conv_mfma (general, code {code})"), flops, e0, e1))
+    if label is None:
+        code = lib.hf_debug_last_path()
+        label = KERNEL_NAMES.get(code, f"conv_mfma (general, code {code})")
+    PROFILE.append((label, flops, e0, e1, nbytes))
     return r
 
 
@@ -382,15 +387,24 @@ def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha
         want_lo = split_for[2] if len(split_for) > 2 else True  # False: consumer with plain fp16 operands
         hi = torch.empty((b, cout // 8, 2 * h, 2 * w, 8), dtype=torch.float16, device=tmp.device)
         lo = torch.empty_like(hi) if want_lo else None
-        check(lib, lib.hf_blur_noise_bias_act_split_f16(_p(hi), _p(lo), _p(tmp), _p(_c(blur_kernel)), _p(noise),
-                                                        _p(_c(noise_w)), nbs, _p(_c(bias)), _p(_c(s_next)), b, cout,
-                                                        2 * h + 1, 2 * w + 1, pitch, alpha, scale, st),
-              "hf_blur_noise_bias_act_split_f16")
+        # algorithmic bytes: the (2h+1)(2w+1) fp32 intermediate read once, one 2-byte value per part written
+        nb = float(b * cout) * (4.0 * (2 * h + 1) * (2 * w + 1) + (4.0 if want_lo else 2.0) * 4 * h * w)
+        code = _launch_profiled(
+            lib, 0.0,
+            lambda: lib.hf_blur_noise_bias_act_split_f16(_p(hi), _p(lo), _p(tmp), _p(_c(blur_kernel)), _p(noise),
+                                                         _p(_c(noise_w)), nbs, _p(_c(bias)), _p(_c(s_next)), b, cout,
+                                                         2 * h + 1, 2 * w + 1, pitch, alpha, scale, st),
+            label="blur4x4_split8", nbytes=nb)
+        check(lib, code, "hf_blur_noise_bias_act_split_f16")
         return SplitActivation(hi, lo, key)
     out = tmp.new_empty((b, cout, 2 * h, 2 * w))
-    check(lib, lib.hf_blur_noise_bias_act_f32(_p(out), _p(tmp), _p(_c(blur_kernel)), _p(noise), _p(_c(noise_w)),
-                                              nbs, _p(_c(bias)), b, cout, 2 * h + 1, 2 * w + 1, pitch, alpha, scale,
-                                              st), "hf_blur_noise_bias_act_f32")
+    nb = float(b * cout) * 4.0 * ((2 * h + 1) * (2 * w + 1) + 4 * h * w)
+    code = _launch_profiled(
+        lib, 0.0,
+        lambda: lib.hf_blur_noise_bias_act_f32(_p(out), _p(tmp), _p(_c(blur_kernel)), _p(noise), _p(_c(noise_w)),
+                                               nbs, _p(_c(bias)), b, cout, 2 * h + 1, 2 * w + 1, pitch, alpha, scale, st),
+        label="blur4x4_noise_bias_act", nbytes=nb)
+    check(lib, code, "hf_blur_noise_bias_act_f32")
     return out
 
 
@@ -401,8 +415,12 @@ def torgb(lib, st, x, wt, s, bias, skip, up_kernel):
     if skip is not None and tuple(skip.shape) != (b, 3, h // 2, w // 2):
         raise ValueError(f"skip must be [B,3,H/2,W/2]; got {tuple(skip.shape)} for x {tuple(x.shape)}")
     out = x.new_empty((b, 3, h, w))
-    check(lib, lib.hf_torgb_f32(_p(out), _p(x), _p(wt), _p(s), _p(_c(bias)), _p(skip), _p(_c(up_kernel)), b, cin,
-                                h, w, st), "hf_torgb_f32")
+    nb = float(b) * 4.0 * h * w * (cin + 3 + (0.75 if skip is not None else 0.0))  # x read, rgb written, skip read
+    code = _launch_profiled(
+        lib, 0.0,
+        lambda: lib.hf_torgb_f32(_p(out), _p(x), _p(wt), _p(s), _p(_c(bias)), _p(skip), _p(_c(up_kernel)), b, cin, h, w, st),
+        label="torgb_kernel" if h * w > 4096 else "torgb_small_kernel", nbytes=nb)
+    check(lib, code, "hf_torgb_f32")
     return out
 
 

@@ -65,3 +65,92 @@ def test_graph_runner_matches_eager():
         for scale in (1.0, 0.5):
             w = (lat * scale).to(dev)
             assert torch.equal(runner(w), fn(w))
+
+
+def _hairfast(dev):
+    from hairfastgan_amd.hair_swap import HairFast, SyntheticStages, get_parser
+
+    args = get_parser().parse_args([])
+    args.device = dev
+    gen_shapes = O.generator_param_shapes(1024, 512, 8, 2)
+    state = {"g_ema": C.generator_params(gen_shapes), "latent_avg": torch.zeros(512)}
+    return HairFast(args, stages=SyntheticStages(), generator_state=state,
+                    e4e_state=C.params_from_shapes("e4e", E.e4e_param_shapes()),
+                    fs_state=C.params_from_shapes("fs", E.fs_param_shapes()))
+
+
+def test_hairfast_swap_call_surface():
+    """`HairFast(args).swap(face, shape, color, benchmark=False, align=False, seed=None, exp_name=None)`
+    (hair_swap.py:27-103): runs the whole stage sequence on the HIP hot path with SyntheticStages in
+    between; seeded runs reproduce; equal images collapse like the reference's equal_replacer."""
+    import inspect
+
+    from hairfastgan_amd.hair_swap import HairFast, Stages
+
+    assert list(inspect.signature(HairFast.swap).parameters)[:8] == ["self", "face_img", "shape_img", "color_img", "benchmark",
+                                                                     "align", "seed", "exp_name"]
+    dev = torch.device("cuda:0")
+    hf = _hairfast(dev)
+    g = torch.Generator().manual_seed(1)
+    face, shape, color = (torch.randint(0, 256, (3, 1024, 1024), dtype=torch.uint8, generator=g) for _ in range(3))
+    calls = []
+    gen_fwd = hf.net.generator.forward
+
+    def spy(styles, **kw):
+        calls.append((styles[0].shape[0], kw.get("start_layer", 0), kw.get("end_layer", 8)))
+        return gen_fwd(styles, **kw)
+
+    hf.net.generator.forward = spy
+    out = hf.swap(face, shape, color, seed=7)
+    hf.net.generator.forward = gen_fwd
+    assert out.shape == (3, 1024, 1024) and torch.isfinite(out).all()
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    # the generator calls of one swap: batch, start_layer, end_layer (Embedding.py:78,90; Alignment.py:63 batched
+    # for both pairs; Embedding.py:52; Blending.py:62; the PostProcess stand-in; Blending.py:68)
+    assert calls == [(3, 3, 3), (3, 0, 3), (2, 0, 8), (2, 0, 3), (1, 4, 8), (1, 4, 4), (1, 5, 8)], calls
+    again = hf.swap(face, shape, color, seed=7)
+    assert torch.equal(out, again)
+    # shape == color: one rotation only, align_color reuses align_shape (hair_swap.py:53-56)
+    calls.clear()
+    hf.net.generator.forward = spy
+    hf.swap(face, shape, shape.clone())
+    hf.net.generator.forward = gen_fwd
+    assert (1, 0, 8) in calls and (2, 0, 8) not in calls
+    with pytest.raises(NotImplementedError, match="outside this backend's scope"):
+        Stages().segment(None)
+    with pytest.raises(NotImplementedError, match="dlib"):
+        hf.swap(face, shape, color, align=True)
+
+
+def test_swap_many_forced_rccl_single_rank():
+    """BASELINE configs[3] code path with RCCL actually initialised on the hardware (world size 1,
+    HF_FORCE_DIST=1): sharding, H2D prefetch stream, uint8 conversion and the chunked all-gather."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from hairfastgan_amd import parallel\n"
+        "import torch.distributed as dist\n"
+        "rank, world, local = parallel.init_from_env()\n"
+        "assert dist.is_initialized() and dist.get_backend() == 'nccl'\n"
+        "sys.path.insert(0, os.path.join(sys.path[0], 'tests'))\n"
+        "from test_gpu_schedule import _hairfast\n"
+        "dev = torch.device('cuda', local)\n"
+        "hf = _hairfast(dev)\n"
+        "def load(i):\n"
+        "    g = torch.Generator().manual_seed(i)\n"
+        "    return tuple(torch.randint(0, 256, (3, 1024, 1024), dtype=torch.uint8, generator=g).pin_memory() for _ in range(3))\n"
+        "imgs, n = parallel.swap_many(lambda a, b, c: hf.swap(a, b, c, seed=i_seed[0]), 3, load, device=dev, chunk=2)\n"
+        "torch.cuda.synchronize()\n"
+        "assert n == 3 and imgs.shape == (3, 3, 1024, 1024) and imgs.dtype == torch.uint8\n"
+        "ref = parallel.to_uint8_image(hf.swap(*load(1), seed=i_seed[0]) * 2 - 1)\n"
+        "assert torch.equal(imgs[1], ref), 'gathered image differs from a direct swap'\n"
+        "dist.barrier(); dist.destroy_process_group(); print('RCCL_OK')\n").replace("i_seed[0]", "11")
+    env = dict(os.environ, HF_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

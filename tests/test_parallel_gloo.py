@@ -61,3 +61,54 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _swap_worker(rank, world, port, n_total, chunk, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from hairfastgan_amd import parallel
+
+    parallel.init_from_env("gloo")
+    calls = []
+
+    def load_triple(i):  # three "images" whose content identifies the triple
+        return tuple(torch.full((3, 4, 4), (3 * i + k) % 256, dtype=torch.uint8) for k in range(3))
+
+    def swap_fn(face, shape, color):  # a stand-in for HairFast.swap: float image in [0,1] derived from all three inputs
+        calls.append(int(face[0, 0, 0]) // 3)
+        return ((face.float() + shape.float() + color.float()) / 3.0 / 255.0)
+
+    got, n_local = parallel.swap_many(swap_fn, n_total, load_triple, chunk=chunk)
+    q.put((rank, n_local, calls, got[:, 0, 0, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,chunk", [(7, 2), (8, 3), (2, 8)])
+def test_swap_many_world2(n_total, chunk):
+    """BASELINE configs[3] driver (parallel.swap_many) at world size 2 over gloo: contiguous shards, ragged
+    chunked all-gathers, every rank ends with all images in triple order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_swap_worker, args=(r, 2, port, n_total, chunk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [float(round(((3 * i) % 256 + (3 * i + 1) % 256 + (3 * i + 2) % 256) / 3.0)) for i in range(n_total)]
+    seen = []
+    for rank, n_local, calls, got in res:
+        assert [float(v) for v in got] == want, (rank, got, want)
+        assert len(calls) == n_local
+        seen += calls
+    assert sorted(seen) == list(range(n_total))  # every triple swapped exactly once, on one rank
+
+
+def test_swap_many_single_process():
+    from hairfastgan_amd import parallel
+
+    got, n = parallel.swap_many(lambda a, b, c: a.float() / 255.0, 5, lambda i: tuple(torch.full((3, 2, 2), 10 * i, dtype=torch.uint8) for _ in range(3)), chunk=2)
+    assert n == 5 and got[:, 0, 0, 0].tolist() == [0, 10, 20, 30, 40]
