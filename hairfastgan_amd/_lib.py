@@ -43,6 +43,7 @@ SIGNATURES = {
     "hf_conv_prepare_f32": [_f, _f, _i, _i, _i, _fl, _st],
     "hf_bn_fold_f32": [_f, _f, _f, _f, _f, _f, _f, _fl, _i, _st],
     "hf_conv2d_f32": [_f, _f, _f, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _f, _ll, _st],
+    "hf_conv2d_f16_f32": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _ll, _st],
     "hf_plane_mean_f32": [_f, _f, _i, _i, _st],
     "hf_se_gate_f32": [_f, _f, _f, _f, _i, _i, _i, _st],
     "hf_scale_shortcut_add_f32": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _st],

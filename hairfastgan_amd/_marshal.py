@@ -31,6 +31,8 @@ KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modc
     571: "conv_mfma_h<1,2,2,4,pre>", 572: "conv_mfma_h<2,2,1,8,pre>", 573: "conv_mfma_h<1,2,1,8,pre>", 575: "conv_mfma_h<1,2,1,8,tw128,pre>",
     551: "conv_mfma_h<1,2,2,4>", 552: "conv_mfma_h<2,2,1,8>", 553: "conv_mfma_h<1,2,1,8>", 555: "conv_mfma_h<1,2,1,8,tw128>",
     561: "conv_mfma_h<1,2,2,4,up>", 563: "conv_mfma_h<1,2,1,8,up>",
+    # csrc/convh_enc.hip (encoder convs on the fp16 matrix cores)
+    601: "conv_enc_h<64x256>", 602: "conv_enc_h<64x128,stride2>", 603: "conv_enc_h<64x128>",
 }
 
 
@@ -477,6 +479,66 @@ def conv2d(lib, st, x, wt, k, stride=1, in_scale=None, in_shift=None, out_scale=
                                   act, _p(_c(slope)), float(alpha), _p(residual), b, cin, cout, h, w, k, stride, groups,
                                   x_gstride, _p(ws), max(n, 0), st))
     check(lib, code, "hf_conv2d_f32")
+    return out
+
+
+def _pow2_ceil(v):
+    p = 1
+    while p < v:
+        p <<= 1
+    return p
+
+
+def conv2d_f16_supported(cin, cout, h, w, k, stride):
+    """Shapes hf_conv2d_f16_f32 takes (include/hairfast_hip.h; mirrors launch_enc's tile geometry)."""
+    if k != 3 or cin % 16 or cout % 64 or stride not in (1, 2):
+        return False
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    tw = min(32, _pow2_ceil(ow))
+    return tw >= 16 and _pow2_ceil(oh) >= 128 // tw
+
+
+def conv_split_weights_f16(lib, st, wt):
+    """Prepared conv weights [9,cin,cout] or [G,9,cin,cout] -> (hi, lo) fp16 blobs in the layout
+    hf_conv2d_f16_f32 takes: per group [9*cin*cout halves | 16-byte trailer] (hi) and 9*cin*cout halves (lo)."""
+    wt = _c(wt)
+    w4 = wt if wt.ndim == 4 else wt.unsqueeze(0)
+    g, taps, cin, cout = w4.shape
+    if taps != 9 or cin % 16:
+        raise ValueError(f"f16 MFMA path needs 3x3 weights with cin % 16 == 0; got {tuple(wt.shape)}")
+    n = 9 * cin * cout
+    hi = torch.empty(g * (n + 8), dtype=torch.float16, device=wt.device)
+    lo = torch.empty(g * n, dtype=torch.float16, device=wt.device)
+    for i in range(g):
+        check(lib, lib.hf_conv_split_weights_f16(hi[i * (n + 8):].data_ptr(), lo[i * n:].data_ptr(), w4[i].data_ptr(), cin, cout, st),
+              "hf_conv_split_weights_f16")
+    return hi, lo
+
+
+def conv2d_f16(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None, in_shift=None, out_scale=None, bias=None,
+               act=ACT_NONE, slope=None, alpha=0.0, residual=None, groups=1, x_shared=True):
+    """hf_conv2d_f16_f32: conv2d(k=3) on the fp16 matrix cores; argument meaning as conv2d()."""
+    x = _c(x)
+    if groups > 1 and not x_shared:
+        g_, b, cin, h, w = x.shape
+        if g_ != groups:
+            raise ValueError("x must be [groups, B, cin, H, W]")
+        x_gstride = b * cin * h * w
+    else:
+        b, cin, h, w = x.shape
+        x_gstride = 0
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    out = x.new_empty((groups, b, cout, oh, ow) if groups > 1 else (b, cout, oh, ow))
+    if residual is not None:
+        residual = _c(residual)
+        if tuple(residual.shape) != tuple(out.shape):
+            raise ValueError(f"residual {tuple(residual.shape)} != output {tuple(out.shape)}")
+    code = _launch_profiled(
+        lib, 2.0 * cin * cout * 9 * oh * ow * b * groups,
+        lambda: lib.hf_conv2d_f16_f32(_p(out), _p(x), _p(wt_hi), _p(wt_lo), nterms, _p(in_scale), _p(in_shift), _p(_c(out_scale)),
+                                      _p(_c(bias)), act, _p(_c(slope)), float(alpha), _p(residual), b, cin, cout, h, w, stride,
+                                      groups, x_gstride, st))
+    check(lib, code, "hf_conv2d_f16_f32")
     return out
 
 

@@ -23,7 +23,7 @@ def require_gpu(*tensors):
             raise RuntimeError(
                 "hairfastgan_amd ops run on the MI355X only (got a CPU tensor); there is no CPU fallback - "
                 "the CPU restatement lives in oracle/ and is test infrastructure")
-        if grad and t.requires_grad:
+        if grad and t.requires_grad and not isinstance(t, torch.nn.Parameter):  # module parameters are frozen by contract
             raise RuntimeError(
                 "hairfastgan_amd is inference only: an input requires grad while autograd is enabled; "
                 "wrap the call in torch.inference_mode() / torch.no_grad() or detach the input")

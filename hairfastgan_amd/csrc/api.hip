@@ -16,7 +16,8 @@ extern "C" int hf_abi_version(void) { return 7; }
 // per-translation-unit counters of the kernels that split fp32 into fp16 (hi, lo) pairs
 extern "C" unsigned long long hf_f16_overflow_count_convh(int reset);
 extern "C" unsigned long long hf_f16_overflow_count_blur(int reset);
+extern "C" unsigned long long hf_f16_overflow_count_enc(int reset);
 
 extern "C" long long hf_f16_overflow_count(int reset) {
-  return (long long)(hf_f16_overflow_count_convh(reset) + hf_f16_overflow_count_blur(reset));
+  return (long long)(hf_f16_overflow_count_convh(reset) + hf_f16_overflow_count_blur(reset) + hf_f16_overflow_count_enc(reset));
 }

@@ -1,0 +1,318 @@
+// convh_enc.hip - the encoders' 3x3 convolutions (stride 1 and 2) on the fp16 matrix cores.
+//
+// Reference operators: nn.Conv2d 3x3 with the surrounding inference-mode BatchNorm2d / PReLU /
+// LeakyReLU / residual add of the IR-SE bottleneck (models/encoder4editing/models/encoders/
+// helpers.py:93-120), the e4e style heads (psp_encoders.py:34-55, stride 2, grouped by family),
+// IBasicBlock (models/FeatureStyleEncoder/arcface/iresnet.py:28-57) and the PostProcess trunk
+// (models/Encoders.py:35-57).  Same contract as hf_conv2d_f32 (csrc/modconv.hip):
+//   y = act( out_scale[co] * conv3x3_{stride, pad 1}( in_scale[ci]*x + in_shift[ci] ) + bias[co] ) + residual
+// but the products run on v_mfma_f32_32x32x16_f16 - 16x the rate of the fp32 MFMA the round-1
+// encoders used - in the operand modes of csrc/convh.hip: nterms 3 (fp32 operands split into fp16
+// (hi, lo) pairs, hi*hi + hi*lo + lo*hi: fp32-class accuracy) or nterms 1 (operands rounded to fp16).
+//
+// Structure (one block per output tile; the generator's kernel in convh.hip additionally walks tiles
+// persistently and takes pre-split input - encoder layers are too small for either to pay):
+//   block tile = CT = 64 output channels x PT output pixels of ONE image (th rows x tw in {16, 32}
+//   columns), waves = 2 (channels) x WAVES_PX, each 1 x 2 MFMA tiles;
+//   K loop in stages of 16 input channels x 9 taps, double-buffered in LDS:
+//     weights    [tap][kgroup][cout][8 halves] hi (+ lo) by LDS-DMA from the prepared layout of
+//                hf_conv_split_weights_f16 (pre-scaled by 2^k, un-scaled in the epilogue),
+//     activations one (halo pixel, kgroup) item per thread and step: 8 coalesced plane loads
+//                (lanes = consecutive input columns), * in_scale + in_shift on REAL pixels (the zero
+//                padding stays zero: the reason the BatchNorm in front of a conv cannot be folded
+//                into its weights), saturating hi/lo split, one 16-byte LDS write per part;
+//   STRIDE 2: the halo tile is (2 th + 1) x (2 tw + 1) input pixels, stored with its columns split by
+//     parity ([row][parity][col/2]) so that the B fragment of every tap is again 32 consecutive
+//     16-byte units (tap kx reads parity kx&1 from column px + (kx>>1));
+//   epilogue = conv_common.h's store_tile (out scale, bias, PReLU / LeakyReLU, residual, groups).
+// Grouped launches (blockIdx.y = group * co_tiles + co_tile) run the style heads of an e4e family
+// level by level; every group's weights are a self-contained [9*cin*cout halves | 16-byte trailer].
+#define HF_WANT_F16_SPLIT
+#include "conv_common.h"
+
+using namespace hf_detail;
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr int KH = 16;  // input channels per stage = K of one MFMA
+
+// 16-byte units of one activation part per kgroup that the LDS tile is sized for
+template <int PT, int STRIDE>
+constexpr int enc_npix() {
+  // tw = 32: th = PT/32;  tw = 16: th = PT/16
+  constexpr int a = (STRIDE == 1) ? (PT / 32 + 2) * (32 + 2) : (2 * (PT / 32) + 1) * 2 * (32 + 1);
+  constexpr int b = (STRIDE == 1) ? (PT / 16 + 2) * (16 + 2) : (2 * (PT / 16) + 1) * 2 * (16 + 1);
+  return a > b ? a : b;
+}
+
+template <int NTERMS, int PG, int WAVES_PX, int STRIDE>
+__global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
+                                                              const _Float16 *__restrict__ wtl_all) {
+  constexpr int CT_TILES = 1, WAVES_CO = 2;
+  constexpr int NW = WAVES_CO * WAVES_PX;
+  constexpr int NT = 64 * NW;
+  constexpr int CT = 32 * CT_TILES * WAVES_CO;  // 64
+  constexpr int PT = 32 * PG * WAVES_PX;
+  constexpr int NPIX = enc_npix<PT, STRIDE>();
+  constexpr int NPART = (NTERMS == 3) ? 2 : 1;
+  constexpr int W_UNITS = 9 * 2 * CT;
+  constexpr int X_UNITS = 2 * NPIX;
+  constexpr int BUF_UNITS = NPART * (W_UNITS + X_UNITS);
+  constexpr int N_WPIECE = NPART * W_UNITS / 64;
+  constexpr int ND = (N_WPIECE + NW - 1) / NW;
+  constexpr int XE = (X_UNITS + NT - 1) / NT;
+  constexpr int OFF_WL = W_UNITS, OFF_XH = NPART * W_UNITS, OFF_XL = NPART * W_UNITS + X_UNITS;
+  static_assert(XE <= 8, "conversion schedule: one item per tap-step");
+
+  HF_DYN_LDS;
+  half8 *lds = reinterpret_cast<half8 *>(hf_dyn_lds);  // [2][BUF_UNITS]
+  float *sl = reinterpret_cast<float *>(lds + 2 * BUF_UNITS);  // in_scale [cin], in_shift [cin]
+  const int cin4 = (P.cin + 3) & ~3;
+  float *tl = sl + cin4;
+
+  const GroupOfs go = group_offsets(P);
+  const int grp = (P.groups > 1) ? (int)blockIdx.y / P.co_tiles : 0;
+  const long long wn = 9LL * P.cin * P.cout;
+  const _Float16 *wth = wth_all + (long long)grp * (wn + 8);  // [weights | trailer] per group
+  const _Float16 *wtl = wtl_all ? wtl_all + (long long)grp * wn : nullptr;
+  const float w_unscale = *reinterpret_cast<const float *>(wth + wn);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wave_co = (wave / WAVES_PX) * 32;
+  const int wave_pg = (wave % WAVES_PX) * PG;
+  const int co0 = go.co_tile * CT;
+
+  // ---- tile (uniform): OUTPUT pixels [ty0, ty0+th) x [tx0, tx0+tw) of image b0 ----
+  const TileGeom G = P.g[0];
+  int t = blockIdx.x;
+  const int tx = t % G.tiles_x;
+  t /= G.tiles_x;
+  const int ty = t % G.tiles_y;
+  const int b0 = t / G.tiles_y;
+  const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
+  const int ty0 = ty * th, tx0 = tx * tw;
+  // halo tile: input rows STRIDE*ty0-1 .. (hp rows), columns STRIDE*tx0-1 .. (wcols columns);
+  // LDS row pitch `wp` units; STRIDE 2: a row is [even columns: tw+1 units][odd columns: tw+1 units]
+  const int hp = (th - 1) * STRIDE + 3, wcols = (tw - 1) * STRIDE + 3;
+  const int wp2 = tw + 1;
+  const int wp = (STRIDE == 1) ? wcols : 2 * wp2;
+  const int n_items = hp * wcols;  // per kgroup, natural (row-major input) order: coalesced loads
+
+  const long long plane = (long long)P.h * P.w;
+  const int iplane = (int)plane;
+  const float *xb = P.x + go.x + (long long)b0 * P.cin * plane;
+
+  // ---- per-thread staging items (stage invariant): plane offset of the input pixel (-1 zero fill,
+  // -2 none) and the 16-byte LDS unit (incl. kgroup) it goes to ----
+  int e_src[XE], e_dst[XE], e_kg[XE];
+#pragma unroll
+  for (int e = 0; e < XE; ++e) {
+    const int i = tid + e * NT;
+    const int kg = i / n_items, v = i - kg * n_items;
+    e_src[e] = -2;
+    e_dst[e] = 0;
+    e_kg[e] = kg;
+    if (kg < 2) {
+      const int hr = v / wcols, hc = v - hr * wcols;
+      const int ys = ty0 * STRIDE - 1 + hr, xc = tx0 * STRIDE - 1 + hc;
+      e_src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
+      e_dst[e] = kg * NPIX + ((STRIDE == 1) ? hr * wp + hc : hr * wp + (hc & 1) * wp2 + (hc >> 1));
+    }
+  }
+  for (int i = tid; i < P.cin; i += NT) {
+    sl[i] = P.s ? P.s[i] : 1.0f;
+    tl[i] = P.t ? P.t[i] : 0.0f;
+  }
+
+  const unsigned lds_addr0 = hf_lds_addr(lds);
+  auto dma_piece = [&](int i, int chunk, int bufsel) {
+    const int pc = wave + i * NW;
+    if (pc < N_WPIECE) {
+      const int part = pc / (W_UNITS / 64), q = pc % (W_UNITS / 64);
+      const int u = q * 64 + lane;           // unit inside the part: (tap*2 + kg)*CT + co
+      const int row = u / CT, col = u % CT;  // row = tap*2 + kg
+      int off = (row * P.cout + co0 + col) * 16;
+      HF_OPAQUE_I32(off);
+      const _Float16 *src = (part ? wtl : wth) + (long long)chunk * 18 * P.cout * 8;
+      hf_glds16_raw_s(src, (unsigned)off, lds_addr0 + (unsigned)(bufsel * BUF_UNITS + part * W_UNITS + q * 64) * 16u);
+    }
+  };
+  float xr[XE][8];
+  auto load_item = [&](int e, int chunk) {
+    const char *xc = reinterpret_cast<const char *>(xb + (long long)chunk * KH * plane);
+    int off = (e_src[e] >= 0) ? e_kg[e] * 8 * iplane + e_src[e] : 0;
+    HF_OPAQUE_I32(off);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xr[e][k] = *reinterpret_cast<const float *>(xc + (unsigned)((off + k * iplane) * 4));
+  };
+  auto convert_item = [&](int e, int chunk, half8 *buf) {
+    if (e_src[e] == -2) return;
+    half8 hi, lo;
+    bool ovf = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ci = chunk * KH + e_kg[e] * 8 + k;
+      const float v = (e_src[e] >= 0) ? fmaf(xr[e][k], sl[ci], tl[ci]) : 0.0f;
+      _Float16 hv, lv;
+      hf_split_f16(v, hv, lv, ovf);
+      hi[k] = hv;
+      lo[k] = lv;
+    }
+    hf_note_overflow(ovf);
+    buf[OFF_XH + e_dst[e]] = hi;
+    if (NTERMS == 3) buf[OFF_XL + e_dst[e]] = lo;
+  };
+
+  f32x16 acc[1][CT_TILES][PG];
+#pragma unroll
+  for (int g = 0; g < PG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][g][r] = 0.0f;
+
+  // LDS unit (inside a kgroup) of the lane's pixel of group g at tap (0, 0)
+  int pix0[PG];
+#pragma unroll
+  for (int g = 0; g < PG; ++g) {
+    const int p = (wave_pg + g) * 32 + li;
+    const int py = (p >> G.lg_tw) & (th - 1), px = p & (tw - 1);
+    pix0[g] = py * STRIDE * wp + px;
+  }
+
+  const int nchunks = P.cin / KH;
+  __syncthreads();  // sl / tl visible
+#pragma unroll
+  for (int i = 0; i < ND; ++i) dma_piece(i, 0, 0);
+#pragma unroll
+  for (int e = 0; e < XE; ++e) load_item(e, 0);
+#pragma unroll
+  for (int e = 0; e < XE; ++e) convert_item(e, 0, lds);
+  hf_barrier_keep_young<0>();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int cb = c & 1;
+    half8 *buf = lds + cb * BUF_UNITS, *nbuf = lds + (cb ^ 1) * BUF_UNITS;
+    const bool more = c + 1 < nchunks;
+    const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT
+    const half8 *b_hi = buf + OFF_XH + lh * NPIX;
+    half8 ah[2], al[2], bh[2][PG], bl[2][PG];
+    auto fetch = [&](int slot, int tap) {
+      const int ky = tap / 3, kx = tap % 3;
+      const int toff = (STRIDE == 1) ? ky * wp + kx : ky * wp + (kx & 1) * wp2 + (kx >> 1);
+      ah[slot] = a_hi[tap * 2 * CT];
+      if (NTERMS == 3) al[slot] = a_hi[OFF_WL + tap * 2 * CT];
+#pragma unroll
+      for (int g = 0; g < PG; ++g) {
+        bh[slot][g] = b_hi[pix0[g] + toff];
+        if (NTERMS == 3) bl[slot][g] = b_hi[X_UNITS + pix0[g] + toff];
+      }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int s_ = tap & 1;
+      if (tap + 1 < 9) fetch(s_ ^ 1, tap + 1);
+      if (more) {
+        if (tap == 0) {
+#pragma unroll
+          for (int e = 0; e < XE; ++e) load_item(e, c + 1);
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+          if (i / ((ND + 2) / 3) == tap) dma_piece(i, c + 1, cb ^ 1);
+        if (tap >= 9 - XE) convert_item(tap - (9 - XE), c + 1, nbuf);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < PG; ++g) acc[0][0][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bh[s_][g], acc[0][0][g], 0, 0, 0);
+      if (NTERMS == 3) {
+#pragma unroll
+        for (int g = 0; g < PG; ++g) acc[0][0][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bl[s_][g], acc[0][0][g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < PG; ++g) acc[0][0][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s_], bh[s_][g], acc[0][0][g], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    hf_barrier_keep_young<0>();  // next stage complete (DMA landed, conversions written), current one free
+  }
+
+  // undo the weights' power-of-two pre-scale (exact), then the shared epilogue
+#pragma unroll
+  for (int g = 0; g < PG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][g][r] *= w_unscale;
+  store_tile<CT_TILES, PG, false>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+}
+
+template <int NTERMS, int PG, int WAVES_PX, int STRIDE>
+int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_t st) {
+  constexpr int CT = 64, NT = 128 * WAVES_PX;
+  constexpr int PT = 32 * PG * WAVES_PX;
+  constexpr int NPIX = enc_npix<PT, STRIDE>();
+  constexpr int NPART = (NTERMS == 3) ? 2 : 1;
+  if (P.cin % KH || P.cout % CT || P.stride != STRIDE) return HF_E_INVALID;
+  if ((long long)P.cin * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
+  P.splits = 1;
+  P.n_geom = 1;
+  P.g[0] = make_geom(0, 0, P.out_h, P.out_w, P.batch, PT, 0);
+  const TileGeom &G = P.g[0];
+  const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
+  if (G.lg_nb != 0 || tw * th != PT || (tw != 16 && tw != 32)) return HF_E_INVALID;  // one image per tile, 16 / 32 columns
+  const int hp = (th - 1) * STRIDE + 3, wcols = (tw - 1) * STRIDE + 3;
+  const int units = (STRIDE == 1) ? hp * wcols : hp * 2 * (tw + 1);
+  if (units > NPIX || 2 * hp * wcols > 8 * NT) return HF_E_INVALID;
+  P.co_tiles = P.cout / CT;
+  const int groups = P.groups > 1 ? P.groups : 1;
+  dim3 grid(geom_blocks(G), P.co_tiles * groups);
+  if (grid.y > 65535) return HF_E_INVALID;
+  const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float);
+  if (lds > 160 * 1024) return HF_E_INVALID;
+  hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE>), grid, dim3(NT), lds, st, P, wth, wtl);
+  return hf_launch_status();
+}
+
+}  // namespace
+
+extern "C" unsigned long long hf_f16_overflow_count_enc(int reset) { return hf_f16_overflow_read_tu(reset); }
+
+extern "C" int hf_conv2d_f16_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
+                                 const float *in_scale, const float *in_shift, const float *out_scale, const float *bias,
+                                 int act, const float *slope, float alpha, const float *residual, int batch, int cin,
+                                 int cout, int h, int w, int stride, int groups, long long x_group_stride, void *stream) {
+  if (!out || !x || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2) ||
+      act < ACT_NONE || act > ACT_PRELU || (act == ACT_PRELU && !slope) || groups < 1 || x_group_stride < 0 ||
+      (nterms != 1 && nterms != 3) || (nterms == 3 && !wt_lo))
+    return HF_E_INVALID;
+  if (groups > 1 && (in_scale || in_shift)) return HF_E_INVALID;  // grouped form: plain conv + epilogue (as hf_conv2d_f32)
+  ConvParams P{};
+  P.out = out; P.x = x; P.s = in_scale; P.t = in_shift; P.d = out_scale; P.bias = bias;
+  P.slope = slope; P.residual = residual;
+  P.s_bstride = 0; P.d_bstride = 0;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w;
+  P.out_h = (h - 1) / stride + 1; P.out_w = (w - 1) / stride + 1; P.out_wv = P.out_w;
+  P.stride = stride;
+  P.act = act; P.alpha = alpha; P.scale = 1.0f;
+  P.groups = groups; P.x_gstride = x_group_stride; P.wt_gstride = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const _Float16 *hi = static_cast<const _Float16 *>(wt_hi), *lo = static_cast<const _Float16 *>(wt_lo);
+  int rc;
+  if (stride == 2) {
+    // 64 co x 128 output px (the halo of a stride-2 tile is 4x its output): 4 waves
+    rc = (nterms == 3) ? launch_enc<3, 2, 2, 2>(P, hi, lo, st) : launch_enc<1, 2, 2, 2>(P, hi, lo, st);
+    if (rc == HF_OK) note_path(6, 2);
+    return rc;
+  }
+  // 64 co x 256 px (8 waves) when that still fills the chip, else 64 co x 128 px (4 waves)
+  const long long blocks256 = (long long)batch * groups * hf_cdiv((long long)P.out_h * P.out_w, 256) * (cout / 64);
+  rc = HF_E_INVALID;
+  if (blocks256 >= 384) {
+    rc = (nterms == 3) ? launch_enc<3, 2, 4, 1>(P, hi, lo, st) : launch_enc<1, 2, 4, 1>(P, hi, lo, st);
+    if (rc == HF_OK) note_path(6, 1);
+  }
+  if (rc == HF_E_INVALID) {
+    rc = (nterms == 3) ? launch_enc<3, 2, 2, 1>(P, hi, lo, st) : launch_enc<1, 2, 2, 1>(P, hi, lo, st);
+    if (rc == HF_OK) note_path(6, 3);
+  }
+  return rc;
+}

@@ -5,7 +5,7 @@ import torch
 from torch import nn
 
 from .. import _marshal as M
-from .._runtime import lib, require_gpu, stream
+from .._runtime import conv_precision, lib, require_gpu, stream
 
 
 class FrozenPlanMixin:
@@ -38,10 +38,34 @@ def fold_bn(bn, conv_bias=None):
                      None if conv_bias is None else conv_bias.detach())
 
 
+class PreparedConv:
+    """A Conv2d's weights in the layouts the kernels take: `wt` [k*k,cin,cout] (or [G,k*k,cin,cout]
+    for a grouped launch) for the fp32-MFMA kernels and, derived on first use, the fp16 (hi, lo)
+    split of it for the fp16 matrix-core kernel (csrc/convh_enc.hip)."""
+
+    def __init__(self, wt, k):
+        self.wt, self.k = wt, k
+        self.cin, self.cout = wt.shape[-2], wt.shape[-1]
+        self._f16 = None
+
+    def f16(self):
+        if self._f16 is None:
+            self._f16 = M.conv_split_weights_f16(lib(), stream(), self.wt)
+        return self._f16
+
+
 def prep_conv(conv):
     require_gpu(conv.weight)
-    return M.conv_prepare(lib(), stream(), conv.weight.detach())
+    return PreparedConv(M.conv_prepare(lib(), stream(), conv.weight.detach()), conv.kernel_size[0])
 
 
-def conv(x, wt, k, stride=1, **kw):
-    return M.conv2d(lib(), stream(), x, wt, k, stride, **kw)
+def conv(x, w, k, stride=1, **kw):
+    """Conv2d + folded BN / activation / residual.  3x3 convs whose shape the fp16 matrix-core kernel
+    takes run there in the process-wide operand mode (_runtime.conv_precision: f16x3 = fp32-class
+    split operands, f16 = rounded operands); everything else, and mode f32, on the fp32 MFMA."""
+    mode = conv_precision()
+    h, wd = x.shape[-2], x.shape[-1]
+    if mode != "f32" and M.conv2d_f16_supported(w.cin, w.cout, h, wd, k, stride):
+        hi, lo = w.f16()
+        return M.conv2d_f16(lib(), stream(), x, hi, lo, 3 if mode == "f16x3" else 1, w.cout, stride, **kw)
+    return M.conv2d(lib(), stream(), x, w.wt, k, stride, **kw)

@@ -17,7 +17,7 @@ from torch import nn
 
 from .. import _marshal as M
 from .._runtime import lib, require_gpu, stream
-from ._fused import FrozenPlanMixin, conv, fold_bn, prep_conv
+from ._fused import FrozenPlanMixin, PreparedConv, conv, fold_bn, prep_conv
 
 # get_blocks(50): (in_channel, depth, stride) per unit (helpers.py:30-37)
 _IR50 = ([(64, 64, 2)] + [(64, 64, 1)] * 2 + [(64, 128, 2)] + [(128, 128, 1)] * 3 +
@@ -166,12 +166,12 @@ class Encoder4Editing(FrozenPlanMixin, nn.Module):  # psp_encoders.py:124-200
             for lvl in range(len(convs[0])):
                 wt = torch.stack([M.conv_prepare(L, st, c[lvl].weight.detach()) for c in convs]).contiguous()
                 bias = torch.stack([c[lvl].bias.detach() for c in convs]).contiguous()
-                levels.append((wt, bias))
+                levels.append((PreparedConv(wt, 3), bias))
             self._plan[key] = levels
         G = hi - lo
         x, shared = feats, True
         for wt, bias in self._plan[key]:
-            x = M.conv2d(L, st, x, wt, 3, 2, bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=G, x_shared=shared)
+            x = conv(x, wt, 3, 2, bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=G, x_shared=shared)
             shared = False
         return [self.styles[lo + g].linear(x[g].reshape(-1, 512)) for g in range(G)]
 

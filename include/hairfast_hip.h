@@ -300,6 +300,23 @@ int hf_conv2d_f32(float *out, const float *x, const float *wt, const float *in_s
                   void *stream);
 long long hf_conv2d_workspace_floats(int batch, int cin, int cout, int h, int w, int k, int stride, int groups);
 
+/* hf_conv2d_f32 for k = 3 on the fp16 matrix cores (v_mfma_f32_32x32x16_f16; csrc/convh_enc.hip): same
+ * arithmetic contract - in_scale/in_shift on real pixels, out_scale/bias, activation, residual, groups -
+ * with the products in the operand modes of hf_modconv3x3_f16_f32 (nterms 3: fp32 operands split into
+ * fp16 (hi, lo) pairs, fp32-class accuracy; nterms 1: operands rounded to fp16), fp32 tensors and
+ * accumulation.  Replaces the same reference chains as hf_conv2d_f32 (helpers.py:99-115,
+ * psp_encoders.py:41-47, iresnet.py:44-56, feature_style_encoder.py:33-40, models/Encoders.py:35-57).
+ * wt_hi / wt_lo: per group, hf_conv_split_weights_f16 of that group's prepared weights
+ * ([9][cin][cout] from hf_conv_prepare_f32): group g's hi block starts at wt_hi + g*(9*cin*cout + 8) halves
+ * (its 16-byte trailer included), its lo block at wt_lo + g*9*cin*cout halves.
+ * Shapes: cin % 16 == 0, cout % 64 == 0, output planes at least 9 pixels wide and tall enough for one
+ * 128-pixel tile of 16 or 32 columns; anything else returns HF_E_INVALID and the caller uses
+ * hf_conv2d_f32.  No workspace. */
+int hf_conv2d_f16_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
+                      const float *in_scale, const float *in_shift, const float *out_scale, const float *bias, int act,
+                      const float *slope, float alpha, const float *residual, int batch, int cin, int cout, int h, int w,
+                      int stride, int groups, long long x_group_stride, void *stream);
+
 /* out[p] = mean of plane p (AdaptiveAvgPool2d(1) of SEModule, helpers.py:60,68). */
 int hf_plane_mean_f32(float *out, const float *x, int planes, int hw, void *stream);
 /* gate[b,c] = sigmoid(fc2 . relu(fc1 . pooled[b])) ; fc1 [reduced,channels], fc2 [channels,reduced]
@@ -351,7 +368,8 @@ int hf_debug_set_dispatch(int same_cfg, int up_cfg);
 /* Which kernel the last modulated-conv call used: 100 * family + tile configuration id,
  * family 1 = general, 2 = pipelined (double-buffered DMA), 3 = split-K (id 0), 5 = fp16 matrix
  * cores (hf_modconv3x3_f16_f32: ids 51-56, 51/52 can be forced through same_cfg; +20 = pre-split input;
- * hf_modconv3x3_up_f16_f32: ids 61/63, +20 = pre-split input).  Tests use
+ * hf_modconv3x3_up_f16_f32: ids 61/63, +20 = pre-split input), 6 = hf_conv2d_f16_f32 (1: 64x256 tile,
+ * 2: stride 2, 3: 64x128 tile).  Tests use
  * it to make sure a shape exercises the path it is meant to; bench.py to label launches. */
 int hf_debug_last_path(void);
 /* The fp16 matrix-core kernels launch one resident block per CU and let it walk several tiles

@@ -125,3 +125,69 @@ def test_fs_encoder_vs_reference_golden(golden):
     out3 = fs.test(img=C.fs_inputs(3)[0].to(dev), return_latent=True)  # batch 3: Embedding.py:74
     close(out3[2], G["fs_s_B3"])
     close(out3[3][:, ::16], G["fs_content_chan16_B3"])
+
+
+@pytest.mark.parametrize("nterms,tol", [(3, 5e-6), (1, 4e-3)])
+@pytest.mark.parametrize("B,cin,cout,H,W,stride,groups", [
+    (3, 64, 64, 256, 256, 1, 1), (3, 64, 64, 256, 256, 2, 1), (3, 128, 128, 64, 64, 1, 1), (3, 256, 256, 32, 32, 1, 1),
+    (3, 512, 512, 16, 16, 1, 1), (3, 256, 512, 32, 32, 1, 1), (3, 512, 512, 32, 32, 2, 1), (1, 1024, 1024, 64, 64, 1, 1),
+    (3, 512, 512, 64, 64, 2, 11), (2, 64, 128, 100, 72, 1, 1), (2, 64, 64, 61, 77, 2, 1)])
+def test_conv2d_f16_matrix_cores_encoder_shapes(nterms, tol, B, cin, cout, H, W, stride, groups):
+    """hf_conv2d_f16_f32 (csrc/convh_enc.hip) on the encoders' / PostProcess's real layer shapes against
+    the exact-fp32 MFMA kernel: pre-conv BN affine, post-conv affine, PReLU, residual; the grouped
+    stride-2 launch of the e4e fine style heads; ragged planes."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = _dev()
+    torch.manual_seed(cin + H + stride)
+    L, st = lib(), stream()
+    x = torch.randn(B, cin, H, W, device=dev)
+    assert M.conv2d_f16_supported(cin, cout, H, W, 3, stride)
+    if groups == 1:
+        w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+        a, t = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.2
+        g, bsh, slope = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.2, torch.rand(cout, device=dev) * 0.5
+        wt = M.conv_prepare(L, st, w)
+        hi, lo = M.conv_split_weights_f16(L, st, wt)
+        oh, ow = (H - 1) // stride + 1, (W - 1) // stride + 1
+        res = torch.randn(B, cout, oh, ow, device=dev)
+        kw = dict(in_scale=a, in_shift=t, out_scale=g, bias=bsh, act=M.ACT_PRELU, slope=slope, residual=res)
+        ref = M.conv2d(L, st, x, wt, 3, stride, **kw)
+        y = M.conv2d_f16(L, st, x, hi, lo, nterms, cout, stride, **kw)
+    else:
+        ws = torch.randn(groups, cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+        bias = torch.randn(groups, cout, device=dev)
+        wt = torch.stack([M.conv_prepare(L, st, ws[g]) for g in range(groups)]).contiguous()
+        hi, lo = M.conv_split_weights_f16(L, st, wt)
+        kw = dict(bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=groups, x_shared=True)
+        ref = M.conv2d(L, st, x, wt, 3, stride, **kw)
+        y = M.conv2d_f16(L, st, x, hi, lo, nterms, cout, stride, **kw)
+    torch.cuda.synchronize()
+    assert L.hf_debug_last_path() // 100 == 6
+    assert y.shape == ref.shape and torch.isfinite(y).all()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((y - ref).abs().max()) < tol * scale, float((y - ref).abs().max()) / scale
+
+
+def test_encoders_precision_modes(golden):
+    """The encoder goldens in the other operand modes: exact fp32 MFMA (f32) at the fp32 tolerance,
+    fp16 operands (f16) within 2e-2 of the W+ codes (the default f16x3 mode is what every other test runs)."""
+    from hairfastgan_amd import _runtime
+    from hairfastgan_amd.encoders import Encoder4Editing, get_latents
+
+    dev = _dev()
+    G = golden("encoders.npz")
+    enc = _load(Encoder4Editing(50, "ir_se", argparse.Namespace(stylegan_size=1024)), C.params_from_shapes("e4e", E.e4e_param_shapes()),
+                dev, strip=0)
+    x, latent_avg = C.e4e_inputs(2)
+    net = argparse.Namespace(encoder=enc, opts=argparse.Namespace(start_from_latent_avg=True), latent_avg=latent_avg.to(dev))
+    for mode, rel in (("f32", REL), ("f16", 2e-2)):
+        prev = _runtime.set_conv_precision(mode)
+        try:
+            with torch.inference_mode():
+                w = get_latents(net, x.to(dev))
+        finally:
+            _runtime.set_conv_precision(prev)
+        err = close(w, G["e4e_w"], rel)
+        print(f"e4e {mode}: max-abs {err:.3e}")

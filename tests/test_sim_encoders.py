@@ -163,3 +163,60 @@ def test_pipelined_stride2(simlib, B, cin, cout, H, W, code):
     assert simlib.hf_debug_last_path() == code
     ref = F.conv2d(x, w, stride=2, padding=1) * g.view(1, -1, 1, 1) + bsh.view(1, -1, 1, 1)
     assert maxdiff(y, ref) < TOL * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("nterms,tol", [(3, 5e-6), (1, 4e-3)])
+@pytest.mark.parametrize("stride,B,cin,cout,H,W,path", [
+    (1, 2, 32, 64, 16, 32, 603), (1, 1, 16, 128, 20, 40, 603), (1, 2, 48, 64, 16, 16, 603),   # tw 32 / ragged / tw 16
+    (2, 2, 32, 64, 16, 64, 602), (2, 1, 16, 64, 31, 33, 602), (2, 2, 32, 64, 32, 32, 602),   # stride 2: tw 32 / odd planes / tw 16
+])
+def test_conv2d_f16_matrix_cores(simlib, nterms, tol, stride, B, cin, cout, H, W, path):
+    """csrc/convh_enc.hip: the encoders' 3x3 convs on the fp16 matrix cores (stride 1 and the
+    parity-split stride 2 form), pre-conv affine on real pixels only, post-conv affine, PReLU,
+    residual - against the fp32-MFMA kernel and torch."""
+    torch.manual_seed(stride * 100 + cin + W)
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    a, t = torch.rand(cin) + 0.5, torch.randn(cin) * 0.2
+    g, bsh, slope = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2, torch.rand(cout) * 0.5
+    wt = M.conv_prepare(simlib, None, w)
+    assert M.conv2d_f16_supported(cin, cout, H, W, 3, stride)
+    hi, lo = M.conv_split_weights_f16(simlib, None, wt)
+    ref_core = F.conv2d(x * a.view(1, -1, 1, 1) + t.view(1, -1, 1, 1), w, stride=stride, padding=1)
+    ref = F.prelu(ref_core * g.view(1, -1, 1, 1) + bsh.view(1, -1, 1, 1), slope)
+    res = torch.randn_like(ref)
+    kw = dict(in_scale=a, in_shift=t, out_scale=g, bias=bsh, act=M.ACT_PRELU, slope=slope, residual=res)
+    y32 = M.conv2d(simlib, None, x, wt, 3, stride, **kw)
+    y = M.conv2d_f16(simlib, None, x, hi, lo, nterms, cout, stride, **kw)
+    assert simlib.hf_debug_last_path() == path
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxdiff(y, y32) < tol * scale
+    assert maxdiff(y, ref + res) < max(tol, TOL) * scale
+    # plain conv + bias + LeakyReLU (the style heads' form)
+    y = M.conv2d_f16(simlib, None, x, hi, lo, nterms, cout, stride, bias=bsh, act=M.ACT_LRELU, alpha=0.01)
+    ref = F.leaky_relu(F.conv2d(x, w, bsh, stride=stride, padding=1), 0.01)
+    assert maxdiff(y, ref) < max(tol, TOL) * max(1.0, float(ref.abs().max()))
+
+
+def test_conv2d_f16_grouped(simlib):
+    """Grouped launch (the e4e style heads of a family): per-group weight blobs with their own
+    pre-scale trailers, shared and per-group inputs."""
+    torch.manual_seed(9)
+    G, B, cin, cout, H, W = 3, 2, 16, 64, 32, 32
+    x = torch.randn(B, cin, H, W)
+    ws = [torch.randn(cout, cin, 3, 3) * (0.02 * 10 ** gi) for gi in range(G)]  # very different magnitudes per group
+    bias = torch.randn(G, cout)
+    wt = torch.stack([M.conv_prepare(simlib, None, w) for w in ws]).contiguous()
+    hi, lo = M.conv_split_weights_f16(simlib, None, wt)
+    y = M.conv2d_f16(simlib, None, x, hi, lo, 3, cout, 2, bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=G, x_shared=True)
+    assert y.shape == (G, B, cout, 16, 16)
+    for gi in range(G):
+        ref = F.leaky_relu(F.conv2d(x, ws[gi], bias[gi], stride=2, padding=1), 0.01)
+        assert maxdiff(y[gi], ref) < TOL * max(1.0, float(ref.abs().max()))
+    x2 = torch.randn(G, B, cin, H, W)
+    y2 = M.conv2d_f16(simlib, None, x2, hi, lo, 3, cout, 1, bias=bias, groups=G, x_shared=False)
+    for gi in range(G):
+        ref = F.conv2d(x2[gi], ws[gi], bias[gi], padding=1)
+        assert maxdiff(y2[gi], ref) < TOL * max(1.0, float(ref.abs().max()))
+    assert not M.conv2d_f16_supported(16, 64, 8, 8, 3, 1) and not M.conv2d_f16_supported(16, 32, 32, 32, 3, 1)
+    assert not M.conv2d_f16_supported(16, 64, 16, 16, 3, 2) and M.conv2d_f16_supported(16, 64, 16, 16, 3, 1)

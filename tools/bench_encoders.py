@@ -34,15 +34,26 @@ def main():
     fs = FSEncoder()
     fs.enc.load_state_dict(C.params_from_shapes("fs", E.fs_param_shapes()))
     fs = fs.to(dev)
-    with torch.inference_mode():
-        for B in (1, 2, 3, 8):
-            x = torch.randn(B, 3, 256, 256, device=dev)
-            img = torch.randn(B, 3, 1024, 1024, device=dev)
-            t1 = timeit(lambda: e4e(x))
-            t2 = timeit(lambda: fs.test(img=img, return_latent=True))
-            print(f"B={B}: e4e {t1:7.2f} ms ({145.0 * B / t1:6.1f} TFLOP/s)   fs-encoder {t2:7.2f} ms ({69.6 * B / t2:6.1f} TFLOP/s)",
-                  flush=True)
+    from hairfastgan_amd import _runtime
+    from hairfastgan_amd.graphs import GraphRunner
 
+    modes = sys.argv[1:] or ["f16x3"]
+    for mode in modes:
+        _runtime.set_conv_precision(mode)
+        print(f"--- conv precision {mode}", flush=True)
+        with torch.inference_mode():
+            for B in (1, 2, 3, 8):
+                x = torch.randn(B, 3, 256, 256, device=dev)
+                img = torch.randn(B, 3, 1024, 1024, device=dev)
+                t1 = timeit(lambda: e4e(x))
+                t2 = timeit(lambda: fs.test(img=img, return_latent=True))
+                line = (f"B={B}: e4e {t1:7.2f} ms ({145.0 * B / t1:6.1f} TFLOP/s)   fs-encoder {t2:7.2f} ms "
+                        f"({69.6 * B / t2:6.1f} TFLOP/s)")
+                if B <= 3:  # hipGraph replay: the launch-bound regime
+                    g1 = GraphRunner(lambda a: e4e(a), x)
+                    g2 = GraphRunner(lambda a: fs.test(img=a, return_latent=True)[2:], img)
+                    line += f"   hipGraph: e4e {timeit(lambda: g1(x)):6.2f} ms  fs {timeit(lambda: g2(img)):6.2f} ms"
+                print(line, flush=True)
 
 if __name__ == "__main__":
     main()
