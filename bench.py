@@ -53,6 +53,7 @@ DTYPES = {
 }
 GFLOP_PER_IMAGE = 148.52       # modulated-conv FLOPs of one 0->8 forward
 GFLOP_PER_TRIPLE = 1545.0      # hot-path FLOPs of one swap (encoders + generator calls)
+GFLOP_POSTPROCESS = 774.0      # PostProcessModel (594 + 2 x 90 GFLOP)
 PMC_PROFILE = os.path.join("profiles", "pmc_traffic.json")
 
 
@@ -82,11 +83,15 @@ def build_hairfast(sd, dev):
     """HairFast(args) on synthetic weights with SyntheticStages for the out-of-scope networks."""
     from hairfastgan_amd.hair_swap import HairFast, SyntheticStages, get_parser
     from oracle import ref_encoders as E
+    from oracle import ref_postprocess as PP
 
     args = get_parser().parse_args([])
     args.device = dev
+    pp_shapes = PP.post_process_param_shapes()
+    pp_shapes.pop("latent_avg")
     return HairFast(args, stages=SyntheticStages(), generator_state={"g_ema": sd, "latent_avg": torch.zeros(512)},
-                    e4e_state=synth_state("e4e", E.e4e_param_shapes()), fs_state=synth_state("fs", E.fs_param_shapes()))
+                    e4e_state=synth_state("e4e", E.e4e_param_shapes()), fs_state=synth_state("fs", E.fs_param_shapes()),
+                    pp_state=synth_state("pp", pp_shapes))
 
 
 def cpu_baseline(sd, budget_s=30.0):
@@ -314,13 +319,14 @@ def main():
                    "data": "synthetic",
                    "config": {"workload": f"{args.triples} synthetic 1024^2 triples sharded over {world} GPU(s): host uint8 -> H2D -> "
                                           "HairFast.swap (e4e B=3, FS-encoder B=3, gen 3->3 B=3, gen 0->3 B=3, gen 0->8 B=2 [both "
-                                          "Alignment rotations batched], e4e B=2, gen 0->3 B=2, gen 4->8 B=1, gen 4->4 B=1 "
-                                          "[PostProcess stand-in], gen 5->8 B=1; out-of-scope networks = SyntheticStages) -> uint8 -> "
+                                          "Alignment rotations batched], e4e B=2, gen 0->3 B=2, gen 4->8 B=1, PostProcess encoder "
+                                          "[774 GFLOP], gen 5->8 B=1; out-of-scope networks = SyntheticStages) -> uint8 -> "
                                           "chunked RCCL all-gather; wall from first H2D to last gather (BASELINE.json configs[3])",
                               "triples": args.triples, "triples_per_gpu": n_local, "parallelism": f"replica x{world}, block-partitioned triples",
                               "weights": "synthetic closed-form (oracle/synth.py)", "conv_precision": precision,
                               "gather": "RCCL all_gather_into_tensor of uint8 images per 8 local triples (async)" if use_dist else "single process: no collective"},
-                   "algorithmic_tflops_hot_path": round(args.triples * GFLOP_PER_TRIPLE / elapsed / 1e3, 2)}
+                   "algorithmic_tflops_hot_path": round(args.triples * (GFLOP_PER_TRIPLE + GFLOP_POSTPROCESS) / elapsed / 1e3, 2),
+                   "gflop_per_triple": GFLOP_PER_TRIPLE + GFLOP_POSTPROCESS}
             if prof:
                 out.update(kernel_report(prof, elapsed, precision))
             print(json.dumps(out), flush=True)

@@ -1,8 +1,10 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > gpurun_out/r02a_tests.log
-python bench.py --steps 10 --warmup 2 > gpurun_out/r02a_bench.log 2>gpurun_out/r02a_bench.err
-HF_FORCE_DIST=1 MASTER_PORT=29701 python bench.py --workload swap256 --triples 32 --warmup 2 > gpurun_out/r02a_swap32.log 2>gpurun_out/r02a_swap32.err
-python tools/bench_encoders.py > gpurun_out/r02a_encoders.log 2>&1
-tail -5 gpurun_out/r02a_tests.log
+python tools/bench_enc_layers.py > gpurun_out/r02c_enc_layers.log 2>&1
+python -m pytest tests/test_gpu_encoders.py -m gpu -x -q 2>&1 | tail -15 > gpurun_out/r02c_enc_tests.log
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_schedule.py -m gpu -q -k "scaled_activations or forced_rccl" 2>&1 | tail -80 > gpurun_out/r02c_fail_tests.log
+HAIRFAST_ENC_PRESPLIT=heads python tools/bench_encoders.py f16x3 > gpurun_out/r02c_encoders_heads.log 2>&1
+HAIRFAST_ENC_PRESPLIT=all python tools/bench_encoders.py f16x3 > gpurun_out/r02c_encoders_all.log 2>&1
+HAIRFAST_ENC_PRESPLIT=none python tools/bench_encoders.py f16x3 > gpurun_out/r02c_encoders_none.log 2>&1
+cat gpurun_out/r02c_enc_layers.log; tail -3 gpurun_out/r02c_enc_tests.log; grep "B=3" gpurun_out/r02c_encoders_*.log

@@ -43,7 +43,8 @@ SIGNATURES = {
     "hf_conv_prepare_f32": [_f, _f, _i, _i, _i, _fl, _st],
     "hf_bn_fold_f32": [_f, _f, _f, _f, _f, _f, _f, _fl, _i, _st],
     "hf_conv2d_f32": [_f, _f, _f, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _f, _ll, _st],
-    "hf_conv2d_f16_f32": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _ll, _st],
+    "hf_conv2d_f16_f32": [_f, _f, _f, _f, _f, _f, _i, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _ll, _f, _ll, _st],
+    "hf_split_activation_f16": [_f, _f, _f, _f, _f, _ll, _i, _i, _i, _st],
     "hf_plane_mean_f32": [_f, _f, _i, _i, _st],
     "hf_se_gate_f32": [_f, _f, _f, _f, _i, _i, _i, _st],
     "hf_scale_shortcut_add_f32": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _st],
@@ -53,6 +54,10 @@ SIGNATURES = {
     "hf_linear_f32": [_f, _f, _ll, _f, _f, _i, _i, _i, _fl, _st],
     "hf_equal_linear_f32": [_f, _f, _ll, _f, _f, _i, _i, _i, _fl, _i, _fl, _fl, _st],
     "hf_pixel_norm_f32": [_f, _f, _i, _i, _st],
+    "hf_layernorm_f32": [_f, _f, _f, _f, _i, _i, _fl, _i, _fl, _st],
+    "hf_modulate_f32": [_f, _f, _f, _f, _ll, _i, _fl, _st],
+    "hf_pixel_norm_dim1_f32": [_f, _f, _i, _i, _i, _st],
+    "hf_axpby_bcast_f32": [_f, _f, _fl, _f, _fl, _ll, _ll, _st],
     "hf_add_bcast_f32": [_f, _f, _f, _ll, _ll, _st],
     "hf_debug_set_dispatch": [_i, _i],
     "hf_debug_last_path": [],
@@ -79,6 +84,8 @@ def bind(cdll):
     cdll.hf_modconv_workspace_floats.restype = ctypes.c_longlong
     cdll.hf_conv2d_workspace_floats.argtypes = [_i, _i, _i, _i, _i, _i, _i, _i]
     cdll.hf_conv2d_workspace_floats.restype = ctypes.c_longlong
+    cdll.hf_conv2d_f16_workspace_floats.argtypes = [_i, _i, _i, _i, _i, _i, _i]
+    cdll.hf_conv2d_f16_workspace_floats.restype = ctypes.c_longlong
     cdll.hf_f16_overflow_count.argtypes = [_i]
     cdll.hf_f16_overflow_count.restype = ctypes.c_longlong
     cdll.hf_abi_version.argtypes = []

@@ -515,29 +515,57 @@ def conv_split_weights_f16(lib, st, wt):
     return hi, lo
 
 
+def split_activation_f16(lib, st, x, in_scale=None, in_shift=None, want_lo=True):
+    """hf_split_activation_f16: x [..., C, H, W] fp32 -> SplitActivation of in_scale*x + in_shift
+    (fp16 hi/lo pairs, K-blocked [images, C/8, H, W, 8]); leading dims are flattened into images."""
+    x = _c(x)
+    c, h, w = x.shape[-3:]
+    images = x.numel() // (c * h * w)
+    hi = torch.empty((images, c // 8, h, w, 8), dtype=torch.float16, device=x.device)
+    lo = torch.empty_like(hi) if want_lo else None
+    check(lib, lib.hf_split_activation_f16(_p(hi), _p(lo), _p(x), _p(_c(in_scale)), _p(_c(in_shift)), images, c, h, w, st),
+          "hf_split_activation_f16")
+    return SplitActivation(hi, lo, None)
+
+
 def conv2d_f16(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None, in_shift=None, out_scale=None, bias=None,
                act=ACT_NONE, slope=None, alpha=0.0, residual=None, groups=1, x_shared=True):
-    """hf_conv2d_f16_f32: conv2d(k=3) on the fp16 matrix cores; argument meaning as conv2d()."""
-    x = _c(x)
-    if groups > 1 and not x_shared:
-        g_, b, cin, h, w = x.shape
-        if g_ != groups:
-            raise ValueError("x must be [groups, B, cin, H, W]")
-        x_gstride = b * cin * h * w
+    """hf_conv2d_f16_f32: conv2d(k=3) on the fp16 matrix cores; argument meaning as conv2d().
+    x may be a SplitActivation (split_activation_f16 of the input, any in_scale / in_shift already applied):
+    [B] images, or [groups*B] images with x_shared=False."""
+    pre = isinstance(x, SplitActivation)
+    if pre:
+        if in_scale is not None or in_shift is not None:
+            raise ValueError("a pre-split input carries its affine already")
+        n_img, cin, h, w = x.shape
+        b = n_img if (groups == 1 or x_shared) else n_img // groups
+        x_gstride = 0 if (groups == 1 or x_shared) else 1
+        dev = x.hi.device
     else:
-        b, cin, h, w = x.shape
-        x_gstride = 0
+        x = _c(x)
+        dev = x.device
+        if groups > 1 and not x_shared:
+            g_, b, cin, h, w = x.shape
+            if g_ != groups:
+                raise ValueError("x must be [groups, B, cin, H, W]")
+            x_gstride = b * cin * h * w
+        else:
+            b, cin, h, w = x.shape
+            x_gstride = 0
     oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
-    out = x.new_empty((groups, b, cout, oh, ow) if groups > 1 else (b, cout, oh, ow))
+    out = torch.empty((groups, b, cout, oh, ow) if groups > 1 else (b, cout, oh, ow), dtype=torch.float32, device=dev)
     if residual is not None:
         residual = _c(residual)
         if tuple(residual.shape) != tuple(out.shape):
             raise ValueError(f"residual {tuple(residual.shape)} != output {tuple(out.shape)}")
+    n = lib.hf_conv2d_f16_workspace_floats(b, cin, cout, h, w, stride, groups)
+    ws = torch.empty((n,), dtype=torch.float32, device=dev) if n > 0 else None
     code = _launch_profiled(
         lib, 2.0 * cin * cout * 9 * oh * ow * b * groups,
-        lambda: lib.hf_conv2d_f16_f32(_p(out), _p(x), _p(wt_hi), _p(wt_lo), nterms, _p(in_scale), _p(in_shift), _p(_c(out_scale)),
+        lambda: lib.hf_conv2d_f16_f32(_p(out), None if pre else _p(x), _p(x.hi) if pre else None, _p(x.lo) if pre else None,
+                                      _p(wt_hi), _p(wt_lo), nterms, _p(in_scale), _p(in_shift), _p(_c(out_scale)),
                                       _p(_c(bias)), act, _p(_c(slope)), float(alpha), _p(residual), b, cin, cout, h, w, stride,
-                                      groups, x_gstride, st))
+                                      groups, x_gstride, _p(ws), max(n, 0), st))
     check(lib, code, "hf_conv2d_f16_f32")
     return out
 
@@ -602,10 +630,8 @@ def linear(lib, st, x, weight, bias, scale=1.0):
     weight = _c(weight)
     n = weight.shape[0]
     out = x.new_empty((b, n))
-    for b0 in range(0, b, 8):
-        nb = min(8, b - b0)
-        check(lib, lib.hf_linear_f32(out[b0:].data_ptr(), x[b0:].data_ptr(), x.stride(0) if b > 1 else k, _p(weight),
-                                     _p(_c(bias)), nb, k, n, float(scale), st), "hf_linear_f32")
+    check(lib, lib.hf_linear_f32(_p(out), _p(x), x.stride(0) if b > 1 else k, _p(weight), _p(_c(bias)), b, k, n, float(scale), st),
+          "hf_linear_f32")
     return out
 
 
@@ -621,11 +647,9 @@ def equal_linear(lib, st, x, weight, bias, lr_mul=1.0, fused_lrelu=False, alpha=
     weight = _c(weight)
     n = weight.shape[0]
     out = x2.new_empty((b, n))
-    for b0 in range(0, b, 8):
-        nb = min(8, b - b0)
-        check(lib, lib.hf_equal_linear_f32(out[b0:].data_ptr(), x2[b0:].data_ptr(), x2.stride(0) if b > 1 else k, _p(weight),
-                                           _p(_c(bias)), nb, k, n, float(lr_mul), 1 if fused_lrelu else 0, float(alpha),
-                                           float(act_scale), st), "hf_equal_linear_f32")
+    check(lib, lib.hf_equal_linear_f32(_p(out), _p(x2), x2.stride(0) if b > 1 else k, _p(weight), _p(_c(bias)), b, k, n,
+                                       float(lr_mul), 1 if fused_lrelu else 0, float(alpha), float(act_scale), st),
+          "hf_equal_linear_f32")
     return out.reshape(*lead, n)
 
 
@@ -636,6 +660,44 @@ def pixel_norm(lib, st, x):
         raise ValueError("pixel_norm expects [B, dim] (the mapping network's z)")
     out = torch.empty_like(x)
     check(lib, lib.hf_pixel_norm_f32(_p(out), _p(x), x.shape[0], x.shape[1], st), "hf_pixel_norm_f32")
+    return out
+
+
+def layernorm(lib, st, x, dim, gamma=None, beta=None, eps=1e-5, lrelu=False, alpha=0.01):
+    """F.layer_norm over the trailing `dim` elements (x viewed as [rows, dim]), optional affine + LeakyReLU."""
+    x = _c(x)
+    if x.numel() % dim:
+        raise ValueError("dim must divide the tensor")
+    out = torch.empty_like(x)
+    check(lib, lib.hf_layernorm_f32(_p(out), _p(x), _p(_c(gamma)), _p(_c(beta)), x.numel() // dim, dim, float(eps),
+                                    1 if lrelu else 0, float(alpha), st), "hf_layernorm_f32")
+    return out
+
+
+def modulate(lib, st, x, gamma, beta, lrelu=False, alpha=0.01):
+    x, gamma, beta = _c(x), _c(gamma), _c(beta)
+    if gamma.shape != x.shape or beta.shape != x.shape:
+        raise ValueError("gamma / beta must have x's shape")
+    out = torch.empty_like(x)
+    check(lib, lib.hf_modulate_f32(_p(out), _p(x), _p(gamma), _p(beta), x.numel(), 1 if lrelu else 0, float(alpha), st),
+          "hf_modulate_f32")
+    return out
+
+
+def pixel_norm_dim1(lib, st, x):
+    x = _c(x)
+    b, layers, d = x.shape
+    out = torch.empty_like(x)
+    check(lib, lib.hf_pixel_norm_dim1_f32(_p(out), _p(x), b, layers, d, st), "hf_pixel_norm_dim1_f32")
+    return out
+
+
+def axpby(lib, st, a, alpha, bvec, beta=1.0):
+    """alpha * a + beta * bvec, bvec broadcast periodically over a (hf_axpby_bcast_f32)."""
+    a, bvec = _c(a), _c(bvec)
+    out = torch.empty_like(a)
+    check(lib, lib.hf_axpby_bcast_f32(_p(out), _p(a), float(alpha), _p(bvec), float(beta), a.numel(), bvec.numel(), st),
+          "hf_axpby_bcast_f32")
     return out
 
 

@@ -598,7 +598,9 @@ __global__ __launch_bounds__(256) void split_weights_absmax(unsigned int *__rest
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(wt[i]));
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(trailer + 1, __float_as_uint(m));  // non-negative floats order like their bits
+  // one atomic per wave, and only when it can still raise the maximum (a plain read first: thousands of
+  // waves hammering one address with atomics took 190 us per call)
+  if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > trailer[1]) atomicMax(trailer + 1, __float_as_uint(m));
 }
 __global__ void split_weights_clear(unsigned int *trailer) {
   if (threadIdx.x < 4) trailer[threadIdx.x] = 0u;
@@ -769,7 +771,7 @@ extern "C" int hf_conv_split_weights_f16(void *wt_hi, void *wt_lo, const float *
   if (g > 4096) g = 4096;
   unsigned int *trailer = reinterpret_cast<unsigned int *>(static_cast<_Float16 *>(wt_hi) + n);
   hipLaunchKernelGGL(split_weights_clear, dim3(1), dim3(64), 0, (hipStream_t)stream, trailer);
-  hipLaunchKernelGGL(split_weights_absmax, dim3((int)g), dim3(256), 0, (hipStream_t)stream, trailer, wt, n);
+  hipLaunchKernelGGL(split_weights_absmax, dim3((int)(g > 512 ? 512 : g)), dim3(256), 0, (hipStream_t)stream, trailer, wt, n);
   hipLaunchKernelGGL(split_weights, dim3((int)g), dim3(256), 0, (hipStream_t)stream, static_cast<_Float16 *>(wt_hi),
                      static_cast<_Float16 *>(wt_lo), wt, cin, cout);
   return hf_launch_status();

@@ -46,7 +46,11 @@ constexpr int enc_npix() {
   return a > b ? a : b;
 }
 
-template <int NTERMS, int PG, int WAVES_PX, int STRIDE>
+// PRE: the activations arrive already affine-transformed, split into fp16 (hi, lo) and K-blocked
+// ([image][cin/8][h][w][8 halves], hf_split_activation_f16; ConvParams::xh / xl): the halo tile is
+// fetched by LDS-DMA like the weights - no per-element loads, no conversion (a shared input feeding
+// many output-channel tiles / groups is then converted once instead of once per block).
+template <int NTERMS, int PG, int WAVES_PX, int STRIDE, bool PRE>
 __global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
                                                               const _Float16 *__restrict__ wtl_all) {
   constexpr int CT_TILES = 1, WAVES_CO = 2;
@@ -102,29 +106,50 @@ __global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P,
 
   const long long plane = (long long)P.h * P.w;
   const int iplane = (int)plane;
-  const float *xb = P.x + go.x + (long long)b0 * P.cin * plane;
+  const float *xb = PRE ? nullptr : P.x + go.x + (long long)b0 * P.cin * plane;
+  // PRE: image base of the split tensors; a per-group input ([groups][batch] images) when x_gstride != 0
+  const long long img = (long long)(P.x_gstride ? grp * P.batch : 0) + b0;
+  const char *xh_b = PRE ? static_cast<const char *>(P.xh) + img * (P.cin / 8) * plane * 16 : nullptr;
+  const char *xl_b = (PRE && NTERMS == 3) ? static_cast<const char *>(P.xl) + img * (P.cin / 8) * plane * 16 : nullptr;
 
   // ---- per-thread staging items (stage invariant): plane offset of the input pixel (-1 zero fill,
-  // -2 none) and the 16-byte LDS unit (incl. kgroup) it goes to ----
+  // -2 none) and the 16-byte LDS unit (incl. kgroup) it goes to.  Register staging enumerates the
+  // halo in input order (coalesced loads); PRE enumerates LDS units (a DMA piece fills 64 consecutive
+  // units, each lane fetching its own pixel's 16-byte unit) ----
   int e_src[XE], e_dst[XE], e_kg[XE];
 #pragma unroll
   for (int e = 0; e < XE; ++e) {
     const int i = tid + e * NT;
-    const int kg = i / n_items, v = i - kg * n_items;
     e_src[e] = -2;
     e_dst[e] = 0;
-    e_kg[e] = kg;
-    if (kg < 2) {
-      const int hr = v / wcols, hc = v - hr * wcols;
-      const int ys = ty0 * STRIDE - 1 + hr, xc = tx0 * STRIDE - 1 + hc;
-      e_src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
-      e_dst[e] = kg * NPIX + ((STRIDE == 1) ? hr * wp + hc : hr * wp + (hc & 1) * wp2 + (hc >> 1));
+    if (!PRE) {
+      const int kg = i / n_items, v = i - kg * n_items;
+      e_kg[e] = kg;
+      if (kg < 2) {
+        const int hr = v / wcols, hc = v - hr * wcols;
+        const int ys = ty0 * STRIDE - 1 + hr, xc = tx0 * STRIDE - 1 + hc;
+        e_src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
+        e_dst[e] = kg * NPIX + ((STRIDE == 1) ? hr * wp + hc : hr * wp + (hc & 1) * wp2 + (hc >> 1));
+      }
+    } else {
+      const int kg = i / NPIX, u = i - kg * NPIX;
+      e_kg[e] = kg;
+      e_dst[e] = i;
+      if (i < X_UNITS && u < hp * wp) {
+        const int hr = u / wp, r = u - hr * wp;
+        const int hc = (STRIDE == 1) ? r : 2 * (r % wp2) + (r / wp2);
+        if (hc < wcols) {
+          const int ys = ty0 * STRIDE - 1 + hr, xc = tx0 * STRIDE - 1 + hc;
+          e_src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
+        }
+      }
     }
   }
-  for (int i = tid; i < P.cin; i += NT) {
-    sl[i] = P.s ? P.s[i] : 1.0f;
-    tl[i] = P.t ? P.t[i] : 0.0f;
-  }
+  if (!PRE)
+    for (int i = tid; i < P.cin; i += NT) {
+      sl[i] = P.s ? P.s[i] : 1.0f;
+      tl[i] = P.t ? P.t[i] : 0.0f;
+    }
 
   const unsigned lds_addr0 = hf_lds_addr(lds);
   auto dma_piece = [&](int i, int chunk, int bufsel) {
@@ -138,6 +163,18 @@ __global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P,
       const _Float16 *src = (part ? wtl : wth) + (long long)chunk * 18 * P.cout * 8;
       hf_glds16_raw_s(src, (unsigned)off, lds_addr0 + (unsigned)(bufsel * BUF_UNITS + part * W_UNITS + q * 64) * 16u);
     }
+  };
+  // PRE: item e of stage `chunk` straight into LDS (units of pixels outside the image were zeroed once)
+  auto dma_x = [&](int e, int chunk, int bufsel) {
+    const int i = tid + e * NT;
+    if (i - lane >= X_UNITS) return;  // whole piece beyond the part (uniform per wave)
+    const bool inside = e_src[e] >= 0;
+    int off = inside ? (e_kg[e] * iplane + e_src[e]) * 16 : 0;
+    HF_OPAQUE_I32(off);
+    const long long cofs = (long long)chunk * 2 * plane * 16;  // 2 channel blocks per stage
+    const unsigned dst = lds_addr0 + (unsigned)(bufsel * BUF_UNITS + OFF_XH + (i - lane)) * 16u;
+    hf_glds16_raw_s_if(inside, xh_b + cofs, (unsigned)off, dst);
+    if (NTERMS == 3) hf_glds16_raw_s_if(inside, xl_b + cofs, (unsigned)off, dst + (unsigned)X_UNITS * 16u);
   };
   float xr[XE][8];
   auto load_item = [&](int e, int chunk) {
@@ -180,20 +217,36 @@ __global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P,
     pix0[g] = py * STRIDE * wp + px;
   }
 
-  const int nchunks = P.cin / KH;
-  __syncthreads();  // sl / tl visible
+  const int nchunks_all = P.cin / KH;
+  const int c_begin = (P.splits > 1) ? (int)blockIdx.z * P.chunks_per_split : 0;
+  const int c_end = (P.splits > 1) ? min(nchunks_all, c_begin + P.chunks_per_split) : nchunks_all;
+  if (PRE) {  // zero the activation regions of both buffers once: DMA-masked units (padding) stay zero
+    half8 z;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) dma_piece(i, 0, 0);
+    for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.0f;
+    for (int i = tid; i < NPART * X_UNITS; i += NT) {
+      lds[OFF_XH + i] = z;
+      lds[BUF_UNITS + OFF_XH + i] = z;
+    }
+  }
+  __syncthreads();  // sl / tl (or the zero fill) visible
 #pragma unroll
-  for (int e = 0; e < XE; ++e) load_item(e, 0);
+  for (int i = 0; i < ND; ++i) dma_piece(i, c_begin, 0);
+  if (PRE) {
 #pragma unroll
-  for (int e = 0; e < XE; ++e) convert_item(e, 0, lds);
+    for (int e = 0; e < XE; ++e) dma_x(e, c_begin, 0);
+  } else {
+#pragma unroll
+    for (int e = 0; e < XE; ++e) load_item(e, c_begin);
+#pragma unroll
+    for (int e = 0; e < XE; ++e) convert_item(e, c_begin, lds);
+  }
   hf_barrier_keep_young<0>();
 
-  for (int c = 0; c < nchunks; ++c) {
-    const int cb = c & 1;
+  for (int c = c_begin; c < c_end; ++c) {
+    const int cb = (c - c_begin) & 1;
     half8 *buf = lds + cb * BUF_UNITS, *nbuf = lds + (cb ^ 1) * BUF_UNITS;
-    const bool more = c + 1 < nchunks;
+    const bool more = c + 1 < c_end;
     const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT
     const half8 *b_hi = buf + OFF_XH + lh * NPIX;
     half8 ah[2], al[2], bh[2][PG], bl[2][PG];
@@ -214,14 +267,20 @@ __global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P,
       const int s_ = tap & 1;
       if (tap + 1 < 9) fetch(s_ ^ 1, tap + 1);
       if (more) {
-        if (tap == 0) {
+        if (!PRE && tap == 0) {
 #pragma unroll
           for (int e = 0; e < XE; ++e) load_item(e, c + 1);
         }
 #pragma unroll
         for (int i = 0; i < ND; ++i)
           if (i / ((ND + 2) / 3) == tap) dma_piece(i, c + 1, cb ^ 1);
-        if (tap >= 9 - XE) convert_item(tap - (9 - XE), c + 1, nbuf);
+        if (PRE) {
+#pragma unroll
+          for (int e = 0; e < XE; ++e)
+            if (e == tap) dma_x(e, c + 1, cb ^ 1);
+        } else if (tap >= 9 - XE) {
+          convert_item(tap - (9 - XE), c + 1, nbuf);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -245,15 +304,25 @@ __global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P,
   store_tile<CT_TILES, PG, false>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
+// split-K plan: fill the chip (>= ~1.5 blocks per CU) when the output grid alone cannot, keeping at
+// least 4 K stages per block; 1 = off
+inline int enc_splitk_plan(long long blocks, int nchunks) {
+  if (blocks >= 256 || nchunks < 8) return 1;
+  int s = (int)((384 + blocks - 1) / blocks);
+  if (s > nchunks / 4) s = nchunks / 4;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : s;
+}
+
 template <int NTERMS, int PG, int WAVES_PX, int STRIDE>
-int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_t st) {
+int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *workspace, long long workspace_floats,
+               hipStream_t st, bool plan_only = false) {
   constexpr int CT = 64, NT = 128 * WAVES_PX;
   constexpr int PT = 32 * PG * WAVES_PX;
   constexpr int NPIX = enc_npix<PT, STRIDE>();
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;
   if (P.cin % KH || P.cout % CT || P.stride != STRIDE) return HF_E_INVALID;
   if ((long long)P.cin * P.h * P.w >= (1LL << 31)) return HF_E_INVALID;
-  P.splits = 1;
   P.n_geom = 1;
   P.g[0] = make_geom(0, 0, P.out_h, P.out_w, P.batch, PT, 0);
   const TileGeom &G = P.g[0];
@@ -264,29 +333,100 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStrea
   if (units > NPIX || 2 * hp * wcols > 8 * NT) return HF_E_INVALID;
   P.co_tiles = P.cout / CT;
   const int groups = P.groups > 1 ? P.groups : 1;
-  dim3 grid(geom_blocks(G), P.co_tiles * groups);
+  const long long blocks = (long long)geom_blocks(G) * P.co_tiles * groups;
+  P.splits = enc_splitk_plan(blocks, P.cin / KH);
+  P.chunks_per_split = hf_cdiv(P.cin / KH, P.splits);
+  P.splits = hf_cdiv(P.cin / KH, P.chunks_per_split);  // no empty split
+  P.zslab = (long long)groups * P.batch * P.cout * P.out_h * P.out_w;
+  if (plan_only) return HF_OK;
+  if (P.splits > 1) {
+    if (!workspace || workspace_floats < P.splits * P.zslab) return HF_E_WORKSPACE;
+    P.partial = workspace;
+  }
+  dim3 grid(geom_blocks(G), P.co_tiles * groups, P.splits);
   if (grid.y > 65535) return HF_E_INVALID;
   const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float);
   if (lds > 160 * 1024) return HF_E_INVALID;
-  hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE>), grid, dim3(NT), lds, st, P, wth, wtl);
-  return hf_launch_status();
+  if (P.xh) {
+    if ((long long)2 * P.h * P.w * 16 >= (1LL << 31) || (NTERMS == 3 && !P.xl)) return HF_E_INVALID;
+    hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, true>), grid, dim3(NT), lds, st, P, wth, wtl);
+  } else {
+    hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, false>), grid, dim3(NT), lds, st, P, wth, wtl);
+  }
+  int rc = hf_launch_status();
+  if (rc == HF_OK && P.splits > 1) rc = launch_splitk_reduce(P, true, st);  // deterministic second pass + epilogue
+  return rc;
+}
+
+// the tile configuration hf_conv2d_f16_f32 uses for a shape (shared by the workspace query)
+template <int NTERMS>
+int run_enc(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *ws, long long wsn, hipStream_t st, bool plan_only) {
+  int rc;
+  if (P.stride == 2) {
+    // 64 co x 128 output px (the halo of a stride-2 tile is 4x its output): 4 waves
+    rc = launch_enc<NTERMS, 2, 2, 2>(P, hi, lo, ws, wsn, st, plan_only);
+    if (rc == HF_OK && !plan_only) note_path(6, 2);
+    return rc;
+  }
+  // 64 co x 256 px (8 waves) when that still fills the chip, else 64 co x 128 px (4 waves)
+  const int groups = P.groups > 1 ? P.groups : 1;
+  const long long blocks256 = (long long)P.batch * groups * hf_cdiv((long long)P.out_h * P.out_w, 256) * (P.cout / 64);
+  rc = HF_E_INVALID;
+  if (blocks256 >= 384) {
+    rc = launch_enc<NTERMS, 2, 4, 1>(P, hi, lo, ws, wsn, st, plan_only);
+    if (rc == HF_OK && !plan_only) note_path(6, 1);
+  }
+  if (rc == HF_E_INVALID) {
+    rc = launch_enc<NTERMS, 2, 2, 1>(P, hi, lo, ws, wsn, st, plan_only);
+    if (rc == HF_OK && !plan_only) note_path(6, 3);
+  }
+  return rc;
+}
+
+// s*x + t (per input channel; null = identity) split into fp16 (hi, lo) and K-blocked
+// [image][c/8][h][w][8 halves]: one thread per (image, channel block, pixel), 8 coalesced plane loads
+__global__ __launch_bounds__(256) void split_activation(half8 *__restrict__ hi, half8 *__restrict__ lo,
+                                                        const float *__restrict__ x, const float *__restrict__ s,
+                                                        const float *__restrict__ t, int channels, long long plane,
+                                                        long long total) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int cblocks = channels >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long pix = i % plane, r = i / plane;
+    const int cb = (int)(r % cblocks);
+    const long long im = r / cblocks;
+    const float *src = x + (im * channels + cb * 8) * plane + pix;
+    half8 h8, l8;
+    bool ovf = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = cb * 8 + k;
+      const float v = fmaf(src[k * plane], s ? s[c] : 1.0f, t ? t[c] : 0.0f);
+      _Float16 hv, lv;
+      hf_split_f16(v, hv, lv, ovf);
+      h8[k] = hv;
+      l8[k] = lv;
+    }
+    hf_note_overflow(ovf);
+    hi[i] = h8;
+    if (lo) lo[i] = l8;
+  }
 }
 
 }  // namespace
 
 extern "C" unsigned long long hf_f16_overflow_count_enc(int reset) { return hf_f16_overflow_read_tu(reset); }
 
-extern "C" int hf_conv2d_f16_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
-                                 const float *in_scale, const float *in_shift, const float *out_scale, const float *bias,
-                                 int act, const float *slope, float alpha, const float *residual, int batch, int cin,
-                                 int cout, int h, int w, int stride, int groups, long long x_group_stride, void *stream) {
-  if (!out || !x || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2) ||
-      act < ACT_NONE || act > ACT_PRELU || (act == ACT_PRELU && !slope) || groups < 1 || x_group_stride < 0 ||
-      (nterms != 1 && nterms != 3) || (nterms == 3 && !wt_lo))
+static int enc_fill(ConvParams &P, float *out, const float *x, const void *x_hi, const void *x_lo, const float *in_scale,
+                    const float *in_shift, const float *out_scale, const float *bias, int act, const float *slope,
+                    float alpha, const float *residual, int batch, int cin, int cout, int h, int w, int stride, int groups,
+                    long long x_group_stride) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2) || act < ACT_NONE ||
+      act > ACT_PRELU || (act == ACT_PRELU && !slope) || groups < 1 || x_group_stride < 0)
     return HF_E_INVALID;
   if (groups > 1 && (in_scale || in_shift)) return HF_E_INVALID;  // grouped form: plain conv + epilogue (as hf_conv2d_f32)
-  ConvParams P{};
-  P.out = out; P.x = x; P.s = in_scale; P.t = in_shift; P.d = out_scale; P.bias = bias;
+  if (x_hi && (in_scale || in_shift)) return HF_E_INVALID;        // pre-split input: the affine went into the split
+  P.out = out; P.x = x; P.xh = x_hi; P.xl = x_lo; P.s = in_scale; P.t = in_shift; P.d = out_scale; P.bias = bias;
   P.slope = slope; P.residual = residual;
   P.s_bstride = 0; P.d_bstride = 0;
   P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w;
@@ -294,25 +434,41 @@ extern "C" int hf_conv2d_f16_f32(float *out, const float *x, const void *wt_hi, 
   P.stride = stride;
   P.act = act; P.alpha = alpha; P.scale = 1.0f;
   P.groups = groups; P.x_gstride = x_group_stride; P.wt_gstride = 0;
+  return HF_OK;
+}
+
+extern "C" long long hf_conv2d_f16_workspace_floats(int batch, int cin, int cout, int h, int w, int stride, int groups) {
+  ConvParams P{};
+  if (enc_fill(P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0.0f, nullptr, batch,
+               cin, cout, h, w, stride, groups, 0) != HF_OK)
+    return 0;
+  if (run_enc<3>(P, nullptr, nullptr, nullptr, 0, nullptr, true) != HF_OK) return 0;
+  return P.splits > 1 ? P.splits * P.zslab : 0;
+}
+
+extern "C" int hf_conv2d_f16_f32(float *out, const float *x, const void *x_hi, const void *x_lo, const void *wt_hi,
+                                 const void *wt_lo, int nterms, const float *in_scale, const float *in_shift,
+                                 const float *out_scale, const float *bias, int act, const float *slope, float alpha,
+                                 const float *residual, int batch, int cin, int cout, int h, int w, int stride, int groups,
+                                 long long x_group_stride, float *workspace, long long workspace_floats, void *stream) {
+  if (!out || (!x && !x_hi) || !wt_hi || (nterms != 1 && nterms != 3) || (nterms == 3 && !wt_lo)) return HF_E_INVALID;
+  ConvParams P{};
+  int rc = enc_fill(P, out, x, x_hi, x_lo, in_scale, in_shift, out_scale, bias, act, slope, alpha, residual, batch, cin, cout, h,
+                    w, stride, groups, x_group_stride);
+  if (rc != HF_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const _Float16 *hi = static_cast<const _Float16 *>(wt_hi), *lo = static_cast<const _Float16 *>(wt_lo);
-  int rc;
-  if (stride == 2) {
-    // 64 co x 128 output px (the halo of a stride-2 tile is 4x its output): 4 waves
-    rc = (nterms == 3) ? launch_enc<3, 2, 2, 2>(P, hi, lo, st) : launch_enc<1, 2, 2, 2>(P, hi, lo, st);
-    if (rc == HF_OK) note_path(6, 2);
-    return rc;
-  }
-  // 64 co x 256 px (8 waves) when that still fills the chip, else 64 co x 128 px (4 waves)
-  const long long blocks256 = (long long)batch * groups * hf_cdiv((long long)P.out_h * P.out_w, 256) * (cout / 64);
-  rc = HF_E_INVALID;
-  if (blocks256 >= 384) {
-    rc = (nterms == 3) ? launch_enc<3, 2, 4, 1>(P, hi, lo, st) : launch_enc<1, 2, 4, 1>(P, hi, lo, st);
-    if (rc == HF_OK) note_path(6, 1);
-  }
-  if (rc == HF_E_INVALID) {
-    rc = (nterms == 3) ? launch_enc<3, 2, 2, 1>(P, hi, lo, st) : launch_enc<1, 2, 2, 1>(P, hi, lo, st);
-    if (rc == HF_OK) note_path(6, 3);
-  }
-  return rc;
+  return (nterms == 3) ? run_enc<3>(P, hi, lo, workspace, workspace_floats, st, false)
+                       : run_enc<1>(P, hi, lo, workspace, workspace_floats, st, false);
+}
+
+extern "C" int hf_split_activation_f16(void *out_hi, void *out_lo, const float *x, const float *in_scale, const float *in_shift,
+                                       long long images, int channels, int h, int w, void *stream) {
+  if (!out_hi || !x || images <= 0 || channels <= 0 || (channels & 7) || h <= 0 || w <= 0) return HF_E_INVALID;
+  const long long plane = (long long)h * w, total = images * (channels >> 3) * plane;
+  long long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(split_activation, dim3((int)g), dim3(256), 0, (hipStream_t)stream, static_cast<half8 *>(out_hi),
+                     static_cast<half8 *>(out_lo), x, in_scale, in_shift, channels, plane, total);
+  return hf_launch_status();
 }

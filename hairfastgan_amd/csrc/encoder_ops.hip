@@ -171,6 +171,10 @@ __global__ __launch_bounds__(256) void linear_kernel(float *__restrict__ out, co
   const int lane = threadIdx.x & 63;
   const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kLinRows;
   if (n0 >= out_f) return;
+  // blockIdx.y: chunk of kLinMaxBatch input rows (any number of rows in one launch)
+  x += (long long)blockIdx.y * kLinMaxBatch * x_stride;
+  out += (long long)blockIdx.y * kLinMaxBatch * out_f;
+  batch = min(kLinMaxBatch, batch - (int)blockIdx.y * kLinMaxBatch);
   float acc[kLinRows][kLinMaxBatch];
 #pragma unroll
   for (int r = 0; r < kLinRows; ++r)
@@ -231,11 +235,77 @@ __global__ __launch_bounds__(256) void pixel_norm_rows(float *__restrict__ out, 
   for (int k = lane; k < dim; k += 64) out[(long long)r * dim + k] = xr[k] * inv;
 }
 
+// LayerNorm over the last `dim` elements of each row (F.layer_norm: biased variance, eps inside the
+// sqrt), optional elementwise affine (gamma/beta [dim]) and LeakyReLU(alpha) on top; one block per row.
+__global__ __launch_bounds__(256) void layernorm_rows(float *__restrict__ out, const float *__restrict__ x,
+                                                      const float *__restrict__ gamma, const float *__restrict__ beta, int dim,
+                                                      float eps, int act, float alpha) {
+  HF_DYN_LDS;
+  float *red = reinterpret_cast<float *>(hf_dyn_lds);  // [8]
+  const float *xr = x + (long long)blockIdx.x * dim;
+  float *orow = out + (long long)blockIdx.x * dim;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float s = 0.0f;
+  for (int k = threadIdx.x; k < dim; k += 256) s += xr[k];
+  s = hf_wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)dim;
+  float v = 0.0f;
+  for (int k = threadIdx.x; k < dim; k += 256) {
+    const float d = xr[k] - mean;
+    v = fmaf(d, d, v);
+  }
+  v = hf_wave_sum(v);
+  if (lane == 0) red[4 + wave] = v;
+  __syncthreads();
+  const float inv = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)dim + eps);
+  for (int k = threadIdx.x; k < dim; k += 256) {
+    float y = (xr[k] - mean) * inv;
+    if (gamma) y = fmaf(y, gamma[k], beta ? beta[k] : 0.0f);
+    if (act) y = y > 0.0f ? y : y * alpha;
+    orow[k] = y;
+  }
+}
+
+// out = x * (1 + gamma) + beta, optionally LeakyReLU(alpha)  (ModulationModule.forward, Encoders.py:29-31)
+__global__ __launch_bounds__(256) void modulate_kernel(float *__restrict__ out, const float *__restrict__ x,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta, long long n,
+                                                       int act, float alpha) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float y = fmaf(x[i], 1.0f + gamma[i], beta[i]);
+    if (act) y = y > 0.0f ? y : y * alpha;
+    out[i] = y;
+  }
+}
+
+// PixelNorm over dim 1 of [B, L, D] (the reference applies models/stylegan2/model.py:16-21 to W+ codes:
+// the mean runs over the L = 18 layers, Encoders.py:123-124): one thread per (b, d)
+__global__ __launch_bounds__(256) void pixel_norm_dim1(float *__restrict__ out, const float *__restrict__ x, int batch, int L,
+                                                       int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * D) return;
+  const int b = i / D, d = i - b * D;
+  const float *xb = x + (long long)b * L * D + d;
+  float acc = 0.0f;
+  for (int l = 0; l < L; ++l) acc = fmaf(xb[(long long)l * D], xb[(long long)l * D], acc);
+  const float inv = rsqrtf(acc / (float)L + 1e-8f);
+  for (int l = 0; l < L; ++l) out[(long long)b * L * D + (long long)l * D + d] = xb[(long long)l * D] * inv;
+}
+
 __global__ __launch_bounds__(256) void add_bcast(float *__restrict__ out, const float *__restrict__ a,
                                                  const float *__restrict__ b, long long n, long long period) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
     out[i] = a[i] + b[i % period];
+}
+
+__global__ __launch_bounds__(256) void axpby_bcast(float *__restrict__ out, const float *__restrict__ a, float alpha,
+                                                   const float *__restrict__ b, float beta, long long n, long long period) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = fmaf(alpha, a[i], beta * b[i % period]);
 }
 
 inline int grid_for(long long n) {
@@ -319,28 +389,58 @@ extern "C" int hf_downscale2x_f32(float *out, const float *x, int planes, int h,
 
 extern "C" int hf_linear_f32(float *out, const float *x, long long x_stride, const float *w, const float *bias,
                              int batch, int in_features, int out_features, float scale, void *stream) {
-  if (!out || !x || !w || batch <= 0 || batch > kLinMaxBatch || in_features <= 0 || out_features <= 0)
+  if (!out || !x || !w || batch <= 0 || batch > 65535 * kLinMaxBatch || in_features <= 0 || out_features <= 0)
     return HF_E_INVALID;
-  hipLaunchKernelGGL(linear_kernel, dim3(hf_cdiv(out_features, 4 * kLinRows)), dim3(256), 0, (hipStream_t)stream,
-                     out, x, x_stride, w, bias, batch, in_features, out_features, scale, 1.0f, 0, 0.0f, 1.0f);
+  hipLaunchKernelGGL(linear_kernel, dim3(hf_cdiv(out_features, 4 * kLinRows), hf_cdiv(batch, kLinMaxBatch)), dim3(256), 0,
+                     (hipStream_t)stream, out, x, x_stride, w, bias, batch, in_features, out_features, scale, 1.0f, 0, 0.0f, 1.0f);
   return hf_launch_status();
 }
 
 extern "C" int hf_equal_linear_f32(float *out, const float *x, long long x_stride, const float *w, const float *bias,
                                    int batch, int in_features, int out_features, float lr_mul, int fused_lrelu,
                                    float alpha, float act_scale, void *stream) {
-  if (!out || !x || !w || batch <= 0 || batch > kLinMaxBatch || in_features <= 0 || out_features <= 0)
+  if (!out || !x || !w || batch <= 0 || batch > 65535 * kLinMaxBatch || in_features <= 0 || out_features <= 0)
     return HF_E_INVALID;
   const float scale = (1.0f / sqrtf((float)in_features)) * lr_mul;
-  hipLaunchKernelGGL(linear_kernel, dim3(hf_cdiv(out_features, 4 * kLinRows)), dim3(256), 0, (hipStream_t)stream,
-                     out, x, x_stride, w, bias, batch, in_features, out_features, scale, lr_mul, fused_lrelu ? 1 : 0,
-                     alpha, act_scale);
+  hipLaunchKernelGGL(linear_kernel, dim3(hf_cdiv(out_features, 4 * kLinRows), hf_cdiv(batch, kLinMaxBatch)), dim3(256), 0,
+                     (hipStream_t)stream, out, x, x_stride, w, bias, batch, in_features, out_features, scale, lr_mul,
+                     fused_lrelu ? 1 : 0, alpha, act_scale);
   return hf_launch_status();
 }
 
 extern "C" int hf_pixel_norm_f32(float *out, const float *x, int rows, int dim, void *stream) {
   if (!out || !x || rows <= 0 || dim <= 0) return HF_E_INVALID;
   hipLaunchKernelGGL(pixel_norm_rows, dim3(hf_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, out, x, rows, dim);
+  return hf_launch_status();
+}
+
+extern "C" int hf_layernorm_f32(float *out, const float *x, const float *gamma, const float *beta, int rows, int dim, float eps,
+                                int lrelu, float alpha, void *stream) {
+  if (!out || !x || rows <= 0 || dim <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(layernorm_rows, dim3(rows), dim3(256), 32, (hipStream_t)stream, out, x, gamma, beta, dim, eps, lrelu ? 1 : 0,
+                     alpha);
+  return hf_launch_status();
+}
+
+extern "C" int hf_modulate_f32(float *out, const float *x, const float *gamma, const float *beta, long long n, int lrelu,
+                               float alpha, void *stream) {
+  if (!out || !x || !gamma || !beta || n <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(modulate_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, x, gamma, beta, n, lrelu ? 1 : 0,
+                     alpha);
+  return hf_launch_status();
+}
+
+extern "C" int hf_pixel_norm_dim1_f32(float *out, const float *x, int batch, int layers, int dim, void *stream) {
+  if (!out || !x || batch <= 0 || layers <= 0 || dim <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(pixel_norm_dim1, dim3(hf_cdiv((long long)batch * dim, 256)), dim3(256), 0, (hipStream_t)stream, out, x, batch,
+                     layers, dim);
+  return hf_launch_status();
+}
+
+extern "C" int hf_axpby_bcast_f32(float *out, const float *a, float alpha, const float *b, float beta, long long n,
+                                  long long b_period, void *stream) {
+  if (!out || !a || !b || n <= 0 || b_period <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(axpby_bcast, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, a, alpha, b, beta, n, b_period);
   return hf_launch_status();
 }
 

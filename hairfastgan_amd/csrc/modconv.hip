@@ -748,13 +748,15 @@ inline int splitk_plan(int batch, int cin, int cout, int out_h, int out_w, bool 
   return s < 2 ? 1 : s;
 }
 
-int launch_splitk_reduce(ConvParams &P, bool with_epilogue, hipStream_t st) {
+}  // namespace
+int hf_detail::launch_splitk_reduce(ConvParams &P, bool with_epilogue, hipStream_t st) {
   const long long slab = (long long)max(1, P.groups) * P.batch * P.cout * P.out_h * P.out_w;
   long long g = (slab + 255) / 256;
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(splitk_reduce, dim3((int)g), dim3(256), 0, st, P, slab, with_epilogue ? 1 : 0);
   return hf_launch_status();
 }
+namespace {
 
 // Tuning hook (hf_debug_set_dispatch): 0 = built-in heuristics.
 int g_force_same = 0, g_force_up = 0;

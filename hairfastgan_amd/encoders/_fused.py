@@ -1,6 +1,8 @@
 """Shared plumbing of the encoder mirrors: parameter containers are plain torch.nn layers
 (so that state-dict keys equal the reference's), the arithmetic goes through the C ABI
 with inference-mode BatchNorm folded into per-channel affines once per checkpoint."""
+import os
+
 import torch
 from torch import nn
 
@@ -59,13 +61,24 @@ def prep_conv(conv):
     return PreparedConv(M.conv_prepare(lib(), stream(), conv.weight.detach()), conv.kernel_size[0])
 
 
-def conv(x, w, k, stride=1, **kw):
+# Which convs hand the fp16-core kernel a PRE-SPLIT input (one hf_split_activation_f16 pass, then LDS-DMA
+# staging) instead of converting while staging: "heads" = the e4e style-head levels, whose input feeds
+# up to 88 (group, channel-tile) block columns; "all" = every eligible conv; "none".  Tuning knob.
+PRESPLIT = os.environ.get("HAIRFAST_ENC_PRESPLIT", "heads")
+
+
+def conv(x, w, k, stride=1, presplit=False, **kw):
     """Conv2d + folded BN / activation / residual.  3x3 convs whose shape the fp16 matrix-core kernel
     takes run there in the process-wide operand mode (_runtime.conv_precision: f16x3 = fp32-class
-    split operands, f16 = rounded operands); everything else, and mode f32, on the fp32 MFMA."""
+    split operands, f16 = rounded operands); everything else, and mode f32, on the fp32 MFMA.
+    presplit: this conv's input is shared by many block columns - convert it once (see PRESPLIT)."""
     mode = conv_precision()
     h, wd = x.shape[-2], x.shape[-1]
     if mode != "f32" and M.conv2d_f16_supported(w.cin, w.cout, h, wd, k, stride):
         hi, lo = w.f16()
-        return M.conv2d_f16(lib(), stream(), x, hi, lo, 3 if mode == "f16x3" else 1, w.cout, stride, **kw)
+        nterms = 3 if mode == "f16x3" else 1
+        if PRESPLIT == "all" or (presplit and PRESPLIT == "heads"):
+            x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None),
+                                       want_lo=nterms == 3)
+        return M.conv2d_f16(lib(), stream(), x, hi, lo, nterms, w.cout, stride, **kw)
     return M.conv2d(lib(), stream(), x, w.wt, k, stride, **kw)

@@ -171,7 +171,7 @@ class Encoder4Editing(FrozenPlanMixin, nn.Module):  # psp_encoders.py:124-200
         G = hi - lo
         x, shared = feats, True
         for wt, bias in self._plan[key]:
-            x = conv(x, wt, 3, 2, bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=G, x_shared=shared)
+            x = conv(x, wt, 3, 2, presplit=True, bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=G, x_shared=shared)
             shared = False
         return [self.styles[lo + g].linear(x[g].reshape(-1, 512)) for g in range(G)]
 

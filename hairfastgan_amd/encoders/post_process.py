@@ -1,0 +1,152 @@
+"""PostProcessModel on the MI355X kernels - host-side mirror of
+models/Encoders.py:106-137 (`PostProcessModel`), :13-32 (`ModulationModule`), :35-57
+(`FeatureiResnet`) and models/Net.py:396-477 (`FeatureEncoderMult(fs_layers=[9])`).
+
+It sits immediately before the last generator call of a swap (models/Blending.py:66-68):
+`S_final, F_final = post_process(I_1, I_blend_256)`, then `generator([S_final], start_layer=5,
+end_layer=8, layer_in=F_final)`.  774 GFLOP per triple - more than the generator's share of a swap -
+almost all of it 3x3 convolutions at 64x64 with 512...1024 channels, which run on the fp16
+matrix-core kernel of csrc/convh_enc.hip (IBasicBlock of encoders/fs_encoder.py: BN before the conv
+as an affine on real pixels, BN + PReLU / residual in the epilogue).
+
+Same parameter names as the reference (`encoder_face.*`, `to_feature.res_blocks.*`,
+`to_latent_1.*`, `to_latent_2.*`; `latent_avg` is a tensor attribute there, loaded from
+pretrained_models/PostProcess/latent_avg.pt, and a non-persistent buffer here).
+
+One scheduling change: the reference encodes source and target with two batch-1 calls of the same
+`encoder_face` (:120-121); here they are one batch-2 forward (frozen weights, independent samples).
+Inference only.
+"""
+import torch
+from torch import nn
+
+from .. import _marshal as M
+from .._runtime import lib, require_gpu, stream
+from ._fused import FrozenPlanMixin, conv, fold_bn, prep_conv
+from .fs_encoder import _IRESNET50, IBasicBlock, _make_layer
+
+
+class FeatureEncoderMult(FrozenPlanMixin, nn.Module):  # models/Net.py:396-477 with fs_layers=[9], ranks=None
+    def __init__(self, n_styles=18):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(3, 64, 3, 1, 1, bias=False), nn.BatchNorm2d(64, eps=1e-05), nn.PReLU(64))
+        inpl = 64
+        for li, (planes, blocks) in enumerate(_IRESNET50):
+            setattr(self, f"block_{li + 1}", _make_layer(inpl, planes, blocks))
+            inpl = planes
+        # max(fs_layers) > 7: scale 2 -> the content branches off block_2 (128 channels, 64x64), 3x3 stride 1
+        self.content_layer = nn.ModuleList([nn.Sequential(
+            nn.BatchNorm2d(128, eps=1e-05), nn.Conv2d(128, 512, 3, 1, 1, bias=False), nn.BatchNorm2d(512, eps=1e-05),
+            nn.PReLU(num_parameters=512), nn.Conv2d(512, 512, 3, 1, 1, bias=False), nn.BatchNorm2d(512, eps=1e-05))])
+        self.avg_pool = nn.AdaptiveAvgPool2d((3, 3))
+        self.styles = nn.ModuleList([nn.Linear(960 * 9, 512) for _ in range(n_styles)])
+        self._plan = None
+
+    def forward(self, x):
+        """x [B,3,256,256] -> (latents [B,18,512], [content [B,512,64,64]])."""
+        require_gpu(x)
+        if tuple(x.shape[-2:]) != (256, 256):
+            raise NotImplementedError("transform_to_256 (torchvision Resize, models/Net.py:12-14) is the identity only on 256x256 "
+                                      "inputs - which is what Blending.py:66 passes")
+        L, st = lib(), stream()
+        if self._plan is None:
+            c, cl = self.conv, self.content_layer[0]
+            self._plan = {
+                "w_in": prep_conv(c[0]), "bn_in": fold_bn(c[1]), "slope_in": c[2].weight.detach(),
+                "c_bn0": fold_bn(cl[0]), "c_w1": prep_conv(cl[1]), "c_bn2": fold_bn(cl[2]),
+                "c_slope": cl[3].weight.detach(), "c_w4": prep_conv(cl[4]), "c_bn5": fold_bn(cl[5]),
+                "head_w": torch.cat([m.weight.detach() for m in self.styles], 0).contiguous(),
+                "head_b": torch.cat([m.bias.detach() for m in self.styles], 0).contiguous()}
+        p = self._plan
+        x = conv(x, p["w_in"], 3, 1, out_scale=p["bn_in"][0], bias=p["bn_in"][1], act=M.ACT_PRELU, slope=p["slope_in"])
+        b = x.shape[0]
+        pooled = x.new_empty((b, 960, 3, 3))
+        c_off, content = 0, None
+        for li in range(4):
+            x = getattr(self, f"block_{li + 1}")(x)
+            if li == 1:
+                c = conv(x, p["c_w1"], 3, 1, in_scale=p["c_bn0"][0], in_shift=p["c_bn0"][1], out_scale=p["c_bn2"][0],
+                         bias=p["c_bn2"][1], act=M.ACT_PRELU, slope=p["c_slope"])
+                content = conv(c, p["c_w4"], 3, 1, out_scale=p["c_bn5"][0], bias=p["c_bn5"][1])
+            M.adaptive_avgpool_into(L, st, pooled, x, c_off)
+            c_off += x.shape[1]
+        out = M.linear(L, st, pooled.reshape(b, -1), p["head_w"], p["head_b"], 1.0)
+        return out.reshape(b, len(self.styles), 512), [content]
+
+
+class ModulationModule(nn.Module):  # models/Encoders.py:13-32
+    def __init__(self, layernum, last=False, inp=512, middle=512):
+        super().__init__()
+        self.layernum, self.last = layernum, last
+        self.fc = nn.Linear(512, 512)
+        self.norm = nn.LayerNorm([layernum, 512], elementwise_affine=False)
+        self.gamma_function = nn.Sequential(nn.Linear(inp, middle), nn.LayerNorm([middle]), nn.LeakyReLU(), nn.Linear(middle, 512))
+        self.beta_function = nn.Sequential(nn.Linear(inp, middle), nn.LayerNorm([middle]), nn.LeakyReLU(), nn.Linear(middle, 512))
+        self.leakyrelu = nn.LeakyReLU()
+
+    def forward(self, x, embedding):
+        """x, embedding [B, layernum, 512] -> [B, layernum, 512]: 9 launches (3 weight-streaming linears per
+        branch, LayerNorm + LeakyReLU fused, one modulation pass)."""
+        require_gpu(x, embedding)
+        L, st = lib(), stream()
+        lin = lambda t, m: M.linear(L, st, t.reshape(-1, t.shape[-1]), m.weight.detach(), m.bias.detach(), 1.0)  # noqa: E731
+        shape = x.shape
+        h = M.layernorm(L, st, lin(x, self.fc), self.layernum * 512, eps=self.norm.eps)
+
+        def mlp(f):
+            mid = M.layernorm(L, st, lin(embedding, f[0]), f[1].normalized_shape[0], f[1].weight.detach(), f[1].bias.detach(),
+                              eps=f[1].eps, lrelu=True, alpha=f[2].negative_slope)
+            return lin(mid, f[3])
+
+        out = M.modulate(L, st, h, mlp(self.gamma_function), mlp(self.beta_function), lrelu=not self.last,
+                         alpha=self.leakyrelu.negative_slope)
+        return out.reshape(shape)
+
+
+class FeatureiResnet(nn.Module):  # models/Encoders.py:35-57
+    def __init__(self, blocks, inplanes=1024):
+        super().__init__()
+        res_blocks = {}
+        for n, (planes, num_blocks) in enumerate(blocks, start=1):
+            for k in range(1, num_blocks + 1):
+                downsample = None
+                if inplanes != planes:
+                    downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, 1, bias=False), nn.BatchNorm2d(planes, eps=1e-05))
+                res_blocks[f"res_block_{n}_{k}"] = IBasicBlock(inplanes, planes, 1, downsample)
+                inplanes = planes
+        self.res_blocks = nn.ModuleDict(res_blocks)
+
+    def forward(self, x):
+        for module in self.res_blocks.values():
+            x = module(x)
+        return x
+
+
+class PostProcessModel(nn.Module):  # models/Encoders.py:106-137
+    def __init__(self, latent_avg=None):
+        super().__init__()
+        self.encoder_face = FeatureEncoderMult()
+        self.register_buffer("latent_avg", torch.zeros(18, 512) if latent_avg is None else latent_avg.clone(), persistent=False)
+        self.to_feature = FeatureiResnet([[1024, 2], [768, 2], [512, 2]])
+        self.to_latent_1 = nn.ModuleList([ModulationModule(18, i == 4) for i in range(5)])
+        self.to_latent_2 = nn.ModuleList([ModulationModule(18, i == 4) for i in range(5)])
+
+    @torch.inference_mode()
+    def forward(self, source, target):
+        """(source, target) [B,3,256,256] normalised -> (S_final [B,18,512], F_final [B,512,64,64])."""
+        require_gpu(source, target)
+        L, st = lib(), stream()
+        b = source.shape[0]
+        s_both, (f_both,) = self.encoder_face(torch.cat((source, target), 0))  # one batch-2B forward (the reference: two calls)
+        s_face, s_hair = s_both[:b].contiguous(), s_both[b:].contiguous()
+        dt_face = M.pixel_norm_dim1(L, st, s_face)
+        dt_hair = M.pixel_norm_dim1(L, st, s_hair)
+        for mod in self.to_latent_1:
+            dt_face = mod(dt_face, s_hair)
+        for mod in self.to_latent_2:
+            dt_hair = mod(dt_hair, s_face)
+        total = M.axpby(L, st, dt_face, 1.0, dt_hair, 1.0)                          # dt_face + dt_hair
+        final_s = M.axpby(L, st, total, 0.1, self.latent_avg.reshape(-1), 1.0)      # latent_avg + 0.1 * (...), :131
+        cat_f = torch.cat((f_both[:b], f_both[b:]), dim=1)                # [B,1024,64,64]
+        final_f = self.to_feature(cat_f)
+        return final_s, final_f

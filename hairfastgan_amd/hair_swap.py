@@ -7,13 +7,13 @@ exp_name=None)` (hair_swap.py:27-103) with the three stage objects the reference
 
 What runs where:
 
-* the HOT PATH of every stage - the e4e and FeatureStyle encoder forwards and all generator
-  calls, with the batch sizes and layer ranges the reference issues (Embedding.py:51-53,71-90,
-  Alignment.py:63, Blending.py:62,68) - runs on the HIP library (hairfastgan_amd.encoders,
-  hairfastgan_amd.stylegan2);
+* the HOT PATH of every stage - the e4e and FeatureStyle encoder forwards, the PostProcess encoder
+   and all generator calls, with the batch sizes and layer ranges the
+  reference issues (Embedding.py:51-53,71-90, Alignment.py:63, Blending.py:62,66,68) - runs on the HIP
+  library (hairfastgan_amd.encoders, hairfastgan_amd.stylegan2);
 * the networks BETWEEN those calls that SURVEY.md section 8 leaves out of scope (BiSeNet face
   parsing, the Rotate encoder, the CtrlHair shape adaptor, SEAN inpainting, the CLIP blending
-  encoder, the PostProcess encoder) are `Stages`: named callables injected at construction.
+  encoder) are `Stages`: named callables injected at construction.
   With the reference installed they are its own modules (INTEGRATION.md shows the binding);
   `SyntheticStages` provides shape- and dtype-faithful stand-ins so that the complete call
   schedule can be executed and timed on a box that has neither the reference nor checkpoints;
@@ -37,7 +37,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .encoders import Encoder4Editing, FSEncoder, get_latents
+from .encoders import Encoder4Editing, FSEncoder, PostProcessModel, get_latents
 from .net import Net
 
 
@@ -168,10 +168,8 @@ class Stages:
         """models/Encoders.py ClipBlendingModel: -> S_blend[:, 6:18] [1,12,512]."""
         self._missing("blend")
 
-    def post_process(self, image_face_256, image_blend_256):
-        """models/Encoders.py:106-137 PostProcessModel: ([1,3,256,256], [1,3,256,256]) ->
-        (S_final [1,18,512], F_final [1,512,64,64])."""
-        self._missing("post_process")
+    # post_process (models/Encoders.py:106-137 PostProcessModel) is NOT a stage any more: SURVEY.md section 8
+    # row f1 is built natively (hairfastgan_amd.encoders.PostProcessModel, owned by Blending).
 
 
 class SyntheticStages(Stages):
@@ -207,7 +205,6 @@ class SyntheticStages(Stages):
     def blend(self, s_face_6_18, s_color_6_18, image_face_masked, image_color_masked):
         return 0.5 * (s_face_6_18 + s_color_6_18)
 
-    # post_process: bound per HairFast instance (it re-uses that instance's generator), see HairFast.__init__
 
 
 # ---------------------------------------------------------------------------------------------
@@ -361,11 +358,16 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
 
 
 class Blending(nn.Module):  # models/Blending.py:11-82
-    def __init__(self, opts, net=None, stages=None):
+    def __init__(self, opts, net=None, stages=None, pp_state=None, pp_latent_avg=None):
         super().__init__()
         self.opts = opts
         self.net = net if net is not None else Net(opts)
         self.stages = stages or Stages()
+        # :28-29 PostProcessModel().load_state_dict(torch.load(pp_checkpoint)['model_state_dict']); latent_avg.pt
+        self.post_process = PostProcessModel(latent_avg=pp_latent_avg).eval()
+        if pp_state is not None:
+            self.post_process.load_state_dict(pp_state)
+        self.post_process.to(opts.device)
         self.dilate_erosion = DilateErosion(dilate_erosion=opts.smooth, device=opts.device)
         self.downsample_256 = BicubicDownSample(factor=4)
 
@@ -389,7 +391,7 @@ class Blending(nn.Module):  # models/Blending.py:11-82
         I_blend, _ = self.net.generator([S_blend], input_is_latent=True, return_latents=False, start_layer=4, end_layer=8,
                                         layer_in=latent_F_align)
         I_blend_256 = self.downsample_256(I_blend)
-        S_final, F_final = self.stages.post_process(I_1, I_blend_256)  # Post Process
+        S_final, F_final = self.post_process(I_1, I_blend_256)  # Post Process (native: encoders/post_process.py)
         I_final, _ = self.net.generator([S_final], input_is_latent=True, return_latents=False, start_layer=5, end_layer=8,
                                         layer_in=F_final)
         return ((I_final[0] + 1) / 2).clip(0, 1)
@@ -402,33 +404,25 @@ class HairFast:
       stages          the out-of-scope networks (Stages; SyntheticStages() for schedule runs)
       generator_state {'g_ema': ..., 'latent_avg': ...} instead of args.ckpt
       e4e_state / fs_state (+ e4e_latent_avg / fs_dlatent_avg)  encoder state dicts
+      pp_state (+ pp_latent_avg)  PostProcessModel state dict ('model_state_dict' of args.pp_checkpoint)
     """
 
     def __init__(self, args, *, stages=None, generator_state=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
-                 fs_dlatent_avg=None):
+                 fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None):
         self.args = args
         self.stages = stages or Stages()
         self.net = Net(args, state=generator_state)
         self.embed = Embedding(args, net=self.net, stages=self.stages, e4e_state=e4e_state, fs_state=fs_state,
                                e4e_latent_avg=e4e_latent_avg, fs_dlatent_avg=fs_dlatent_avg)
         self.align = Alignment(args, self.embed.get_e4e_embed, net=self.net, stages=self.stages)
-        self.blend = Blending(args, net=self.net, stages=self.stages)
+        self.blend = Blending(args, net=self.net, stages=self.stages, pp_state=pp_state, pp_latent_avg=pp_latent_avg)
         self._times = []
-        if isinstance(self.stages, SyntheticStages):
-            # PostProcess stand-in: S of the face, F = the 64^2 F-space tensor the generator itself derives
-            def post_process(image_face_256, image_blend_256, _self=self):
-                e = _self._last_embed["face"]
-                f64, _ = _self.net.generator([e["S"]], input_is_latent=True, return_latents=False, start_layer=4,
-                                             end_layer=4, layer_in=e["F"])
-                return e["S"], f64
-            self.stages.post_process = post_process
 
     def _swap_from_tensors(self, face, shape, color, **kwargs):  # hair_swap.py:38-61
         images_to_name = defaultdict(list)
         for image, name in zip((face, shape, color), ("face", "shape", "color")):
             images_to_name[image].append(name)
         name_to_embed = self.embed.embedding_images(images_to_name, **kwargs)  # Embedding stage
-        self._last_embed = name_to_embed
         pairs = [("face", "shape")] + ([("face", "color")] if shape is not color else [])
         rotated = self.align.rotate_images(pairs, name_to_embed)               # both Rotate forwards as one batch
         align_shape = self.align.align_images("face", "shape", name_to_embed, rotated=rotated, **kwargs)

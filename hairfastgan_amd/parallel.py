@@ -121,7 +121,10 @@ def swap_many(swap_fn, n_total, load_triple, device=None, chunk=8, group=None):
             imgs, ev = nxt
             nxt = fetch(lo + j + 1) if j + 1 < n_local else None
             if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                for t in imgs:  # allocated on the copy stream, consumed on this one: keep the block from being
+                    t.record_stream(cur)  # handed to the NEXT prefetch while these kernels still read it
             done.append(to_uint8_image(swap_fn(*imgs) * 2.0 - 1.0))
         mine = done[k * chunk:k * chunk + cs]
         send = torch.stack(mine + [torch.zeros_like(done[0])] * (cs - len(mine)))

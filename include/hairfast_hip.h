@@ -311,11 +311,26 @@ long long hf_conv2d_workspace_floats(int batch, int cin, int cout, int h, int w,
  * (its 16-byte trailer included), its lo block at wt_lo + g*9*cin*cout halves.
  * Shapes: cin % 16 == 0, cout % 64 == 0, output planes at least 9 pixels wide and tall enough for one
  * 128-pixel tile of 16 or 32 columns; anything else returns HF_E_INVALID and the caller uses
- * hf_conv2d_f32.  No workspace. */
-int hf_conv2d_f16_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
-                      const float *in_scale, const float *in_shift, const float *out_scale, const float *bias, int act,
-                      const float *slope, float alpha, const float *residual, int batch, int cin, int cout, int h, int w,
-                      int stride, int groups, long long x_group_stride, void *stream);
+ * hf_conv2d_f32.
+ * x_hi / x_lo (NULL = off): the input already transformed, split and K-blocked by
+ * hf_split_activation_f16 ([images][cin/8][h][w][8] fp16; x, in_scale, in_shift then unused and the
+ * latter two must be NULL): the kernel stages activations by LDS-DMA - worth it when one input feeds
+ * many output-channel tiles / groups (the e4e style heads: 88 block columns per input tile).  With
+ * groups > 1 and x_group_stride != 0 the split tensors hold [groups][batch] images.
+ * workspace: hf_conv2d_f16_workspace_floats() floats (layers whose output grid cannot fill the chip
+ * run split-K over the input channels + a deterministic second pass); 0 -> may be NULL. */
+int hf_conv2d_f16_f32(float *out, const float *x, const void *x_hi, const void *x_lo, const void *wt_hi,
+                      const void *wt_lo, int nterms, const float *in_scale, const float *in_shift,
+                      const float *out_scale, const float *bias, int act, const float *slope, float alpha,
+                      const float *residual, int batch, int cin, int cout, int h, int w, int stride, int groups,
+                      long long x_group_stride, float *workspace, long long workspace_floats, void *stream);
+long long hf_conv2d_f16_workspace_floats(int batch, int cin, int cout, int h, int w, int stride, int groups);
+/* in_scale[c]*x + in_shift[c] (NULL = identity) split into fp16 pairs hi = fp16(v), lo = fp16(v - hi)
+ * (saturating, hf_f16_overflow_count) and K-blocked: out_hi / out_lo [images][channels/8][h][w][8];
+ * x [images][channels][h][w] fp32, channels % 8 == 0.  out_lo may be NULL (nterms 1 consumer).
+ * The producer-side form of the conversion hf_conv2d_f16_f32 otherwise does per block while staging. */
+int hf_split_activation_f16(void *out_hi, void *out_lo, const float *x, const float *in_scale, const float *in_shift,
+                            long long images, int channels, int h, int w, void *stream);
 
 /* out[p] = mean of plane p (AdaptiveAvgPool2d(1) of SEModule, helpers.py:60,68). */
 int hf_plane_mean_f32(float *out, const float *x, int planes, int hw, void *stream);
@@ -339,7 +354,7 @@ int hf_adaptive_avgpool_f32(float *out, const float *x, int batch, int channels,
                             int out_channels_total, int out_channel_offset, void *stream);
 /* F.interpolate(x, scale_factor=0.5, mode='bilinear') on [planes,h,w], h and w even (trainer.py:61-64). */
 int hf_downscale2x_f32(float *out, const float *x, int planes, int h, int w, void *stream);
-/* out[b,n] = scale * sum_k x[b*x_stride+k] * w[n*in_features+k] + bias[n]; batch <= 8.
+/* out[b,n] = scale * sum_k x[b*x_stride+k] * w[n*in_features+k] + bias[n] (rows in chunks of 8 per block column).
  * nn.Linear (scale 1; feature_style_encoder.py:46, 62-63) and EqualLinear (scale
  * 1/sqrt(in_features); psp_encoders.py:48, 53). */
 int hf_linear_f32(float *out, const float *x, long long x_stride, const float *w, const float *bias, int batch,
@@ -348,12 +363,27 @@ int hf_linear_f32(float *out, const float *x, long long x_stride, const float *w
  *   out[b,n] = (sum_k x[b,k] * w[n,k]) * lr_mul/sqrt(in_features) + bias[n] * lr_mul
  * and, with fused_lrelu != 0 (activation='fused_lrelu', :154-156), leaky_relu(., alpha) * act_scale on
  * top - one layer of the z -> w mapping network (:384-393: lr_mul 0.01, alpha 0.2, act_scale sqrt 2).
- * bias may be NULL; batch <= 8 per launch. */
+ * bias may be NULL. */
 int hf_equal_linear_f32(float *out, const float *x, long long x_stride, const float *w, const float *bias, int batch,
                         int in_features, int out_features, float lr_mul, int fused_lrelu, float alpha, float act_scale,
                         void *stream);
 /* PixelNorm.forward (models/stylegan2/model.py:16-21) on [rows, dim]: x * rsqrt(mean_k x^2 + 1e-8). */
 int hf_pixel_norm_f32(float *out, const float *x, int rows, int dim, void *stream);
+/* ---- PostProcessModel's latent branch (models/Encoders.py:13-32, 119-131) ----
+ * F.layer_norm over the last `dim` elements of each of `rows` rows (biased variance, eps inside the sqrt):
+ * gamma / beta [dim] = elementwise affine (both NULL: LayerNorm(elementwise_affine=False), :19), lrelu != 0
+ * applies LeakyReLU(alpha) on top (the LayerNorm -> LeakyReLU of gamma_function / beta_function, :20-21). */
+int hf_layernorm_f32(float *out, const float *x, const float *gamma, const float *beta, int rows, int dim, float eps,
+                     int lrelu, float alpha, void *stream);
+/* out = x * (1 + gamma) + beta (all [n]), lrelu != 0: LeakyReLU(alpha) on top (ModulationModule.forward :29-31). */
+int hf_modulate_f32(float *out, const float *x, const float *gamma, const float *beta, long long n, int lrelu, float alpha,
+                    void *stream);
+/* PixelNorm over dim 1 of x [batch, layers, dim] - what models/stylegan2/model.py:16-21 computes when the
+ * reference applies it to W+ codes (Encoders.py:123-124): x * rsqrt(mean over the layers of x^2 + 1e-8). */
+int hf_pixel_norm_dim1_f32(float *out, const float *x, int batch, int layers, int dim, void *stream);
+/* out[i] = alpha * a[i] + beta * b[i % b_period]   (latent_avg + 0.1 * (dt_face + dt_hair), Encoders.py:131) */
+int hf_axpby_bcast_f32(float *out, const float *a, float alpha, const float *b, float beta, long long n, long long b_period,
+                       void *stream);
 /* out[i] = a[i] + b[i % b_period] */
 int hf_add_bcast_f32(float *out, const float *a, const float *b, long long n, long long b_period, void *stream);
 

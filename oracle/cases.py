@@ -199,3 +199,11 @@ def fs_inputs(B=2):
     img = t(synth.pseudo_normal(f"enc/fs/img/{B}", (B, 3, 1024, 1024))) * 0.5
     dlatent_avg = t(synth.pseudo_normal("enc/fs/dlatent_avg", (18, 512))) * 0.1
     return img, dlatent_avg
+
+
+def pp_inputs():
+    """PostProcessModel inputs (Blending.py:66): source = the face image, target = the blended image,
+    both normalised [1,3,256,256]."""
+    src = t(synth.pseudo_normal("pp/source", (1, 3, 256, 256))) * 0.5
+    tgt = t(synth.pseudo_normal("pp/target", (1, 3, 256, 256))) * 0.5
+    return src, tgt

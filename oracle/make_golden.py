@@ -76,6 +76,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
+    ap.add_argument("--only", default=None,
+                    help="comma list of sections to (re)generate (default all): basic,gen64,gen1024,enc_units,encoders,glue,pp")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -86,11 +88,16 @@ def main():
     from oracle import cases as C
 
     report = {}
+    only = set(args.only.split(",")) if args.only else None
+    want = lambda name: only is None or name in only  # noqa: E731
+    rep_path = os.path.join(args.out, "oracle_vs_reference.json")
+    if only is not None and os.path.exists(rep_path):
+        report.update(json.load(open(rep_path))["max_abs_diff"])  # keep the entries of the sections not re-run
 
     # ---------------- (i) upfirdn2d, modes 1 and 3 (+ one down=2 sanity case) ---
     k4 = C.blur_kernel4()
     g = {}
-    for name, c in C.UPFIRDN_CASES.items():
+    for name, c in (C.UPFIRDN_CASES.items() if want("basic") else ()):
         x = C.upfirdn_input(name)
         y = ref_op.upfirdn2d(x, k4, up=c["up"], down=c["down"], pad=c["pad"])
         yo = O.upfirdn2d(x, k4, up=c["up"], down=c["down"], pad=c["pad"])
@@ -98,20 +105,22 @@ def main():
         if x.numel() <= 2000:
             report[f"upfirdn_loops/{name}"] = maxdiff(y, O.upfirdn2d_loops(x, k4, c["up"], c["down"], c["pad"]))
         g[name] = y.numpy()
-    np.savez_compressed(os.path.join(args.out, "upfirdn2d.npz"), **g)
+    if want("basic"):
+        np.savez_compressed(os.path.join(args.out, "upfirdn2d.npz"), **g)
 
     # ---------------- (ii) fused bias + leaky relu -----------------------------
     g = {}
-    for name in C.ACT_CASES:
+    for name in (C.ACT_CASES if want("basic") else ()):
         x, b = C.act_inputs(name)
         y = ref_op.fused_leaky_relu(x, b)
         report[f"act/{name}"] = maxdiff(y, O.fused_leaky_relu(x, b))
         g[name] = y.numpy()
-    np.savez_compressed(os.path.join(args.out, "fused_act.npz"), **g)
+    if want("basic"):
+        np.savez_compressed(os.path.join(args.out, "fused_act.npz"), **g)
 
     # ---------------- (iii) small modulated conv / styled conv / to_rgb --------
     g = {}
-    for name, cin, cout, sdim, B, H, W in C.MODCONV_SMALL:
+    for name, cin, cout, sdim, B, H, W in (C.MODCONV_SMALL if want("basic") else ()):
         d = C.modconv_small_inputs(name)
         x, w = d["x"], d["w"]
         for up in (False, True):
@@ -137,7 +146,8 @@ def main():
             yo = O.to_rgb(P, "L", d["x_rgb"], w, sk)
             report[f"mc/{name}/rgb/skip{int(use_skip)}"] = maxdiff(y, yo)
             g[f"{name}_rgb_skip{int(use_skip)}"] = y.numpy()
-    np.savez_compressed(os.path.join(args.out, "modconv_small.npz"), **g)
+    if want("basic"):
+        np.savez_compressed(os.path.join(args.out, "modconv_small.npz"), **g)
 
     # ---------------- (iv) generators -----------------------------------------
     def run_generator(tag):
@@ -205,9 +215,10 @@ def main():
             out[f"{tag}_from_z_full"] = y.numpy()
         return out
 
-    g = run_generator("g64")
-    np.savez_compressed(os.path.join(args.out, "generator_64.npz"), **g)
-    if not args.skip_big:
+    if want("gen64"):
+        g = run_generator("g64")
+        np.savez_compressed(os.path.join(args.out, "generator_64.npz"), **g)
+    if not args.skip_big and want("gen1024"):
         g = run_generator("g1024")
         np.savez_compressed(os.path.join(args.out, "generator_1024.npz"), **g)
 
@@ -233,13 +244,13 @@ def main():
         mod.load_state_dict(sd, strict=False)
         return mod.eval()
 
-    for name, (in_c, depth, stride, B, H, W) in C.IRSE_UNIT_CASES.items():
+    for name, (in_c, depth, stride, B, H, W) in (C.IRSE_UNIT_CASES.items() if want("enc_units") else ()):
         P = C.params_from_shapes(name, C.irse_unit_shapes(in_c, depth))
         x = C.unit_input(name, (B, in_c, H, W))
         y = load_unit(ref_helpers.bottleneck_IR_SE(in_c, depth, stride), P)(x)
         report[f"enc/{name}"] = maxdiff(y, E.ir_se_unit(P, "u", x, in_c, depth, stride))
         g[name] = y.numpy()
-    for name, (in_c, planes, stride, B, H, W) in C.IBASIC_CASES.items():
+    for name, (in_c, planes, stride, B, H, W) in (C.IBASIC_CASES.items() if want("enc_units") else ()):
         P = C.params_from_shapes(name, C.ibasic_shapes(in_c, planes, stride))
         x = C.unit_input(name, (B, in_c, H, W))
         ds = None
@@ -248,15 +259,16 @@ def main():
         y = load_unit(ref_iresnet.IBasicBlock(in_c, planes, stride, ds), P)(x)
         report[f"enc/{name}"] = maxdiff(y, E.ibasic_block(P, "u", x, stride))
         g[name] = y.numpy()
-    for name, (c, spatial, B) in C.STYLE_BLOCK_CASES.items():
+    for name, (c, spatial, B) in (C.STYLE_BLOCK_CASES.items() if want("enc_units") else ()):
         P = C.params_from_shapes(name, C.style_block_shapes(c, spatial))
         x = C.unit_input(name, (B, c, spatial, spatial))
         y = load_unit(ref_psp.GradualStyleBlock(c, c, spatial), P)(x)
         report[f"enc/{name}"] = maxdiff(y, E.gradual_style_block(P, "u", x))
         g[name] = y.numpy()
-    np.savez_compressed(os.path.join(args.out, "encoder_units.npz"), **g)
+    if want("enc_units"):
+        np.savez_compressed(os.path.join(args.out, "encoder_units.npz"), **g)
 
-    if not args.skip_big:
+    if not args.skip_big and want("encoders"):
         import argparse as _ap
         import tempfile
 
@@ -320,8 +332,93 @@ def main():
         print("done fs B3", report["enc/fs_s_B3"], report["enc/fs_content_B3"], flush=True)
         np.savez_compressed(os.path.join(args.out, "encoders.npz"), **g)
 
+    # ---------------- (vi) glue ops + PostProcessModel --------------------
+    import types as _types
+
+    tvt_mod = sys.modules["torchvision.transforms"]
+
+    class _Id:  # Compose / Resize / Normalize are only CONSTRUCTED at import time (models/Net.py:12-14, Encoders.py:75)
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x):
+            return x
+
+    for nm in ("Compose", "Resize", "Normalize", "ToTensor", "InterpolationMode"):
+        if not hasattr(tvt_mod, nm):
+            setattr(tvt_mod, nm, _Id)
+    tvt_mod.Compose = lambda ts: (lambda x: x)  # transform_to_256 = Resize((256, 256)): the identity on 256^2 inputs
+    tvt_mod.functional = _types.ModuleType("torchvision.transforms.functional")
+    sys.modules["torchvision.transforms.functional"] = tvt_mod.functional
+    tvt_mod.transforms = tvt_mod
+    sys.modules["torchvision.utils"].save_image = lambda *a, **k: None
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    for m in ("gdown", "clip"):
+        sys.modules.setdefault(m, _types.ModuleType(m))
+    from utils.bicubic import BicubicDownSample as RefBicubic
+    from utils.image_utils import DilateErosion as RefDilateErosion
+
+    from hairfastgan_amd import hair_swap as HS  # torch glue of the product (CPU-runnable), checked against the reference
+
+    g = {}
+    xg = C.unit_input("glue/bicubic", (2, 3, 64, 64))
+    assert want("glue") or want("pp") or only is not None
+    for f in (2, 4):
+        y = RefBicubic(factor=f, cuda=False)(xg)
+        report[f"glue/bicubic{f}"] = maxdiff(y, HS.BicubicDownSample(f)(xg))
+        g[f"bicubic{f}"] = y.numpy()
+    mask = (C.unit_input("glue/mask", (3, 1, 48, 48)) > 0.3).float()
+    d_ref, e_ref = RefDilateErosion(dilate_erosion=3, device="cpu").mask(mask)
+    d_my, e_my = HS.DilateErosion(3, "cpu").mask(mask)
+    report["glue/dilate"], report["glue/erode"] = maxdiff(d_ref, d_my), maxdiff(e_ref, e_my)
+    g["dilate3"], g["erode3"] = d_ref.numpy(), e_ref.numpy()
+    np.savez_compressed(os.path.join(args.out, "glue.npz"), **g)
+
+    if not args.skip_big and want("pp"):
+        import argparse as _ap
+        import tempfile
+
+        from models import Encoders as ref_enc
+        from models import Net as ref_net
+        from oracle import ref_postprocess as PP
+
+        tmp = tempfile.mktemp()
+        torch.save(ref_net.iresnet50().state_dict(), tmp)
+        pp = ref_enc.PostProcessModel.__new__(ref_enc.PostProcessModel)  # the constructor reads checkpoint files
+        torch.nn.Module.__init__(pp)
+        pp.encoder_face = ref_net.FeatureEncoderMult(fs_layers=[9], opts=_ap.Namespace(arcface_model_path=tmp))
+        os.remove(tmp)
+        pp.to_feature = ref_enc.FeatureiResnet([[1024, 2], [768, 2], [512, 2]])
+        pp.to_latent_1 = torch.nn.ModuleList([ref_enc.ModulationModule(18, i == 4) for i in range(5)])
+        pp.to_latent_2 = torch.nn.ModuleList([ref_enc.ModulationModule(18, i == 4) for i in range(5)])
+        pp.pixelnorm = ref_enc.PixelNorm()
+        pp.eval()
+        shapes = {k_: tuple(v_.shape) for k_, v_ in pp.state_dict().items()}
+        mine = PP.post_process_param_shapes()
+        lat_shape = mine.pop("latent_avg")
+        assert shapes == mine and list(shapes) == list(mine), "PostProcess state-dict layout mismatch"
+        P = C.params_from_shapes("pp", shapes)
+        pp.load_state_dict(P)
+        P["latent_avg"] = C.params_from_shapes("pp", {"latent_avg": lat_shape})["latent_avg"] * 0.1
+        pp.latent_avg = P["latent_avg"]
+        src, tgt = C.pp_inputs()
+        s_ref, f_ref = pp(src, tgt)
+        s_o, f_o = PP.post_process_forward(P, src, tgt)
+        report["pp/s"], report["pp/f"] = maxdiff(s_ref, s_o), maxdiff(f_ref, f_o)
+        g = {"pp_s": s_ref.numpy(), "pp_f_chan16": f_ref[:, ::16].numpy().copy(), "pp_f_stats": stats(f_ref),
+             "pp_f_samples": strided_samples(f_ref, 1024)}
+        # unit-level goldens (small): one ModulationModule, FeatureiResnet-style block at small width
+        xm, em = C.unit_input("pp/mod/x", (2, 18, 512)), C.unit_input("pp/mod/e", (2, 18, 512))
+        g["pp_mod_mid"] = pp.to_latent_1[0](xm, em).numpy()
+        g["pp_mod_last"] = pp.to_latent_1[4](xm, em).numpy()
+        report["pp/mod"] = max(maxdiff(torch.from_numpy(g["pp_mod_mid"]), PP.modulation_module(P, "to_latent_1.0", xm, em, 18, False)),
+                               maxdiff(torch.from_numpy(g["pp_mod_last"]), PP.modulation_module(P, "to_latent_1.4", xm, em, 18, True)))
+        np.savez_compressed(os.path.join(args.out, "postprocess.npz"), **g)
+        print("done postprocess", report["pp/s"], report["pp/f"], flush=True)
+
     worst = max(report.values())
-    with open(os.path.join(args.out, "oracle_vs_reference.json"), "w") as f:
+    with open(rep_path, "w") as f:
         json.dump({"torch": torch.__version__, "max_abs_diff": report, "worst": worst}, f, indent=1, sort_keys=True)
     print(json.dumps(report, indent=1, sort_keys=True))
     print("worst oracle-vs-reference max-abs diff:", worst)

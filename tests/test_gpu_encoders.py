@@ -191,3 +191,30 @@ def test_encoders_precision_modes(golden):
             _runtime.set_conv_precision(prev)
         err = close(w, G["e4e_w"], rel)
         print(f"e4e {mode}: max-abs {err:.3e}")
+
+
+def test_postprocess_vs_reference_golden(golden):
+    """PostProcessModel (FeatureEncoderMult on source + target, ten ModulationModules,
+    FeatureiResnet 1024 -> 768 -> 512 @ 64x64) on the HIP path against golden vectors from the real reference."""
+    from hairfastgan_amd.encoders import PostProcessModel
+    from oracle import ref_postprocess as PP
+
+    dev = _dev()
+    G = golden("postprocess.npz")
+    shapes = PP.post_process_param_shapes()
+    lat_shape = shapes.pop("latent_avg")
+    P = C.params_from_shapes("pp", shapes)
+    latent_avg = C.params_from_shapes("pp", {"latent_avg": lat_shape})["latent_avg"] * 0.1
+    pp = PostProcessModel(latent_avg=latent_avg)
+    pp.load_state_dict(P)
+    pp = pp.eval().to(dev)
+    src, tgt = C.pp_inputs()
+    s, f = pp(src.to(dev), tgt.to(dev))
+    s2, f2 = pp(src.to(dev), tgt.to(dev))
+    assert torch.equal(s, s2) and torch.equal(f, f2)
+    assert s.shape == (1, 18, 512) and f.shape == (1, 512, 64, 64)
+    close(s, G["pp_s"])
+    close(f[:, ::16], G["pp_f_chan16"])
+    fd = f.double()
+    stats = np.array([fd.mean().item(), fd.std().item(), fd.min().item(), fd.max().item()])
+    assert np.allclose(stats, G["pp_f_stats"], rtol=0, atol=REL * max(1.0, abs(G["pp_f_stats"][2]), abs(G["pp_f_stats"][3])))

@@ -700,7 +700,10 @@ def test_generator1024_scaled_activations_f16x3_vs_f32(scale):
     ref_scale = float(ref.abs().max())
     assert ref_scale > 0.05 * scale  # the image really is ~scale times the usual one
     err = float((y - ref).abs().max())
-    assert err <= REL * ref_scale, (err, ref_scale)
+    # fp32 tolerance for ordinary and large activations; with activations of size 1e-3 the split's
+    # absolute floor (2^-25 per operand, include/hairfast_hip.h) shows: + ~6e-8 / |activation| relative
+    tol = REL + 6e-8 / min(1.0, scale)
+    assert err <= tol * ref_scale, (err, ref_scale, tol)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -74,9 +74,14 @@ def _hairfast(dev):
     args.device = dev
     gen_shapes = O.generator_param_shapes(1024, 512, 8, 2)
     state = {"g_ema": C.generator_params(gen_shapes), "latent_avg": torch.zeros(512)}
+    from oracle import ref_postprocess as PP
+
+    pp_shapes = PP.post_process_param_shapes()
+    pp_shapes.pop("latent_avg")
     return HairFast(args, stages=SyntheticStages(), generator_state=state,
                     e4e_state=C.params_from_shapes("e4e", E.e4e_param_shapes()),
-                    fs_state=C.params_from_shapes("fs", E.fs_param_shapes()))
+                    fs_state=C.params_from_shapes("fs", E.fs_param_shapes()),
+                    pp_state=C.params_from_shapes("pp", pp_shapes))
 
 
 def test_hairfast_swap_call_surface():
@@ -106,8 +111,8 @@ def test_hairfast_swap_call_surface():
     assert out.shape == (3, 1024, 1024) and torch.isfinite(out).all()
     assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
     # the generator calls of one swap: batch, start_layer, end_layer (Embedding.py:78,90; Alignment.py:63 batched
-    # for both pairs; Embedding.py:52; Blending.py:62; the PostProcess stand-in; Blending.py:68)
-    assert calls == [(3, 3, 3), (3, 0, 3), (2, 0, 8), (2, 0, 3), (1, 4, 8), (1, 4, 4), (1, 5, 8)], calls
+    # for both pairs; Embedding.py:52; Blending.py:62; Blending.py:68 on the native PostProcess outputs)
+    assert calls == [(3, 3, 3), (3, 0, 3), (2, 0, 8), (2, 0, 3), (1, 4, 8), (1, 5, 8)], calls
     again = hf.swap(face, shape, color, seed=7)
     assert torch.equal(out, again)
     # shape == color: one rotation only, align_color reuses align_shape (hair_swap.py:53-56)

@@ -22,7 +22,7 @@ def sim_backend(simlib, monkeypatch):
     import hairfastgan_amd.encoders  # noqa: F401
 
     mods = [sys.modules[n] for n in ("hairfastgan_amd.encoders._fused", "hairfastgan_amd.encoders.e4e",
-                                     "hairfastgan_amd.encoders.fs_encoder")]
+                                     "hairfastgan_amd.encoders.fs_encoder", "hairfastgan_amd.encoders.post_process")]
     for mod in mods:
         monkeypatch.setattr(mod, "lib", lambda: simlib)
         monkeypatch.setattr(mod, "stream", lambda: None)
@@ -220,3 +220,100 @@ def test_conv2d_f16_grouped(simlib):
         assert maxdiff(y2[gi], ref) < TOL * max(1.0, float(ref.abs().max()))
     assert not M.conv2d_f16_supported(16, 64, 8, 8, 3, 1) and not M.conv2d_f16_supported(16, 32, 32, 32, 3, 1)
     assert not M.conv2d_f16_supported(16, 64, 16, 16, 3, 2) and M.conv2d_f16_supported(16, 64, 16, 16, 3, 1)
+
+
+@pytest.mark.parametrize("stride,B,cin,cout,H,W", [(1, 2, 32, 64, 16, 32), (1, 1, 48, 64, 17, 20), (2, 2, 32, 64, 16, 64),
+                                                  (2, 1, 16, 64, 31, 33), (2, 2, 32, 64, 32, 32)])
+def test_conv2d_f16_presplit_input(simlib, stride, B, cin, cout, H, W):
+    """PRE mode of csrc/convh_enc.hip: the input arrives split + K-blocked (hf_split_activation_f16, the
+    pre-conv affine applied there) and is staged by LDS-DMA, incl. the parity-split stride-2 tile and the
+    zero padding - bit-identical to the in-kernel conversion."""
+    torch.manual_seed(stride + W)
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    a, t = torch.rand(cin) + 0.5, torch.randn(cin) * 0.2
+    bsh = torch.randn(cout)
+    wt = M.conv_prepare(simlib, None, w)
+    hi, lo = M.conv_split_weights_f16(simlib, None, wt)
+    for nterms in (3, 1):
+        ref = M.conv2d_f16(simlib, None, x, hi, lo, nterms, cout, stride, in_scale=a, in_shift=t, bias=bsh, act=M.ACT_LRELU, alpha=0.01)
+        xs = M.split_activation_f16(simlib, None, x, a, t, want_lo=nterms == 3)
+        v = (x * a.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)).reshape(B, cin // 8, 8, H, W).permute(0, 1, 3, 4, 2)
+        back = xs.hi.float() + (xs.lo.float() if nterms == 3 else 0)
+        assert maxdiff(back, v) < (2e-6 if nterms == 3 else 2e-3) * float(v.abs().max())  # (the kernel uses one fma)
+        y = M.conv2d_f16(simlib, None, xs, hi, lo, nterms, cout, stride, bias=bsh, act=M.ACT_LRELU, alpha=0.01)
+        assert torch.equal(y, ref)
+
+
+def test_conv2d_f16_split_k_and_grouped_presplit(simlib):
+    """Few output tiles + many input channels: split-K over the K stages with the deterministic second pass
+    (epilogue incl. PReLU + residual there); grouped launch on pre-split shared / per-group inputs."""
+    torch.manual_seed(21)
+    B, cin, cout, H, W = 1, 256, 64, 16, 16
+    assert simlib.hf_conv2d_f16_workspace_floats(B, cin, cout, H, W, 1, 1) > 0  # 2 tiles, 16 stages -> split
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    a, t = torch.rand(cin) + 0.5, torch.randn(cin) * 0.2
+    g, bsh, slope = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2, torch.rand(cout) * 0.5
+    wt = M.conv_prepare(simlib, None, w)
+    hi, lo = M.conv_split_weights_f16(simlib, None, wt)
+    ref = F.prelu(F.conv2d(x * a.view(1, -1, 1, 1) + t.view(1, -1, 1, 1), w, padding=1) * g.view(1, -1, 1, 1) + bsh.view(1, -1, 1, 1), slope)
+    res = torch.randn_like(ref)
+    y = M.conv2d_f16(simlib, None, x, hi, lo, 3, cout, 1, in_scale=a, in_shift=t, out_scale=g, bias=bsh, act=M.ACT_PRELU, slope=slope,
+                     residual=res)
+    assert maxdiff(y, ref + res) < TOL * max(1.0, float(ref.abs().max()))
+    G, B, cin, cout, H, W = 2, 2, 16, 64, 32, 32
+    x = torch.randn(B, cin, H, W)
+    ws = [torch.randn(cout, cin, 3, 3) / 12 for _ in range(G)]
+    bias = torch.randn(G, cout)
+    hi, lo = M.conv_split_weights_f16(simlib, None, torch.stack([M.conv_prepare(simlib, None, w_) for w_ in ws]).contiguous())
+    y = M.conv2d_f16(simlib, None, M.split_activation_f16(simlib, None, x), hi, lo, 3, cout, 2, bias=bias, act=M.ACT_LRELU, alpha=0.01,
+                     groups=G, x_shared=True)
+    for gi in range(G):
+        assert maxdiff(y[gi], F.leaky_relu(F.conv2d(x, ws[gi], bias[gi], stride=2, padding=1), 0.01)) < TOL * 10
+    x2 = torch.randn(G, B, cin, H, W)
+    y2 = M.conv2d_f16(simlib, None, M.split_activation_f16(simlib, None, x2), hi, lo, 3, cout, 1, bias=bias, groups=G, x_shared=False)
+    for gi in range(G):
+        assert maxdiff(y2[gi], F.conv2d(x2[gi], ws[gi], bias[gi], padding=1)) < TOL * 10
+
+
+def test_postprocess_modulation_module(sim_backend, golden):
+    """SURVEY section 8 row f1, latent branch: ModulationModule (Linear, LayerNorm([18,512]) without affine,
+    the two Linear-LayerNorm-LeakyReLU-Linear branches, x*(1+gamma)+beta, LeakyReLU unless last) on the HIP
+    kernels against the reference's golden outputs; PixelNorm over the layer dim; the final axpby."""
+    from hairfastgan_amd.encoders.post_process import ModulationModule
+    from oracle import ref_postprocess as PP
+
+    G = golden("postprocess.npz")
+    shapes = PP.post_process_param_shapes()
+    shapes.pop("latent_avg")
+    P = C.params_from_shapes("pp", shapes)
+    xm, em = C.unit_input("pp/mod/x", (2, 18, 512)), C.unit_input("pp/mod/e", (2, 18, 512))
+    for idx, key in ((0, "pp_mod_mid"), (4, "pp_mod_last")):
+        m = ModulationModule(18, idx == 4)
+        m.load_state_dict({k[len(f"to_latent_1.{idx}."):]: v for k, v in P.items() if k.startswith(f"to_latent_1.{idx}.")})
+        y = m(xm, em)
+        ref = torch.from_numpy(G[key])
+        assert maxdiff(y, ref) < 1e-4 * max(1.0, float(ref.abs().max()))
+        assert maxdiff(ref, PP.modulation_module(P, f"to_latent_1.{idx}", xm, em, 18, idx == 4)) == 0
+    x = torch.randn(3, 18, 64)
+    simlib = sim_backend[0].lib()
+    assert maxdiff(M.pixel_norm_dim1(simlib, None, x), PP.pixel_norm(x)) < 1e-6
+    a, b = torch.randn(2, 18, 32), torch.randn(18, 32)
+    assert maxdiff(M.axpby(simlib, None, a, 0.1, b.reshape(-1), 1.0), 0.1 * a + b) < 1e-6
+    assert maxdiff(M.layernorm(simlib, None, a, 18 * 32), F.layer_norm(a, [18, 32])) < 1e-5
+    g_, b_ = torch.rand(32) + 0.5, torch.randn(32)
+    assert maxdiff(M.layernorm(simlib, None, a, 32, g_, b_, lrelu=True), F.leaky_relu(F.layer_norm(a, [32], g_, b_))) < 1e-5
+    rows = torch.randn(19, 40)  # > 8 rows: several row chunks in one launch
+    wl, bl = torch.randn(7, 40), torch.randn(7)
+    assert maxdiff(M.linear(simlib, None, rows, wl, bl, 1.0), F.linear(rows, wl, bl)) < 1e-5
+
+
+def test_postprocess_state_dict_matches_reference_layout():
+    from hairfastgan_amd.encoders import PostProcessModel
+    from oracle import ref_postprocess as PP
+
+    want = PP.post_process_param_shapes()
+    want.pop("latent_avg")
+    got = {k: tuple(v.shape) for k, v in PostProcessModel().state_dict().items()}
+    assert got == want and list(got) == list(want)
