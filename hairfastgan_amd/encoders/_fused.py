@@ -64,7 +64,7 @@ def prep_conv(conv):
 # Which convs hand the fp16-core kernel a PRE-SPLIT input (one hf_split_activation_f16 pass, then LDS-DMA
 # staging) instead of converting while staging: "heads" = the e4e style-head levels, whose input feeds
 # up to 88 (group, channel-tile) block columns; "all" = every eligible conv; "none".  Tuning knob.
-PRESPLIT = os.environ.get("HAIRFAST_ENC_PRESPLIT", "heads")
+PRESPLIT = os.environ.get("HAIRFAST_ENC_PRESPLIT", "all")
 
 
 def conv(x, w, k, stride=1, presplit=False, **kw):

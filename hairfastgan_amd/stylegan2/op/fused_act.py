@@ -1,4 +1,5 @@
-"""fused bias + leaky ReLU on the HIP kernel hf_fused_bias_act_f32.
+"""fused bias + leaky ReLU on the HIP kernel hf_fused_bias_act_f32, through the registered operator
+`torch.ops.hairfast.fused_bias_act` (hairfastgan_amd/ops.py).
 
 Interface of the reference's models/stylegan2/op/fused_act.py:73-96 (module
 `FusedLeakyReLU(channel)` with parameter `.bias [C]`; function
@@ -9,13 +10,13 @@ hard-codes 0.2 (fused_act.py:90), `negative_slope` is honoured as in its CUDA br
 import torch
 from torch import nn
 
-from ... import _marshal as M
-from ..._runtime import lib, require_gpu, stream
+from ... import ops  # noqa: F401  (registers torch.ops.hairfast.*)
+from ..._runtime import require_gpu
 
 
 def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
     require_gpu(input, bias)
-    return M.fused_bias_act(lib(), stream(), input, bias, float(negative_slope), float(scale))
+    return torch.ops.hairfast.fused_bias_act(input, None if bias is None else bias.detach(), float(negative_slope), float(scale))
 
 
 class FusedLeakyReLU(nn.Module):

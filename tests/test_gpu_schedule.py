@@ -152,7 +152,8 @@ def test_swap_many_forced_rccl_single_rank():
         "imgs, n = parallel.swap_many(lambda a, b, c: hf.swap(a, b, c, seed=i_seed[0]), 3, load, device=dev, chunk=2)\n"
         "torch.cuda.synchronize()\n"
         "assert n == 3 and imgs.shape == (3, 3, 1024, 1024) and imgs.dtype == torch.uint8\n"
-        "ref = parallel.to_uint8_image(hf.swap(*load(1), seed=i_seed[0]) * 2 - 1)\n"
+        "# same input path as swap_many (device uint8 tensors: torch's GPU `x / 255` is x * (1/255), one ulp off the CPU's)\n"
+        "ref = parallel.to_uint8_image(hf.swap(*[t.to(dev) for t in load(1)], seed=i_seed[0]) * 2 - 1)\n"
         "assert torch.equal(imgs[1], ref), 'gathered image differs from a direct swap'\n"
         "dist.barrier(); dist.destroy_process_group(); print('RCCL_OK')\n").replace("i_seed[0]", "11")
     env = dict(os.environ, HF_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", RANK="0", WORLD_SIZE="1",

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert set(_lib.SIGNATURES) | {"hf_strerror", "hf_abi_version", "hf_modconv_workspace_floats", "hf_conv2d_workspace_floats",
-                                    "hf_f16_overflow_count"} == declared
+                                    "hf_f16_overflow_count", "hf_conv2d_f16_workspace_floats"} == declared
     bound = _lib.bind(lib)
     assert bound.hf_abi_version() == 7
     assert bound.hf_strerror(-1) == b"invalid argument"
@@ -154,3 +154,27 @@ def test_cached_plans_drop_when_loaded_through_a_parent():
         assert m._plan is None
     assert conv._prep is None and conv._prep_f16 is None
     assert "_style_jobs" not in holder.g.__dict__
+
+
+def test_torch_custom_ops_are_registered():
+    """north_star: the kernels are 'exposed as torch custom ops'.  torch.ops.hairfast.* exist with schemas,
+    propagate shapes on meta tensors (what FakeTensor / torch.compile tracing uses) and have no CPU kernel."""
+    import hairfastgan_amd.ops  # noqa: F401
+
+    ops = torch.ops.hairfast
+    for name in ("upfirdn2d", "fused_bias_act", "noise_bias_act", "modulated_conv3x3", "modulated_conv3x3_up", "to_rgb", "conv2d"):
+        assert hasattr(ops, name)
+        assert "Tensor" in str(getattr(ops, name).default._schema)
+    x = torch.empty(2, 5, 9, 9, device="meta")
+    k = torch.empty(4, 4, device="meta")
+    assert ops.upfirdn2d(x, k, 1, 1, 1, 1, 1, 1, 1, 1).shape == (2, 5, 8, 8)      # Blur: pad (1,1)
+    assert ops.upfirdn2d(x, k, 2, 2, 1, 1, 2, 1, 2, 1).shape == (2, 5, 18, 18)    # Upsample: pad (2,1)
+    assert ops.fused_bias_act(x, torch.empty(5, device="meta"), 0.2, 1.4).shape == x.shape
+    wt = torch.empty(9, 5, 8, device="meta")
+    s, d = torch.empty(2, 5, device="meta"), torch.empty(2, 8, device="meta")
+    assert ops.modulated_conv3x3(x, wt, s, d, None, None, None, 0.2, 1.4).shape == (2, 8, 9, 9)
+    assert ops.modulated_conv3x3_up(x, wt, s, d, k, None, None, None, 0.2, 1.4).shape == (2, 8, 18, 18)
+    assert ops.to_rgb(x, torch.empty(1, 5, 3, device="meta"), s, None, None, None).shape == (2, 3, 9, 9)
+    assert ops.conv2d(x, wt, 3, 2, None, None, None, None, 0, None, 0.0, None).shape == (2, 8, 5, 5)
+    with pytest.raises((NotImplementedError, RuntimeError)):  # no CPU kernel registered: the dispatcher refuses
+        ops.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(4, 4), 1, 1, 1, 1, 1, 1, 1, 1)
