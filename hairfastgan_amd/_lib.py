@@ -35,6 +35,8 @@ SIGNATURES = {
     "hf_modconv3x3_f16_pre_f32": [_f, _f, _f, _f, _f, _i, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _f, _f, _f, _f, _f, _f, _st],
     "hf_modconv3x3_up_f16_pre_f32": [_f, _f, _f, _f, _f, _i, _f, _i, _i, _i, _i, _i, _i, _st],
     "hf_modconv3x3_up_f16_f32": [_f, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _st],
+    "hf_modconv3x3_up_blur_f16_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, ctypes.POINTER(ctypes.c_float),
+                                      ctypes.POINTER(ctypes.c_float), _f, _f, _ll, _f, _f, _i, _i, _i, _i, _i, _fl, _fl, _st],
     "hf_modconv3x3_up_f32": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _ll, _st],
     "hf_modconv_up_pitch": [_i],
     "hf_blur_noise_bias_act_f32": [_f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _st],

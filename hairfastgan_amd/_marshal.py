@@ -31,6 +31,7 @@ KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modc
     571: "conv_mfma_h<1,2,2,4,pre>", 572: "conv_mfma_h<2,2,1,8,pre>", 573: "conv_mfma_h<1,2,1,8,pre>", 575: "conv_mfma_h<1,2,1,8,tw128,pre>",
     551: "conv_mfma_h<1,2,2,4>", 552: "conv_mfma_h<2,2,1,8>", 553: "conv_mfma_h<1,2,1,8>", 555: "conv_mfma_h<1,2,1,8,tw128>",
     561: "conv_mfma_h<1,2,2,4,up>", 563: "conv_mfma_h<1,2,1,8,up>",
+    573: "conv_mfma_h<1,2,1,8,up,fuse>", 593: "conv_mfma_h<1,2,1,8,up,pre,fuse>",
     # csrc/convh_enc.hip (encoder convs on the fp16 matrix cores)
     601: "conv_enc_h<64x256>", 602: "conv_enc_h<64x128,stride2>", 603: "conv_enc_h<64x128>",
 }
@@ -408,6 +409,55 @@ def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha
         label="blur4x4_noise_bias_act", nbytes=nb)
     check(lib, code, "hf_blur_noise_bias_act_f32")
     return out
+
+
+def blur_factors(kernel4x4):
+    """(kx, ky): the 1-D factors of a rank-1 4x4 blur kernel (k[r][j] = ky[r]*kx[j]) as ctypes float[4] arrays,
+    or None when the kernel is not separable.  Reads the kernel on the host (synchronises): callers cache it."""
+    import ctypes
+
+    k = kernel4x4.detach().double().cpu()
+    if tuple(k.shape) != (4, 4) or float(k[0, 0]) == 0.0:
+        return None
+    kx, ky = k[0, :].clone(), k[:, 0] / k[0, 0]
+    if not torch.allclose(torch.outer(ky, kx), k, rtol=1e-6, atol=1e-12):
+        return None
+    arr = ctypes.c_float * 4
+    return arr(*[float(v) for v in kx]), arr(*[float(v) for v in ky])
+
+
+def modconv3x3_up_fused_supported(cin, cout, h, w):
+    """Shapes hf_modconv3x3_up_blur_f16_f32 takes."""
+    return cin % 16 == 0 and cout % 32 == 0 and h >= 16 and w >= 32
+
+
+def modconv3x3_up_fused(lib, st, x, wt_hi, wt_lo, s, d, factors, noise, noise_w, bias, alpha=0.2, scale=SQRT2, split_for=None):
+    """hf_modconv3x3_up_blur_f16_f32: transposed conv + blur + noise + bias + lrelu in one kernel (f16x3).
+    x: fp32 tensor (with s) or SplitActivation.  Returns the fp32 activation, or - split_for = s_next [B,cout] -
+    the SplitActivation of s_next * activation for a pre-split consumer (one output form per launch)."""
+    pre = isinstance(x, SplitActivation)
+    if not pre:
+        x = _c(x)
+    b, cin, h, w = x.shape
+    cout = wt_hi.shape[3]
+    dev = x.hi.device if pre else x.device
+    noise, nbs = _noise_args(noise, b, 4 * h * w)
+    out = sh = sl = s_next = None
+    if split_for is not None:
+        s_next = _c(split_for)
+        sh = torch.empty((b, cout // 8, 2 * h, 2 * w, 8), dtype=torch.float16, device=dev)
+        sl = torch.empty_like(sh)
+    else:
+        out = torch.empty((b, cout, 2 * h, 2 * w), dtype=torch.float32, device=dev)
+    kx, ky = factors
+    code = _launch_profiled(
+        lib, 2.0 * cin * cout * 9 * h * w * b,
+        lambda: lib.hf_modconv3x3_up_blur_f16_f32(_p(out), _p(sh), _p(sl), None if pre else _p(x), _p(x.hi) if pre else None,
+                                                  _p(x.lo) if pre else None, _p(wt_hi), _p(wt_lo), None if pre else _p(s), _p(d),
+                                                  kx, ky, _p(noise), _p(_c(noise_w)), nbs, _p(_c(bias)), _p(s_next), b, cin, cout,
+                                                  h, w, alpha, scale, st))
+    check(lib, code, "hf_modconv3x3_up_blur_f16_f32")
+    return out if split_for is None else SplitActivation(sh, sl, None)
 
 
 def torgb(lib, st, x, wt, s, bias, skip, up_kernel):

@@ -71,6 +71,7 @@ struct ConvParams {
   // (hi, lo), K-blocked [batch][cout/8][h][w][8], for a consumer that takes pre-split input
   void *oh, *ol;
   const float *s_next;
+  float blur_kx[4], blur_ky[4];  // convh.hip FUSE: flipped 1-D factors of the (rank-1) 4x4 blur kernel applied in the epilogue
   int n_tiles;                 // convh.hip: tiles over all families; a block walks blockIdx.x + k*gridDim.x
   TileGeom g[3];
 };

@@ -28,6 +28,8 @@
 // chunk.  LDS-DMA and register loads retire through different paths, so vmcnt cannot order one
 // against the other: everything is issued early in the chunk and drained at its barrier.
 #define HF_WANT_F16_SPLIT
+#include <type_traits>
+
 #include "conv_common.h"
 
 using namespace hf_detail;
@@ -77,7 +79,15 @@ constexpr int halo_pixels_max() {
 // tap feeding exactly one phase from x[Y - (ky==2), X - (kx==2)]; no zero-insertion flops.
 // PRE: the activations arrive pre-split and K-blocked (ConvParams::xh/xl): the stage's halo tile
 // is fetched by LDS-DMA like the weights - no per-element loads, no conversion, no s.
-template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool MOD, bool UP, int TWMAX, bool PRE>
+// FUSE (UP only): the 4x4 blur + noise + bias + leaky ReLU of the upsampling StyledConv (model.py:263,
+// :337-343) in the epilogue - the (2h+1)^2 intermediate is never written.  Tiles of th x 32 phase-domain
+// positions OVERLAP by two positions (origin -1, stride th-2 / 30): a block computes the transposed conv on
+// its whole tile and emits the blurred output of the interior positions, whose 4-tap windows it then holds
+// completely (T is zero outside [0,2h] x [0,2w], which the zero-filled halo reproduces by itself, so there
+// are no rim tile families).  Horizontal taps come from the neighbouring lanes (shuffles), vertical taps
+// from the wave's other row or - across waves - through the LDS stage buffer that is free during the
+// epilogue, four channels per lane at a time.  The blur kernel must be separable (rank 1).
+template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool MOD, bool UP, int TWMAX, bool PRE, bool FUSE = false>
 __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const ConvParams P,
                                                                           const _Float16 *__restrict__ wth,
                                                                           const _Float16 *__restrict__ wtl) {
@@ -100,7 +110,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   constexpr int DMA_PER_STEP = PRE ? 1 : (ND + 2) / 3;
   constexpr int XE = (X_UNITS + NT - 1) / NT;           // (pixel, kgroup) items per thread per stage
   static_assert(W_UNITS % 64 == 0, "weight part must be whole 1 KiB pieces");
-  static_assert(!PRE || (ND <= 9 && 2 * XE <= 9), "PRE issue schedule: one weight DMA per tap-step, activations in odd steps");
+  static_assert(!FUSE || (UP && CT_TILES == 1 && WAVES_CO == 1 && TWMAX == 32), "FUSE: 32 co x (PG*WAVES_PX rows of 32 positions)");
+  static_assert(!FUSE || BUF_UNITS * 16 >= NW * 6 * 64 * 16, "FUSE: the exchange of one channel quad must fit a stage buffer");
+  static_assert(!PRE || (ND <= 9 && XE <= 8), "PRE issue schedule: one weight DMA per tap-step, activations in odd steps (or every step)");
 
   HF_DYN_LDS;
   half8 *lds = reinterpret_cast<half8 *>(hf_dyn_lds);               // [2][BUF_UNITS] 16-byte units
@@ -158,6 +170,10 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     T.b0 = r / G.tiles_y;  // one image per tile
     T.ty0 = G.y0 + (ty << G.lg_th);
     T.tx0 = G.x0 + (tx << G.lg_tw);
+    if (FUSE) {  // overlapping tiles: origin -1, interior (th-2) x (tw-2) positions per tile
+      T.ty0 = ty * ((1 << G.lg_th) - 2) - 1;
+      T.tx0 = tx * ((1 << G.lg_tw) - 2) - 1;
+    }
     return T;
   };
   // staging items of this thread: (halo pixel, kgroup) -> offset inside a channel plane
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     for (int i = tid; i < CT; i += NT) {
       ep[i] = (P.d ? P.d[(long long)b * P.d_bstride + co0 + i] : 1.0f) * w_unscale;
       ep[CT + i] = P.bias ? P.bias[co0 + i] : 0.0f;
-      ep[2 * CT + i] = (!UP && P.oh && P.s_next) ? P.s_next[(long long)b * P.cout + co0 + i] : 1.0f;
+      ep[2 * CT + i] = ((!UP || FUSE) && P.oh && P.s_next) ? P.s_next[(long long)b * P.cout + co0 + i] : 1.0f;
     }
     if (!UP && P.rgb_out) {
       float *rw = rgbw_base + slot * 3 * CT;
@@ -433,6 +449,138 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     }
   };
 
+  // ---- FUSE: blur + noise + bias + lrelu (+ split) epilogue of the transposed conv --------------------
+  // acc[pr*2+pc][0][g][r] = T[2Y+pr][2X+pc] of position (Y, X) = (ty0 + wave_pg + g, tx0 + li), channel
+  // co0 + (r&3) + 8*(r>>2) + 4*lh.  out[oy][ox] = sum_{r,j} ky[r] kx[j] T[oy-1+r][ox-1+j] with the FLIPPED
+  // 1-D factors of the blur kernel (upfirdn2d is a true convolution, op/upfirdn2d.py:186).
+  // 1-D factors of the rank-1 blur kernel, already flipped, as kernel arguments (scalar registers)
+  const float kxf[4] = {P.blur_kx[0], P.blur_kx[1], P.blur_kx[2], P.blur_kx[3]};
+  const float kyf[4] = {P.blur_ky[0], P.blur_ky[1], P.blur_ky[2], P.blur_ky[3]};
+  // SPLIT (compile time): write the fp16 (hi, lo) split of s_next*out (P.oh / P.ol) or the fp32 tensor (P.out).
+  // The launcher guarantees bias != NULL, act == leaky ReLU with 0 <= alpha <= 1 (so lrelu(v) = max(v, alpha*v))
+  // and scale > 0 (positively homogeneous: folded into d, the noise weight and the bias).
+  auto epilogue_fused = [&](auto SPLIT_T, const Tile &T, int slot, const float (&nz)[PG][4], int freebuf) {
+    constexpr bool SPLIT = decltype(SPLIT_T)::value;
+    bool ovf_tile = false;
+    int li_o = li, lh_o = lh;
+    HF_OPAQUE_I32(li_o);
+    HF_OPAQUE_I32(lh_o);
+    const float *ep = ep_base + slot * 3 * CT;
+    const int wv = wave;  // WAVES_CO == 1: wave = pixel wave, tile rows wave*PG + g
+    // 2. vertical pass per channel quad q (registers 4q..4q+3): the rows of the neighbouring WAVES travel
+    //    through LDS (24 floats per lane and wave), the wave's own rows are in registers
+    float *xch = reinterpret_cast<float *>(lds + freebuf * BUF_UNITS);  // [wave][24][64 lanes]
+    const int row0 = wv * PG;  // tile row of g = 0
+    const int Y0 = T.ty0 + row0, X = T.tx0 + li_o;
+    const float nw_f = (P.noise ? P.noise_w[0] : 0.0f) * P.scale;
+    const long long oplane = (long long)(2 * P.h) * (2 * P.w);
+    // byte offset of output pixel (2*Y0, 2*X) inside a 16-byte-unit plane / a float plane (32-bit: <= 64 MiB planes)
+    const int pix00 = (2 * Y0) * (2 * P.w) + 2 * X;
+    const bool colv = li_o >= 1 && li_o <= 30 && X >= 0 && X < P.w;
+    char *oh_b = SPLIT ? static_cast<char *>(P.oh) + ((long long)T.b0 * (P.cout >> 3) + (co0 >> 3)) * oplane * 16 : nullptr;
+    char *ol_b = SPLIT ? static_cast<char *>(P.ol) + ((long long)T.b0 * (P.cout >> 3) + (co0 >> 3)) * oplane * 16 : nullptr;
+    float *of_b = SPLIT ? nullptr : P.out + ((long long)T.b0 * P.cout + co0) * oplane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_sched_barrier(0);  // one channel quad at a time: keeps the live set small
+      // horizontal pass of this quad: (T[.][2X], T[.][2X+1]) -> (H[.][2X], H[.][2X+1]) from the neighbouring lanes'
+      // values; the accumulators are only READ (writing elements back into the 16-wide accumulator vectors makes
+      // the compiler copy whole register tuples).  Lanes 0 / 31 of a half-wave hold tile-edge positions whose
+      // results are never used (their neighbours belong to the other half).
+      float H[4][PG][4];  // [pr*2+pc][g][k]
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int g = 0; g < PG; ++g)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float t0 = acc[2 * pr][0][g][4 * q + k], t1 = acc[2 * pr + 1][0][g][4 * q + k];
+            const float l1 = hf_lane_up(t1), r0 = hf_lane_down(t0), r1 = hf_lane_down(t1);
+            H[2 * pr][g][k] = fmaf(kxf[3], r0, fmaf(kxf[2], t1, fmaf(kxf[1], t0, kxf[0] * l1)));
+            H[2 * pr + 1][g][k] = fmaf(kxf[3], r1, fmaf(kxf[2], r0, fmaf(kxf[1], t1, kxf[0] * t0)));
+          }
+      // publish (one 16-byte unit per lane and slot): slots 0..3 = the g = 0 row for the wave ABOVE (index pr*2+pc),
+      // 4..5 = phase 1 of the last row for the wave BELOW (index pc); values are read back right where they are
+      // used (nothing but the current output pixel's operands is live: the epilogue must not spill - a scratch
+      // reload waits for every output store issued before it)
+      float4 *xq = reinterpret_cast<float4 *>(xch);  // [wave][6][64 lanes]
+      float4 *mine = xq + (wv * 6) * 64 + lane;
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) mine[ph * 64] = make_float4(H[ph][0][0], H[ph][0][1], H[ph][0][2], H[ph][0][3]);
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc)
+        mine[(4 + pc) * 64] = make_float4(H[2 + pc][PG - 1][0], H[2 + pc][PG - 1][1], H[2 + pc][PG - 1][2], H[2 + pc][PG - 1][3]);
+      hf_barrier_lds();
+      const float4 *above = xq + (max(wv - 1, 0) * 6) * 64 + lane, *below = xq + (min(wv + 1, NW - 1) * 6) * 64 + lane;
+      const int c4 = 8 * q + 4 * lh_o;  // first of the lane's 4 channels (tile relative)
+      // the lane's 4 channels are one half (lh) of the 16-byte unit of channel block q
+      const long long cb_ofs = (long long)q * oplane * 16 + lh_o * 8;
+#pragma unroll
+      for (int g = 0; g < PG; ++g) {
+        const int rr = row0 + g, Y = Y0 + g;
+        const bool pv = colv && rr >= 1 && rr <= PT / 32 - 2 && Y >= 0 && Y < P.h;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) {
+            // the H rows 2Y+a-1 .. 2Y+a+2 of this column: (Y-1, 1), (Y, 0), (Y, 1), (Y+1, 0), (Y+1, 1)
+            float hm1[4], h2[4], h3[4];
+            if (g == 0 && a == 0) {
+              const float4 u = above[(4 + pc) * 64];
+              hm1[0] = u.x; hm1[1] = u.y; hm1[2] = u.z; hm1[3] = u.w;
+            }
+            if (g == PG - 1) {
+              const float4 d0 = below[pc * 64];
+              h2[0] = d0.x; h2[1] = d0.y; h2[2] = d0.z; h2[3] = d0.w;
+              if (a == 1) {
+                const float4 d1 = below[(2 + pc) * 64];
+                h3[0] = d1.x; h3[1] = d1.y; h3[2] = d1.z; h3[3] = d1.w;
+              }
+            }
+            const float4 dm = *reinterpret_cast<const float4 *>(ep + c4), bs = *reinterpret_cast<const float4 *>(ep + CT + c4);
+            const float dmv[4] = {dm.x, dm.y, dm.z, dm.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float h_m1 = (g == 0) ? hm1[k] : H[2 + pc][g == 0 ? 0 : g - 1][k];
+              const float h_0 = H[pc][g][k], h_1 = H[2 + pc][g][k];
+              const float h_2 = (g == PG - 1) ? h2[k] : H[pc][g == PG - 1 ? g : g + 1][k];
+              const float h_3 = (g == PG - 1) ? h3[k] : H[2 + pc][g == PG - 1 ? g : g + 1][k];
+              float o = (a == 0) ? fmaf(kyf[3], h_2, fmaf(kyf[2], h_1, fmaf(kyf[1], h_0, kyf[0] * h_m1)))
+                                 : fmaf(kyf[3], h_3, fmaf(kyf[2], h_2, fmaf(kyf[1], h_1, kyf[0] * h_0)));
+              o = fmaf(o, dmv[k] * P.scale, fmaf(nw_f, nz[g][a * 2 + pc], bsv[k] * P.scale));
+              v[k] = fmaxf(o, o * P.alpha);
+            }
+            if (pv) {
+              const int pix = pix00 + (2 * g + a) * (2 * P.w) + pc;
+              if (!SPLIT) {
+                float *ob = of_b + (long long)c4 * oplane + pix;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ob[k * oplane] = v[k];
+              } else {
+                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                const float4 sn = *reinterpret_cast<const float4 *>(ep + 2 * CT + c4);
+                const float snv[4] = {sn.x, sn.y, sn.z, sn.w};
+                half4 h4, l4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  _Float16 hv, lv;
+                  hf_split_f16(v[k] * snv[k], hv, lv, ovf_tile);
+                  h4[k] = hv;
+                  l4[k] = lv;
+                }
+                *reinterpret_cast<half4 *>(oh_b + cb_ofs + (long long)pix * 16) = h4;
+                *reinterpret_cast<half4 *>(ol_b + cb_ofs + (long long)pix * 16) = l4;
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+      hf_barrier_lds();  // everyone has read: the region may be overwritten (next quad / next tile's DMA)
+    }
+    hf_note_overflow(ovf_tile);
+  };
+
   int stage = 0;  // LDS buffer = stage & 1, running across tiles
   int trace_n = 0;
   (void)trace_n;
@@ -451,8 +599,13 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       for (int r = 0; r < NROW; ++r) pixrow[g][r] = po + r * wp;
     }
     float nzr[PG];
+    float nzf[PG][4];  // FUSE: noise of output pixels (2Y+a, 2X+b), index a*2+b
 #pragma unroll
-    for (int g = 0; g < PG; ++g) nzr[g] = 0.0f;
+    for (int g = 0; g < PG; ++g) {
+      nzr[g] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) nzf[g][k] = 0.0f;
+    }
     // the block's next tile, and its image's s into the other slot (read only after
     // the barriers of this tile's first nchunks-1 stages; nchunks >= 2)
     const int t_next = t_cur + gridDim.x;
@@ -497,6 +650,15 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
           nzr[g] = P.noise[(long long)cur.b0 * P.noise_bstride + (long long)Y * P.out_w + X];
         }
       }
+      if (FUSE && last && P.noise) {  // the 2x2 output pixels of the lane's position, per row group
+#pragma unroll
+        for (int g = 0; g < PG; ++g) {
+          const int Y = min(max(cur.ty0 + wave_pg + g, 0), P.h - 1), X = min(max(cur.tx0 + li, 0), P.w - 1);
+          const float *np = P.noise + (long long)cur.b0 * P.noise_bstride + (long long)(2 * Y) * (2 * P.w) + 2 * X;
+          const float2 n0 = *reinterpret_cast<const float2 *>(np), n1 = *reinterpret_cast<const float2 *>(np + 2 * P.w);
+          nzf[g][0] = n0.x; nzf[g][1] = n0.y; nzf[g][2] = n1.x; nzf[g][3] = n1.y;
+        }
+      }
       const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT + ct*32
       const half8 *b_hi = buf + OFF_XH + lh * NPIX;      // + pixrow + tap column
       // fragments of tap+1 are fetched from LDS while the MFMAs of tap run
@@ -536,7 +698,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
         if (PRE && more1) {  // activation DMAs in tap-steps 1, 3, 5, ...
 #pragma unroll
           for (int e = 0; e < XE; ++e)
-            if (tap == 1 + 2 * e) dma_x(e, cpf, cb ^ 1);
+            if (tap == ((2 * XE <= 9) ? 1 + 2 * e : 1 + e)) dma_x(e, cpf, cb ^ 1);
         }
         if (!PRE && more1 && tap == 0) {
 #pragma unroll
@@ -574,7 +736,12 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       HF_TRACE_POINT(3);  // after the barrier
     }
 
-    epilogue(G, cur, ep_slot, nzr);
+    if (FUSE) {
+      if (P.oh) epilogue_fused(std::true_type{}, cur, ep_slot, nzf, ((stage - 1) & 1));
+      else epilogue_fused(std::false_type{}, cur, ep_slot, nzf, ((stage - 1) & 1));
+    } else {
+      epilogue(G, cur, ep_slot, nzr);
+    }
     HF_TRACE_POINT(4);  // epilogue issued
     if (!has_next) break;
     zero_acc();
@@ -632,7 +799,7 @@ __global__ __launch_bounds__(256) void split_weights(_Float16 *__restrict__ wth,
   }
 }
 
-template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int TWMAX = 32, bool PRE = false>
+template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int TWMAX = 32, bool PRE = false, bool FUSE = false>
 int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_t st) {
   constexpr int NT = 64 * WAVES_CO * WAVES_PX;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
@@ -653,8 +820,13 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
       P.g[0].tiles_x = hf_cdiv(P.w, tw); P.g[0].tiles_y = hf_cdiv(P.h, th);
     }
   }
+  if (FUSE) {  // overlapping th x 32 tiles, origin -1, (th-2) x 30 interior positions each (see the kernel)
+    constexpr int TH = PT / 32;
+    P.g[0].lg_tw = 5; P.g[0].lg_th = ilog2(TH); P.g[0].lg_nb = 0;
+    P.g[0].tiles_x = hf_cdiv(P.w, 30); P.g[0].tiles_y = hf_cdiv(P.h, TH - 2); P.g[0].tiles_b = P.batch;
+  }
   int nblocks = geom_blocks(P.g[0]);
-  if (UP) {  // + the Y = h row (incl. corner) and the X = w column of the (h+1)x(w+1) phase domain
+  if (UP && !FUSE) {  // + the Y = h row (incl. corner) and the X = w column of the (h+1)x(w+1) phase domain
     P.n_geom = 3;
     constexpr int RIM = PT >= 512 ? 4 : 2;
     P.g[1] = make_geom(P.h, 0, 1, P.w + 1, P.batch, PT, nblocks, true, RIM);
@@ -689,14 +861,15 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
   if (PRE) {
     if (!P.xh || (NTERMS == 3 && !P.xl) || P.s || (P.cin & 15)) return HF_E_INVALID;
     if ((long long)2 * P.h * P.w * 16 >= (1LL << 31)) return HF_E_INVALID;  // 32-bit offsets inside a stage
-    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, false, UP, TWMAX, PRE>), grid, dim3(NT), lds, st, P,
-                       wth, wtl);
+    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, false, UP, TWMAX, PRE, FUSE>), grid, dim3(NT), lds, st,
+                       P, wth, wtl);
   } else if (P.s) {
-    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, true, UP, TWMAX, false>), grid, dim3(NT), lds, st, P,
-                       wth, wtl);
+    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, true, UP, TWMAX, false, FUSE>), grid, dim3(NT), lds, st,
+                       P, wth, wtl);
   } else {
-    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, false, UP, TWMAX, false>), grid, dim3(NT), lds, st, P,
-                       wth, wtl);
+    if (FUSE) return HF_E_INVALID;  // the generator always modulates
+    hipLaunchKernelGGL((conv_mfma_h<NTERMS, CT_TILES, PG, WAVES_CO, WAVES_PX, false, UP, TWMAX, false, false>), grid, dim3(NT), lds,
+                       st, P, wth, wtl);
   }
   return hf_launch_status();
 }
@@ -812,6 +985,40 @@ extern "C" int hf_modconv3x3_up_f16_f32(float *tmp, const float *x, const void *
   P.out_wv = 2 * w + 1;
   P.stride = 1;
   return launch_conv_h(P, nterms, true, wt_hi, wt_lo, (hipStream_t)stream);
+}
+
+extern "C" int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *split_lo, const float *x, const void *x_hi,
+                                             const void *x_lo, const void *wt_hi, const void *wt_lo, const float *s,
+                                             const float *d, const float *blur_k1d_x, const float *blur_k1d_y, const float *noise, const float *noise_w,
+                                             long long noise_bstride, const float *bias, const float *s_next, int batch, int cin,
+                                             int cout, int h, int w, float alpha, float scale, void *stream) {
+  if ((!out == !split_hi) || (!x && !x_hi) || !wt_hi || !wt_lo || !blur_k1d_x || !blur_k1d_y || batch <= 0 || cin <= 0 || cout <= 0 ||
+      h < 2 || w < 2 || (noise && !noise_w) || (x_hi && !x_lo) || (!x_hi && !s) || (cout % 32) || (cin % 16) ||
+      (split_hi && (!split_lo || (cout & 7))) || !bias || !(alpha >= 0.0f && alpha <= 1.0f) || !(scale > 0.0f))
+    return HF_E_INVALID;  // exactly one output form; the epilogue assumes bias + leaky ReLU (0 <= alpha <= 1), scale > 0
+  ConvParams P{};
+  P.out = out; P.x = x; P.xh = x_hi; P.xl = x_lo; P.s = x_hi ? nullptr : s; P.d = d; P.noise = noise; P.noise_w = noise_w;
+  P.bias = bias;
+  P.s_bstride = cin; P.d_bstride = cout;
+  P.groups = 1;
+  P.noise_bstride = noise_bstride;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w;
+  P.out_h = 2 * h; P.out_w = 2 * w; P.out_wv = 2 * w;
+  P.stride = 1;
+  P.act = bias ? ACT_LRELU : ACT_NONE;
+  P.alpha = alpha; P.scale = scale;
+  P.oh = split_hi; P.ol = split_lo; P.s_next = s_next;
+  for (int j = 0; j < 4; ++j) {  // upfirdn2d is a true convolution: flipped taps (op/upfirdn2d.py:186)
+    P.blur_kx[j] = blur_k1d_x[3 - j];
+    P.blur_ky[j] = blur_k1d_y[3 - j];
+  }
+  const _Float16 *hi = static_cast<const _Float16 *>(wt_hi), *lo = static_cast<const _Float16 *>(wt_lo);
+  // 32 co x 512 positions (16 rows x 32), 8 waves x 2 rows - the tile shape of the unfused <1,2,1,8,up> kernel.
+  // (An 8-row / 4-wave form with two blocks per CU measured 2x slower: 43 % halo recompute and half the rows per barrier.)
+  int rc = x_hi ? launch_h<3, 1, 2, 1, 8, true, 32, true, true>(P, hi, lo, (hipStream_t)stream)
+                : launch_h<3, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
+  if (rc == HF_OK) note_path(5, x_hi ? 93 : 73);
+  return rc;
 }
 
 extern "C" int hf_debug_set_persistent_blocks(int blocks) {

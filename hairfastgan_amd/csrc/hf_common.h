@@ -140,6 +140,19 @@ __device__ __forceinline__ void hf_note_overflow(bool ovf) {
 }
 #endif  // HF_WANT_F16_SPLIT
 
+// Value of the neighbouring lane (lane-1 / lane+1) by a DPP wavefront shift: one VALU instruction, no LDS
+// round trip (the __shfl_* forms are ds_bpermute with an address register and ~100 cycles of latency each).
+// Lane 0 (up) / lane 63 (down) receive 0.
+#ifndef HF_LANE_SHIFT_DEFINED
+#define HF_LANE_SHIFT_DEFINED
+__device__ __forceinline__ float hf_lane_up(float v) {  // from lane-1: DPP wave_shr:1 (0x138)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float hf_lane_down(float v) {  // from lane+1: DPP wave_shl:1 (0x130)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+#endif
+
 static inline int hf_launch_status() {
   return hipGetLastError() == hipSuccess ? HF_OK : HF_E_LAUNCH;
 }

@@ -17,6 +17,7 @@ Forward / inference only: parameters are frozen in HairFast (models/Net.py:44-46
 and every stage runs under torch.inference_mode().
 """
 import math
+import os
 import random
 
 import torch
@@ -26,6 +27,14 @@ from torch.nn import functional as F
 from .. import _marshal as M
 from .._runtime import conv_precision, lib, require_gpu, stream
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
+
+
+# Smallest input height of an upsampling StyledConv that runs as one fused kernel (transposed conv + blur +
+# noise + bias + lrelu, csrc/convh.hip FUSE) instead of conv -> (2h+1)^2 intermediate -> blur pass; the fused
+# form recomputes a 1-position halo per 16x32 tile (+22 % matrix work) and saves 8 bytes of HBM traffic per
+# intermediate element, which pays on the bandwidth-bound high-resolution layers (batch 8, tools/probes/fuse_layers.py:
+# 512->1024: 1100 -> 639 us, 256->512: 604 -> 441, 128->256: 456 -> 425, 64->128: 351 -> 408 - hence 128).
+FUSE_BLUR_MIN_H = int(os.environ.get("HAIRFAST_FUSE_BLUR_MIN_H", "128"))
 
 
 class PixelNorm(nn.Module):  # :16-21 (mapping network only; not on the HairFast hot path)
@@ -178,11 +187,32 @@ class ModulatedConv2d(nn.Module):  # :183-279
         return (conv_precision() != "f32" and not self.upsample and self.kernel_size == 3
                 and M.torgb_fusable(cin, self.out_channel, h, w))
 
+    def blur_factors(self):
+        """1-D factors of the module's blur kernel when it is separable (it is: make_kernel of a 1-D list,
+        :24-32), else None; read once per kernel buffer (a host round trip)."""
+        k = self.blur.kernel
+        key = (k.data_ptr(), k._version if not k.is_inference() else None)
+        cached = self.__dict__.get("_blur_fac")
+        if cached is None or cached[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return None if cached is None else cached[1]
+            cached = self.__dict__["_blur_fac"] = (key, M.blur_factors(k))
+        return cached[1]
+
     def conv_up(self, input, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=math.sqrt(2), split_for=None):
         """Transposed 3x3 conv + blur (+ fused noise/bias/lrelu), matrix cores per the mode.
-        split_for=(key, s_next): the blur pass writes a SplitActivation for the next conv."""
+        split_for=(key, s_next): the blur pass writes a SplitActivation for the next conv.
+        Large planes in f16x3 mode run the ONE-kernel form (hf_modconv3x3_up_blur_f16_f32: no (2h+1)^2
+        intermediate); FUSE_BLUR_MIN_H is the smallest input height that takes it."""
         mode = conv_precision()
         _, cin, h, w = input.shape
+        if (mode == "f16x3" and h >= FUSE_BLUR_MIN_H and noise is not None and bias is not None and 0.0 <= alpha <= 1.0
+                and M.modconv3x3_up_fused_supported(cin, self.out_channel, h, w)):
+            fac = self.blur_factors()
+            if fac is not None:
+                hi, lo = self.prepared_f16()
+                return M.modconv3x3_up_fused(lib(), stream(), input, hi, lo, s, d, fac, noise, noise_w, bias, alpha, scale,
+                                             split_for=None if split_for is None else split_for[1])
         f16 = None
         if mode != "f32" and M.modconv3x3_up_f16_supported(cin, self.out_channel, h, w):
             hi, lo = self.prepared_f16()

@@ -208,6 +208,25 @@ int hf_modconv3x3_up_f16_f32(float *tmp, const float *x, const void *wt_hi, cons
                              const float *s, const float *d, int batch, int cin, int cout, int h, int w,
                              int tmp_pitch, void *stream);
 
+/* The whole upsampling StyledConv in ONE kernel (csrc/convh.hip, FUSE): transposed 3x3 conv (stride 2) of
+ * s*x on the fp16 matrix cores (f16x3 operands), demodulation, 4x4 blur with pad (1,1), noise, bias, leaky
+ * ReLU - models/stylegan2/model.py:252-263 + :337-343 - without the [batch,cout,2h+1,2w+1] intermediate
+ * that hf_modconv3x3_up_f16_f32 writes and hf_blur_noise_bias_act_*_f32 reads back (8 bytes of HBM traffic
+ * per intermediate element, ~1 ms of a batch-8 1024^2 forward).  Blocks compute overlapping tiles of
+ * 16 x 32 phase-domain positions and emit the blurred output of the 14 x 30 interior ones.
+ *   x (fp32, with s) or x_hi/x_lo (pre-split, s already applied; x, s unused)      input [batch,cin,h,w]
+ *   out (fp32 [batch,cout,2h,2w]) and / or split_hi/split_lo (fp16 pairs of s_next*out, K-blocked
+ *   [batch][cout/8][2h][2w][8], for a pre-split consumer; s_next NULL = 1) - at least one of the two.
+ *   blur_k1d_x / blur_k1d_y: HOST pointers to the 4 taps of the two 1-D factors of the blur kernel
+ *   (kernel4x4[r][j] = blur_k1d_y[r] * blur_k1d_x[j]; the module's `blur.kernel` is such an outer product,
+ *   model.py:24-32): the fused form needs a separable kernel - callers with a general 4x4 kernel use the
+ *   two-pass entry points.  cin % 16 == 0, cout % 32 == 0; nterms is 3 (f16x3). */
+int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *split_lo, const float *x, const void *x_hi,
+                                  const void *x_lo, const void *wt_hi, const void *wt_lo, const float *s, const float *d,
+                                  const float *blur_k1d_x, const float *blur_k1d_y, const float *noise, const float *noise_w,
+                                  long long noise_bstride, const float *bias, const float *s_next, int batch, int cin, int cout,
+                                  int h, int w, float alpha, float scale, void *stream);
+
 /* Scratch (in floats) the two modulated-conv entry points need for this shape: the
  * small-plane layers (4x4 .. 16x16) run split-K over the input channels and reduce the
  * partial sums in a second, deterministic pass.  0 = no workspace needed (workspace
@@ -398,7 +417,8 @@ int hf_debug_set_dispatch(int same_cfg, int up_cfg);
 /* Which kernel the last modulated-conv call used: 100 * family + tile configuration id,
  * family 1 = general, 2 = pipelined (double-buffered DMA), 3 = split-K (id 0), 5 = fp16 matrix
  * cores (hf_modconv3x3_f16_f32: ids 51-56, 51/52 can be forced through same_cfg; +20 = pre-split input;
- * hf_modconv3x3_up_f16_f32: ids 61/63, +20 = pre-split input), 6 = hf_conv2d_f16_f32 (1: 64x256 tile,
+ * hf_modconv3x3_up_f16_f32: ids 61/63, +20 = pre-split input; hf_modconv3x3_up_blur_f16_f32: 73, pre-split 93),
+ * 6 = hf_conv2d_f16_f32 (1: 64x256 tile,
  * 2: stride 2, 3: 64x128 tile).  Tests use
  * it to make sure a shape exercises the path it is meant to; bench.py to label launches. */
 int hf_debug_last_path(void);

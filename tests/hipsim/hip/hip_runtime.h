@@ -27,6 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 void syncthreads();
 float shfl_xor(float v, int mask);
 float shfl_rel(float v, int delta);  // value of lane (lane + delta), own value if out of the wave
+float shfl_rel0(float v, int delta);  // same, 0 if out of the wave (DPP wavefront shifts)
 f32x16 mfma32x32x2(float a, float b, f32x16 c);
 f32x16 mfma32x32x16h(const float *a8, const float *b8, f32x16 c);
 void glds16(const float *gsrc_lane, float *lds_wave_base);
@@ -84,6 +85,9 @@ inline void hf_glds4(const float *gsrc_lane, float *lds_wave_base) { ::hipsim::g
 inline void hf_glds16_if(bool a, const float *g, float *l) { ::hipsim::glds_masked(a, 16, g, l); }
 inline void hf_glds4_if(bool a, const float *g, float *l) { ::hipsim::glds_masked(a, 4, g, l); }
 
+#define HF_LANE_SHIFT_DEFINED
+inline float hf_lane_up(float v) { return ::hipsim::shfl_rel0(v, -1); }
+inline float hf_lane_down(float v) { return ::hipsim::shfl_rel0(v, 1); }
 #define HF_OPAQUE_F32(v) ((void)0)
 #define HF_OPAQUE_I32(v) ((void)0)
 #define HF_BARRIER_KEEP_DEFINED

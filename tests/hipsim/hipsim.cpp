@@ -195,6 +195,12 @@ float shfl_rel(float v, int delta) {
   return g_f[g_cur].fres;
 }
 
+float shfl_rel0(float v, int delta) {  // DPP wavefront shift: lanes without a source lane read 0
+  const int lane = g_cur % 64;
+  const float r = shfl_rel(v, delta);
+  return (lane + delta < 0 || lane + delta > 63) ? 0.0f : r;
+}
+
 f32x16 mfma32x32x2(float a, float b, f32x16 c) {
   Fiber &f = g_f[g_cur];
   f.op = OP_MFMA; f.a = a; f.b = b; f.c = c; f.state = WAIT_WAVE;

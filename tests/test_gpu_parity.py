@@ -781,3 +781,51 @@ def test_ops_refuse_autograd():
         g([lat], input_is_latent=True, noise=[n.to(dev) for n in nz])
     with torch.no_grad():
         g([lat], input_is_latent=True, noise=[n.to(dev) for n in nz])
+
+
+# ------------------------------------------------------------------------------------------------
+# The upsampling StyledConv as ONE kernel (transposed conv + blur + noise + bias + lrelu; no (2h+1)^2 intermediate)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 64, 32, 512, 512), (2, 128, 64, 256, 256), (1, 256, 128, 128, 128), (3, 32, 32, 75, 100),
+                                   (1, 512, 256, 64, 64)])
+def test_modconv_up_fused_blur(shape):
+    """hf_modconv3x3_up_blur_f16_f32 against the two-pass path (hf_modconv3x3_up_f16_f32 + blur pass) on the
+    generator's real layer shapes: same MFMA products, the separable blur only reassociates the 16-tap sum
+    (<= 2e-6 relative); the split output equals the split of the fused fp32 output bit for bit; pre-split
+    input equals fp32 input bit for bit; repeatable."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib as _lib_fn, stream
+
+    B, cin, cout, H, W = shape
+    torch.manual_seed(13)
+    dev = _dev()
+    lib, st = _lib_fn(), stream()
+    x = torch.randn(B, cin, H, W, device=dev)
+    wgt = torch.randn(1, cout, cin, 3, 3, device=dev)
+    mw, mb, sty = torch.randn(cin, 16, device=dev), torch.randn(cin, device=dev), torch.randn(B, 16, device=dev)
+    nz, nw, bias = torch.randn(B, 1, 2 * H, 2 * W, device=dev), torch.tensor([0.3], device=dev), torch.randn(cout, device=dev)
+    wt, wsq = M.prepare_weights(lib, st, wgt)
+    s = M.modulation(lib, st, sty, mw, mb)
+    dm = M.demod(lib, st, s, wsq)
+    M.style_normalize(lib, st, s, dm)
+    hi, lo = M.split_weights_f16(lib, st, wt)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0).to(dev)
+    fac = M.blur_factors(k4)
+    ref = M.modconv3x3_up(lib, st, x, wt, s, dm, k4, nz, nw, bias, f16=(hi, lo, 3))
+    y = M.modconv3x3_up_fused(lib, st, x, hi, lo, s, dm, fac, nz, nw, bias)
+    assert lib.hf_debug_last_path() == 573
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((y - ref).abs().max()) < 2e-6 * scale
+    assert torch.equal(y, M.modconv3x3_up_fused(lib, st, x, hi, lo, s, dm, fac, nz, nw, bias))
+    s2 = torch.rand(B, cout, device=dev) + 0.5
+    sp = M.modconv3x3_up_fused(lib, st, x, hi, lo, s, dm, fac, nz, nw, bias, split_for=s2)
+    eh, el = M.split_activation_reference(y, s2)
+    assert torch.equal(sp.hi, eh) and torch.equal(sp.lo, el)
+    xh, xl = M.split_activation_reference(x, s)
+    y3 = M.modconv3x3_up_fused(lib, st, M.SplitActivation(xh, xl, None), hi, lo, None, dm, fac, nz, nw, bias)
+    assert lib.hf_debug_last_path() == 593
+    assert torch.equal(y3, y)
+    if cin <= 64 and H * W <= 10000:
+        full = O.fused_leaky_relu(O.modulated_conv2d(x.cpu(), sty.cpu(), wgt.cpu(), mw.cpu(), mb.cpu(), True, True)
+                                  + nw.cpu() * nz.cpu(), bias.cpu())
+        assert float((y.cpu() - full).abs().max()) < 1e-5 * scale

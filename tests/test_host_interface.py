@@ -124,9 +124,17 @@ def test_kernels_use_no_scratch_memory():
         results = list(pool.map(remarks, files))
     for f, out in results:
         assert out.returncode == 0, out.stderr[-2000:]
-        sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
-        assert sizes, f"{f}: no kernel resource remarks"
-        assert max(sizes) == 0, f"{f}: scratch {max(sizes)} bytes/lane"
+        pairs = re.findall(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", out.stderr, flags=re.S)
+        assert pairs, f"{f}: no kernel resource remarks"
+        for name, size in pairs:
+            # The one exception: the fused upsampling kernel (conv_mfma_h<..., FUSE = true>, csrc/convh.hip) holds 128
+            # accumulator registers through a blur epilogue inside a 256-register budget (8 waves per block); what is
+            # left spills a few values in the PROLOGUE and reloads them outside the epilogue's store phase (a reload
+            # behind a store waits for the store's acknowledgement).  Bounded here so that it cannot grow unnoticed;
+            # the pre-split-input form the generator's fast path uses is at 28 bytes.
+            fused = "conv_mfma_h" in name and name.endswith("ELb1EEEvN9hf_detail10ConvParamsEPKDF16_S4_")
+            limit = (32 if "ELb1ELb1EEEv" in name else 192) if fused else 0
+            assert int(size) <= limit, f"{f}: {name}: scratch {size} bytes/lane (limit {limit})"
 
 
 def test_cached_plans_drop_when_loaded_through_a_parent():

@@ -370,7 +370,7 @@ def test_presplit_chain_same_res_to_transposed(simlib, shape):
     out, nxt = M.modconv3x3_f16_pre(simlib, None, act, h1[0], h1[1], 3, d1, nz, nw, bias, split_for=s2)
     eh, el = M.split_activation_reference(out, s2)
     assert torch.equal(nxt.hi, eh) and torch.equal(nxt.lo, el)
-    only_split = M.modconv3x3_f16_pre(simlib, None, act, h1[0], h1[1], 3, d1, nz, nw, bias, split_for=s2, want_out=False)
+    only_split = M.modconv3x3_f16_pre(simlib, None, act, h1[0], h1[1], 3, d1, nz, nw, bias, split_for=s2)
     assert only_split[0] is None and torch.equal(only_split[1].hi, eh)
     k4 = O.blur_kernel_1d_to_2d(gain=4.0)
     nz2, b2 = torch.randn(B, 1, 2 * H, 2 * W), torch.randn(cup)
@@ -486,3 +486,69 @@ def test_mapping_network_kernels(simlib, golden):
     w = torch.randn(7, 24)
     y = M.equal_linear(simlib, None, xx, w, None, 1.0, False)
     assert maxdiff(y, xx @ w.t() / 24 ** 0.5) < 1e-5
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [(1, 16, 32, 16, 32), (2, 32, 32, 20, 45), (1, 16, 64, 30, 61)])
+def test_modconv_up_fused_blur(simlib, B, cin, cout, H, W):
+    """csrc/convh.hip FUSE: transposed conv + 4x4 blur + noise + bias + lrelu in one kernel (overlapping tiles of
+    16 x 32 phase positions, horizontal taps by lane shifts, vertical taps through the free LDS stage buffer)
+    against the two-pass path and the oracle: fp32 output, split output, pre-split input, several tiles per
+    dimension with ragged edges, two cout tiles."""
+    torch.manual_seed(B + W)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+    nz, nw, bias = torch.randn(B, 1, 2 * H, 2 * W), torch.tensor([0.3]), torch.randn(cout)
+    wt, wsq = M.prepare_weights(simlib, None, wgt)
+    s = M.modulation(simlib, None, sty, mw, mb)
+    dm = M.demod(simlib, None, s, wsq)
+    M.style_normalize(simlib, None, s, dm)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0)
+    fac = M.blur_factors(k4)
+    assert fac is not None and M.blur_factors(torch.rand(4, 4)) is None
+    assert M.modconv3x3_up_fused_supported(cin, cout, H, W)
+    ref = M.modconv3x3_up(simlib, None, x, wt, s, dm, k4, nz, nw, bias, f16=(hi, lo, 3))
+    y = M.modconv3x3_up_fused(simlib, None, x, hi, lo, s, dm, fac, nz, nw, bias)
+    assert simlib.hf_debug_last_path() == 573
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxdiff(y, ref) < 2e-6 * scale  # same products; the separable 4+4-tap blur reassociates the 16-tap sum
+    full = O.fused_leaky_relu(O.modulated_conv2d(x, sty, wgt, mw, mb, True, True) + nw * nz, bias)
+    assert maxdiff(y, full) < TOL * max(1.0, float(full.abs().max()))
+    # split output for the next conv + pre-split input
+    s2 = torch.rand(B, cout) + 0.5
+    sp = M.modconv3x3_up_fused(simlib, None, x, hi, lo, s, dm, fac, nz, nw, bias, split_for=s2)
+    eh, el = M.split_activation_reference(y, s2)
+    assert torch.equal(sp.hi, eh) and torch.equal(sp.lo, el)
+    xh, xl = M.split_activation_reference(x, s)
+    y3 = M.modconv3x3_up_fused(simlib, None, M.SplitActivation(xh, xl, None), hi, lo, None, dm, fac, nz, nw, bias, split_for=s2)
+    assert simlib.hf_debug_last_path() == 593
+    assert torch.equal(y3.hi, eh) and torch.equal(y3.lo, el)
+
+
+@pytest.mark.parametrize("blocks", [1, 3])
+def test_modconv_up_fused_blur_persistent_walk(simlib, blocks):
+    """The fused kernel under the resident-block tile walk: the LDS stage buffer that carries the vertical
+    exchange is handed back to the next tile's DMA prefetch; several images (second parameter slot)."""
+    B, cin, cout, H, W = 3, 32, 32, 30, 40
+    torch.manual_seed(77)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+    nz, nw, bias = torch.randn(B, 1, 2 * H, 2 * W), torch.tensor([0.3]), torch.randn(cout)
+    wt, wsq = M.prepare_weights(simlib, None, wgt)
+    s = M.modulation(simlib, None, sty, mw, mb)
+    dm = M.demod(simlib, None, s, wsq)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0)
+    ref = M.modconv3x3_up_fused(simlib, None, x, hi, lo, s, dm, M.blur_factors(k4), nz, nw, bias)
+    try:
+        simlib.hf_debug_set_persistent_blocks(blocks)
+        y = M.modconv3x3_up_fused(simlib, None, x, hi, lo, s, dm, M.blur_factors(k4), nz, nw, bias)
+        xh, xl = M.split_activation_reference(x, s)
+        y2 = M.modconv3x3_up_fused(simlib, None, M.SplitActivation(xh, xl, None), hi, lo, None, dm, M.blur_factors(k4), nz, nw, bias)
+    finally:
+        simlib.hf_debug_set_persistent_blocks(0)
+    assert torch.equal(y, ref) and torch.equal(y2, ref)
+    full = O.fused_leaky_relu(O.modulated_conv2d(x, sty, wgt, mw, mb, True, True) + nw * nz, bias)
+    assert maxdiff(y, full) < TOL * max(1.0, float(full.abs().max()))
