@@ -471,6 +471,14 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
         return real_up(lib, st, x, *a, **k)
 
     monkeypatch.setattr(M, "modconv3x3_up", up)
+    up_fused, real_fused = [], M.modconv3x3_up_fused
+
+    def fusedup(lib, st, x, *a, **k):
+        assert isinstance(x, M.SplitActivation) and k.get("split_for") is not None  # pre-split in, split out
+        up_fused.append(x.shape[2])
+        return real_fused(lib, st, x, *a, **k)
+
+    monkeypatch.setattr(M, "modconv3x3_up_fused", fusedup)
 
     def rgb(lib, st, x, *a):
         plain_rgb.append(x.shape[1])
@@ -482,7 +490,9 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
         y, _ = g([lat], input_is_latent=True, noise=nz)
         assert fused == [512, 1024]
         assert presplit == [32, 64, 128, 256, 512, 1024]  # blur -> conv hand-over without an fp32 activation
-        assert up_pre == [32, 64, 128, 256, 512]  # conv epilogue -> next block's transposed conv, pre-split
+        # conv epilogue -> next block's transposed conv, pre-split: two-pass up to 64^2 inputs, then the one-kernel
+        # form (transposed conv + blur + noise + bias + lrelu, no (2h+1)^2 intermediate) from 128^2 inputs upward
+        assert up_pre == [32, 64] and up_fused == [128, 256, 512]
         assert plain_rgb.count(3) == 2 and len(plain_rgb) == 9  # two finishing passes on 3-channel input
         # a ToRGB asked for a different style must not use the stashed product
         out = g.convs[15](torch.randn(1, 32, 1024, 1024, device=dev), lat[:, 16], noise=nz[16],
