@@ -82,6 +82,7 @@ def build_generator(dev):
 def build_hairfast(sd, dev):
     """HairFast(args) on synthetic weights with SyntheticStages for the out-of-scope networks."""
     from hairfastgan_amd.hair_swap import HairFast, SyntheticStages, get_parser
+    from oracle import cases as C
     from oracle import ref_encoders as E
     from oracle import ref_postprocess as PP
 
@@ -91,7 +92,7 @@ def build_hairfast(sd, dev):
     pp_shapes.pop("latent_avg")
     return HairFast(args, stages=SyntheticStages(), generator_state={"g_ema": sd, "latent_avg": torch.zeros(512)},
                     e4e_state=synth_state("e4e", E.e4e_param_shapes()), fs_state=synth_state("fs", E.fs_param_shapes()),
-                    pp_state=synth_state("pp", pp_shapes))
+                    pp_state=synth_state("pp", pp_shapes), bisenet_state=C.bisenet_params())
 
 
 def cpu_baseline(sd, budget_s=30.0):
@@ -320,7 +321,7 @@ def main():
                    "config": {"workload": f"{args.triples} synthetic 1024^2 triples sharded over {world} GPU(s): host uint8 -> H2D -> "
                                           "HairFast.swap (e4e B=3, FS-encoder B=3, gen 3->3 B=3, gen 0->3 B=3, gen 0->8 B=2 [both "
                                           "Alignment rotations batched], e4e B=2, gen 0->3 B=2, gen 4->8 B=1, PostProcess encoder "
-                                          "[774 GFLOP], gen 5->8 B=1; out-of-scope networks = SyntheticStages) -> uint8 -> "
+                                          "[774 GFLOP], gen 5->8 B=1, BiSeNet parsing x5; Rotate / shape adaptor / SEAN / CLIP blend = SyntheticStages) -> uint8 -> "
                                           "chunked RCCL all-gather; wall from first H2D to last gather (BASELINE.json configs[3])",
                               "triples": args.triples, "triples_per_gpu": n_local, "parallelism": f"replica x{world}, block-partitioned triples",
                               "weights": "synthetic closed-form (oracle/synth.py)", "conv_precision": precision,

@@ -480,6 +480,7 @@ def torgb(lib, st, x, wt, s, bias, skip, up_kernel):
 # encoders
 # ----------------------------------------------------------------------------------------
 ACT_NONE, ACT_LRELU, ACT_PRELU = 0, 1, 2
+ACT_RESIDUAL_FIRST = 16  # OR-ed into act: residual added before the activation (HF_ACT_RESIDUAL_FIRST)
 
 
 def conv_prepare(lib, st, weight, scale=1.0):
@@ -710,6 +711,43 @@ def pixel_norm(lib, st, x):
         raise ValueError("pixel_norm expects [B, dim] (the mapping network's z)")
     out = torch.empty_like(x)
     check(lib, lib.hf_pixel_norm_f32(_p(out), _p(x), x.shape[0], x.shape[1], st), "hf_pixel_norm_f32")
+    return out
+
+
+def maxpool3x3s2(lib, st, x):
+    x = _c(x)
+    b, c, h, w = x.shape
+    out = x.new_empty((b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1))
+    check(lib, lib.hf_maxpool3x3s2_f32(_p(out), _p(x), b * c, h, w, st), "hf_maxpool3x3s2_f32")
+    return out
+
+
+def gate(lib, st, x, logit, add_plane=None, add_bcast=None, plus_one=0.0):
+    """x * (sigmoid(logit[b,c]) + plus_one) + add_plane + add_bcast[b,c] (hf_gate_f32)."""
+    x = _c(x)
+    b, c, h, w = x.shape
+    out = torch.empty_like(x)
+    check(lib, lib.hf_gate_f32(_p(out), _p(x), _p(_c(logit)), _p(_c(add_plane)), _p(_c(add_bcast)), float(plus_one), b * c, h * w, st),
+          "hf_gate_f32")
+    return out
+
+
+def upsample_nearest(lib, st, x, oh, ow):
+    x = _c(x)
+    b, c, h, w = x.shape
+    out = x.new_empty((b, c, oh, ow))
+    check(lib, lib.hf_upsample_nearest_f32(_p(out), _p(x), b * c, h, w, oh, ow, st), "hf_upsample_nearest_f32")
+    return out
+
+
+def parsing_mask(lib, st, logits, remap, full_hw, out_hw):
+    """hf_parsing_mask_i64: class logits [B,C,h,w] -> int64 mask [B,1,oh,ow] (bilinear up to full_hw, nearest resize
+    to out_hw, first-max argmax, label permutation remap int32 [C])."""
+    logits = _c(logits)
+    b, c, h, w = logits.shape
+    out = torch.empty((b, 1, out_hw[0], out_hw[1]), dtype=torch.int64, device=logits.device)
+    check(lib, lib.hf_parsing_mask_i64(_p(out), _p(logits), _p(remap), b, c, h, w, full_hw[0], full_hw[1], out_hw[0], out_hw[1], st),
+          "hf_parsing_mask_i64")
     return out
 
 

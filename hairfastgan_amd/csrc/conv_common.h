@@ -41,7 +41,8 @@ struct ConvParams {
   const float *d;        // output scale d[b*d_bstride + co]   (demodulation / post-conv BN scale) or null
   const float *noise, *noise_w, *bias;
   const float *slope;    // PReLU slopes [cout]
-  const float *residual; // added after the activation, same shape as out
+  const float *residual; // added after the activation (residual_pre: before it), same shape as out
+  int residual_pre;
   long long noise_bstride;
   int s_bstride, d_bstride;
   int batch, cin, cout, h, w;  // input plane h x w
@@ -170,8 +171,10 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
           const long long pofs = (long long)Y * P.out_w + X;
           float v = acc[0][ct][g][r] * dm;
           if (full) {
-            v = apply_act(v + nz + bsv[r], P.act, P.alpha, P.scale, slv[r]);
-            if (P.residual) v += P.residual[go.o + obofs + pofs];
+            v = v + nz + bsv[r];
+            if (P.residual && P.residual_pre) v += P.residual[go.o + obofs + pofs];
+            v = apply_act(v, P.act, P.alpha, P.scale, slv[r]);
+            if (P.residual && !P.residual_pre) v += P.residual[go.o + obofs + pofs];
           }
           HF_STORE_OUT(&ob[pofs], v);
         }

@@ -421,9 +421,11 @@ static int enc_fill(ConvParams &P, float *out, const float *x, const void *x_hi,
                     const float *in_shift, const float *out_scale, const float *bias, int act, const float *slope,
                     float alpha, const float *residual, int batch, int cin, int cout, int h, int w, int stride, int groups,
                     long long x_group_stride) {
-  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2) || act < ACT_NONE ||
-      act > ACT_PRELU || (act == ACT_PRELU && !slope) || groups < 1 || x_group_stride < 0)
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2) || groups < 1 || x_group_stride < 0)
     return HF_E_INVALID;
+  P.residual_pre = (act & HF_ACT_RESIDUAL_FIRST) ? 1 : 0;
+  act &= ~HF_ACT_RESIDUAL_FIRST;
+  if (act < ACT_NONE || act > ACT_PRELU || (act == ACT_PRELU && !slope)) return HF_E_INVALID;
   if (groups > 1 && (in_scale || in_shift)) return HF_E_INVALID;  // grouped form: plain conv + epilogue (as hf_conv2d_f32)
   if (x_hi && (in_scale || in_shift)) return HF_E_INVALID;        // pre-split input: the affine went into the split
   P.out = out; P.x = x; P.xh = x_hi; P.xl = x_lo; P.s = in_scale; P.t = in_shift; P.d = out_scale; P.bias = bias;

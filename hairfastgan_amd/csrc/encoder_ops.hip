@@ -301,6 +301,96 @@ __global__ __launch_bounds__(256) void add_bcast(float *__restrict__ out, const 
     out[i] = a[i] + b[i % period];
 }
 
+// ---- BiSeNet face parsing (models/CtrlHair/external_code/face_parsing/model.py, resnet.py) ----
+// MaxPool2d(kernel 3, stride 2, padding 1) (resnet.py:62): padding behaves like -inf
+__global__ __launch_bounds__(256) void maxpool3x3s2(float *__restrict__ out, const float *__restrict__ x, long long planes, int h,
+                                                    int w, int oh, int ow) {
+  const long long total = planes * oh * ow, stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+    const float *src = x + (i / ((long long)oh * ow)) * h * w;
+    float m = -3.402823466e38f;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int iy = 2 * oy + dy, ix = 2 * ox + dx;
+        if (iy >= 0 && iy < h && ix >= 0 && ix < w) m = fmaxf(m, src[(long long)iy * w + ix]);
+      }
+    out[i] = m;
+  }
+}
+
+// out[p][i] = x[p][i] * (sigmoid(logit[p]) + plus_one) + add_plane[p][i] + add_bcast[p]
+// (AttentionRefinementModule: feat * sigmoid(bn(conv(avgpool))) [+ the next stage's term], model.py:80-86, 111-122;
+//  FeatureFusionModule: feat * atten + feat, model.py:200-207); add_* may be NULL
+__global__ __launch_bounds__(256) void gate_kernel(float *__restrict__ out, const float *__restrict__ x,
+                                                   const float *__restrict__ logit, const float *__restrict__ add_plane,
+                                                   const float *__restrict__ add_bcast, float plus_one, long long planes, int hw) {
+  const long long total = planes * hw, stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long p = i / hw;
+    const float g = 1.0f / (1.0f + expf(-logit[p])) + plus_one;
+    float v = x[i] * g;
+    if (add_plane) v += add_plane[i];
+    if (add_bcast) v += add_bcast[p];
+    out[i] = v;
+  }
+}
+
+// F.interpolate(mode='nearest') to (oh, ow): src index = min(floor(dst * in / out), in - 1)
+__global__ __launch_bounds__(256) void upsample_nearest(float *__restrict__ out, const float *__restrict__ x, long long planes,
+                                                        int h, int w, int oh, int ow) {
+  const long long total = planes * oh * ow, stride = (long long)gridDim.x * blockDim.x;
+  const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+    const int iy = min((int)floorf(oy * sy), h - 1), ix = min((int)floorf(ox * sx), w - 1);
+    out[i] = x[(i / ((long long)oh * ow)) * h * w + (long long)iy * w + ix];
+  }
+}
+
+// get_segmentation's tail in one pass (model.py:249, my_parsing_util.py:86-95, models/Net.py:111-114): for every
+// pixel of the (oh, ow) nearest-resized mask take its source pixel in the (H, W) full-resolution plane, evaluate the
+// bilinear (align_corners=True) up-sampling of the `classes` logit planes [h, w] there - ATen's formula and operation
+// order, no fused multiply-adds, so that equal inputs give equal values - take the FIRST maximum, apply the label
+// permutation.  The [classes, H, W] logits and the [H, W] mask are never materialised.
+__global__ __launch_bounds__(256) void parsing_mask(long long *__restrict__ out, const float *__restrict__ logits,
+                                                    const int *__restrict__ remap, int classes, int h, int w, int H, int W,
+                                                    int oh, int ow, long long total) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const float ry = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.0f, rx = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+  const float ny = (float)H / (float)oh, nx = (float)W / (float)ow;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+    const long long img = i / ((long long)oh * ow);
+    const int Y = min((int)floorf(oy * ny), H - 1), X = min((int)floorf(ox * nx), W - 1);  // nearest resize
+    const float fy = ry * Y, fx = rx * X;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int yp = (y0 < h - 1) ? 1 : 0, xp = (x0 < w - 1) ? 1 : 0;
+    float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+    float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    HF_OPAQUE_F32(ly0); HF_OPAQUE_F32(ly1); HF_OPAQUE_F32(lx0); HF_OPAQUE_F32(lx1);
+    const float *base = logits + img * classes * h * w + (long long)y0 * w + x0;
+    float best = 0.0f;
+    int arg = 0;
+    for (int c = 0; c < classes; ++c) {
+      const float *pl = base + (long long)c * h * w;
+      // h0lambda * (w0lambda * a + w1lambda * b) + h1lambda * (w0lambda * c + w1lambda * d), products and sums rounded separately
+      float t0 = lx0 * pl[0], t1 = lx1 * pl[xp], t2 = lx0 * pl[yp * w], t3 = lx1 * pl[yp * w + xp];
+      HF_OPAQUE_F32(t0); HF_OPAQUE_F32(t1); HF_OPAQUE_F32(t2); HF_OPAQUE_F32(t3);
+      float top = t0 + t1, bot = t2 + t3;
+      HF_OPAQUE_F32(top); HF_OPAQUE_F32(bot);
+      float u0 = ly0 * top, u1 = ly1 * bot;
+      HF_OPAQUE_F32(u0); HF_OPAQUE_F32(u1);
+      const float v = u0 + u1;
+      if (c == 0 || v > best) {
+        best = v;
+        arg = c;
+      }
+    }
+    out[i] = remap ? remap[arg] : arg;
+  }
+}
+
 __global__ __launch_bounds__(256) void axpby_bcast(float *__restrict__ out, const float *__restrict__ a, float alpha,
                                                    const float *__restrict__ b, float beta, long long n, long long period) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -319,7 +409,7 @@ inline int grid_for(long long n) {
 
 extern "C" int hf_conv_prepare_f32(float *wt, const float *weight, int cout, int cin, int k, float scale,
                                    void *stream) {
-  if (!wt || !weight || cout <= 0 || cin <= 0 || (k != 1 && k != 3)) return HF_E_INVALID;
+  if (!wt || !weight || cout <= 0 || cin <= 0 || (k != 1 && k != 3 && k != 7)) return HF_E_INVALID;
   hipLaunchKernelGGL(conv_prepare, dim3(grid_for((long long)cout * cin)), dim3(256), 0, (hipStream_t)stream, wt,
                      weight, cout, cin, k * k, scale);
   return hf_launch_status();
@@ -434,6 +524,38 @@ extern "C" int hf_pixel_norm_dim1_f32(float *out, const float *x, int batch, int
   if (!out || !x || batch <= 0 || layers <= 0 || dim <= 0) return HF_E_INVALID;
   hipLaunchKernelGGL(pixel_norm_dim1, dim3(hf_cdiv((long long)batch * dim, 256)), dim3(256), 0, (hipStream_t)stream, out, x, batch,
                      layers, dim);
+  return hf_launch_status();
+}
+
+extern "C" int hf_maxpool3x3s2_f32(float *out, const float *x, long long planes, int h, int w, void *stream) {
+  if (!out || !x || planes <= 0 || h <= 0 || w <= 0) return HF_E_INVALID;
+  const int oh = (h - 1) / 2 + 1, ow = (w - 1) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2, dim3(grid_for(planes * oh * ow)), dim3(256), 0, (hipStream_t)stream, out, x, planes, h, w, oh, ow);
+  return hf_launch_status();
+}
+
+extern "C" int hf_gate_f32(float *out, const float *x, const float *logit, const float *add_plane, const float *add_bcast,
+                           float plus_one, long long planes, int hw, void *stream) {
+  if (!out || !x || !logit || planes <= 0 || hw <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(gate_kernel, dim3(grid_for(planes * hw)), dim3(256), 0, (hipStream_t)stream, out, x, logit, add_plane,
+                     add_bcast, plus_one, planes, hw);
+  return hf_launch_status();
+}
+
+extern "C" int hf_upsample_nearest_f32(float *out, const float *x, long long planes, int h, int w, int oh, int ow, void *stream) {
+  if (!out || !x || planes <= 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(upsample_nearest, dim3(grid_for(planes * oh * ow)), dim3(256), 0, (hipStream_t)stream, out, x, planes, h, w,
+                     oh, ow);
+  return hf_launch_status();
+}
+
+extern "C" int hf_parsing_mask_i64(long long *out, const float *logits, const int *remap, int images, int classes, int h, int w,
+                                   int full_h, int full_w, int out_h, int out_w, void *stream) {
+  if (!out || !logits || images <= 0 || classes <= 0 || h <= 0 || w <= 0 || full_h <= 0 || full_w <= 0 || out_h <= 0 || out_w <= 0)
+    return HF_E_INVALID;
+  const long long total = (long long)images * out_h * out_w;
+  hipLaunchKernelGGL(parsing_mask, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, out, logits, remap, classes, h, w,
+                     full_h, full_w, out_h, out_w, total);
   return hf_launch_status();
 }
 

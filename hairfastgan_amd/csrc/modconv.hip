@@ -92,7 +92,8 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NPH][CT_TILES][PG], con
                                            const float *b_base, int xstride, const int (&pixoff)[PG], int wp,
                                            Side &&side) {
   auto bload = [&](int tap, int kk, int g) {
-    const int ky = tap / 3, kx = tap % 3;
+    constexpr int KW = (TAPS == 49) ? 7 : 3;  // square kernels: 1x1, 3x3, 7x7 (BiSeNet's ResNet stem)
+    const int ky = tap / KW, kx = tap % KW;
     const int toff = (TAPS == 1) ? 0 : (UP ? ((ky == 2 ? 0 : 1) * wp + (kx == 2 ? 0 : 1)) : (ky * wp + kx));
     return b_base[2 * kk * xstride + pixoff[g] + toff];
   };
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const ConvParams P) {
   static_assert(!(UP && TAPS != 9), "transposed conv is 3x3");
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
   constexpr int NPH = UP ? 4 : 1;
-  constexpr int KH = (TAPS == 9) ? 3 : 1;
+  constexpr int KH = (TAPS == 49) ? 7 : ((TAPS == 9) ? 3 : 1);
 
   HF_DYN_LDS;
   float *wl = reinterpret_cast<float *>(hf_dyn_lds);  // [TAPS][KC][CT]
@@ -604,8 +605,9 @@ __global__ __launch_bounds__(256) void splitk_reduce(const ConvParams P, long lo
     if (with_epilogue) {
       if (P.noise) v = fmaf(nw, P.noise[b * P.noise_bstride + (i % oplane)], v);
       if (P.bias) v += P.bias[gc];
+      if (P.residual && P.residual_pre) v += P.residual[i];
       v = apply_act(v, P.act, P.alpha, P.scale, P.act == ACT_PRELU ? P.slope[gc] : 0.0f);
-      if (P.residual) v += P.residual[i];
+      if (P.residual && !P.residual_pre) v += P.residual[i];
     }
     P.out[i] = v;
   }
@@ -619,7 +621,7 @@ template <int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool UP, int TAPS>
 int launch_conv(ConvParams &P, hipStream_t st) {
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
   constexpr int PT = 32 * PG * WAVES_PX;
-  const int ext = UP ? 1 : (TAPS == 9 ? 2 : 0);
+  const int ext = UP ? 1 : (TAPS == 49 ? 6 : (TAPS == 9 ? 2 : 0));
   const int stride = UP ? 1 : P.stride;
   int nblocks = 0;
   if (UP) {
@@ -926,12 +928,15 @@ extern "C" int hf_conv2d_f32(float *out, const float *x, const float *wt, const 
                              const float *slope, float alpha, const float *residual, int batch, int cin,
                              int cout, int h, int w, int k, int stride, int groups, long long x_group_stride,
                              float *workspace, long long workspace_floats, void *stream) {
-  if (!out || !x || !wt || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (k != 1 && k != 3) ||
-      (stride != 1 && stride != 2) || act < ACT_NONE || act > ACT_PRELU || (act == ACT_PRELU && !slope) ||
-      groups < 1 || x_group_stride < 0)
+  if (!out || !x || !wt || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (k != 1 && k != 3 && k != 7) ||
+      (stride != 1 && stride != 2) || groups < 1 || x_group_stride < 0)
     return HF_E_INVALID;
+  const int residual_pre = (act & HF_ACT_RESIDUAL_FIRST) ? 1 : 0;  // residual added BEFORE the activation (ResNet BasicBlock)
+  act &= ~HF_ACT_RESIDUAL_FIRST;
+  if (act < ACT_NONE || act > ACT_PRELU || (act == ACT_PRELU && !slope)) return HF_E_INVALID;
   if (groups > 1 && (in_scale || in_shift)) return HF_E_INVALID;  // grouped form: plain conv + epilogue
   ConvParams P{};
+  P.residual_pre = residual_pre;
   P.out = out; P.x = x; P.wt = wt; P.s = in_scale; P.t = in_shift; P.d = out_scale; P.bias = bias;
   P.slope = slope; P.residual = residual;
   P.s_bstride = 0; P.d_bstride = 0;
@@ -941,6 +946,12 @@ extern "C" int hf_conv2d_f32(float *out, const float *x, const float *wt, const 
   P.act = act; P.alpha = alpha; P.scale = 1.0f;
   P.groups = groups; P.x_gstride = x_group_stride; P.wt_gstride = (long long)k * k * cin * cout;
   hipStream_t st = (hipStream_t)stream;
+  if (k == 7) {  // 7x7 (the 3 -> 64 stride-2 stem of BiSeNet's ResNet18, resnet.py:59): general kernel, 64 co x 64 px
+    if (groups > 1) return HF_E_INVALID;
+    g_last_cfg = 7;
+    g_last_path = 1;
+    return launch_conv<1, 1, 2, 2, false, 49>(P, st);
+  }
   if (k == 3 && stride == 1) return run_conv3x3_s1(P, workspace, workspace_floats, st);
   // strided 3x3 and 1x1 (a few % of the encoders' FLOPs): split-K when the grid is small,
   // the pipelined stride-2 kernel for the large 3x3 ones, else the general kernel

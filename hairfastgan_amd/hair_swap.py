@@ -11,9 +11,9 @@ What runs where:
    and all generator calls, with the batch sizes and layer ranges the
   reference issues (Embedding.py:51-53,71-90, Alignment.py:63, Blending.py:62,66,68) - runs on the HIP
   library (hairfastgan_amd.encoders, hairfastgan_amd.stylegan2);
-* the networks BETWEEN those calls that SURVEY.md section 8 leaves out of scope (BiSeNet face
-  parsing, the Rotate encoder, the CtrlHair shape adaptor, SEAN inpainting, the CLIP blending
-  encoder) are `Stages`: named callables injected at construction.
+* BiSeNet face parsing + get_segmentation (row f2) likewise (hairfastgan_amd.face_parsing);
+* the networks BETWEEN those calls that SURVEY.md section 8 leaves out of scope (the Rotate encoder,
+  the CtrlHair shape adaptor, SEAN inpainting, the CLIP blending encoder) are `Stages`: named callables injected at construction.
   With the reference installed they are its own modules (INTEGRATION.md shows the binding);
   `SyntheticStages` provides shape- and dtype-faithful stand-ins so that the complete call
   schedule can be executed and timed on a box that has neither the reference nor checkpoints;
@@ -38,6 +38,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .encoders import Encoder4Editing, FSEncoder, PostProcessModel, get_latents
+from .face_parsing import BiSeNet, get_segmentation
 from .net import Net
 
 
@@ -144,11 +145,6 @@ class Stages:
             f"stage '{what}' is outside this backend's scope (SURVEY.md section 8); construct HairFast with "
             f"stages=<object providing {what}()> - the reference's own module (INTEGRATION.md) or SyntheticStages")
 
-    def segment(self, image_rgb_normalised):
-        """models/Net.py:108-115 get_segmentation (BiSeNet + CelebAMask label remap):
-        [1,3,H,W] ImageNet-normalised -> long [1,1,256,256] labels (13 = hair)."""
-        self._missing("segment")
-
     def rotate(self, w_source_0_6, w_target_0_6):
         """models/Encoders.py:60-103 RotateModel: ([1,6,512], [1,6,512]) -> [1,6,512]."""
         self._missing("rotate")
@@ -168,8 +164,9 @@ class Stages:
         """models/Encoders.py ClipBlendingModel: -> S_blend[:, 6:18] [1,12,512]."""
         self._missing("blend")
 
-    # post_process (models/Encoders.py:106-137 PostProcessModel) is NOT a stage any more: SURVEY.md section 8
-    # row f1 is built natively (hairfastgan_amd.encoders.PostProcessModel, owned by Blending).
+    # Not stages any more (built natively, SURVEY.md section 8 rows f1 / f2): PostProcessModel
+    # (hairfastgan_amd.encoders.PostProcessModel, owned by Blending) and BiSeNet face parsing / get_segmentation
+    # (hairfastgan_amd.face_parsing, owned by HairFast and shared by Embedding and Alignment).
 
 
 class SyntheticStages(Stages):
@@ -177,17 +174,6 @@ class SyntheticStages(Stages):
     that the whole call schedule of a swap runs where neither the reference nor any checkpoint
     exists (the GPU box).  They are NOT models: the images they lead to are meaningless; the
     hot-path work they trigger (which kernels, which batch sizes, which layer ranges) is exact."""
-
-    def segment(self, image_rgb_normalised):
-        x = F.adaptive_avg_pool2d(image_rgb_normalised.mean(1, keepdim=True), (256, 256))
-        yy, xx = torch.meshgrid(torch.linspace(-1, 1, 256, device=x.device), torch.linspace(-1, 1, 256, device=x.device),
-                                indexing="ij")
-        hair = ((xx ** 2 + (yy + 0.35) ** 2) < 0.45) & (x[0, 0] > x.mean() - 10.0)
-        face = (xx ** 2 + (yy - 0.1) ** 2) < 0.25
-        lab = torch.zeros(256, 256, dtype=torch.long, device=x.device)
-        lab[hair] = 13
-        lab[face & ~hair] = 1
-        return lab[None, None]
 
     def rotate(self, w_source_0_6, w_target_0_6):
         return w_source_0_6 + 0.25 * (w_target_0_6 - w_source_0_6)
@@ -212,11 +198,12 @@ class SyntheticStages(Stages):
 # ---------------------------------------------------------------------------------------------
 class Embedding(nn.Module):  # models/Embedding.py:17-117
     def __init__(self, opts, net=None, stages=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
-                 fs_dlatent_avg=None):
+                 fs_dlatent_avg=None, parsing=None):
         super().__init__()
         self.opts = opts
         self.net = net if net is not None else Net(opts)
         self.stages = stages or Stages()
+        self.parsing = parsing if parsing is not None else BiSeNet(19).eval().to(opts.device)  # models/Net.py:29 singleton
         dev = opts.device
         # models/encoder4editing/utils/model_utils.py setup_model: pSp(opts).encoder + latent_avg
         self.e4e = argparse.Namespace(
@@ -269,7 +256,7 @@ class Embedding(nn.Module):  # models/Embedding.py:17-117
             latent_S = output.pop()  # [bs, 18, 512]
             latent_F, _ = self.net.generator([latent_S], input_is_latent=True, return_latents=False, start_layer=3,
                                              end_layer=3, layer_in=latent)
-            masks = torch.cat([self.stages.segment(im.unsqueeze(0)) for im in self.to_bisenet(im_512)])  # BiSeNet
+            masks = torch.cat([get_segmentation(self.parsing, im.unsqueeze(0)) for im in self.to_bisenet(im_512)])  # BiSeNet
             if len(images_to_name) > 1:  # mixing if we change the colour or the shape
                 hair_mask = (masks == 13).float()
                 hair_mask = F.interpolate(hair_mask, size=(32, 32), mode="bicubic")
@@ -286,12 +273,13 @@ class Embedding(nn.Module):  # models/Embedding.py:17-117
 
 
 class Alignment(nn.Module):  # models/Alignment.py:15-175
-    def __init__(self, opts, latent_encoder=None, net=None, stages=None):
+    def __init__(self, opts, latent_encoder=None, net=None, stages=None, parsing=None):
         super().__init__()
         self.opts = opts
         self.latent_encoder = latent_encoder
         self.net = net if net is not None else Net(opts)
         self.stages = stages or Stages()
+        self.parsing = parsing if parsing is not None else BiSeNet(19).eval().to(opts.device)
         self.dilate_erosion = DilateErosion(dilate_erosion=opts.smooth, device=opts.device)
 
     @torch.inference_mode()
@@ -310,7 +298,7 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
         out = {}
         for k, key in enumerate(todo):
             seg_in = Embedding.to_bisenet(((I_rot[k:k + 1] + 1) / 2).clip(0, 1))
-            out[key] = (I_rot[k:k + 1], self.stages.segment(seg_in))
+            out[key] = (I_rot[k:k + 1], get_segmentation(self.parsing, seg_in))  # the 1024^2 image is parsed (:65-67)
         return out
 
     @torch.inference_mode()
@@ -405,16 +393,21 @@ class HairFast:
       generator_state {'g_ema': ..., 'latent_avg': ...} instead of args.ckpt
       e4e_state / fs_state (+ e4e_latent_avg / fs_dlatent_avg)  encoder state dicts
       pp_state (+ pp_latent_avg)  PostProcessModel state dict ('model_state_dict' of args.pp_checkpoint)
+      bisenet_state   BiSeNet state dict (pretrained_models/BiSeNet/face_parsing_79999_iter.pth)
     """
 
     def __init__(self, args, *, stages=None, generator_state=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
-                 fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None):
+                 fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None, bisenet_state=None):
         self.args = args
         self.stages = stages or Stages()
         self.net = Net(args, state=generator_state)
+        self.parsing = BiSeNet(19).eval()  # pretrained_models/BiSeNet/face_parsing_79999_iter.pth (my_parsing_util.py:77-79)
+        if bisenet_state is not None:
+            self.parsing.load_state_dict(bisenet_state)
+        self.parsing.to(args.device)
         self.embed = Embedding(args, net=self.net, stages=self.stages, e4e_state=e4e_state, fs_state=fs_state,
-                               e4e_latent_avg=e4e_latent_avg, fs_dlatent_avg=fs_dlatent_avg)
-        self.align = Alignment(args, self.embed.get_e4e_embed, net=self.net, stages=self.stages)
+                               e4e_latent_avg=e4e_latent_avg, fs_dlatent_avg=fs_dlatent_avg, parsing=self.parsing)
+        self.align = Alignment(args, self.embed.get_e4e_embed, net=self.net, stages=self.stages, parsing=self.parsing)
         self.blend = Blending(args, net=self.net, stages=self.stages, pp_state=pp_state, pp_latent_avg=pp_latent_avg)
         self._times = []
 

@@ -23,6 +23,10 @@ extern "C" {
 #define HF_E_LAUNCH (-2)    /* hipGetLastError() reported a launch failure */
 #define HF_E_WORKSPACE (-3) /* caller-provided workspace too small */
 
+/* OR-ed into the `act` argument of hf_conv2d_f32 / hf_conv2d_f16_f32: add `residual` BEFORE the activation
+ * (ResNet BasicBlock: relu(shortcut + bn(conv)), resnet.py:41-45) instead of after it (IBasicBlock) */
+#define HF_ACT_RESIDUAL_FIRST 16
+
 const char *hf_strerror(int code);
 /* ABI version of this header; bumped on any signature change. */
 int hf_abi_version(void);
@@ -288,7 +292,7 @@ int hf_torgb_f32(float *out, const float *x, const float *wt, const float *s, co
  * operators around it.  All tensors NCHW fp32.
  * =========================================================================== */
 
-/* Conv2d weight [cout,cin,k,k] (torch layout) -> wt[k*k][cin][cout] * scale; k = 1 or 3.
+/* Conv2d weight [cout,cin,k,k] (torch layout) -> wt[k*k][cin][cout] * scale; k = 1, 3 or 7.
  * One-time re-layout of frozen parameters. */
 int hf_conv_prepare_f32(float *wt, const float *weight, int cout, int cin, int k, float scale, void *stream);
 
@@ -304,7 +308,7 @@ int hf_bn_fold_f32(float *scale, float *shift, const float *gamma, const float *
  *   out_scale / bias    : the BatchNorm AFTER the conv (and/or the conv's own bias);
  *   act                 : 0 none, 1 LeakyReLU(alpha), 2 PReLU(slope[co]);
  *   residual            : [batch,cout,oh,ow] added last (IBasicBlock's `out += identity`).
- * Any of the pointers may be NULL.  k in {1,3}, stride in {1,2}; oh = (h-1)/stride + 1.
+ * Any of the pointers may be NULL.  k in {1,3,7} (7: ungrouped), stride in {1,2}; oh = (h-1)/stride + 1.
  * Replaces: nn.Conv2d + BatchNorm2d + PReLU/LeakyReLU (+ add) chains of
  * helpers.py:99-115, psp_encoders.py:41-47, iresnet.py:44-56, feature_style_encoder.py:33-40.
  * groups > 1: `groups` independent convolutions of this shape in one launch (the e4e style
@@ -388,6 +392,27 @@ int hf_equal_linear_f32(float *out, const float *x, long long x_stride, const fl
                         void *stream);
 /* PixelNorm.forward (models/stylegan2/model.py:16-21) on [rows, dim]: x * rsqrt(mean_k x^2 + 1e-8). */
 int hf_pixel_norm_f32(float *out, const float *x, int rows, int dim, void *stream);
+/* ---- BiSeNet face parsing + get_segmentation (models/CtrlHair/external_code/face_parsing/model.py:230-253,
+ * resnet.py:19-77, my_parsing_util.py:72-95, models/Net.py:108-115) - its convolutions are hf_conv2d_f32 /
+ * hf_conv2d_f16_f32 (k = 7 for the ResNet stem; act | HF_ACT_RESIDUAL_FIRST for `relu(shortcut + residual)`) ---- */
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on [planes, h, w] -> [planes, (h-1)/2+1, (w-1)/2+1] (resnet.py:62) */
+int hf_maxpool3x3s2_f32(float *out, const float *x, long long planes, int h, int w, void *stream);
+/* out[p][i] = x[p][i] * (sigmoid(logit[p]) + plus_one) + add_plane[p][i] + add_bcast[p]   (add_* may be NULL):
+ * AttentionRefinementModule's `feat * sigmoid(atten)` with the following `+ avg_up` / `+ feat32_up` (model.py:80-86,
+ * 111-122; avg_up is a 1x1 map broadcast over the plane), FeatureFusionModule's `feat * atten + feat` (plus_one = 1). */
+int hf_gate_f32(float *out, const float *x, const float *logit, const float *add_plane, const float *add_bcast,
+                float plus_one, long long planes, int hw, void *stream);
+/* F.interpolate(mode='nearest') of [planes, h, w] to [planes, oh, ow] (model.py:112, 116, 121) */
+int hf_upsample_nearest_f32(float *out, const float *x, long long planes, int h, int w, int oh, int ow, void *stream);
+/* The tail of get_segmentation in one pass: bilinear (align_corners=True) up-sampling of the class logits
+ * [images, classes, h, w] to (full_h, full_w) (model.py:249) evaluated ONLY at the source pixels of the nearest resize to
+ * (out_h, out_w) (models/Net.py:112-114; out = full for resize=False), argmax over the classes (first maximum,
+ * my_parsing_util.py:86) and the label permutation remap[classes] (swap_parsing_label_to_celeba_mask, :89-95; NULL = none).
+ * The interpolation follows ATen's formula and operation order without fused multiply-adds: equal logits give equal
+ * indices.  out: int64 [images, out_h, out_w]. */
+int hf_parsing_mask_i64(long long *out, const float *logits, const int *remap, int images, int classes, int h, int w,
+                        int full_h, int full_w, int out_h, int out_w, void *stream);
+
 /* ---- PostProcessModel's latent branch (models/Encoders.py:13-32, 119-131) ----
  * F.layer_norm over the last `dim` elements of each of `rows` rows (biased variance, eps inside the sqrt):
  * gamma / beta [dim] = elementwise affine (both NULL: LayerNorm(elementwise_affine=False), :19), lrelu != 0

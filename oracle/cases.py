@@ -207,3 +207,31 @@ def pp_inputs():
     src = t(synth.pseudo_normal("pp/source", (1, 3, 256, 256))) * 0.5
     tgt = t(synth.pseudo_normal("pp/target", (1, 3, 256, 256))) * 0.5
     return src, tgt
+
+
+def bisenet_input(tag):
+    """ImageNet-normalised image for BiSeNet / get_segmentation: "512" = the [1,3,512,512] case of
+    Embedding.py:81 (a smooth pattern + noise so that the argmax map has regions, not salt and pepper),
+    "320x384" = a non-square plane (odd feature-map sizes on the way down)."""
+    h, w = (512, 512) if tag == "512" else (320, 384)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, h), torch.linspace(-1, 1, w), indexing="ij")
+    base = torch.stack([torch.sin(3 * xx + yy), torch.cos(2 * yy - xx), xx * yy])[None]
+    return (base * 1.5 + 0.3 * t(synth.pseudo_normal(f"bisenet/x/{tag}", (1, 3, h, w)))).contiguous()
+
+
+def bisenet_params():
+    """Synthetic BiSeNet parameters: the closed-form fill, except for the three class-score convs, whose rows would
+    otherwise be near-copies of each other (one class wins everywhere): pseudo-random rows give an argmax map with
+    many regions and a spread of top-1 / top-2 margins, which is what the mask-index parity check needs."""
+    from . import ref_bisenet as BS
+
+    P = params_from_shapes("bisenet", BS.bisenet_param_shapes())
+    for k in list(P):
+        if P[k].ndim == 4:                                    # conv gains x3: activations of O(1) that follow the
+            P[k] = P[k] * 3.0                                 # image instead of the BatchNorm shifts
+        elif k.endswith(".bias") or k.endswith("running_mean"):
+            P[k] = P[k] * 0.1
+    for name in ("conv_out", "conv_out16", "conv_out32"):
+        k = f"{name}.conv_out.weight"
+        P[k] = t(synth.pseudo_normal(f"bisenet/{k}", tuple(P[k].shape))) * 0.5
+    return P

@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
     ap.add_argument("--only", default=None,
-                    help="comma list of sections to (re)generate (default all): basic,gen64,gen1024,enc_units,encoders,glue,pp")
+                    help="comma list of sections to (re)generate (default all): basic,gen64,gen1024,enc_units,encoders,glue,pp,bisenet")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -416,6 +416,44 @@ def main():
                                maxdiff(torch.from_numpy(g["pp_mod_last"]), PP.modulation_module(P, "to_latent_1.4", xm, em, 18, True)))
         np.savez_compressed(os.path.join(args.out, "postprocess.npz"), **g)
         print("done postprocess", report["pp/s"], report["pp/f"], flush=True)
+
+    # ---------------- (vii) BiSeNet face parsing + label remap --------------------
+    if not args.skip_big and want("bisenet"):
+        import torch.utils.model_zoo as _mz
+
+        from oracle import ref_bisenet as BS
+
+        shapes_all = BS.bisenet_param_shapes()
+        P = C.bisenet_params()
+        # Resnet18.__init__ downloads torchvision's resnet18 (resnet.py:79-85): hand it synthetic tensors instead
+        _mz.load_url = lambda *a, **k: {k_[len("cp.resnet."):]: v_ for k_, v_ in P.items() if k_.startswith("cp.resnet.")}
+        from models.CtrlHair.external_code.face_parsing import model as ref_bs
+        from models.CtrlHair.external_code.face_parsing.my_parsing_util import FaceParsing_tensor
+
+        net = ref_bs.BiSeNet(n_classes=19).eval()
+        shapes = {k_: tuple(v_.shape) for k_, v_ in net.state_dict().items()}
+        assert shapes == shapes_all and list(shapes) == list(shapes_all), "BiSeNet state-dict layout mismatch"
+        net.load_state_dict(P)
+        g = {}
+        for tag, size in (("512", 512), ("320x384", None)):
+            x = C.bisenet_input(tag)
+            logits = net(x)[0]
+            lo = BS.bisenet_logits(P, x)
+            report[f"bisenet/logits_{tag}"] = maxdiff(logits, lo)
+            parsing = logits.squeeze(0).argmax(0)
+            celeba = FaceParsing_tensor.swap_parsing_label_to_celeba_mask(parsing)
+            mask_o = BS.get_segmentation(P, x, resize=False)[0, 0]
+            report[f"bisenet/mask_{tag}"] = float((celeba != mask_o).sum())
+            mask256 = torch.nn.functional.interpolate(celeba[None, None].float(), size=(256, 256), mode="nearest").long()
+            report[f"bisenet/mask256_{tag}"] = float((mask256 != BS.get_segmentation(P, x, resize=True)).sum())
+            top2 = logits[0].topk(2, dim=0).values
+            g[f"logits_stats_{tag}"] = stats(logits)
+            g[f"logits_samples_{tag}"] = strided_samples(logits, 2048)
+            g[f"mask_{tag}"] = celeba.to(torch.uint8).numpy()
+            g[f"mask256_{tag}"] = mask256[0, 0].to(torch.uint8).numpy()
+            g[f"margin_{tag}"] = (top2[0] - top2[1]).to(torch.float16).numpy()  # top-1 minus top-2 logit per pixel
+        np.savez_compressed(os.path.join(args.out, "bisenet.npz"), **g)
+        print("done bisenet", {k_: v_ for k_, v_ in report.items() if k_.startswith("bisenet")}, flush=True)
 
     worst = max(report.values())
     with open(rep_path, "w") as f:

@@ -81,7 +81,7 @@ def _hairfast(dev):
     return HairFast(args, stages=SyntheticStages(), generator_state=state,
                     e4e_state=C.params_from_shapes("e4e", E.e4e_param_shapes()),
                     fs_state=C.params_from_shapes("fs", E.fs_param_shapes()),
-                    pp_state=C.params_from_shapes("pp", pp_shapes))
+                    pp_state=C.params_from_shapes("pp", pp_shapes), bisenet_state=C.bisenet_params())
 
 
 def test_hairfast_swap_call_surface():
@@ -122,7 +122,7 @@ def test_hairfast_swap_call_surface():
     hf.net.generator.forward = gen_fwd
     assert (1, 0, 8) in calls and (2, 0, 8) not in calls
     with pytest.raises(NotImplementedError, match="outside this backend's scope"):
-        Stages().segment(None)
+        Stages().rotate(None, None)
     with pytest.raises(NotImplementedError, match="dlib"):
         hf.swap(face, shape, color, align=True)
 

@@ -1,0 +1,95 @@
+"""CPU tests (kernel sources interpreted by tests/hipsim) of the face-parsing path:
+the oracle against the reference's golden masks, and the HIP-path BiSeNet mirror against the oracle on a small image."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hairfastgan_amd import _marshal as M
+from oracle import cases as C
+from oracle import ref_bisenet as BS
+
+
+def test_oracle_reproduces_reference_masks(golden):
+    """oracle/ref_bisenet.py vs the golden vectors make_golden.py produced with the real BiSeNet class, its label
+    permutation and the nearest resize: identical logits samples and identical mask indices."""
+    G = golden("bisenet.npz")
+    P = C.bisenet_params()
+    x = C.bisenet_input("320x384")
+    logits = BS.bisenet_logits(P, x)
+    f = logits.reshape(-1)
+    step = max(1, f.numel() // 2048)
+    assert np.array_equal(f[::step][:2048].numpy(), G["logits_samples_320x384"])
+    assert np.array_equal(BS.get_segmentation(P, x, resize=False)[0, 0].numpy().astype(np.uint8), G["mask_320x384"])
+    assert np.array_equal(BS.get_segmentation(P, x, resize=True)[0, 0].numpy().astype(np.uint8), G["mask256_320x384"])
+    assert len(np.unique(G["mask_512"])) >= 5  # the synthetic parameters give a map with several regions
+
+
+@pytest.fixture()
+def sim_parsing(simlib, monkeypatch):
+    import hairfastgan_amd.encoders  # noqa: F401
+    import hairfastgan_amd.face_parsing  # noqa: F401
+
+    for n in ("hairfastgan_amd.encoders._fused", "hairfastgan_amd.face_parsing"):
+        mod = sys.modules[n]
+        monkeypatch.setattr(mod, "lib", lambda: simlib)
+        monkeypatch.setattr(mod, "stream", lambda: None)
+        monkeypatch.setattr(mod, "require_gpu", lambda *a: None)
+    return simlib
+
+
+def test_small_ops(simlib):
+    torch.manual_seed(1)
+    x = torch.randn(2, 3, 9, 12)
+    assert torch.equal(M.maxpool3x3s2(simlib, None, x), F.max_pool2d(x, 3, 2, 1))
+    assert torch.equal(M.upsample_nearest(simlib, None, x, 18, 24), F.interpolate(x, (18, 24), mode="nearest"))
+    assert torch.equal(M.upsample_nearest(simlib, None, x, 13, 17), F.interpolate(x, (13, 17), mode="nearest"))
+    lg, ap, ab = torch.randn(2, 3), torch.randn(2, 3, 9, 12), torch.randn(2, 3)
+    ref = x * (torch.sigmoid(lg)[:, :, None, None] + 1.0) + ap + ab[:, :, None, None]
+    assert float((M.gate(simlib, None, x, lg, ap, ab, 1.0) - ref).abs().max()) < 1e-6
+    # 7x7 stride-2 conv (the ResNet stem) and the residual-before-activation epilogue
+    w = torch.randn(8, 3, 7, 7) * 0.1
+    xx = torch.randn(1, 3, 20, 28)
+    wt = M.conv_prepare(simlib, None, w)
+    y = M.conv2d(simlib, None, xx, wt, 7, 2, act=M.ACT_LRELU, alpha=0.0)
+    assert float((y - F.relu(F.conv2d(xx, w, stride=2, padding=3))).abs().max()) < 2e-5
+    w3 = torch.randn(8, 8, 3, 3) * 0.1
+    res = torch.randn(1, 8, 10, 14)
+    y2 = M.conv2d(simlib, None, y, M.conv_prepare(simlib, None, w3), 3, 1, act=M.ACT_LRELU | M.ACT_RESIDUAL_FIRST, alpha=0.0,
+                  residual=res)
+    assert float((y2 - F.relu(F.conv2d(y, w3, padding=1) + res)).abs().max()) < 2e-5
+    # parsing tail: bilinear (align_corners) + argmax + remap + nearest resize == the torch composition, bit for bit
+    logits = torch.randn(2, 19, 8, 10)
+    remap = torch.tensor(BS.LABEL_REMAP, dtype=torch.int32)
+    full = F.interpolate(logits, (40, 56), mode="bilinear", align_corners=True).argmax(1, keepdim=True)
+    want = torch.tensor(BS.LABEL_REMAP)[full]
+    assert torch.equal(M.parsing_mask(simlib, None, logits, remap, (40, 56), (40, 56)), want)
+    want_r = F.interpolate(want.float(), (16, 16), mode="nearest").long()
+    assert torch.equal(M.parsing_mask(simlib, None, logits, remap, (40, 56), (16, 16)), want_r)
+
+
+def test_bisenet_small_image_vs_oracle(sim_parsing):
+    """The whole BiSeNet mirror (ResNet18 stem / blocks with the residual before the ReLU, both attention refinement
+    modules, feature fusion, output head, fused interpolation + argmax + remap) on a 64 x 96 image."""
+    from hairfastgan_amd.face_parsing import BiSeNet, get_segmentation
+
+    P = C.bisenet_params()
+    net = BiSeNet(19).eval()
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == BS.bisenet_param_shapes()
+    assert list(net.state_dict()) == list(BS.bisenet_param_shapes())
+    net.load_state_dict(P)
+    x = C.bisenet_input("320x384")[:, :, :64, :96].contiguous()
+    low = net.logits_low(x)
+    ref_full = BS.bisenet_logits(P, x)
+    got_full = F.interpolate(low, (64, 96), mode="bilinear", align_corners=True)
+    scale = float(ref_full.abs().max())
+    assert float((got_full - ref_full).abs().max()) < 1e-4 * scale
+    mask = get_segmentation(net, x, resize=False)
+    ref_mask = BS.get_segmentation(P, x, resize=False)
+    top2 = ref_full[0].topk(2, dim=0).values
+    margin = top2[0] - top2[1]
+    flips = mask[0, 0] != ref_mask[0, 0]
+    assert int(flips.sum()) == 0 or float(margin[flips].max()) < 2e-4 * scale  # indices agree wherever the decision is not a near-tie
+    assert tuple(get_segmentation(net, x).shape) == (1, 1, 256, 256)
