@@ -230,8 +230,8 @@ inline int geom_xs(const TileGeom &g, int stride, int ext) {
 // accumulators (fp32-class accuracy, 5.3x the fp32 MFMA rate); nterms 1: plain fp16 operands.
 // Returns HF_E_INVALID when the shape does not qualify.
 int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wt_hi, const void *wt_lo, hipStream_t st);
-extern int g_h_blocks;           // hf_debug_set_persistent_blocks: resident blocks the convh.hip grid is sized for (0 = 256 CUs)
-extern int g_force_h;            // hf_debug_set_dispatch same_cfg 51/52: force the convh.hip tile configuration
+extern thread_local int g_h_blocks;           // hf_debug_set_persistent_blocks: resident blocks the convh.hip grid is sized for (0 = 256 CUs)
+extern thread_local int g_force_h;            // hf_debug_set_dispatch same_cfg 51/52: force the convh.hip tile configuration
 void note_path(int path, int cfg);  // records what hf_debug_last_path reports
 // split-K second pass (modconv.hip): out = epilogue(d * sum_z partial[z]), deterministic
 int launch_splitk_reduce(ConvParams &P, bool with_epilogue, hipStream_t st);

@@ -878,8 +878,9 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
 
 namespace hf_detail {
 
-int g_force_h = 0;
-int g_h_blocks = 0;
+// tuning / test hooks: per-thread state (no process-global mutable state in the library)
+thread_local int g_force_h = 0;
+thread_local int g_h_blocks = 0;
 
 int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const void *wtl, hipStream_t st) {
   const _Float16 *h = static_cast<const _Float16 *>(wth), *l = static_cast<const _Float16 *>(wtl);

@@ -761,9 +761,9 @@ int hf_detail::launch_splitk_reduce(ConvParams &P, bool with_epilogue, hipStream
 namespace {
 
 // Tuning hook (hf_debug_set_dispatch): 0 = built-in heuristics.
-int g_force_same = 0, g_force_up = 0;
-int g_last_cfg = 0;   // tile configuration id of the last conv call (see the dispatch switches)
-int g_last_path = 0;  // 1 = general kernel, 2 = pipelined kernel, 3 = split-K (general kernel + reduce)
+thread_local int g_force_same = 0, g_force_up = 0;  // per-thread (hf_debug_set_dispatch)
+thread_local int g_last_cfg = 0;   // tile configuration id of the last conv call (see the dispatch switches)
+thread_local int g_last_path = 0;  // 1 = general kernel, 2 = pipelined kernel, 3 = split-K (general kernel + reduce)
 
 // split-K through `workspace` with the small-plane general configuration
 template <bool UP, int TAPS>

@@ -279,14 +279,19 @@ class StyledConv(nn.Module):  # :309-343
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None, rgb=None):
+    def forward(self, input, style, noise=None):
         """conv -> +noise -> bias -> leaky-ReLU*sqrt2 with the last three fused into the
-        producing kernel's epilogue (same-res) or into the blur pass (upsample).
-        rgb = ToRGB.coefficients(style) of the layer's ToRGB (only when conv.fuses_torgb(input)):
-        ToRGB's 1x1 modulated conv is computed in the same epilogue and travels with the returned
-        tensor (attribute _hf_fused_rgb); that ToRGB's forward picks it up instead of re-reading
-        the feature map.  The return value stays a plain Tensor (module hooks see what they
-        always saw)."""
+        producing kernel's epilogue (same-res) or into the blur pass / the one-kernel upsampling form."""
+        return self._run(input, style, noise, None)
+
+    def forward_rgb(self, input, style, noise, rgb):
+        """forward() that ALSO returns ToRGB's raw 1x1 modulated conv of its output, computed in the same
+        epilogue (only when conv.fuses_torgb(input)): (out, raw [B,3,H,W]).  rgb = ToRGB.coefficients(style) of the
+        layer's ToRGB; the caller hands `raw` to that ToRGB's finish() instead of letting it re-read the feature
+        map.  An explicit second return value - nothing is attached to tensors."""
+        return self._run(input, style, noise, rgb)
+
+    def _run(self, input, style, noise, rgb):
         require_gpu(input, style, noise)
         conv = self.conv
         wt, s, d = conv.style_coefficients(style)
@@ -296,16 +301,15 @@ class StyledConv(nn.Module):  # :309-343
             noise = input.new_empty(b, 1, oh, ow).normal_()
         act = self.activate
         if conv.upsample:
+            assert rgb is None
             return conv.conv_up(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
                                 act.negative_slope, act.scale)
         if rgb is None:
             return conv.conv_same_res(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
                                       act.negative_slope, act.scale)
-        key, rgb_wt, rgb_s = rgb
-        out, raw = conv.conv_same_res(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
-                                      act.negative_slope, act.scale, rgb=(rgb_wt, rgb_s))
-        out._hf_fused_rgb = (key, raw)
-        return out
+        rgb_wt, rgb_s = rgb
+        return conv.conv_same_res(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
+                                  act.negative_slope, act.scale, rgb=(rgb_wt, rgb_s))
 
     # -- producer -> consumer hand-over without an fp32 round trip (Generator's fast path) --------
     def forward_split(self, input, style, noise, s_next, coeffs=None):
@@ -326,10 +330,11 @@ class StyledConv(nn.Module):  # :309-343
 
     def forward_from_split(self, split, coeffs, noise=None, rgb=None, want_out=True, split_for=None):
         """Same-resolution StyledConv on a SplitActivation produced for it (coeffs = this layer's
-        conv.style_coefficients(style), whose s went into the split).  Returns (out, next_split):
-        out is what forward() returns - or, with want_out=False, an empty placeholder carrying
-        _hf_fused_rgb when nobody reads the fp32 activation; next_split (split_for = the next
-        layer's modulation) is the SplitActivation for the transposed conv above, else None."""
+        conv.style_coefficients(style), whose s went into the split).  Returns (out, raw, next_split):
+        out is what forward() returns, or None with want_out=False (nobody reads the fp32 activation);
+        raw (rgb = ToRGB.coefficients of the layer's ToRGB) is that ToRGB's 1x1 conv from the epilogue, else None;
+        next_split (split_for = the next layer's modulation) is the SplitActivation for the transposed conv
+        above, else None."""
         conv = self.conv
         assert not conv.upsample
         _, s, d = coeffs
@@ -341,17 +346,13 @@ class StyledConv(nn.Module):  # :309-343
         hi, lo = conv.prepared_f16()
         nterms = 3 if conv_precision() == "f16x3" else 1
         res = M.modconv3x3_f16_pre(lib(), stream(), split, hi, lo, nterms, d, noise, self.noise.weight.detach(),
-                                   act.bias.detach(), act.negative_slope, act.scale,
-                                   rgb=None if rgb is None else (rgb[1], rgb[2]), want_out=want_out, split_for=split_for)
+                                   act.bias.detach(), act.negative_slope, act.scale, rgb=rgb, want_out=want_out,
+                                   split_for=split_for)
         res = list(res) if isinstance(res, tuple) else [res]
         out = res.pop(0)
         raw = res.pop(0) if rgb is not None else None
         nxt = res.pop(0) if split_for is not None else None
-        if out is None:
-            out = (raw if raw is not None else nxt.hi).new_empty(0, dtype=torch.float32)
-        if rgb is not None:
-            out._hf_fused_rgb = (rgb[0], raw)
-        return out, nxt
+        return out, raw, nxt
 
 
 def _observed(*modules):
@@ -382,22 +383,17 @@ class ToRGB(nn.Module):  # :346-365
 
     def forward(self, input, style, skip=None):
         require_gpu(input, style, skip)
-        fused = getattr(input, "_hf_fused_rgb", None)
-        if fused is not None and fused[0] == self._fusion_key(style):
-            return self._finish(fused[1], skip)
         wt, s, _ = self.conv.style_coefficients(style)
         return M.torgb(lib(), stream(), input, wt, s, self.bias.detach(), skip, self._skip_kernel(skip))
 
-    def _fusion_key(self, style):
-        return (id(self), style.data_ptr(), tuple(style.shape), tuple(style.stride()))
-
     def coefficients(self, style):
-        """(key, wt [1,cin,3], s [B,cin]) for the producer that fuses the 1x1 conv (StyledConv rgb=)."""
+        """(wt [1,cin,3], s [B,cin]) for the producer that fuses the 1x1 conv (StyledConv.forward_rgb)."""
         wt, s, _ = self.conv.style_coefficients(style)
-        return self._fusion_key(style), wt, s
+        return wt, s
 
-    def _finish(self, raw, skip=None):
-        """bias + upsampled skip on top of the raw 1x1 conv the producer computed: the same kernel
+    def finish(self, raw, skip=None):
+        """forward() when the producing StyledConv already computed the raw 1x1 modulated conv in its epilogue
+        (StyledConv.forward_rgb / forward_from_split): bias + upsampled skip on top of `raw` - the same kernel
         with a 3-channel input and identity weights."""
         require_gpu(raw, skip)
         eye = getattr(self, "_eye", None)
@@ -566,17 +562,19 @@ class Generator(nn.Module):  # :368-565
                     # fp32 activation: read by a stand-alone ToRGB, returned on an early exit, or fed
                     # to the next block as a plain tensor
                     want_out = not fused_rgb or (not is_last and s_up is None)
-                    out, split_in = conv_same.forward_from_split(split, coeffs, noise[2 * block], rgb=rgb,
-                                                                 want_out=want_out, split_for=s_up)
+                    out, raw, split_in = conv_same.forward_from_split(split, coeffs, noise[2 * block],
+                                                                      rgb=rgb if fused_rgb else None, want_out=want_out,
+                                                                      split_for=s_up)
                 else:
                     assert not isinstance(src, M.SplitActivation)  # a split is only produced for a fast block
-                    split_in = None
+                    split_in = raw = None
                     out = conv_up(src, latent[:, i], noise=noise[2 * block - 1])
-                    if conv_same.conv.fuses_torgb(out):  # ToRGB's 1x1 conv in conv_same's epilogue
-                        out = conv_same(out, latent[:, i + 1], noise=noise[2 * block], rgb=to_rgb.coefficients(rgb_style))
+                    if conv_same.conv.fuses_torgb(out) and not _observed(conv_same, to_rgb):  # ToRGB's 1x1 conv in the epilogue
+                        out, raw = conv_same.forward_rgb(out, latent[:, i + 1], noise[2 * block], to_rgb.coefficients(rgb_style))
                     else:
                         out = conv_same(out, latent[:, i + 1], noise=noise[2 * block])
-                skip = to_rgb(out, rgb_style, skip)
+                # the raw 1x1 product travels as an explicit value from the producing conv to its ToRGB
+                skip = to_rgb.finish(raw, skip) if raw is not None else to_rgb(out, rgb_style, skip)
             i += 2
         image = skip
         return (image, latent) if return_latents else (image, None)

@@ -436,7 +436,9 @@ int hf_add_bcast_f32(float *out, const float *a, const float *b, long long n, lo
  * configuration hf_modconv3x3_f32 / hf_modconv3x3_up_f32 dispatch to
  * (see the switch statements at the bottom of csrc/modconv.hip); 0 restores the
  * built-in heuristics.  Shapes a forced configuration cannot handle fall back
- * to the general kernel.  Process-global, not thread-safe: benchmarks only.
+ * to the general kernel.  The setting - like everything the three hf_debug_* hooks touch - is PER CALLING
+ * THREAD (thread_local): the library holds no process-global mutable state and its entry points are
+ * thread-compatible.  Benchmarks and tests only.
  */
 int hf_debug_set_dispatch(int same_cfg, int up_cfg);
 /* Which kernel the last modulated-conv call used: 100 * family + tile configuration id,

@@ -494,14 +494,13 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
         # form (transposed conv + blur + noise + bias + lrelu, no (2h+1)^2 intermediate) from 128^2 inputs upward
         assert up_pre == [32, 64] and up_fused == [128, 256, 512]
         assert plain_rgb.count(3) == 2 and len(plain_rgb) == 9  # two finishing passes on 3-channel input
-        # a ToRGB asked for a different style must not use the stashed product
-        out = g.convs[15](torch.randn(1, 32, 1024, 1024, device=dev), lat[:, 16], noise=nz[16],
-                          rgb=g.to_rgbs[7].coefficients(lat[:, 17]))
-        other = lat[:, 3].contiguous()
-        a = g.to_rgbs[7](out, other)
-        delattr(out, "_hf_fused_rgb")
-        b = g.to_rgbs[7](out, other)
-        assert torch.equal(a, b)
+        # module API: forward_rgb's explicit (out, raw) pair finished by ToRGB.finish equals the stand-alone ToRGB
+        x32 = torch.randn(1, 32, 1024, 1024, device=dev)
+        out, raw = g.convs[15].forward_rgb(x32, lat[:, 16], nz[16], g.to_rgbs[7].coefficients(lat[:, 17]))
+        a = g.to_rgbs[7].finish(raw, None)
+        b = g.to_rgbs[7](out, lat[:, 17])
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+        assert torch.equal(out, g.convs[15](x32, lat[:, 16], noise=nz[16])) and not hasattr(out, "_hf_fused_rgb")
     assert y.shape == (1, 3, 1024, 1024)
 
 

@@ -18,12 +18,22 @@ def sim_backend(simlib, monkeypatch):
 
     fa = sys.modules["hairfastgan_amd.stylegan2.op.fused_act"]
     up = sys.modules["hairfastgan_amd.stylegan2.op.upfirdn2d"]  # the package attribute is the function
+    ops = sys.modules["hairfastgan_amd.ops"]
 
-    for mod in (model, fa, up):
+    for mod in (model, ops):
         monkeypatch.setattr(mod, "lib", lambda: simlib)
         monkeypatch.setattr(mod, "stream", lambda: None)
+    for mod in (model, fa, up):
         monkeypatch.setattr(mod, "require_gpu", lambda *a: None)
-    return model
+    # the public ops dispatch through torch.ops.hairfast.* (CUDA kernels only): give the dispatcher CPU kernels that
+    # run the interpreted sources for the duration of the test
+    import torch as _torch
+
+    cpu_lib = _torch.library.Library("hairfast", "IMPL")
+    cpu_lib.impl("fused_bias_act", ops._fused_bias_act, "CPU")
+    cpu_lib.impl("upfirdn2d", ops._upfirdn2d, "CPU")
+    yield model
+    cpu_lib._destroy()
 
 
 def _build(model, size, n_mlp=2):
