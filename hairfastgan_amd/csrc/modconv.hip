@@ -771,8 +771,11 @@ int run_splitk(ConvParams &P, int sk, float *workspace, long long workspace_floa
   if (!workspace || workspace_floats < (long long)sk * max(1, P.groups) * P.batch * P.cout * P.out_h * P.out_w)
     return HF_E_WORKSPACE;
   const int nchunks = (P.cin + KC - 1) / KC;
-  P.splits = sk;
   P.chunks_per_split = (nchunks + sk - 1) / sk;
+  // no EMPTY split (5 splits of 2 chunks over 8 chunks): the pipelined kernel prefetches its first chunk
+  // unconditionally, an empty split would read past the end of x (a memory fault when x ends a mapped region)
+  sk = (nchunks + P.chunks_per_split - 1) / P.chunks_per_split;
+  P.splits = sk;
   P.partial = workspace;
   int rc = HF_E_INVALID;
   if (!UP && TAPS == 9) {  // double-buffered 64 co x 64 px kernel when the shape qualifies

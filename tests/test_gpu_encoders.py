@@ -218,3 +218,25 @@ def test_postprocess_vs_reference_golden(golden):
     fd = f.double()
     stats = np.array([fd.mean().item(), fd.std().item(), fd.min().item(), fd.max().item()])
     assert np.allclose(stats, G["pp_f_stats"], rtol=0, atol=REL * max(1.0, abs(G["pp_f_stats"][2]), abs(G["pp_f_stats"][3])))
+
+
+def test_split_k_without_empty_splits():
+    """Regression (round 2): 64 channels = 8 K chunks over a plane that asks for 5 splits gave a fifth, EMPTY split whose
+    pipelined kernel still prefetched 'its' first chunk - past the end of x (a GPU memory fault when x ends a mapped
+    region, as the 80 x 96 max-pool output of BiSeNet does).  x is placed at the very end of a fresh 2 MiB-aligned block."""
+    import torch.nn.functional as F
+
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = _dev()
+    torch.manual_seed(2)
+    cin, cout, h, w = 64, 64, 80, 96
+    n = cin * h * w
+    torch.cuda.empty_cache()
+    block = torch.empty(20 * 1024 * 1024 // 4, device=dev)  # a 20 MiB segment of its own: x fills its tail
+    x = block[-n:].view(1, cin, h, w).normal_()
+    wgt = torch.randn(cout, cin, 3, 3, device=dev) / 24.0
+    y = M.conv2d(lib(), stream(), x, M.conv_prepare(lib(), stream(), wgt), 3, 1, act=M.ACT_LRELU, alpha=0.0)
+    torch.cuda.synchronize()
+    close(y, F.relu(F.conv2d(x.cpu(), wgt.cpu(), padding=1)))

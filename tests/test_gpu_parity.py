@@ -591,7 +591,10 @@ def test_generator1024_fast_paths_equal_the_module_by_module_path():
         for h in hooks:
             h.remove()
     assert len(seen) == 16 and all(t is torch.Tensor for t in seen)
-    assert torch.equal(fast, slow)
+    # the conv inputs are bit-identical by construction (pre-split hand-over == in-kernel split); the images differ only
+    # through the two top ToRGBs, which the hooked path runs stand-alone (a hook on the StyledConv must see the module
+    # being called, so its epilogue cannot also produce the ToRGB product) instead of in the conv epilogue
+    assert float((fast - slow).abs().max()) <= 2e-6 * max(1.0, float(slow.abs().max()))
 
 
 # ------------------------------------------------------------------------------------------------
