@@ -56,6 +56,8 @@ SIGNATURES = {
     "hf_linear_f32": [_f, _f, _ll, _f, _f, _i, _i, _i, _fl, _st],
     "hf_equal_linear_f32": [_f, _f, _ll, _f, _f, _i, _i, _i, _fl, _i, _fl, _fl, _st],
     "hf_pixel_norm_f32": [_f, _f, _i, _i, _st],
+    "hf_bicubic_down_f32": [_f, _f, _f, _ll, _i, _i, _i, _st],
+    "hf_dilate_erode_f32": [_f, _f, _f, _ll, _i, _i, _i, _st],
     "hf_maxpool3x3s2_f32": [_f, _f, _ll, _i, _i, _st],
     "hf_gate_f32": [_f, _f, _f, _f, _f, _fl, _ll, _i, _st],
     "hf_upsample_nearest_f32": [_f, _f, _ll, _i, _i, _i, _i, _st],

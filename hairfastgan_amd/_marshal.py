@@ -714,6 +714,24 @@ def pixel_norm(lib, st, x):
     return out
 
 
+def bicubic_down(lib, st, x, k1d, factor):
+    """BicubicDownSample.forward (utils/bicubic.py): x [B,C,H,W] -> [B,C,H/factor,W/factor]."""
+    x, k1d = _c(x), _c(k1d)
+    b, c, h, w = x.shape
+    out = x.new_empty((b, c, h // factor, w // factor))
+    check(lib, lib.hf_bicubic_down_f32(_p(out), _p(x), _p(k1d), b * c, h, w, factor, st), "hf_bicubic_down_f32")
+    return out
+
+
+def dilate_erode(lib, st, mask, radius):
+    """DilateErosion.mask on a binary float mask [..., H, W] -> (dilated, eroded)."""
+    mask = _c(mask)
+    h, w = mask.shape[-2:]
+    dil, ero = torch.empty_like(mask), torch.empty_like(mask)
+    check(lib, lib.hf_dilate_erode_f32(_p(dil), _p(ero), _p(mask), mask.numel() // (h * w), h, w, radius, st), "hf_dilate_erode_f32")
+    return dil, ero
+
+
 def maxpool3x3s2(lib, st, x):
     x = _c(x)
     b, c, h, w = x.shape

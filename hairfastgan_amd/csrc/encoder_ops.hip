@@ -391,6 +391,64 @@ __global__ __launch_bounds__(256) void parsing_mask(long long *__restrict__ out,
   }
 }
 
+// ---- the stencils on either side of the hot path ----
+// BicubicDownSample.forward (utils/bicubic.py:38-75): reflect padding, then the separable 4*factor-tap filter k
+// applied down the columns (stride factor) and along the rows (stride factor), fp32.  One thread per output pixel:
+// the column sums of its 4*factor input columns first, then their weighted sum - the reference's order of the
+// two 1-D passes.
+constexpr int kBicMaxTaps = 32;
+__global__ __launch_bounds__(256) void bicubic_down(float *__restrict__ out, const float *__restrict__ x,
+                                                    const float *__restrict__ k1d, long long planes, int h, int w, int factor,
+                                                    int oh, int ow) {
+  const int taps = 4 * factor, lo = (taps - factor) / 2;
+  float k[kBicMaxTaps];
+#pragma unroll
+  for (int i = 0; i < kBicMaxTaps; ++i) k[i] = (i < taps) ? k1d[i] : 0.0f;
+  const long long total = planes * oh * ow, stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int ox = (int)(t % ow), oy = (int)((t / ow) % oh);
+    const float *src = x + (t / ((long long)oh * ow)) * h * w;
+    float acc = 0.0f;
+    for (int j = 0; j < taps; ++j) {
+      int ix = ox * factor + j - lo;
+      ix = ix < 0 ? -ix : (ix >= w ? 2 * (w - 1) - ix : ix);  // F.pad(mode='reflect')
+      float col = 0.0f;
+      for (int i = 0; i < taps; ++i) {
+        int iy = oy * factor + i - lo;
+        iy = iy < 0 ? -iy : (iy >= h ? 2 * (h - 1) - iy : iy);
+        col = fmaf(k[i], src[(long long)iy * w + ix], col);
+      }
+      acc = fmaf(k[j], col, acc);
+    }
+    out[t] = acc;
+  }
+}
+
+// DilateErosion.mask (utils/image_utils.py:42-55) on a BINARY mask: `radius` rounds of the 4-neighbourhood cross
+// (dilation: any neighbour set; erosion: all five set, outside the image counts as unset) = one pass with the
+// diamond |dy| + |dx| <= radius.
+__global__ __launch_bounds__(256) void dilate_erode(float *__restrict__ dil, float *__restrict__ ero,
+                                                    const float *__restrict__ mask, long long planes, int h, int w, int radius) {
+  const long long total = planes * h * w, stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int xx = (int)(t % w), yy = (int)((t / w) % h);
+    const float *src = mask + (t / ((long long)h * w)) * h * w;
+    bool any = false, all = true;
+    for (int dy = -radius; dy <= radius; ++dy) {
+      const int r = radius - (dy < 0 ? -dy : dy);
+      for (int dx = -r; dx <= r; ++dx) {
+        const int y = yy + dy, x_ = xx + dx;
+        const bool in = y >= 0 && y < h && x_ >= 0 && x_ < w;
+        const bool set = in && src[(long long)y * w + x_] > 0.0f;
+        any = any || set;
+        all = all && set;
+      }
+    }
+    dil[t] = any ? 1.0f : 0.0f;
+    ero[t] = all ? 1.0f : 0.0f;
+  }
+}
+
 __global__ __launch_bounds__(256) void axpby_bcast(float *__restrict__ out, const float *__restrict__ a, float alpha,
                                                    const float *__restrict__ b, float beta, long long n, long long period) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -556,6 +614,25 @@ extern "C" int hf_parsing_mask_i64(long long *out, const float *logits, const in
   const long long total = (long long)images * out_h * out_w;
   hipLaunchKernelGGL(parsing_mask, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, out, logits, remap, classes, h, w,
                      full_h, full_w, out_h, out_w, total);
+  return hf_launch_status();
+}
+
+extern "C" int hf_bicubic_down_f32(float *out, const float *x, const float *k1d, long long planes, int h, int w, int factor,
+                                   void *stream) {
+  if (!out || !x || !k1d || planes <= 0 || factor < 1 || 4 * factor > kBicMaxTaps || h % factor || w % factor ||
+      h < 4 * factor || w < 4 * factor)
+    return HF_E_INVALID;
+  const int oh = h / factor, ow = w / factor;
+  hipLaunchKernelGGL(bicubic_down, dim3(grid_for(planes * oh * ow)), dim3(256), 0, (hipStream_t)stream, out, x, k1d, planes, h, w,
+                     factor, oh, ow);
+  return hf_launch_status();
+}
+
+extern "C" int hf_dilate_erode_f32(float *dilated, float *eroded, const float *mask, long long planes, int h, int w, int radius,
+                                   void *stream) {
+  if (!dilated || !eroded || !mask || planes <= 0 || h <= 0 || w <= 0 || radius < 0 || radius > 64) return HF_E_INVALID;
+  hipLaunchKernelGGL(dilate_erode, dim3(grid_for(planes * h * w)), dim3(256), 0, (hipStream_t)stream, dilated, eroded, mask, planes,
+                     h, w, radius);
   return hf_launch_status();
 }
 

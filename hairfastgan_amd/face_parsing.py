@@ -217,5 +217,5 @@ class BiSeNet(FrozenPlanMixin, nn.Module):  # model.py:230-253
 
 def get_segmentation(net, img_rgb, resize=True):
     """models/Net.py:108-115 with the BiSeNet instance passed in (the reference keeps a class-level singleton):
-    img_rgb [1,3,H,W] ImageNet-normalised -> long [1,1,256,256] (or [1,1,H,W])."""
+    img_rgb [B,3,H,W] ImageNet-normalised -> long [B,1,256,256] (or [B,1,H,W]); the reference takes B = 1."""
     return net.parse(img_rgb, resize=resize, remap=True)

@@ -17,8 +17,9 @@ What runs where:
   With the reference installed they are its own modules (INTEGRATION.md shows the binding);
   `SyntheticStages` provides shape- and dtype-faithful stand-ins so that the complete call
   schedule can be executed and timed on a box that has neither the reference nor checkpoints;
-* the small tensor glue between them (normalisation, the bicubic down-samplers, dilation /
-  erosion, mask arithmetic) is written with torch ops, as in the reference.
+* the stencils on either side of the path (BicubicDownSample, DilateErosion: row f2) are HIP kernels too;
+  the remaining glue (normalisation, mask arithmetic, two small F.interpolate calls) is torch elementwise
+  code, as in the reference.
 
 One scheduling change against the reference: the two batch-1
 full generator forwards of `Alignment.shape_module` (Alignment.py:63, once for (face, shape)
@@ -37,6 +38,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _marshal as M
+from ._runtime import lib, require_gpu, stream
 from .encoders import Encoder4Editing, FSEncoder, PostProcessModel, get_latents
 from .face_parsing import BiSeNet, get_segmentation
 from .net import Net
@@ -71,8 +74,9 @@ def _normalize(x, mean, std):
 
 
 class BicubicDownSample(nn.Module):
-    """utils/bicubic.py:6-75: separable bicubic (a = -0.5) down-sampling by `factor` with
-    reflect padding, as two strided 1-D convolutions."""
+    """utils/bicubic.py:6-75: separable bicubic (a = -0.5) down-sampling by `factor` with reflect padding
+    (hf_bicubic_down_f32; the reference's two strided F.conv2d passes fall to MIOpen's naive kernel on this
+    stack: 2 ms per call, a third of a swap)."""
 
     def __init__(self, factor=4):
         super().__init__()
@@ -82,24 +86,21 @@ class BicubicDownSample(nn.Module):
         ax = x.abs()
         k = torch.where(ax <= 1.0, (a + 2.0) * ax ** 3 - (a + 3.0) * ax ** 2 + 1.0,
                         torch.where(ax < 2.0, a * ax ** 3 - 5.0 * a * ax ** 2 + 8.0 * a * ax - 4.0 * a, torch.zeros_like(ax)))
-        k = k / k.sum()
-        self.register_buffer("k1", k.view(1, 1, size, 1).repeat(3, 1, 1, 1), persistent=False)
-        self.register_buffer("k2", k.view(1, 1, 1, size).repeat(3, 1, 1, 1), persistent=False)
+        self.register_buffer("k", k / k.sum(), persistent=False)
 
     def forward(self, x):
-        f = self.factor
-        pad = f * 4 - f
-        lo, hi = pad // 2, pad - pad // 2
-        x = F.conv2d(F.pad(x, (0, 0, lo, hi), "reflect"), self.k1.to(x.device), stride=(f, 1), groups=3)
-        return F.conv2d(F.pad(x, (lo, hi, 0, 0), "reflect"), self.k2.to(x.device), stride=(1, f), groups=3)
+        require_gpu(x)
+        if self.k.device != x.device:
+            self.k = self.k.to(x.device)
+        return M.bicubic_down(lib(), stream(), x, self.k, self.factor)
 
 
 class DilateErosion:
-    """utils/image_utils.py:27-55: `dilate_erosion` rounds of 4-neighbourhood dilation / erosion."""
+    """utils/image_utils.py:27-55: `dilate_erosion` rounds of 4-neighbourhood dilation / erosion of BINARY masks
+    (hf_dilate_erode_f32: one pass with the equivalent diamond)."""
 
     def __init__(self, dilate_erosion=5, device="cuda"):
         self.dilate_erosion = dilate_erosion
-        self.weight = torch.tensor([[0.0, 1.0, 0.0], [1.0, 1.0, 1.0], [0.0, 1.0, 0.0]])[None, None].to(device)
 
     def hair_from_mask(self, mask):
         mask = torch.where(mask == 13, torch.ones_like(mask), torch.zeros_like(mask))
@@ -107,12 +108,8 @@ class DilateErosion:
         return self.mask(mask)
 
     def mask(self, mask):
-        n = len(mask)
-        masks = mask.clone().repeat(*([2] + [1] * (mask.ndim - 1))).float()
-        for _ in range(self.dilate_erosion):
-            masks = F.conv2d(masks, self.weight.to(masks.device), padding=1)
-            masks = torch.cat([(masks[:n] > 0).float(), (masks[n:] == 5.0).float()], 0)
-        return masks[:n], masks[n:]
+        require_gpu(mask)
+        return M.dilate_erode(lib(), stream(), mask.float(), self.dilate_erosion)
 
 
 def equal_replacer(images):
@@ -256,7 +253,8 @@ class Embedding(nn.Module):  # models/Embedding.py:17-117
             latent_S = output.pop()  # [bs, 18, 512]
             latent_F, _ = self.net.generator([latent_S], input_is_latent=True, return_latents=False, start_layer=3,
                                              end_layer=3, layer_in=latent)
-            masks = torch.cat([get_segmentation(self.parsing, im.unsqueeze(0)) for im in self.to_bisenet(im_512)])  # BiSeNet
+            # BiSeNet: the reference parses the images one by one (:81); the batch is one call here (samples are independent)
+            masks = get_segmentation(self.parsing, self.to_bisenet(im_512))
             if len(images_to_name) > 1:  # mixing if we change the colour or the shape
                 hair_mask = (masks == 13).float()
                 hair_mask = F.interpolate(hair_mask, size=(32, 32), mode="bicubic")
@@ -295,11 +293,9 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
             w1, w2 = name_to_embed[a]["W"], name_to_embed[b]["W"]
             lat.append(torch.cat((self.stages.rotate(w2[:, :6], w1[:, :6]), w2[:, 6:]), dim=1))
         I_rot, _ = self.net.generator([torch.cat(lat, 0)], input_is_latent=True, return_latents=False)
-        out = {}
-        for k, key in enumerate(todo):
-            seg_in = Embedding.to_bisenet(((I_rot[k:k + 1] + 1) / 2).clip(0, 1))
-            out[key] = (I_rot[k:k + 1], get_segmentation(self.parsing, seg_in))  # the 1024^2 image is parsed (:65-67)
-        return out
+        seg_in = Embedding.to_bisenet(((I_rot + 1) / 2).clip(0, 1))
+        masks = get_segmentation(self.parsing, seg_in)  # the 1024^2 images are parsed (:65-67), both in one call
+        return {key: (I_rot[k:k + 1], masks[k:k + 1]) for k, key in enumerate(todo)}
 
     @torch.inference_mode()
     def shape_module(self, im_name1, im_name2, name_to_embed, only_target=True, rotated=None, **kwargs):  # :40-99

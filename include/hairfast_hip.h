@@ -413,6 +413,18 @@ int hf_upsample_nearest_f32(float *out, const float *x, long long planes, int h,
 int hf_parsing_mask_i64(long long *out, const float *logits, const int *remap, int images, int classes, int h, int w,
                         int full_h, int full_w, int out_h, int out_w, void *stream);
 
+/* ---- stencils on either side of the hot path ---- */
+/* BicubicDownSample.forward (utils/bicubic.py:38-75): reflect padding + the separable 4*factor-tap bicubic filter
+ * k1d (device, 4*factor floats, normalised; the module's k), stride factor along both axes:
+ * x [planes, h, w] -> out [planes, h/factor, w/factor]; h, w multiples of factor (the pipeline: 1024 -> 512 / 256). */
+int hf_bicubic_down_f32(float *out, const float *x, const float *k1d, long long planes, int h, int w, int factor,
+                        void *stream);
+/* DilateErosion.mask (utils/image_utils.py:42-55) on a BINARY (0/1) mask [planes, h, w]: `radius` = dilate_erosion
+ * rounds of the 4-neighbourhood cross, i.e. one pass with the diamond |dy|+|dx| <= radius; pixels outside the image
+ * count as unset (the conv's zero padding).  dilated / eroded: 0/1 floats, same shape. */
+int hf_dilate_erode_f32(float *dilated, float *eroded, const float *mask, long long planes, int h, int w, int radius,
+                        void *stream);
+
 /* ---- PostProcessModel's latent branch (models/Encoders.py:13-32, 119-131) ----
  * F.layer_norm over the last `dim` elements of each of `rows` rows (biased variance, eps inside the sqrt):
  * gamma / beta [dim] = elementwise affine (both NULL: LayerNorm(elementwise_affine=False), :19), lrelu != 0

@@ -359,20 +359,18 @@ def main():
     from utils.bicubic import BicubicDownSample as RefBicubic
     from utils.image_utils import DilateErosion as RefDilateErosion
 
-    from hairfastgan_amd import hair_swap as HS  # torch glue of the product (CPU-runnable), checked against the reference
-
+    # the reference's own stencil classes -> golden vectors (the product's HIP kernels are checked against them in
+    # tests/test_sim_parsing.py and tests/test_gpu_schedule.py)
     g = {}
     xg = C.unit_input("glue/bicubic", (2, 3, 64, 64))
-    assert want("glue") or want("pp") or only is not None
     for f in (2, 4):
-        y = RefBicubic(factor=f, cuda=False)(xg)
-        report[f"glue/bicubic{f}"] = maxdiff(y, HS.BicubicDownSample(f)(xg))
-        g[f"bicubic{f}"] = y.numpy()
+        g[f"bicubic{f}"] = RefBicubic(factor=f, cuda=False)(xg).numpy()
     mask = (C.unit_input("glue/mask", (3, 1, 48, 48)) > 0.3).float()
     d_ref, e_ref = RefDilateErosion(dilate_erosion=3, device="cpu").mask(mask)
-    d_my, e_my = HS.DilateErosion(3, "cpu").mask(mask)
-    report["glue/dilate"], report["glue/erode"] = maxdiff(d_ref, d_my), maxdiff(e_ref, e_my)
     g["dilate3"], g["erode3"] = d_ref.numpy(), e_ref.numpy()
+    mask5 = (C.unit_input("glue/mask5", (2, 1, 256, 256)) > 0.8).float()
+    d_ref, e_ref = RefDilateErosion(dilate_erosion=5, device="cpu").mask(mask5)
+    g["dilate5"], g["erode5"] = np.packbits(d_ref.numpy().astype(np.uint8)), np.packbits(e_ref.numpy().astype(np.uint8))
     np.savez_compressed(os.path.join(args.out, "glue.npz"), **g)
 
     if not args.skip_big and want("pp"):

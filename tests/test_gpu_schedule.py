@@ -160,3 +160,27 @@ def test_swap_many_forced_rccl_single_rank():
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_glue_stencils_vs_reference_golden(golden):
+    """BicubicDownSample / DilateErosion on the GPU against golden vectors from the reference's classes (incl. the
+    pipeline's own setting: 5 rounds on 256^2 masks)."""
+    import numpy as np
+
+    from hairfastgan_amd.hair_swap import BicubicDownSample, DilateErosion
+
+    dev = torch.device("cuda:0")
+    G = golden("glue.npz")
+    x = C.unit_input("glue/bicubic", (2, 3, 64, 64)).to(dev)
+    for f in (2, 4):
+        y = BicubicDownSample(f).to(dev)(x)
+        assert float((y.cpu() - torch.from_numpy(G[f"bicubic{f}"])).abs().max()) < 2e-6
+    big = torch.rand(1, 3, 1024, 1024, device=dev)
+    assert tuple(BicubicDownSample(4)(big).shape) == (1, 3, 256, 256) and tuple(BicubicDownSample(2)(big).shape) == (1, 3, 512, 512)
+    mask = (C.unit_input("glue/mask", (3, 1, 48, 48)) > 0.3).float().to(dev)
+    d, e = DilateErosion(3, dev).mask(mask)
+    assert torch.equal(d.cpu(), torch.from_numpy(G["dilate3"])) and torch.equal(e.cpu(), torch.from_numpy(G["erode3"]))
+    mask5 = (C.unit_input("glue/mask5", (2, 1, 256, 256)) > 0.8).float().to(dev)
+    d, e = DilateErosion(5, dev).mask(mask5)
+    assert np.array_equal(np.packbits(d.cpu().numpy().astype(np.uint8)), G["dilate5"])
+    assert np.array_equal(np.packbits(e.cpu().numpy().astype(np.uint8)), G["erode5"])

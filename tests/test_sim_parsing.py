@@ -93,3 +93,18 @@ def test_bisenet_small_image_vs_oracle(sim_parsing):
     flips = mask[0, 0] != ref_mask[0, 0]
     assert int(flips.sum()) == 0 or float(margin[flips].max()) < 2e-4 * scale  # indices agree wherever the decision is not a near-tie
     assert tuple(get_segmentation(net, x).shape) == (1, 1, 256, 256)
+
+
+def test_glue_stencils_vs_reference_golden(simlib, golden):
+    """BicubicDownSample (utils/bicubic.py) and DilateErosion.mask (utils/image_utils.py) as HIP kernels against golden
+    vectors from the reference's own classes."""
+    from hairfastgan_amd.hair_swap import BicubicDownSample
+
+    G = golden("glue.npz")
+    x = C.unit_input("glue/bicubic", (2, 3, 64, 64))
+    for f in (2, 4):
+        y = M.bicubic_down(simlib, None, x, BicubicDownSample(f).k, f)
+        assert float((y - torch.from_numpy(G[f"bicubic{f}"])).abs().max()) < 2e-6
+    mask = (C.unit_input("glue/mask", (3, 1, 48, 48)) > 0.3).float()
+    d, e = M.dilate_erode(simlib, None, mask, 3)
+    assert torch.equal(d, torch.from_numpy(G["dilate3"])) and torch.equal(e, torch.from_numpy(G["erode3"]))

@@ -11,13 +11,17 @@ import sys
 
 
 def label(name):
-    m = re.search(r"conv_mfma_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d+)ELb(\d)E", name)
+    m = re.search(r"conv_mfma_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d+)ELb(\d)ELb(\d)E", name)
     if m:
-        nt, ct, pg, wc, wp, mod, up, tw, pre = (int(v) for v in m.groups())
+        nt, ct, pg, wc, wp, mod, up, tw, pre, fuse = (int(v) for v in m.groups())
         return (f"conv_mfma_h<{ct},{pg},{wc},{wp}{',tw%d' % tw if tw > 32 else ''}{',up' if up else ''}"
-                f"{',pre' if pre else ''}>")
+                f"{',pre' if pre else ''}{',fuse' if fuse else ''}>")
     if "blur4x4_split8" in name:
         return "blur4x4_split8"
+    me = re.search(r"conv_enc_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)E", name)
+    if me:
+        nt, pg, wpx, stride, pre = (int(v) for v in me.groups())
+        return f"conv_enc_h<{'64x%d' % (32 * pg * wpx)}{',stride2' if stride == 2 else ''}{',pre' if pre else ''}>"
     name = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     m = re.match(r"(conv_mfma\w*)<(.*)>", name)
     if not m:
@@ -46,7 +50,7 @@ def main():
     busy = gui = None
     if len(sys.argv) > 3:
         busy, gui = agg(sys.argv[3], "SQ_VALU_MFMA_BUSY_CYCLES"), agg(sys.argv[3], "GRBM_GUI_ACTIVE")
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE (separate passes), "
+    out = {"tag": os.environ.get("PROFILE_TAG", "untagged"), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE (separate passes), "
                      "python bench.py --steps 1 --warmup 1 --no-exact-f32; KiB*1024; FETCH_SIZE not doubled (uncalibrated for "
                      "dword halo loads, MI355X_MICROARCH.md HBM section); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
                      "(GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs), i.e. relative to the clock the kernel actually ran at",

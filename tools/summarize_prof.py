@@ -9,13 +9,17 @@ import sys
 
 
 def short(name):
-    m = re.search(r"conv_mfma_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d+)ELb(\d)E", name)
+    m = re.search(r"conv_mfma_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d+)ELb(\d)ELb(\d)E", name)
     if m:  # anonymous-namespace templates come out mangled
-        nt, ct, pg, wc, wp, mod, up, tw, pre = (int(v) for v in m.groups())
+        nt, ct, pg, wc, wp, mod, up, tw, pre, fuse = (int(v) for v in m.groups())
         return (f"conv_mfma_h<NTERMS={nt},{ct},{pg},{wc},{wp}{',tw%d' % tw if tw > 32 else ''}{',up' if up else ''}"
-                f"{',pre' if pre else ''}>")
+                f"{',pre' if pre else ''}{',fuse' if fuse else ''}>")
     if "blur4x4_split8" in name:
         return "blur4x4_split8"
+    me = re.search(r"conv_enc_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)E", name)
+    if me:
+        nt, pg, wpx, stride, pre = (int(v) for v in me.groups())
+        return f"conv_enc_h<{'64x%d' % (32 * pg * wpx)}{',stride2' if stride == 2 else ''}{',pre' if pre else ''}>"
     if "split_weights" in name:
         return "split_weights"
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
