@@ -70,6 +70,7 @@ SIGNATURES = {
     "hf_debug_set_dispatch": [_i, _i],
     "hf_debug_last_path": [],
     "hf_debug_set_persistent_blocks": [_i],
+    "hf_debug_set_tuning": [_i],
 }
 
 

@@ -73,6 +73,7 @@ struct ConvParams {
   void *oh, *ol;
   const float *s_next;
   float blur_kx[4], blur_ky[4];  // convh.hip FUSE: flipped 1-D factors of the (rank-1) 4x4 blur kernel applied in the epilogue
+  int dma_early;               // convh.hip PRE: issue a stage's DMAs in its first tap-step (short K loops) instead of spread
   int n_tiles;                 // convh.hip: tiles over all families; a block walks blockIdx.x + k*gridDim.x
   TileGeom g[3];
 };
@@ -231,6 +232,7 @@ inline int geom_xs(const TileGeom &g, int stride, int ext) {
 // Returns HF_E_INVALID when the shape does not qualify.
 int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wt_hi, const void *wt_lo, hipStream_t st);
 extern thread_local int g_h_blocks;           // hf_debug_set_persistent_blocks: resident blocks the convh.hip grid is sized for (0 = 256 CUs)
+extern thread_local int g_h_tune;             // hf_debug_set_tuning: bit 0 force early stage DMAs, bit 1 force spread ones (convh.hip)
 extern thread_local int g_force_h;            // hf_debug_set_dispatch same_cfg 51/52: force the convh.hip tile configuration
 void note_path(int path, int cfg);  // records what hf_debug_last_path reports
 // split-K second pass (modconv.hip): out = epilogue(d * sum_z partial[z]), deterministic

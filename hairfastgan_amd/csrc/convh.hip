@@ -87,6 +87,24 @@ constexpr int halo_pixels_max() {
 // are no rim tile families).  Horizontal taps come from the neighbouring lanes (shuffles), vertical taps
 // from the wave's other row or - across waves - through the LDS stage buffer that is free during the
 // epilogue, four channels per lane at a time.  The blur kernel must be separable (rank 1).
+// Order in which a chunk's 9 taps are processed.  Same-res: natural order, every tap has its own activation
+// fragment.  UP: a tap reads the input position (Y - (ky==2), X - (kx==2)), so only FOUR distinct activation
+// fragments exist per chunk; the taps are grouped by fragment - {0,1,3,4} {2,5} {6,7} {8} - and a fragment is
+// fetched from LDS once per group instead of once per tap (8*PG instead of 18*PG ds_read_b128 per chunk: with
+// 32-channel-wide wave tiles the fragment reads alone saturated the LDS port at the MFMA rate).
+template <bool UP>
+__host__ __device__ constexpr int tap_at(int i) {
+  return !UP ? i : (i == 2 ? 3 : i == 3 ? 4 : i == 4 ? 2 : i);  // 0 1 3 4 2 5 6 7 8
+}
+template <bool UP>
+__host__ __device__ constexpr int tap_group(int i) {  // index of the activation fragment of position i
+  return !UP ? i : (i < 4 ? 0 : i < 6 ? 1 : i < 8 ? 2 : 3);
+}
+template <bool UP>
+__host__ __device__ constexpr int group_first(int g) {  // first position of group g (9 = none)
+  return !UP ? g : (g == 0 ? 0 : g == 1 ? 4 : g == 2 ? 6 : g == 3 ? 8 : 9);
+}
+
 template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool MOD, bool UP, int TWMAX, bool PRE, bool FUSE = false>
 __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const ConvParams P,
                                                                           const _Float16 *__restrict__ wth,
@@ -665,68 +683,79 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       // UP with in-kernel staging: 128 accumulator registers + the staging registers leave no room
       // for a second fragment set
       constexpr int NSLOT = (UP && !PRE) ? 1 : 2;
+      // PRE: all DMAs of the next stage in the first tap-step (short K loops: HBM latency exceeds the stage's MFMA
+      // time, the copies need the whole stage to land) or spread one per tap-step (long K loops, see DMA_PER_STEP)
+      const bool early = PRE && P.dma_early;
       half8 ah[NSLOT][CT_TILES], al[NSLOT][CT_TILES], bh[NSLOT][PG], bl[NSLOT][PG];
-      auto fetch = [&](int slot, int tap) {
-        const int ky = tap / 3, kx = tap % 3;
-        const int brow = UP ? (ky == 2 ? 0 : 1) : ky, bcol = UP ? (kx == 2 ? 0 : 1) : kx;
+      auto fetch_a = [&](int slot, int tap) {
 #pragma unroll
         for (int ct = 0; ct < CT_TILES; ++ct) {
           ah[slot][ct] = a_hi[tap * 2 * CT + ct * 32];
           if (NTERMS == 3) al[slot][ct] = a_hi[OFF_WL + tap * 2 * CT + ct * 32];
         }
+      };
+      auto fetch_b = [&](int slot, int tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const int brow = UP ? (ky == 2 ? 0 : 1) : ky, bcol = UP ? (kx == 2 ? 0 : 1) : kx;
 #pragma unroll
         for (int g = 0; g < PG; ++g) {
           bh[slot][g] = b_hi[pixrow[g][brow] + bcol];
           if (NTERMS == 3) bl[slot][g] = b_hi[X_UNITS + pixrow[g][brow] + bcol];
         }
       };
-      fetch(0, 0);
+      fetch_a(0, tap_at<UP>(0));
+      fetch_b(0, tap_at<UP>(0));
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int sl_ = (NSLOT == 1) ? 0 : (tap & 1);
+      for (int i = 0; i < 9; ++i) {
+        const int tap = tap_at<UP>(i);  // the side work below is scheduled by POSITION i
+        const int grp = tap_group<UP>(i);
+        const int sa = (NSLOT == 1) ? 0 : (i & 1), sb = (NSLOT == 1) ? 0 : (grp & 1);
         if (NSLOT == 1) {
-          if (tap > 0) fetch(0, tap);
-        } else if (tap + 1 < 9) {
-          fetch(sl_ ^ 1, tap + 1);
+          if (i > 0) fetch_a(0, tap);
+          if (i > 0 && group_first<UP>(grp) == i) fetch_b(0, tap);
+        } else {
+          if (i + 1 < 9) fetch_a(sa ^ 1, tap_at<UP>(i + 1));
+          // the next group's activation fragment, as soon as its slot is free (= when this group starts)
+          if (group_first<UP>(grp) == i && group_first<UP>(grp + 1) < 9) fetch_b(sb ^ 1, tap_at<UP>(group_first<UP>(grp + 1)));
         }
         // ---- side work of this step ----
         if (more1) {
 #pragma unroll
-          for (int i = 0; i < ND; ++i)
-            if (i / DMA_PER_STEP == tap) dma_piece(i, cpf, cb ^ 1);
+          for (int j = 0; j < ND; ++j)
+            if ((early ? 0 : j / DMA_PER_STEP) == i) dma_piece(j, cpf, cb ^ 1);
         }
         if (PRE && more1) {  // activation DMAs in tap-steps 1, 3, 5, ...
 #pragma unroll
           for (int e = 0; e < XE; ++e)
-            if (tap == ((2 * XE <= 9) ? 1 + 2 * e : 1 + e)) dma_x(e, cpf, cb ^ 1);
+            if (i == (early ? 0 : ((2 * XE <= 9) ? 1 + 2 * e : 1 + e))) dma_x(e, cpf, cb ^ 1);
         }
-        if (!PRE && more1 && tap == 0) {
+        if (!PRE && more1 && i == 0) {
 #pragma unroll
           for (int e = 0; e < XE; ++e) load_item(e, cpf);
         }
         // (staggering the conversions over the two waves of a SIMD - early half in taps 3-5 - was
         // measured 5-15 % slower: the early half then waits on its loads)
-        if (more1 && tap == 9 - XE) HF_TRACE_POINT(5);  // before the first conversion (waits for the loads)
-        if (!PRE && more1 && tap >= 9 - XE) convert_item(tap - (9 - XE), cpf, nbuf);
-        if (more1 && tap == 8) HF_TRACE_POINT(6);  // conversions done
+        if (more1 && i == 9 - XE) HF_TRACE_POINT(5);  // before the first conversion (waits for the loads)
+        if (!PRE && more1 && i >= 9 - XE) convert_item(i - (9 - XE), cpf, nbuf);
+        if (more1 && i == 8) HF_TRACE_POINT(6);  // conversions done
         __builtin_amdgcn_sched_barrier(0);
         const int ph = UP ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) : 0;
 #pragma unroll
         for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
           for (int g = 0; g < PG; ++g)
-            acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl_][ct], bh[sl_][g], acc[ph][ct][g], 0, 0, 0);
+            acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sa][ct], bh[sb][g], acc[ph][ct][g], 0, 0, 0);
         if (NTERMS == 3) {
 #pragma unroll
           for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
             for (int g = 0; g < PG; ++g)
-              acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl_][ct], bl[sl_][g], acc[ph][ct][g], 0, 0, 0);
+              acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sa][ct], bl[sb][g], acc[ph][ct][g], 0, 0, 0);
 #pragma unroll
           for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
             for (int g = 0; g < PG; ++g)
-              acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl_][ct], bh[sl_][g], acc[ph][ct][g], 0, 0, 0);
+              acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sa][ct], bh[sb][g], acc[ph][ct][g], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -845,6 +874,7 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
   if (P.rgb_out && (UP || WAVES_CO != 1 || P.cout != CT || !P.rgb_w || !P.rgb_s)) return HF_E_INVALID;
   if (lds > 160 * 1024) return HF_E_INVALID;
   P.n_tiles = nblocks;
+  P.dma_early = (g_h_tune & 1) ? 1 : ((g_h_tune & 2) ? 0 : (P.cin / KH <= 8));
   // LDS allows one block per CU: size the grid to the chip and let each block walk its share
   // of the tiles as one pipeline (the tile-to-tile hand-over needs >= 2 stages per tile)
   const int co_tiles = P.cout / CT;
@@ -881,6 +911,7 @@ namespace hf_detail {
 // tuning / test hooks: per-thread state (no process-global mutable state in the library)
 thread_local int g_force_h = 0;
 thread_local int g_h_blocks = 0;
+thread_local int g_h_tune = 0;
 
 int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const void *wtl, hipStream_t st) {
   const _Float16 *h = static_cast<const _Float16 *>(wth), *l = static_cast<const _Float16 *>(wtl);
@@ -1020,6 +1051,11 @@ extern "C" int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *s
                 : launch_h<3, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
   if (rc == HF_OK) note_path(5, x_hi ? 93 : 73);
   return rc;
+}
+
+extern "C" int hf_debug_set_tuning(int bits) {
+  hf_detail::g_h_tune = bits;
+  return HF_OK;
 }
 
 extern "C" int hf_debug_set_persistent_blocks(int blocks) {

@@ -63,7 +63,8 @@ def prep_conv(conv):
 
 # Which convs hand the fp16-core kernel a PRE-SPLIT input (one hf_split_activation_f16 pass, then LDS-DMA
 # staging) instead of converting while staging: "heads" = the e4e style-head levels, whose input feeds
-# up to 88 (group, channel-tile) block columns; "all" = every eligible conv; "none".  Tuning knob.
+# up to 88 (group, channel-tile) block columns; "all" = also every conv with >= 8 block columns per input tile
+# (512+ output channels: the deep encoder stages, PostProcess's 512-1024 channel trunk); "none".  Tuning knob.
 PRESPLIT = os.environ.get("HAIRFAST_ENC_PRESPLIT", "all")
 
 
@@ -77,7 +78,10 @@ def conv(x, w, k, stride=1, presplit=False, **kw):
     if mode != "f32" and M.conv2d_f16_supported(w.cin, w.cout, h, wd, k, stride):
         hi, lo = w.f16()
         nterms = 3 if mode == "f16x3" else 1
-        if PRESPLIT == "all" or (presplit and PRESPLIT == "heads"):
+        groups = kw.get("groups", 1)
+        # worth a separate pass when the same input tile is converted by many (group, 64-channel) block columns
+        many = groups * (w.cout // 64) >= 8
+        if (PRESPLIT == "all" and many) or (presplit and PRESPLIT in ("all", "heads")):
             x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None),
                                        want_lo=nterms == 3)
         return M.conv2d_f16(lib(), stream(), x, hi, lo, nterms, w.cout, stride, **kw)
