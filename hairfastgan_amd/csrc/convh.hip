@@ -92,16 +92,22 @@ constexpr int halo_pixels_max() {
 // fragments exist per chunk; the taps are grouped by fragment - {0,1,3,4} {2,5} {6,7} {8} - and a fragment is
 // fetched from LDS once per group instead of once per tap (8*PG instead of 18*PG ds_read_b128 per chunk: with
 // 32-channel-wide wave tiles the fragment reads alone saturated the LDS port at the MFMA rate).
-template <bool UP>
+#ifndef HF_H_TAP_NATURAL
+#define HF_H_TAP_NATURAL 0  // experiments: 1 = natural tap order for UP as well (one fragment fetch per tap)
+#endif
+template <bool UP_>
 __host__ __device__ constexpr int tap_at(int i) {
+  constexpr bool UP = UP_ && !HF_H_TAP_NATURAL;
   return !UP ? i : (i == 2 ? 3 : i == 3 ? 4 : i == 4 ? 2 : i);  // 0 1 3 4 2 5 6 7 8
 }
-template <bool UP>
+template <bool UP_>
 __host__ __device__ constexpr int tap_group(int i) {  // index of the activation fragment of position i
+  constexpr bool UP = UP_ && !HF_H_TAP_NATURAL;
   return !UP ? i : (i < 4 ? 0 : i < 6 ? 1 : i < 8 ? 2 : 3);
 }
-template <bool UP>
+template <bool UP_>
 __host__ __device__ constexpr int group_first(int g) {  // first position of group g (9 = none)
+  constexpr bool UP = UP_ && !HF_H_TAP_NATURAL;
   return !UP ? g : (g == 0 ? 0 : g == 1 ? 4 : g == 2 ? 6 : g == 3 ? 8 : 9);
 }
 
@@ -181,6 +187,8 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     if (P.n_geom > 1 && t >= G1.first_block) T.gi = 1;
     if (P.n_geom > 2 && t >= G2.first_block) T.gi = 2;
     const TileGeom G = geom(T.gi);
+    // (integer divisions: a reciprocal-multiply form of these and of the halo-item division below measured
+    // no gain on the same-resolution kernels and 5-9 % slower fused upsampling kernels)
     int r = t - G.first_block;
     const int tx = r % G.tiles_x;
     r /= G.tiles_x;
@@ -214,14 +222,22 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   };
   // 2^-k of the weights' power-of-two pre-scale (trailer of wt_hi, see split_weights): folded into d
   const float w_unscale = *reinterpret_cast<const float *>(wth + 9LL * P.cin * P.cout);
+  // Straight-line epilogue for the generator's standard StyledConv tail (noise + bias + leaky ReLU, * scale):
+  // lrelu is positively homogeneous, so with 0 <= alpha <= 1 and scale > 0
+  //   scale * lrelu(acc*d + n + b) = max(o, alpha*o),  o = acc*(d*scale) + (n*scale + b*scale)
+  // - d*scale and b*scale are folded into the per-image epilogue table below.  Anything else (no bias, other
+  // activations) takes the general epilogue with its run-time switches.
+  const bool fast_ep = !UP && P.bias && P.act == ACT_LRELU && P.alpha >= 0.0f && P.alpha <= 1.0f && P.scale > 0.0f &&
+                       (WAVES_CO == 1 || !P.rgb_out);
+  const float ep_fold = (FUSE || fast_ep) ? P.scale : 1.0f;
   auto load_s = [&](int b, int slot) {
     float *dst = sl_base + slot * P.cin;
     if (MOD)
       for (int i = tid; i < P.cin; i += NT) dst[i] = P.s[(long long)b * P.s_bstride + i];
     float *ep = ep_base + slot * 3 * CT;
     for (int i = tid; i < CT; i += NT) {
-      ep[i] = (P.d ? P.d[(long long)b * P.d_bstride + co0 + i] : 1.0f) * w_unscale;
-      ep[CT + i] = P.bias ? P.bias[co0 + i] : 0.0f;
+      ep[i] = (P.d ? P.d[(long long)b * P.d_bstride + co0 + i] : 1.0f) * w_unscale * ep_fold;
+      ep[CT + i] = P.bias ? P.bias[co0 + i] * ep_fold : 0.0f;
       ep[2 * CT + i] = ((!UP || FUSE) && P.oh && P.s_next) ? P.s_next[(long long)b * P.cout + co0 + i] : 1.0f;
     }
     if (!UP && P.rgb_out) {
@@ -467,6 +483,90 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     }
   };
 
+  // ---- same-resolution fast epilogue (fast_ep): the accumulators are only read and the run-time switches (which
+  // outputs exist) are tested once per channel quad, not per element - the general epilogue spent ~9k cycles per
+  // 512-pixel tile of the 1024^2 layer on scalar branches, a third of the tile.  (One body with uniform branches:
+  // separate compile-time variants made LLVM hoist the common arithmetic above the dispatch and spill it.) ----
+  auto epilogue_fast = [&](const TileGeom &G, const Tile &T, int slot, const float (&nz)[PG]) {
+    const bool OUT = P.out != nullptr, SPLIT = P.oh != nullptr, RGB = WAVES_CO == 1 && P.rgb_out != nullptr;  // uniform
+    int co_w = wave_co, li_o = li, lh_o = lh;
+    HF_OPAQUE_I32(co_w);
+    HF_OPAQUE_I32(li_o);
+    HF_OPAQUE_I32(lh_o);
+    const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
+    const float *ep = ep_base + slot * 3 * CT;
+    const float *rw = rgbw_base + slot * 3 * CT;
+    const unsigned oplane4 = (unsigned)(P.out_h * P.out_w) * 4u;
+    char *ob0 = OUT ? reinterpret_cast<char *>(P.out + ((long long)T.b0 * P.cout + co0) * ((long long)P.out_h * P.out_w)) : nullptr;
+    const float nws = nw_ * P.scale;
+    bool ovf_tile = false;
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+      const int p = (wave_pg + g) * 32 + li_o;
+      const int Y = T.ty0 + ((p >> G.lg_tw) & (th - 1)), X = T.tx0 + (p & (tw - 1));
+      const bool pv = (Y < G.y0 + G.dh) && (X < G.x0 + G.dw);
+      float nzv = nws * nz[g];
+      HF_OPAQUE_F32(nzv);  // a product of its own in every instantiation (no contraction into the add below): the
+                           // tile configurations must agree bit for bit
+      float rgb[3] = {0.0f, 0.0f, 0.0f};
+      if (pv) {
+        const unsigned pix4 = (unsigned)(Y * P.out_w + X) * 4u;
+#pragma unroll
+        for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c4 = co_w + ct * 32 + 8 * q + 4 * lh_o;  // first of the lane's 4 channels (tile-relative)
+            const float4 dm = *reinterpret_cast<const float4 *>(ep + c4);
+            const float4 bs = *reinterpret_cast<const float4 *>(ep + CT + c4);
+            const float dmv[4] = {dm.x, dm.y, dm.z, dm.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float o = fmaf(acc[0][ct][g][4 * q + k], dmv[k], nzv + bsv[k]);
+              v[k] = fmaxf(o, o * P.alpha);
+            }
+            if (OUT) {
+              unsigned off = (unsigned)c4 * oplane4 + pix4;
+#pragma unroll
+              for (int k = 0; k < 4; ++k, off += oplane4) *reinterpret_cast<float *>(ob0 + off) = v[k];
+            }
+            if (SPLIT) {  // the lane's 4 channels = one half (lh) of the 16-byte unit of pixel (Y, X), channel block (co0+c4)/8
+              const float4 sn = *reinterpret_cast<const float4 *>(ep + 2 * CT + c4);
+              const float snv[4] = {sn.x, sn.y, sn.z, sn.w};
+              typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+              half4 h4, l4;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                _Float16 hv, lv;
+                hf_split_f16(v[k] * snv[k], hv, lv, ovf_tile);
+                h4[k] = hv;
+                l4[k] = lv;
+              }
+              const long long unit = (((long long)T.b0 * (P.cout >> 3) + ((co0 + c4) >> 3)) * P.out_h + Y) * P.out_w + X;
+              *reinterpret_cast<half4 *>(static_cast<char *>(P.oh) + unit * 16 + ((co0 + c4) & 4) * 2) = h4;
+              if (P.ol) *reinterpret_cast<half4 *>(static_cast<char *>(P.ol) + unit * 16 + ((co0 + c4) & 4) * 2) = l4;
+            }
+            if (RGB) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const float4 wv = *reinterpret_cast<const float4 *>(rw + c * CT + c4);
+                rgb[c] = fmaf(v[3], wv.w, fmaf(v[2], wv.z, fmaf(v[1], wv.y, fmaf(v[0], wv.x, rgb[c]))));
+              }
+            }
+          }
+      }
+      if (RGB) {  // the two half-waves hold the other channels of the same pixels: add, the low half stores
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          rgb[c] += __shfl_xor(rgb[c], 32, 64);
+          if (pv && lh_o == 0)
+            P.rgb_out[((long long)T.b0 * 3 + c) * ((long long)P.out_h * P.out_w) + (long long)Y * P.out_w + X] = rgb[c];
+        }
+      }
+    }
+    if (SPLIT) hf_note_overflow(ovf_tile);
+  };
+
   // ---- FUSE: blur + noise + bias + lrelu (+ split) epilogue of the transposed conv --------------------
   // acc[pr*2+pc][0][g][r] = T[2Y+pr][2X+pc] of position (Y, X) = (ty0 + wave_pg + g, tx0 + li), channel
   // co0 + (r&3) + 8*(r>>2) + 4*lh.  out[oy][ox] = sum_{r,j} ky[r] kx[j] T[oy-1+r][ox-1+j] with the FLIPPED
@@ -566,7 +666,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
               const float h_3 = (g == PG - 1) ? h3[k] : H[2 + pc][g == PG - 1 ? g : g + 1][k];
               float o = (a == 0) ? fmaf(kyf[3], h_2, fmaf(kyf[2], h_1, fmaf(kyf[1], h_0, kyf[0] * h_m1)))
                                  : fmaf(kyf[3], h_3, fmaf(kyf[2], h_2, fmaf(kyf[1], h_1, kyf[0] * h_0)));
-              o = fmaf(o, dmv[k] * P.scale, fmaf(nw_f, nz[g][a * 2 + pc], bsv[k] * P.scale));
+              o = fmaf(o, dmv[k], fmaf(nw_f, nz[g][a * 2 + pc], bsv[k]));  // d and bias carry the output scale (ep_fold)
               v[k] = fmaxf(o, o * P.alpha);
             }
             if (pv) {
@@ -708,6 +808,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int tap = tap_at<UP>(i);  // the side work below is scheduled by POSITION i
+        HF_TRACE_POINT(10 + i);
         const int grp = tap_group<UP>(i);
         const int sa = (NSLOT == 1) ? 0 : (i & 1), sb = (NSLOT == 1) ? 0 : (grp & 1);
         if (NSLOT == 1) {
@@ -739,6 +840,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
         if (!PRE && more1 && i >= 9 - XE) convert_item(i - (9 - XE), cpf, nbuf);
         if (more1 && i == 8) HF_TRACE_POINT(6);  // conversions done
         __builtin_amdgcn_sched_barrier(0);
+        HF_TRACE_POINT(20 + i);  // side work issued, before the MFMAs
         const int ph = UP ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) : 0;
 #pragma unroll
         for (int ct = 0; ct < CT_TILES; ++ct)
@@ -769,7 +871,14 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       if (P.oh) epilogue_fused(std::true_type{}, cur, ep_slot, nzf, ((stage - 1) & 1));
       else epilogue_fused(std::false_type{}, cur, ep_slot, nzf, ((stage - 1) & 1));
     } else {
-      epilogue(G, cur, ep_slot, nzr);
+      bool done = false;
+      if constexpr (!UP) {
+        if (fast_ep) {
+          epilogue_fast(G, cur, ep_slot, nzr);
+          done = true;
+        }
+      }
+      if (!done) epilogue(G, cur, ep_slot, nzr);
     }
     HF_TRACE_POINT(4);  // epilogue issued
     if (!has_next) break;
@@ -874,7 +983,7 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
   if (P.rgb_out && (UP || WAVES_CO != 1 || P.cout != CT || !P.rgb_w || !P.rgb_s)) return HF_E_INVALID;
   if (lds > 160 * 1024) return HF_E_INVALID;
   P.n_tiles = nblocks;
-  P.dma_early = (g_h_tune & 1) ? 1 : ((g_h_tune & 2) ? 0 : (P.cin / KH <= 8));
+  P.dma_early = (g_h_tune & 1) ? 1 : 0;  // measured (tools/probes/gen_layers.py): spread is 0-8 % faster on every generator layer
   // LDS allows one block per CU: size the grid to the chip and let each block walk its share
   // of the tiles as one pipeline (the tile-to-tile hand-over needs >= 2 stages per tile)
   const int co_tiles = P.cout / CT;
