@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-C=$GRAFT_REPO_ROOT/hairfastgan_amd/csrc
-for v in hip varA varB varC hip; do
-  echo "== $v"; HAIRFAST_HIP_LIB=$C/libhairfast_$v.so PROBE_TUNE=0 python tools/probes/gen_layers.py 2>&1 | grep -v amdgpu
-done > gpurun_out/r02p_variants.log 2>&1
-cat gpurun_out/r02p_variants.log
+python -m pytest tests/test_gpu_parity.py -q -k "fuse or blur or up or range" 2>&1 | tail -4
+PROBE_TUNE=0 python tools/probes/gen_layers.py 2>&1 | grep -v amdgpu > /dev/null
+PROBE_TUNE=0 python tools/probes/gen_layers.py 2>&1 | grep -v amdgpu | tee gpurun_out/r02q_layers.log

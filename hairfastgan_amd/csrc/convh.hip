@@ -669,26 +669,24 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
               o = fmaf(o, dmv[k], fmaf(nw_f, nz[g][a * 2 + pc], bsv[k]));  // d and bias carry the output scale (ep_fold)
               v[k] = fmaxf(o, o * P.alpha);
             }
-            if (pv) {
-              const int pix = pix00 + (2 * g + a) * (2 * P.w) + pc;
-              if (!SPLIT) {
+            const int pix = pix00 + (2 * g + a) * (2 * P.w) + pc;
+            if (!SPLIT) {
+              if (pv) {
                 float *ob = of_b + (long long)c4 * oplane + pix;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ob[k * oplane] = v[k];
-              } else {
-                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-                const float4 sn = *reinterpret_cast<const float4 *>(ep + 2 * CT + c4);
-                const float snv[4] = {sn.x, sn.y, sn.z, sn.w};
-                half4 h4, l4;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  _Float16 hv, lv;
-                  hf_split_f16(v[k] * snv[k], hv, lv, ovf_tile);
-                  h4[k] = hv;
-                  l4[k] = lv;
-                }
-                *reinterpret_cast<half4 *>(oh_b + cb_ofs + (long long)pix * 16) = h4;
-                *reinterpret_cast<half4 *>(ol_b + cb_ofs + (long long)pix * 16) = l4;
+              }
+            } else {
+              // every lane splits (the range vote inside hf_split4_f16 is wave-wide), valid positions store
+              const float4 sn = *reinterpret_cast<const float4 *>(ep + 2 * CT + c4);
+              const float vs[4] = {v[0] * sn.x, v[1] * sn.y, v[2] * sn.z, v[3] * sn.w};
+              hf_half4 h4, l4;
+              bool ovf = false;
+              hf_split4_f16(vs, h4, l4, ovf);
+              if (pv) {
+                ovf_tile = ovf_tile || ovf;
+                *reinterpret_cast<hf_half4 *>(oh_b + cb_ofs + (long long)pix * 16) = h4;
+                *reinterpret_cast<hf_half4 *>(ol_b + cb_ofs + (long long)pix * 16) = l4;
               }
             }
             __builtin_amdgcn_sched_barrier(0);

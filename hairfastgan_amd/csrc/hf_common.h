@@ -138,6 +138,40 @@ __device__ __forceinline__ void hf_split_f16(float v, _Float16 &hi, _Float16 &lo
 __device__ __forceinline__ void hf_note_overflow(bool ovf) {
   if (ovf) atomicAdd(&hf_f16_overflow_dev, 1u);
 }
+// Split of FOUR values with one range test for the whole wave: the largest |v| of the four is compared with the
+// fp16 maximum and the wave votes; in range (the normal case) the split needs no clamps and no per-element tests
+// (4 instead of 9 VALU instructions per element), otherwise the saturating element-wise form above runs.  Both
+// forms give identical bits for values within +-65504.  Convergent: every lane of the wave must call it.
+typedef _Float16 hf_half4 __attribute__((ext_vector_type(4)));
+#ifndef HF_WAVE_ANY_DEFINED
+#define HF_WAVE_ANY_DEFINED
+__device__ __forceinline__ bool hf_wave_any(bool p) { return __any((int)p) != 0; }
+#endif
+__device__ __forceinline__ void hf_split4_f16(const float (&vin)[4], hf_half4 &h, hf_half4 &l, bool &ovf) {
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = vin[k];
+    HF_OPAQUE_F32(v[k]);  // hi and lo from the same fp32-rounded value (see hf_split_f16)
+  }
+  const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  if (hf_wave_any(!(m <= HF_F16_MAX))) {  // also NaN
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      _Float16 hv, lv;
+      hf_split_f16(v[k], hv, lv, ovf);
+      h[k] = hv;
+      l[k] = lv;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const _Float16 hv = (_Float16)v[k];
+      h[k] = hv;
+      l[k] = (_Float16)(v[k] - (float)hv);
+    }
+  }
+}
 #endif  // HF_WANT_F16_SPLIT
 
 // Value of the neighbouring lane (lane-1 / lane+1) by a DPP wavefront shift: one VALU instruction, no LDS

@@ -85,6 +85,12 @@ inline void hf_glds4(const float *gsrc_lane, float *lds_wave_base) { ::hipsim::g
 inline void hf_glds16_if(bool a, const float *g, float *l) { ::hipsim::glds_masked(a, 16, g, l); }
 inline void hf_glds4_if(bool a, const float *g, float *l) { ::hipsim::glds_masked(a, 4, g, l); }
 
+#define HF_WAVE_ANY_DEFINED
+inline bool hf_wave_any(bool p) {  // wave vote through the shuffle rendezvous
+  float v = p ? 1.0f : 0.0f;
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, ::hipsim::shfl_xor(v, m));
+  return v > 0.0f;
+}
 #define HF_LANE_SHIFT_DEFINED
 inline float hf_lane_up(float v) { return ::hipsim::shfl_rel0(v, -1); }
 inline float hf_lane_down(float v) { return ::hipsim::shfl_rel0(v, 1); }
