@@ -256,6 +256,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (generator workload)")
     ap.add_argument("--workload", choices=("generator", "swap256"), default="generator")
     ap.add_argument("--triples", type=int, default=256, help="swap256: triples of the whole job")
+    ap.add_argument("--swap-batch", type=int, default=8,
+                    help="swap256: triples per batched pass over the hot path (HairFast.swap_batch); 1 = one HairFast.swap per triple")
     ap.add_argument("--precision", choices=("f16x3", "f32", "f16"), default=None,
                     help="matrix-core mode of the 3x3 convs (default: HAIRFAST_CONV_PRECISION or f16x3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -303,11 +305,14 @@ def main():
         with torch.inference_mode():
             for i in range(max(1, args.warmup)):
                 hf.swap(*[t.to(dev) for t in load(i)])
+            if args.swap_batch > 1:  # warm the batched shapes too (weight splits, plans)
+                hf.swap_batch([tuple(t.to(dev) for t in load(i)) for i in range(args.swap_batch)])
         barrier()
         prof = None if args.no_kernel_events else []
         _marshal.PROFILE = prof
         t0 = time.perf_counter()
-        images, n_local = parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), args.triples, load, device=dev)
+        images, n_local = parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), args.triples, load, device=dev,
+                                             batch=args.swap_batch, swap_batch_fn=hf.swap_batch if args.swap_batch > 1 else None)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         _marshal.PROFILE = None
@@ -318,7 +323,10 @@ def main():
                    "ms_per_step": round(elapsed / args.triples * 1e3 * world, 4), "ms_per_triple_per_gpu": round(elapsed / max(n_local, 1) * 1e3, 3),
                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPES[precision],
                    "data": "synthetic",
-                   "config": {"workload": f"{args.triples} synthetic 1024^2 triples sharded over {world} GPU(s): host uint8 -> H2D -> "
+                   "config": {"swap_batch": args.swap_batch,
+                              "batching": (f"HairFast.swap_batch: {args.swap_batch} triples per pass - every hot-path call below runs once with "
+                                           f"{args.swap_batch}x the listed batch" if args.swap_batch > 1 else "one HairFast.swap per triple"),
+                              "workload": f"{args.triples} synthetic 1024^2 triples sharded over {world} GPU(s): host uint8 -> H2D -> "
                                           "HairFast.swap (e4e B=3, FS-encoder B=3, gen 3->3 B=3, gen 0->3 B=3, gen 0->8 B=2 [both "
                                           "Alignment rotations batched], e4e B=2, gen 0->3 B=2, gen 4->8 B=1, PostProcess encoder "
                                           "[774 GFLOP], gen 5->8 B=1, BiSeNet parsing x5; Rotate / shape adaptor / SEAN / CLIP blend = SyntheticStages) -> uint8 -> "
@@ -427,14 +435,18 @@ def main():
             load = make_triple_loader(2)
             with torch.inference_mode():
                 hf.swap(*[t.to(dev) for t in load(0)])
+                if args.swap_batch > 1:
+                    hf.swap_batch([tuple(t.to(dev) for t in load(i)) for i in range(args.swap_batch)])
             barrier()
             n_pipe = 2 * args.swap_triples * world
             t0 = time.perf_counter()
-            parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), n_pipe, load, device=dev)
+            parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), n_pipe, load, device=dev, batch=args.swap_batch,
+                               swap_batch_fn=hf.swap_batch if args.swap_batch > 1 else None)
             barrier()
             tp = max_over_ranks(time.perf_counter() - t0)
             pipeline_info = {"metric": "hair_swap_triples_per_sec", "value": round(n_pipe / tp, 3), "unit": "triples/s",
                              "ms_per_triple_per_gpu": round(tp / (n_pipe / world) * 1e3, 2), "triples": n_pipe,
+                             "swap_batch": args.swap_batch,
                              "workload": "python bench.py --workload swap256 on a bounded sample: host uint8 -> H2D -> HairFast.swap "
                                          "(SyntheticStages between the hot-path calls) -> uint8 -> gather (BASELINE.json configs[3])"}
         except Exception as e:

@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py -q -k "fuse or blur or up or range" 2>&1 | tail -4
-PROBE_TUNE=0 python tools/probes/gen_layers.py 2>&1 | grep -v amdgpu > /dev/null
-PROBE_TUNE=0 python tools/probes/gen_layers.py 2>&1 | grep -v amdgpu | tee gpurun_out/r02q_layers.log
+python -m pytest tests/test_gpu_schedule.py -q -x 2>&1 | tail -15
+for b in 1 2 4 8; do
+  python bench.py --workload swap256 --triples 32 --warmup 1 --swap-batch $b --no-kernel-events 2>gpurun_out/r02r_swap_b$b.err | head -c 420; echo
+done | tee gpurun_out/r02r_swapbatch.log

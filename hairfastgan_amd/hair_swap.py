@@ -240,7 +240,7 @@ class Embedding(nn.Module):  # models/Embedding.py:17-117
         device = self.opts.device
         images, names_all = list(images_to_name), list(images_to_name.values())
         name_to_embed = defaultdict(dict)
-        bs = self.opts.batch_size
+        bs = kwargs.get("batch_size") or self.opts.batch_size  # swap_batch: the images of several triples per call
         for b0 in range(0, len(images), bs):
             image = torch.stack([im / 255 if im.dtype is torch.uint8 else im for im in images[b0:b0 + bs]]).to(device)
             names_b = names_all[b0:b0 + bs]
@@ -317,28 +317,42 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
 
     @torch.inference_mode()
     def align_images(self, im_name1, im_name2, name_to_embed, **kwargs):  # :101-175
-        e1, e2 = name_to_embed[im_name1], name_to_embed[im_name2]
-        img1_in, img2_in = e1["image_256"], e2["image_256"]
-        latent_F_1, latent_F_2 = e1["F"], e2["F"]
-        if img1_in is img2_in:
-            hm = self.shape_module(im_name1, im_name2, name_to_embed, only_target=True, **kwargs)["HM_X"]
-            return {"latent_F_align": latent_F_1, "HM_X": hm}
-        inp_mask1, hair_mask1, inp_mask2, hair_mask2, target_mask, hair_mask_target = self.shape_module(
-            im_name1, im_name2, name_to_embed, only_target=False, **kwargs)
-        images = torch.cat([img1_in, img2_in], dim=0)
-        labels = torch.cat([inp_mask1, inp_mask2], dim=0)
-        gen1_sean, gen2_sean = self.stages.sean_inpaint(images, labels, target_mask)  # SEAN for inpaint
-        enc = self.latent_encoder([gen1_sean, gen2_sean])                            # e4e batch 2 + generator 0->3
-        intermediate_align = enc["F"][0].unsqueeze(0)
-        latent_F_out_new = enc["F"][1].unsqueeze(0)
-        masks = torch.cat([1 - (1 - hair_mask1) * (1 - hair_mask_target), hair_mask_target, hair_mask2 * hair_mask_target], 0)
-        dilate, erosion = self.dilate_erosion.mask(masks)
-        free_mask = torch.stack([dilate[0], erosion[1], erosion[2]], dim=0)
-        interpolation_low = 1 - F.interpolate(free_mask.float(), size=(32, 32), mode="bicubic")
-        latent_F_align = intermediate_align + interpolation_low[0] * (latent_F_1 - intermediate_align)
-        latent_F_align = latent_F_out_new + interpolation_low[1] * (latent_F_align - latent_F_out_new)
-        latent_F_align = latent_F_2 + interpolation_low[2] * (latent_F_align - latent_F_2)
-        return {"latent_F_align": latent_F_align, "HM_X": hair_mask_target}
+        return self.align_images_batch([(im_name1, im_name2)], name_to_embed, **kwargs)[0]
+
+    @torch.inference_mode()
+    def align_images_batch(self, pairs, name_to_embed, **kwargs):
+        """align_images (:101-175) for several (im_name1, im_name2) pairs - several triples - at once: the
+        out-of-scope stages run per pair, everything on the hot path once for all pairs (the SEAN outputs of all
+        pairs are ONE e4e batch + ONE generator 0->3 forward, the masks one dilation / erosion call)."""
+        results = [None] * len(pairs)
+        work = []  # (index, e1, e2, masks of the pair)
+        for k, (n1, n2) in enumerate(pairs):
+            e1, e2 = name_to_embed[n1], name_to_embed[n2]
+            if e1["image_256"] is e2["image_256"]:
+                hm = self.shape_module(n1, n2, name_to_embed, only_target=True, **kwargs)["HM_X"]
+                results[k] = {"latent_F_align": e1["F"], "HM_X": hm}
+            else:
+                work.append((k, e1, e2, self.shape_module(n1, n2, name_to_embed, only_target=False, **kwargs)))
+        if not work:
+            return results
+        sean, masks = [], []
+        for k, e1, e2, (inp_mask1, hair_mask1, inp_mask2, hair_mask2, target_mask, hair_mask_target) in work:
+            images = torch.cat([e1["image_256"], e2["image_256"]], dim=0)
+            labels = torch.cat([inp_mask1, inp_mask2], dim=0)
+            sean += list(self.stages.sean_inpaint(images, labels, target_mask))  # SEAN for inpaint (per pair)
+            masks.append(torch.cat([1 - (1 - hair_mask1) * (1 - hair_mask_target), hair_mask_target, hair_mask2 * hair_mask_target], 0))
+        enc_F = self.latent_encoder(sean)["F"]                                   # e4e batch 2P + generator 0->3
+        dilate, erosion = self.dilate_erosion.mask(torch.cat(masks, 0))          # [3P, 1, 256, 256] each
+        free_mask = torch.stack([dilate[0::3], erosion[1::3], erosion[2::3]], dim=1).reshape(-1, *dilate.shape[1:])
+        low = 1 - F.interpolate(free_mask.float(), size=(32, 32), mode="bicubic")  # [3P, 1, 32, 32]
+        for j, (k, e1, e2, m) in enumerate(work):
+            intermediate_align, latent_F_out_new = enc_F[2 * j:2 * j + 1], enc_F[2 * j + 1:2 * j + 2]
+            il = low[3 * j:3 * j + 3]
+            latent_F_align = intermediate_align + il[0] * (e1["F"] - intermediate_align)
+            latent_F_align = latent_F_out_new + il[1] * (latent_F_align - latent_F_out_new)
+            latent_F_align = e2["F"] + il[2] * (latent_F_align - e2["F"])
+            results[k] = {"latent_F_align": latent_F_align, "HM_X": m[5]}
+        return results
 
 
 class Blending(nn.Module):  # models/Blending.py:11-82
@@ -357,28 +371,39 @@ class Blending(nn.Module):  # models/Blending.py:11-82
 
     @torch.inference_mode()
     def blend_images(self, align_shape, align_color, name_to_embed, **kwargs):  # :36-82
-        I_1 = name_to_embed["face"]["image_norm_256"]
-        I_2 = name_to_embed["shape"]["image_norm_256"]
-        I_3 = name_to_embed["color"]["image_norm_256"]
-        mask_de = self.dilate_erosion.hair_from_mask(torch.cat([name_to_embed[x]["mask"] for x in ["face", "color"]], dim=0))
-        HM_1D = mask_de[0][0].unsqueeze(0)
-        HM_3D, HM_3E = mask_de[0][1].unsqueeze(0), mask_de[1][1].unsqueeze(0)
-        latent_S_1, latent_F_align = name_to_embed["face"]["S"], align_shape["latent_F_align"]
-        latent_S_3 = name_to_embed["color"]["S"]
-        HM_XD, _ = self.dilate_erosion.mask(align_color["HM_X"])
-        target_mask = (1 - HM_1D) * (1 - HM_3D) * (1 - HM_XD)
-        if I_1 is not I_3 or I_1 is not I_2:
-            S_blend_6_18 = self.stages.blend(latent_S_1[:, 6:], latent_S_3[:, 6:], I_1 * target_mask, I_3 * HM_3E)
-            S_blend = torch.cat((latent_S_1[:, :6], S_blend_6_18), dim=1)
-        else:
-            S_blend = latent_S_1
-        I_blend, _ = self.net.generator([S_blend], input_is_latent=True, return_latents=False, start_layer=4, end_layer=8,
-                                        layer_in=latent_F_align)
+        return self.blend_images_batch([align_shape], [align_color], name_to_embed, [("face", "shape", "color")], **kwargs)[0]
+
+    @torch.inference_mode()
+    def blend_images_batch(self, aligns_shape, aligns_color, name_to_embed, keys, **kwargs):
+        """blend_images (:36-82) for several triples: keys[t] = the (face, shape, color) entries of triple t in
+        name_to_embed.  The blending encoder (out of scope) runs per triple; the generator 4->8 forward, the
+        bicubic down-sampling, PostProcessModel and the final generator 5->8 forward once with batch T."""
+        T = len(keys)
+        emb = [[name_to_embed[k] for k in key] for key in keys]
+        mask_de = self.dilate_erosion.hair_from_mask(torch.cat([e[i]["mask"] for e in emb for i in (0, 2)], dim=0))  # [2T,...]
+        HM_XD, _ = self.dilate_erosion.mask(torch.cat([a["HM_X"] for a in aligns_color], dim=0))
+        S_blend = []
+        for t, (ef, es, ec) in enumerate(emb):
+            I_1, I_2, I_3 = ef["image_norm_256"], es["image_norm_256"], ec["image_norm_256"]
+            HM_1D = mask_de[0][2 * t].unsqueeze(0)
+            HM_3D, HM_3E = mask_de[0][2 * t + 1].unsqueeze(0), mask_de[1][2 * t + 1].unsqueeze(0)
+            latent_S_1, latent_S_3 = ef["S"], ec["S"]
+            target_mask = (1 - HM_1D) * (1 - HM_3D) * (1 - HM_XD[t:t + 1])
+            if I_1 is not I_3 or I_1 is not I_2:
+                S_blend_6_18 = self.stages.blend(latent_S_1[:, 6:], latent_S_3[:, 6:], I_1 * target_mask, I_3 * HM_3E)
+                S_blend.append(torch.cat((latent_S_1[:, :6], S_blend_6_18), dim=1))
+            else:
+                S_blend.append(latent_S_1)
+        latent_F_align = torch.cat([a["latent_F_align"] for a in aligns_shape], dim=0)
+        I_blend, _ = self.net.generator([torch.cat(S_blend, 0)], input_is_latent=True, return_latents=False, start_layer=4,
+                                        end_layer=8, layer_in=latent_F_align)
         I_blend_256 = self.downsample_256(I_blend)
-        S_final, F_final = self.post_process(I_1, I_blend_256)  # Post Process (native: encoders/post_process.py)
+        I_1_all = torch.cat([e[0]["image_norm_256"] for e in emb], dim=0)
+        S_final, F_final = self.post_process(I_1_all, I_blend_256)  # Post Process (native: encoders/post_process.py)
         I_final, _ = self.net.generator([S_final], input_is_latent=True, return_latents=False, start_layer=5, end_layer=8,
                                         layer_in=F_final)
-        return ((I_final[0] + 1) / 2).clip(0, 1)
+        out = ((I_final + 1) / 2).clip(0, 1)
+        return [out[t] for t in range(T)]
 
 
 class HairFast:
@@ -408,18 +433,36 @@ class HairFast:
         self._times = []
 
     def _swap_from_tensors(self, face, shape, color, **kwargs):  # hair_swap.py:38-61
+        return self._swap_batch_from_tensors([(face, shape, color)], **kwargs)[0]
+
+    def _swap_batch_from_tensors(self, triples, **kwargs):
+        """hair_swap.py:38-61 for T triples at once.  Triples are independent and the parameters frozen, so every
+        hot-path call runs once with the batch of all triples (Embedding: 3T images; Rotate: 2T full forwards + parses;
+        Alignment: e4e on 2T SEAN outputs; Blending: T) instead of T times with batch 3 / 2 / 1 - per-sample results
+        are the same, the GPU sees 256-channel 32^2 convolutions with T times more pixels to fill its 256 CUs with.
+        The out-of-scope stages are called per triple."""
+        T = len(triples)
         images_to_name = defaultdict(list)
-        for image, name in zip((face, shape, color), ("face", "shape", "color")):
-            images_to_name[image].append(name)
+        for t, triple in enumerate(triples):
+            for image, name in zip(triple, ("face", "shape", "color")):
+                images_to_name[image].append((t, name) if T > 1 else name)
+        key = (lambda t, n: (t, n)) if T > 1 else (lambda t, n: n)
+        if T > 1:
+            kwargs = dict(kwargs, batch_size=max(self.args.batch_size, len(images_to_name)))
         name_to_embed = self.embed.embedding_images(images_to_name, **kwargs)  # Embedding stage
-        pairs = [("face", "shape")] + ([("face", "color")] if shape is not color else [])
-        rotated = self.align.rotate_images(pairs, name_to_embed)               # both Rotate forwards as one batch
-        align_shape = self.align.align_images("face", "shape", name_to_embed, rotated=rotated, **kwargs)
-        if shape is not color:
-            align_color = self.align.shape_module("face", "color", name_to_embed, rotated=rotated, **kwargs)
-        else:
-            align_color = align_shape
-        return self.blend.blend_images(align_shape, align_color, name_to_embed, **kwargs)
+        kwargs.pop("batch_size", None)
+        same = [triple[1] is triple[2] for triple in triples]                  # shape is color
+        pairs = []
+        for t in range(T):
+            pairs += [(key(t, "face"), key(t, "shape"))] + ([] if same[t] else [(key(t, "face"), key(t, "color"))])
+        rotated = self.align.rotate_images(pairs, name_to_embed)               # every Rotate forward as one batch
+        aligns_shape = self.align.align_images_batch([(key(t, "face"), key(t, "shape")) for t in range(T)], name_to_embed,
+                                                     rotated=rotated, **kwargs)
+        aligns_color = [aligns_shape[t] if same[t] else
+                        self.align.shape_module(key(t, "face"), key(t, "color"), name_to_embed, rotated=rotated, **kwargs)
+                        for t in range(T)]
+        return self.blend.blend_images_batch(aligns_shape, aligns_color, name_to_embed,
+                                             [tuple(key(t, n) for n in ("face", "shape", "color")) for t in range(T)], **kwargs)
 
     def swap(self, face_img, shape_img, color_img, benchmark=False, align=False, seed=None, exp_name=None, **kwargs):
         """hair_swap.py:63-103.  Images: torch.Tensor [3,H,W] (uint8 or float in [0,1]), numpy HWC
@@ -452,6 +495,33 @@ class HairFast:
         return final_image
 
     __call__ = swap
+
+    def swap_batch(self, triples, seed=None, **kwargs):
+        """Several swaps as ONE batched pass over the hot path (not in the reference: BASELINE.json configs[3],
+        "batched HairFast swap").  triples: sequence of (face, shape, color) with the image forms `swap` takes
+        (tensors / arrays).  Returns a list of [3, size, size] images in [0, 1], one per triple, equal to what
+        `swap` returns for each triple given the same per-layer noise."""
+        prepared = []
+        for triple in triples:
+            imgs = []
+            for img in triple:
+                if isinstance(img, np.ndarray):
+                    img = torch.from_numpy(img).permute(2, 0, 1) if img.ndim == 3 and img.shape[-1] == 3 else torch.from_numpy(img)
+                elif not isinstance(img, torch.Tensor):
+                    raise TypeError(f"Unsupported image format {type(img)}")
+                imgs.append(img)
+            prepared.append(tuple(equal_replacer(imgs)))
+        set_seed(3407 if seed is None else seed)
+        # a triple that repeats an image takes the reference's shortcuts (no mixing / no second Rotate): one by one
+        plain = [t for t, tr in enumerate(prepared) if len({id(x) for x in tr}) == 3]
+        out = [None] * len(prepared)
+        if plain:
+            for t, img in zip(plain, self._swap_batch_from_tensors([prepared[t] for t in plain], **kwargs)):
+                out[t] = img
+        for t, tr in enumerate(prepared):
+            if out[t] is None:
+                out[t] = self._swap_from_tensors(*tr, **kwargs)
+        return out
 
 
 # ---------------------------------------------------------------------------------------------

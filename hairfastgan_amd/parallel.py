@@ -77,7 +77,7 @@ def all_gather_images(local, n_total=None, group=None, async_op=False):
     return finalize(out)
 
 
-def swap_many(swap_fn, n_total, load_triple, device=None, chunk=8, group=None):
+def swap_many(swap_fn, n_total, load_triple, device=None, chunk=8, group=None, batch=1, swap_batch_fn=None):
     """BASELINE.json configs[3]: hair swaps of triples 0..n_total-1, block-partitioned over the ranks
     (one process per GPU, a full replica each - triples share no state, models/Net.py:44-46), results
     returned to every rank as uint8 images in triple order [n_total, 3, H, W].
@@ -85,6 +85,8 @@ def swap_many(swap_fn, n_total, load_triple, device=None, chunk=8, group=None):
       load_triple(i) -> (face, shape, color)   three CPU tensors (uint8 [3,H,W]); pinned memory lets the
                                                host-to-device copy of triple i+1 overlap swap i
       swap_fn(face, shape, color) -> float image [3,H,W] in [0,1]  (HairFast.swap)
+      batch > 1 with swap_batch_fn(list of triples) -> list of images (HairFast.swap_batch): `batch` consecutive
+                                               local triples per call - one batched pass over the hot path
 
     The only collective is the RCCL all-gather of finished images over xGMI (3.1 MB per 1024^2 image),
     issued asynchronously once per `chunk` local triples so that it overlaps the following swaps (one
@@ -112,20 +114,47 @@ def swap_many(swap_fn, n_total, load_triple, device=None, chunk=8, group=None):
             ev.record(copy_stream)
         return on_dev, ev
 
+    if batch > 1 and swap_batch_fn is None:
+        raise ValueError("batch > 1 needs swap_batch_fn")
+    batch = max(1, min(batch, chunk))
+
+    def fetch_group(j0, j1):  # local triples j0..j1-1
+        return [fetch(lo + j) for j in range(j0, j1)]
+
+    def group_end(j0, limit):
+        return min(j0 + batch, limit)
+
     rounds = []  # (k, gathered-or-local tensor, work|None, chunk size)
-    nxt = fetch(lo)
+    first_end = group_end(0, min(chunk, n_local))
+    nxt = fetch_group(0, first_end)
     done = []
     for k in range((n_max + chunk - 1) // chunk):
         cs = min(chunk, n_max - k * chunk)
-        for j in range(k * chunk, min(k * chunk + cs, n_local)):
-            imgs, ev = nxt
-            nxt = fetch(lo + j + 1) if j + 1 < n_local else None
-            if ev is not None:
-                cur = torch.cuda.current_stream()
-                cur.wait_event(ev)
-                for t in imgs:  # allocated on the copy stream, consumed on this one: keep the block from being
-                    t.record_stream(cur)  # handed to the NEXT prefetch while these kernels still read it
-            done.append(to_uint8_image(swap_fn(*imgs) * 2.0 - 1.0))
+        limit = min(k * chunk + cs, n_local)
+        j = k * chunk
+        while j < limit:
+            j1 = group_end(j, limit)
+            cur_group = nxt
+            # prefetch the next group (of this chunk or the first of the next one) while this one is swapped
+            if j1 < n_local:
+                nlimit = limit if j1 < limit else min(j1 + chunk, n_local)
+                nxt = fetch_group(j1, group_end(j1, nlimit))
+            else:
+                nxt = None
+            triples = []
+            for imgs, ev in cur_group:
+                if ev is not None:
+                    cur = torch.cuda.current_stream()
+                    cur.wait_event(ev)
+                    for t in imgs:  # allocated on the copy stream, consumed on this one: keep the block from being
+                        t.record_stream(cur)  # handed to the NEXT prefetch while these kernels still read it
+                triples.append(imgs)
+            if batch > 1:
+                for img in swap_batch_fn(triples):
+                    done.append(to_uint8_image(img * 2.0 - 1.0))
+            else:
+                done.append(to_uint8_image(swap_fn(*triples[0]) * 2.0 - 1.0))
+            j = j1
         mine = done[k * chunk:k * chunk + cs]
         send = torch.stack(mine + [torch.zeros_like(done[0])] * (cs - len(mine)))
         if collective:

@@ -127,6 +127,41 @@ def test_hairfast_swap_call_surface():
         hf.swap(face, shape, color, align=True)
 
 
+def test_swap_batch_equals_single_swaps():
+    """HairFast.swap_batch: two triples as ONE batched pass (every hot-path call with the batch of both triples)
+    give the images of two separate swaps.  Noise strengths are zeroed (the batched and the single calls draw
+    different noise otherwise); what remains are summation-order differences of batch-dependent tile plans -
+    and, rarely, a parsing-mask index that flips on a near-tie of the synthetic BiSeNet."""
+    dev = torch.device("cuda:0")
+    hf = _hairfast(dev)
+    with torch.no_grad():
+        for name, p in hf.net.generator.named_parameters():
+            if name.endswith("noise.weight"):
+                p.zero_()
+    g = torch.Generator().manual_seed(5)
+    triples = [tuple(torch.randint(0, 256, (3, 1024, 1024), dtype=torch.uint8, generator=g).to(dev) for _ in range(3)) for _ in range(2)]
+    calls = []
+    gen_fwd = hf.net.generator.forward
+
+    def spy(styles, **kw):
+        calls.append((styles[0].shape[0], kw.get("start_layer", 0), kw.get("end_layer", 8)))
+        return gen_fwd(styles, **kw)
+
+    hf.net.generator.forward = spy
+    both = hf.swap_batch(triples, seed=3)
+    hf.net.generator.forward = gen_fwd
+    assert calls == [(6, 3, 3), (6, 0, 3), (4, 0, 8), (4, 0, 3), (2, 4, 8), (2, 5, 8)], calls
+    assert len(both) == 2
+    for t, triple in enumerate(triples):
+        one = hf.swap(*triple, seed=3)
+        assert both[t].shape == one.shape == (3, 1024, 1024)
+        diff = (both[t] - one).abs()
+        assert float((diff > 1e-2).float().mean()) < 1e-3, (t, float(diff.max()), float((diff > 1e-2).float().mean()))
+    # a triple that repeats an image takes the single path (the reference's shortcuts), the other one the batched path
+    mixed = hf.swap_batch([triples[0], (triples[1][0], triples[1][1], triples[1][1].clone())], seed=3)
+    assert len(mixed) == 2 and all(torch.isfinite(m).all() for m in mixed)
+
+
 def test_swap_many_forced_rccl_single_rank():
     """BASELINE configs[3] code path with RCCL actually initialised on the hardware (world size 1,
     HF_FORCE_DIST=1): sharding, H2D prefetch stream, uint8 conversion and the chunked all-gather."""

@@ -63,7 +63,7 @@ def test_shard_range_covers_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _swap_worker(rank, world, port, n_total, chunk, q):
+def _swap_worker(rank, world, port, n_total, chunk, q, batch=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from hairfastgan_amd import parallel
@@ -78,20 +78,29 @@ def _swap_worker(rank, world, port, n_total, chunk, q):
         calls.append(int(face[0, 0, 0]) // 3)
         return ((face.float() + shape.float() + color.float()) / 3.0 / 255.0)
 
-    got, n_local = parallel.swap_many(swap_fn, n_total, load_triple, chunk=chunk)
+    groups = []
+
+    def swap_batch_fn(triples):  # HairFast.swap_batch stand-in
+        groups.append(len(triples))
+        return [swap_fn(*t) for t in triples]
+
+    got, n_local = parallel.swap_many(swap_fn, n_total, load_triple, chunk=chunk, batch=batch,
+                                      swap_batch_fn=swap_batch_fn if batch > 1 else None)
+    assert all(1 <= g <= min(batch, chunk) for g in groups) and (batch == 1 or sum(groups) == n_local)
     q.put((rank, n_local, calls, got[:, 0, 0, 0].tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total,chunk", [(7, 2), (8, 3), (2, 8)])
-def test_swap_many_world2(n_total, chunk):
+@pytest.mark.parametrize("n_total,chunk,batch", [(7, 2, 1), (8, 3, 1), (2, 8, 1), (9, 4, 3), (7, 8, 4)])
+def test_swap_many_world2(n_total, chunk, batch):
     """BASELINE configs[3] driver (parallel.swap_many) at world size 2 over gloo: contiguous shards, ragged
-    chunked all-gathers, every rank ends with all images in triple order."""
+    chunked all-gathers, every rank ends with all images in triple order; batch > 1: groups of consecutive local
+    triples go through the batched swap."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_swap_worker, args=(r, 2, port, n_total, chunk, q)) for r in range(2)]
+    procs = [ctx.Process(target=_swap_worker, args=(r, 2, port, n_total, chunk, q, batch)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
@@ -112,3 +121,7 @@ def test_swap_many_single_process():
 
     got, n = parallel.swap_many(lambda a, b, c: a.float() / 255.0, 5, lambda i: tuple(torch.full((3, 2, 2), 10 * i, dtype=torch.uint8) for _ in range(3)), chunk=2)
     assert n == 5 and got[:, 0, 0, 0].tolist() == [0, 10, 20, 30, 40]
+    sizes = []
+    got, n = parallel.swap_many(None, 7, lambda i: tuple(torch.full((3, 2, 2), 10 * i, dtype=torch.uint8) for _ in range(3)), chunk=5, batch=3,
+                                swap_batch_fn=lambda ts: (sizes.append(len(ts)), [t[0].float() / 255.0 for t in ts])[1])
+    assert n == 7 and got[:, 0, 0, 0].tolist() == [0, 10, 20, 30, 40, 50, 60] and sizes == [3, 2, 2]
