@@ -50,10 +50,12 @@ constexpr int enc_npix() {
 // ([image][cin/8][h][w][8 halves], hf_split_activation_f16; ConvParams::xh / xl): the halo tile is
 // fetched by LDS-DMA like the weights - no per-element loads, no conversion (a shared input feeding
 // many output-channel tiles / groups is then converted once instead of once per block).
-template <int NTERMS, int PG, int WAVES_PX, int STRIDE, bool PRE>
-__global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
-                                                              const _Float16 *__restrict__ wtl_all) {
-  constexpr int CT_TILES = 1, WAVES_CO = 2;
+// Wave tiles: WAVES_CO = 2, CT_TILES = 1 (each wave 32 channels x 64 pixels: small layers, many blocks) or
+// WAVES_CO = 1, CT_TILES = 2 (each wave all 64 channels x 64 pixels, 2 x 2 MFMA tiles: 0.67 instead of 1 LDS
+// fragment read per MFMA - the batched swap's layers, which fill the chip with 512-pixel tiles).
+template <int NTERMS, int PG, int WAVES_PX, int STRIDE, bool PRE, int CT_TILES = 1, int WAVES_CO = 2>
+__global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
+                                                                       const _Float16 *__restrict__ wtl_all) {
   constexpr int NW = WAVES_CO * WAVES_PX;
   constexpr int NT = 64 * NW;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;  // 64
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P,
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wave_co = (wave / WAVES_PX) * 32;
+  const int wave_co = (wave / WAVES_PX) * 32 * CT_TILES;
   const int wave_pg = (wave % WAVES_PX) * PG;
   const int co0 = go.co_tile * CT;
 
@@ -204,9 +206,11 @@ __global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P,
 
   f32x16 acc[1][CT_TILES][PG];
 #pragma unroll
-  for (int g = 0; g < PG; ++g)
+  for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][g][r] = 0.0f;
+    for (int g = 0; g < PG; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][ct][g][r] = 0.0f;
 
   // LDS unit (inside a kgroup) of the lane's pixel of group g at tap (0, 0)
   int pix0[PG];
@@ -249,12 +253,15 @@ __global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P,
     const bool more = c + 1 < c_end;
     const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT
     const half8 *b_hi = buf + OFF_XH + lh * NPIX;
-    half8 ah[2], al[2], bh[2][PG], bl[2][PG];
+    half8 ah[2][CT_TILES], al[2][CT_TILES], bh[2][PG], bl[2][PG];
     auto fetch = [&](int slot, int tap) {
       const int ky = tap / 3, kx = tap % 3;
       const int toff = (STRIDE == 1) ? ky * wp + kx : ky * wp + (kx & 1) * wp2 + (kx >> 1);
-      ah[slot] = a_hi[tap * 2 * CT];
-      if (NTERMS == 3) al[slot] = a_hi[OFF_WL + tap * 2 * CT];
+#pragma unroll
+      for (int ct = 0; ct < CT_TILES; ++ct) {
+        ah[slot][ct] = a_hi[tap * 2 * CT + ct * 32];
+        if (NTERMS == 3) al[slot][ct] = a_hi[OFF_WL + tap * 2 * CT + ct * 32];
+      }
 #pragma unroll
       for (int g = 0; g < PG; ++g) {
         bh[slot][g] = b_hi[pix0[g] + toff];
@@ -284,12 +291,21 @@ __global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P,
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int g = 0; g < PG; ++g) acc[0][0][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bh[s_][g], acc[0][0][g], 0, 0, 0);
+      for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+        for (int g = 0; g < PG; ++g)
+          acc[0][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_][ct], bh[s_][g], acc[0][ct][g], 0, 0, 0);
       if (NTERMS == 3) {
 #pragma unroll
-        for (int g = 0; g < PG; ++g) acc[0][0][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bl[s_][g], acc[0][0][g], 0, 0, 0);
+        for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
-        for (int g = 0; g < PG; ++g) acc[0][0][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s_], bh[s_][g], acc[0][0][g], 0, 0, 0);
+          for (int g = 0; g < PG; ++g)
+            acc[0][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_][ct], bl[s_][g], acc[0][ct][g], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+          for (int g = 0; g < PG; ++g)
+            acc[0][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s_][ct], bh[s_][g], acc[0][ct][g], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -298,9 +314,11 @@ __global__ __launch_bounds__(128 * WAVES_PX) void conv_enc_h(const ConvParams P,
 
   // undo the weights' power-of-two pre-scale (exact), then the shared epilogue
 #pragma unroll
-  for (int g = 0; g < PG; ++g)
+  for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][g][r] *= w_unscale;
+    for (int g = 0; g < PG; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][ct][g][r] *= w_unscale;
   store_tile<CT_TILES, PG, false>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
@@ -314,10 +332,11 @@ inline int enc_splitk_plan(long long blocks, int nchunks) {
   return s < 2 ? 1 : s;
 }
 
-template <int NTERMS, int PG, int WAVES_PX, int STRIDE>
+template <int NTERMS, int PG, int WAVES_PX, int STRIDE, int CT_TILES = 1, int WAVES_CO = 2>
 int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *workspace, long long workspace_floats,
                hipStream_t st, bool plan_only = false) {
-  constexpr int CT = 64, NT = 128 * WAVES_PX;
+  constexpr int CT = 32 * CT_TILES * WAVES_CO, NT = 64 * WAVES_CO * WAVES_PX;
+  static_assert(CT == 64, "64 output channels per block");
   constexpr int PT = 32 * PG * WAVES_PX;
   constexpr int NPIX = enc_npix<PT, STRIDE>();
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;
@@ -349,9 +368,9 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
   if (lds > 160 * 1024) return HF_E_INVALID;
   if (P.xh) {
     if ((long long)2 * P.h * P.w * 16 >= (1LL << 31) || (NTERMS == 3 && !P.xl)) return HF_E_INVALID;
-    hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, true>), grid, dim3(NT), lds, st, P, wth, wtl);
+    hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, true, CT_TILES, WAVES_CO>), grid, dim3(NT), lds, st, P, wth, wtl);
   } else {
-    hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, false>), grid, dim3(NT), lds, st, P, wth, wtl);
+    hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, false, CT_TILES, WAVES_CO>), grid, dim3(NT), lds, st, P, wth, wtl);
   }
   int rc = hf_launch_status();
   if (rc == HF_OK && P.splits > 1) rc = launch_splitk_reduce(P, true, st);  // deterministic second pass + epilogue
@@ -368,11 +387,19 @@ int run_enc(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *ws, lo
     if (rc == HF_OK && !plan_only) note_path(6, 2);
     return rc;
   }
-  // 64 co x 256 px (8 waves) when that still fills the chip, else 64 co x 128 px (4 waves)
+  // 64 co x 512 px (8 waves, 2 x 2 MFMA tiles each) when that fills the chip (batched swaps), else
+  // 64 co x 256 px (8 waves, 1 x 2 tiles) when that still does, else 64 co x 128 px (4 waves)
   const int groups = P.groups > 1 ? P.groups : 1;
   const long long blocks256 = (long long)P.batch * groups * hf_cdiv((long long)P.out_h * P.out_w, 256) * (P.cout / 64);
+  const long long blocks512 = (long long)P.batch * groups * hf_cdiv((long long)P.out_h * P.out_w, 512) * (P.cout / 64);
   rc = HF_E_INVALID;
-  if (blocks256 >= 384) {
+  // hf_debug_set_tuning: bit 2 = never the 512-pixel form, bits 8.. = its minimum block count (0: the default)
+  const int min512 = (g_h_tune >> 8) > 0 ? (g_h_tune >> 8) : 512;
+  if (NTERMS == 3 && !(g_h_tune & 4) && blocks512 >= min512) {  // plain fp16 operands: staging-bound, measured slower
+    rc = launch_enc<NTERMS, 2, 8, 1, 2, 1>(P, hi, lo, ws, wsn, st, plan_only);
+    if (rc == HF_OK && !plan_only) note_path(6, 4);
+  }
+  if (rc == HF_E_INVALID && blocks256 >= 384) {
     rc = launch_enc<NTERMS, 2, 4, 1>(P, hi, lo, ws, wsn, st, plan_only);
     if (rc == HF_OK && !plan_only) note_path(6, 1);
   }

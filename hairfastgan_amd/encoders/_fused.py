@@ -79,8 +79,11 @@ def conv(x, w, k, stride=1, presplit=False, **kw):
         hi, lo = w.f16()
         nterms = 3 if mode == "f16x3" else 1
         groups = kw.get("groups", 1)
-        # worth a separate pass when the same input tile is converted by many (group, 64-channel) block columns
-        many = groups * (w.cout // 64) >= 8
+        # worth a separate pass when the same input tile is converted by many (group, 64-channel) block columns -
+        # or, from 128 input channels, when a batched pass (HairFast.swap_batch) makes the extra launch negligible
+        # (tools/bench_enc_layers.py, ENC_BATCH_MULT=8: 256->256 @32^2 128 -> 111 us, 512->512 stride 2 340 -> 160 us)
+        out_px = x.shape[0] * ((h - 1) // stride + 1) * ((wd - 1) // stride + 1)
+        many = groups * (w.cout // 64) >= 8 or (w.cin >= 128 and out_px >= 12288)
         if (PRESPLIT == "all" and many) or (presplit and PRESPLIT in ("all", "heads")):
             x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None),
                                        want_lo=nterms == 3)

@@ -42,7 +42,10 @@ def main():
     dev = torch.device("cuda:0")
     L, st = lib(), stream()
     print(f"{'layer':24s} {'GFLOP':>7s} | {'f32 us':>8s} {'TF/s':>6s} | {'f16x3 us':>8s} {'TF/s':>6s} | {'pre us':>8s} {'TF/s':>6s} | {'f16 us':>8s} {'TF/s':>6s} | split-K")
+    L.hf_debug_set_tuning(int(os.environ.get("ENC_TUNE", "0")))  # 4 = without the 512-pixel tile form
+    mult = int(os.environ.get("ENC_BATCH_MULT", "1"))  # swap_batch: the same layers with `mult` triples per pass
     for label, B, cin, cout, H, W, stride, G in LAYERS:
+        B *= mult
         torch.manual_seed(0)
         x = torch.randn(B, cin, H, W, device=dev)
         w = torch.randn(G, cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
