@@ -1,6 +1,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_encoders.py tests/test_gpu_schedule.py tests/test_gpu_parsing.py -q -x 2>&1 | tail -3
-for b in 8; do
-  python bench.py --workload swap256 --triples 32 --warmup 1 --swap-batch $b --no-kernel-events 2>gpurun_out/r02u_swap_b$b.err | head -c 330; echo
-done | tee gpurun_out/r02u_swapbatch.log
+python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee gpurun_out/r02v_tests.log
+python bench.py --steps 30 --warmup 5 > gpurun_out/r02v_bench.json 2> gpurun_out/r02v_bench.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r02v_bench.json'))
+print({k:d[k] for k in ('value','ms_per_step')}, d.get('roofline'), d.get('exact_f32'), d.get('f16_mode'), d.get('swap_schedule',{}).get('value'), d.get('swap_pipeline'))
+PY

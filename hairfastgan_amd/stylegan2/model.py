@@ -476,11 +476,35 @@ class Generator(nn.Module):  # :368-565
                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
 
         styled = self._batch_styles(latent)
+        if layer_in is None or tuple(layer_in.shape[-2:]) == (2 ** (start_layer + 1),) * 2:  # standard pyramid sizes only
+            noise = self._draw_noise(noise, latent, start_layer, end_layer)
         try:
             return self._run_layers(latent, noise, layer_in, skip, start_layer, end_layer, return_latents)
         finally:
             for conv in styled:
                 conv._coeffs = None
+
+    def _draw_noise(self, noise, latent, start_layer, end_layer):
+        """randomize_noise: the fresh N(0,1) maps of every layer that will run, from ONE normal_() launch on torch's
+        device RNG (the reference draws one tensor per layer inside NoiseInjection, :289-291 - 17 launches per forward;
+        same distribution, same seed -> same images, but a different walk through the Philox stream: bit-level
+        noise parity with a CUDA run does not exist either way).  Stand-alone layers still draw their own."""
+        if any(n is not None for n in noise) or not latent.is_cuda:
+            return noise
+        b = latent.shape[0]
+        run = [i for i in range(self.num_layers)
+               if (i == 0 and start_layer == 0) or (i > 0 and max(start_layer, 1) <= (i + 1) // 2 and
+                                                    ((i + 1) // 2 <= end_layer or (i + 1) // 2 == start_layer))]
+        if not run:
+            return noise
+        sizes = [b * (2 ** ((i + 5) // 2)) ** 2 for i in run]
+        flat = torch.empty(sum(sizes), device=latent.device, dtype=torch.float32).normal_()
+        out, o = list(noise), 0
+        for i, n in zip(run, sizes):
+            r = 2 ** ((i + 5) // 2)
+            out[i] = flat[o:o + n].view(b, 1, r, r)
+            o += n
+        return out
 
     def _batch_styles(self, latent):
         """Modulation (and demodulation) coefficients of every layer from W+ in two launches
