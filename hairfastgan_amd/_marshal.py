@@ -255,7 +255,16 @@ def modconv3x3_f16_supported(cin, cout, h, w):
 
 def torgb_fusable(cin, cout, h, w):
     """Layers whose ToRGB hf_modconv3x3_f16_rgb_f32 computes in the conv epilogue."""
-    return cout in (32, 64) and modconv3x3_f16_supported(cin, cout, h, w) and h * w >= 512
+    if not (cout % 32 == 0 and modconv3x3_f16_supported(cin, cout, h, w)):
+        return False
+    # one slab (cout 32 / 64) from 512 pixels; several slabs need the 64-channel-per-wave tile shape, which only
+    # fills the chip from 64^2 planes (a 32^2 layer on it measured 2x slower than on its own tile shape)
+    return h * w >= (512 if cout in (32, 64) else 4096)
+
+
+def torgb_slabs(cout):
+    """Slabs of the fused ToRGB's raw tensor [B, 3*slabs, H, W] (hf_modconv3x3_f16_rgb_slabs)."""
+    return cout // 64 if cout % 64 == 0 else cout // 32
 
 
 def modconv3x3_f16(lib, st, x, wt_hi, wt_lo, nterms, s, d, noise, noise_w, bias, alpha=0.2, scale=SQRT2, rgb=None):
@@ -271,7 +280,7 @@ def modconv3x3_f16(lib, st, x, wt_hi, wt_lo, nterms, s, d, noise, noise_w, bias,
     noise_w, bias = _c(noise_w), _c(bias)
     if rgb is not None:
         rgb_wt, rgb_s = _c(rgb[0]), _c(rgb[1])
-        raw = x.new_empty((b, 3, h, w))
+        raw = x.new_empty((b, 3 * torgb_slabs(cout), h, w))
         code = _launch_profiled(
             lib, 2.0 * cin * cout * 9 * h * w * b,
             lambda: lib.hf_modconv3x3_f16_rgb_f32(_p(out), _p(x), _p(wt_hi), _p(wt_lo), nterms, _p(s), _p(d), _p(noise),
@@ -316,7 +325,7 @@ def modconv3x3_f16_pre(lib, st, act, wt_hi, wt_lo, nterms, d, noise, noise_w, bi
     raw = rgb_wt = rgb_s = sh = sl = s_next = None
     if rgb is not None:
         rgb_wt, rgb_s = _c(rgb[0]), _c(rgb[1])
-        raw = torch.empty((b, 3, h, w), dtype=torch.float32, device=dev)
+        raw = torch.empty((b, 3 * torgb_slabs(cout), h, w), dtype=torch.float32, device=dev)
     if split_for is not None:
         s_next = _c(split_for)
         sh = torch.empty((b, cout // 8, h, w, 8), dtype=torch.float16, device=dev)

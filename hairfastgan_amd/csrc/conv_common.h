@@ -73,6 +73,7 @@ struct ConvParams {
   void *oh, *ol;
   const float *s_next;
   float blur_kx[4], blur_ky[4];  // convh.hip FUSE: flipped 1-D factors of the (rank-1) 4x4 blur kernel applied in the epilogue
+  int rgb_slabs;               // convh.hip fused ToRGB: slabs of the raw tensor the caller allocated ([B][slabs*3][H][W])
   int dma_early;               // convh.hip PRE: issue a stage's DMAs in its first tap-step (short K loops) instead of spread
   int n_tiles;                 // convh.hip: tiles over all families; a block walks blockIdx.x + k*gridDim.x
   TileGeom g[3];

@@ -227,8 +227,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   //   scale * lrelu(acc*d + n + b) = max(o, alpha*o),  o = acc*(d*scale) + (n*scale + b*scale)
   // - d*scale and b*scale are folded into the per-image epilogue table below.  Anything else (no bias, other
   // activations) takes the general epilogue with its run-time switches.
-  const bool fast_ep = !UP && P.bias && P.act == ACT_LRELU && P.alpha >= 0.0f && P.alpha <= 1.0f && P.scale > 0.0f &&
-                       (WAVES_CO == 1 || !P.rgb_out);
+  const bool fast_ep = !UP && P.bias && P.act == ACT_LRELU && P.alpha >= 0.0f && P.alpha <= 1.0f && P.scale > 0.0f;
   const float ep_fold = (FUSE || fast_ep) ? P.scale : 1.0f;
   auto load_s = [&](int b, int slot) {
     float *dst = sl_base + slot * P.cin;
@@ -488,7 +487,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   // 512-pixel tile of the 1024^2 layer on scalar branches, a third of the tile.  (One body with uniform branches:
   // separate compile-time variants made LLVM hoist the common arithmetic above the dispatch and spill it.) ----
   auto epilogue_fast = [&](const TileGeom &G, const Tile &T, int slot, const float (&nz)[PG]) {
-    const bool OUT = P.out != nullptr, SPLIT = P.oh != nullptr, RGB = WAVES_CO == 1 && P.rgb_out != nullptr;  // uniform
+    const bool OUT = P.out != nullptr, SPLIT = P.oh != nullptr, RGB = P.rgb_out != nullptr;  // uniform
     int co_w = wave_co, li_o = li, lh_o = lh;
     HF_OPAQUE_I32(co_w);
     HF_OPAQUE_I32(li_o);
@@ -555,12 +554,16 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
             }
           }
       }
-      if (RGB) {  // the two half-waves hold the other channels of the same pixels: add, the low half stores
+      if (RGB) {
+        // the two half-waves hold the other channels of the same pixels: add, the low half stores.  A wave covers
+        // 32*CT_TILES of the cout channels: its sum goes to slab (blockIdx.y*WAVES_CO + co-wave) of the
+        // [B][slabs*3][H][W] raw tensor; ToRGB's finishing pass adds the slabs in a fixed order (deterministic)
+        const int slabs = (int)gridDim.y * WAVES_CO, slab = (int)blockIdx.y * WAVES_CO + wave / WAVES_PX;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           rgb[c] += __shfl_xor(rgb[c], 32, 64);
           if (pv && lh_o == 0)
-            P.rgb_out[((long long)T.b0 * 3 + c) * ((long long)P.out_h * P.out_w) + (long long)Y * P.out_w + X] = rgb[c];
+            P.rgb_out[(((long long)T.b0 * slabs + slab) * 3 + c) * ((long long)P.out_h * P.out_w) + (long long)Y * P.out_w + X] = rgb[c];
         }
       }
     }
@@ -978,7 +981,12 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
   const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float) +
                      2 * 3 * CT * sizeof(float) + (P.rgb_out ? 2 * 3 * CT * sizeof(float) : 0);
   // stages + s[2][cin] + epilogue d/bias/s_next [2][3][CT] (+ fused ToRGB weights [2][3][CT])
-  if (P.rgb_out && (UP || WAVES_CO != 1 || P.cout != CT || !P.rgb_w || !P.rgb_s)) return HF_E_INVALID;
+  // fused ToRGB: the standard StyledConv tail (the kernel's fast epilogue) writes one raw slab per 32*CT_TILES output
+  // channels; the general epilogue only handles the one-slab case
+  const bool std_tail = P.bias && P.act == ACT_LRELU && P.alpha >= 0.0f && P.alpha <= 1.0f && P.scale > 0.0f;
+  if (P.rgb_out && (UP || !P.rgb_w || !P.rgb_s || (!std_tail && (WAVES_CO != 1 || P.cout != CT)) ||
+                    P.rgb_slabs != P.cout / (32 * CT_TILES)))
+    return HF_E_INVALID;
   if (lds > 160 * 1024) return HF_E_INVALID;
   P.n_tiles = nblocks;
   P.dma_early = (g_h_tune & 1) ? 1 : 0;  // measured (tools/probes/gen_layers.py): spread is 0-8 % faster on every generator layer
@@ -1165,6 +1173,12 @@ extern "C" int hf_debug_set_tuning(int bits) {
   return HF_OK;
 }
 
+extern "C" int hf_modconv3x3_f16_rgb_slabs(int cout) {
+  // the dispatch below gives a layer with a fused ToRGB the 64-channel-per-wave tile shape when cout % 64 == 0 (cfg 52),
+  // else the 32-channel one (53 / 55)
+  return cout <= 0 || (cout % 32) ? 0 : ((cout % 64) ? cout / 32 : cout / 64);
+}
+
 extern "C" int hf_debug_set_persistent_blocks(int blocks) {
   hf_detail::g_h_blocks = blocks;
   return HF_OK;
@@ -1176,7 +1190,7 @@ extern "C" int hf_modconv3x3_f16_rgb_f32(float *out, const float *x, const void 
                                          int h, int w, float alpha, float scale, float *rgb_raw, const float *rgb_wt,
                                          const float *rgb_s, void *stream) {
   if (!out || !x || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (noise && !noise_w) ||
-      (nterms != 1 && nterms != 3) || !rgb_raw || !rgb_wt || !rgb_s || (cout != 32 && cout != 64))
+      (nterms != 1 && nterms != 3) || !rgb_raw || !rgb_wt || !rgb_s || (cout % 32))
     return HF_E_INVALID;
   ConvParams P{};
   P.out = out; P.x = x; P.s = s; P.d = d; P.noise = noise; P.noise_w = noise_w; P.bias = bias;
@@ -1188,6 +1202,7 @@ extern "C" int hf_modconv3x3_f16_rgb_f32(float *out, const float *x, const void 
   P.act = bias ? ACT_LRELU : ACT_NONE;
   P.alpha = alpha; P.scale = scale;
   P.rgb_out = rgb_raw; P.rgb_w = rgb_wt; P.rgb_s = rgb_s;
+  P.rgb_slabs = hf_modconv3x3_f16_rgb_slabs(cout);
   return launch_conv_h(P, nterms, false, wt_hi, wt_lo, (hipStream_t)stream);
 }
 
@@ -1200,7 +1215,7 @@ extern "C" int hf_modconv3x3_f16_pre_f32(float *out, const void *x_hi, const voi
   if ((!out && !rgb_raw && !split_hi) || !x_hi || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 ||
       (noise && !noise_w) || (nterms != 1 && nterms != 3) || (nterms == 3 && !x_lo))
     return HF_E_INVALID;
-  if (rgb_raw && (!rgb_wt || !rgb_s || (cout != 32 && cout != 64))) return HF_E_INVALID;
+  if (rgb_raw && (!rgb_wt || !rgb_s || (cout % 32))) return HF_E_INVALID;
   ConvParams P{};
   P.out = out; P.xh = x_hi; P.xl = x_lo; P.d = d; P.noise = noise; P.noise_w = noise_w; P.bias = bias;
   P.s_bstride = cin; P.d_bstride = cout;
@@ -1211,6 +1226,7 @@ extern "C" int hf_modconv3x3_f16_pre_f32(float *out, const void *x_hi, const voi
   P.act = bias ? ACT_LRELU : ACT_NONE;
   P.alpha = alpha; P.scale = scale;
   P.rgb_out = rgb_raw; P.rgb_w = rgb_wt; P.rgb_s = rgb_s;
+  P.rgb_slabs = hf_modconv3x3_f16_rgb_slabs(cout);
   P.oh = split_hi; P.ol = split_lo; P.s_next = s_next;
   if (split_hi && ((cout & 7) || (nterms == 3 && !split_lo))) return HF_E_INVALID;
   return launch_conv_h(P, nterms, false, wt_hi, wt_lo, (hipStream_t)stream);

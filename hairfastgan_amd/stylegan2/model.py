@@ -181,8 +181,8 @@ class ModulatedConv2d(nn.Module):  # :183-279
         return M.modconv3x3(lib(), stream(), input, wt, s, d, noise, noise_w, bias, alpha, scale)
 
     def fuses_torgb(self, input):
-        """True when the layer's ToRGB can be computed in this conv's epilogue (fp16-core modes,
-        32/64 output channels: one wave holds every channel of its pixels)."""
+        """True when the layer's ToRGB can be computed in this conv's epilogue (fp16-core modes; a wave sums the
+        64 / 32 output channels it holds, ToRGB.finish adds the slabs)."""
         _, cin, h, w = input.shape
         return (conv_precision() != "f32" and not self.upsample and self.kernel_size == 3
                 and M.torgb_fusable(cin, self.out_channel, h, w))
@@ -396,9 +396,10 @@ class ToRGB(nn.Module):  # :346-365
         (StyledConv.forward_rgb / forward_from_split): bias + upsampled skip on top of `raw` - the same kernel
         with a 3-channel input and identity weights."""
         require_gpu(raw, skip)
+        slabs = raw.shape[1] // 3  # partial sums over 64 (32) output channels each: added here, in a fixed order
         eye = getattr(self, "_eye", None)
-        if eye is None or eye.device != raw.device:
-            eye = self._eye = torch.eye(3, device=raw.device, dtype=raw.dtype).reshape(1, 3, 3)
+        if eye is None or eye.device != raw.device or eye.shape[1] != 3 * slabs:
+            eye = self._eye = torch.eye(3, device=raw.device, dtype=raw.dtype).repeat(slabs, 1).reshape(1, 3 * slabs, 3)
         return M.torgb(lib(), stream(), raw, eye, None, self.bias.detach(), skip, self._skip_kernel(skip))
 
 

@@ -172,13 +172,17 @@ int hf_modconv3x3_f16_f32(float *out, const float *x, const void *wt_hi, const v
                           const float *s, const float *d, const float *noise, const float *noise_w,
                           long long noise_bstride, const float *bias, int batch, int cin, int cout, int h,
                           int w, float alpha, float scale, void *stream);
-/* hf_modconv3x3_f16_f32 with ToRGB's 1x1 modulated conv fused into the epilogue (layers whose
- * cout is 32 or 64: a wave holds every channel of its pixels):
- *   rgb_raw[b,c,Y,X] = sum_co rgb_wt[co*3+c] * rgb_s[b*cout+co] * out[b,co,Y,X]
- * i.e. ToRGB.forward (models/stylegan2/model.py:356-362) before its bias and upsampled skip;
- * finish with hf_torgb_f32(out_rgb, rgb_raw, identity3x3, NULL, bias, skip, k4, batch, 3, h, w).
- * rgb_wt: ToRGB's prepared 1x1 weight ([cout][3], from hf_modconv_prepare_f32), rgb_s: its
- * modulation (hf_modulation_f32).  Saves re-reading the layer's output (4*cout*H*W bytes). */
+/* hf_modconv3x3_f16_f32 with ToRGB's 1x1 modulated conv fused into the epilogue (cout % 32 == 0).  A wave holds
+ * 64 (cout % 64 == 0) or 32 output channels of its pixels and writes their part of the sum into its own slab:
+ *   rgb_raw[b, j*3+c, Y, X] = sum_{co in slab j} rgb_wt[co*3+c] * rgb_s[b*cout+co] * out[b,co,Y,X],
+ *   rgb_raw: [batch][3*slabs][h][w], slabs = hf_modconv3x3_f16_rgb_slabs(cout)  (1 for cout 32 / 64)
+ * i.e. ToRGB.forward (models/stylegan2/model.py:356-362) before its bias and upsampled skip; finish with
+ * hf_torgb_f32(out_rgb, rgb_raw, I, NULL, bias, skip, k4, batch, 3*slabs, h, w), I = `slabs` stacked 3x3 identities
+ * (a fixed summation order: deterministic).  rgb_wt: ToRGB's prepared 1x1 weight ([cout][3], from
+ * hf_modconv_prepare_f32), rgb_s: its modulation (hf_modulation_f32).  Saves re-reading the layer's output
+ * (4*cout*H*W bytes) - and writing it, when nothing else consumes it (hf_modconv3x3_f16_pre_f32 with out = NULL).
+ * More than one slab needs the standard tail (bias != NULL); otherwise HF_E_INVALID. */
+int hf_modconv3x3_f16_rgb_slabs(int cout);
 int hf_modconv3x3_f16_rgb_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
                               const float *s, const float *d, const float *noise, const float *noise_w,
                               long long noise_bstride, const float *bias, int batch, int cin, int cout, int h,

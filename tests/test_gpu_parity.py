@@ -405,7 +405,7 @@ def test_modconv_f16_persistent_tile_walk(up, blocks, shape):
         lib.hf_debug_set_persistent_blocks(0)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 64, 64, 64), (1, 32, 32, 96, 128)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 64, 64), (1, 32, 32, 96, 128), (2, 256, 256, 64, 64), (1, 64, 96, 32, 64)])
 def test_modconv_f16_fused_torgb(shape):
     """Fused ToRGB epilogue (hf_modconv3x3_f16_rgb_f32) + finishing pass == conv followed by the
     stand-alone ToRGB kernel; the conv output itself is unchanged bit for bit."""
@@ -429,10 +429,12 @@ def test_modconv_f16_fused_torgb(shape):
     wtr, _ = M.prepare_weights(lib, st, wrgb)
     sr = M.modulation(lib, st, styr, mwr, mbr)
     k4 = O.blur_kernel_1d_to_2d(gain=4.0).to(dev)
-    assert M.torgb_fusable(cin, cout, H, W)
+    assert M.modconv3x3_f16_supported(cin, cout, H, W) and cout % 32 == 0  # what the kernel takes (torgb_fusable: the policy)
     y, raw = M.modconv3x3_f16(lib, st, x, hi, lo, 3, s, dm, nz, nw, bias, rgb=(wtr, sr))
     y_plain = M.modconv3x3_f16(lib, st, x, hi, lo, 3, s, dm, nz, nw, bias)
-    rgb = M.torgb(lib, st, raw, torch.eye(3, device=dev).reshape(1, 3, 3), None, brgb, skip, k4)
+    slabs = M.torgb_slabs(cout)  # one partial sum per 64 (32) output channels, added by the finishing pass
+    assert raw.shape == (B, 3 * slabs, H, W)
+    rgb = M.torgb(lib, st, raw, torch.eye(3, device=dev).repeat(slabs, 1).reshape(1, 3 * slabs, 3), None, brgb, skip, k4)
     ref = M.torgb(lib, st, y, wtr, sr, brgb, skip, k4)
     torch.cuda.synchronize()
     assert torch.equal(y, y_plain)
@@ -488,12 +490,13 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
     monkeypatch.setattr(M, "torgb", rgb)
     with torch.inference_mode():
         y, _ = g([lat], input_is_latent=True, noise=nz)
-        assert fused == [512, 1024]
+        assert fused == [64, 128, 256, 512, 1024]  # ToRGB's 1x1 conv in the conv epilogue from 64^2 upward (partial sums per 64 channels)
         assert presplit == [32, 64, 128, 256, 512, 1024]  # blur -> conv hand-over without an fp32 activation
         # conv epilogue -> next block's transposed conv, pre-split: two-pass up to 64^2 inputs, then the one-kernel
         # form (transposed conv + blur + noise + bias + lrelu, no (2h+1)^2 intermediate) from 128^2 inputs upward
         assert up_pre == [32, 64] and up_fused == [128, 256, 512]
-        assert plain_rgb.count(3) == 2 and len(plain_rgb) == 9  # two finishing passes on 3-channel input
+        # finishing passes on the raw slabs (8, 4, 2, 1, 1 slabs of 3 channels); the layers below 64^2 run the stand-alone ToRGB
+        assert plain_rgb == [512, 512, 512, 512, 24, 12, 6, 3, 3], plain_rgb
         # module API: forward_rgb's explicit (out, raw) pair finished by ToRGB.finish equals the stand-alone ToRGB
         x32 = torch.randn(1, 32, 1024, 1024, device=dev)
         out, raw = g.convs[15].forward_rgb(x32, lat[:, 16], nz[16], g.to_rgbs[7].coefficients(lat[:, 17]))

@@ -267,7 +267,7 @@ def test_modconv_f16_persistent_tile_walk(simlib, up, blocks):
     assert maxdiff(y, full) < TOL * max(1.0, float(full.abs().max()))
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 64, 16, 32), (1, 16, 32, 20, 40)])
+@pytest.mark.parametrize("shape", [(2, 32, 64, 16, 32), (1, 16, 32, 20, 40), (1, 32, 128, 16, 32), (1, 16, 96, 16, 32)])
 def test_modconv_f16_fused_torgb(simlib, golden, shape):
     """ToRGB's 1x1 modulated conv in the conv epilogue (hf_modconv3x3_f16_rgb_f32) + the finishing
     pass (bias + upsampled skip through hf_torgb_f32 with identity weights) == conv then ToRGB."""
@@ -286,11 +286,13 @@ def test_modconv_f16_fused_torgb(simlib, golden, shape):
     wtr, _ = M.prepare_weights(simlib, None, wrgb)
     sr = M.modulation(simlib, None, styr, mwr, mbr)
     k4 = O.blur_kernel_1d_to_2d(gain=4.0)
-    assert M.torgb_fusable(cin, cout, H, W)
+    assert M.modconv3x3_f16_supported(cin, cout, H, W) and cout % 32 == 0  # what the kernel takes (torgb_fusable: the policy)
     y, raw = M.modconv3x3_f16(simlib, None, x, hi, lo, 3, s, dm, nz, nw, bias, rgb=(wtr, sr))
     y_plain = M.modconv3x3_f16(simlib, None, x, hi, lo, 3, s, dm, nz, nw, bias)
     assert torch.equal(y, y_plain)
-    rgb = M.torgb(simlib, None, raw, torch.eye(3).reshape(1, 3, 3), None, brgb, skip, k4)
+    slabs = M.torgb_slabs(cout)  # one partial sum per 64 (32) output channels, added by the finishing pass
+    assert raw.shape == (B, 3 * slabs, H, W)
+    rgb = M.torgb(simlib, None, raw, torch.eye(3).repeat(slabs, 1).reshape(1, 3 * slabs, 3), None, brgb, skip, k4)
     ref = M.torgb(simlib, None, y, wtr, sr, brgb, skip, k4)
     assert maxdiff(rgb, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
 
