@@ -319,7 +319,10 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
     for (int g = 0; g < PG; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][ct][g][r] *= w_unscale;
-  store_tile<CT_TILES, PG, false>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+  if (P.d_bstride == 0 && !P.noise)
+    store_tile_rows<CT_TILES, PG>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+  else
+    store_tile<CT_TILES, PG, false>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
 // split-K plan: fill the chip (>= ~1.5 blocks per CU) when the output grid alone cannot, keeping at

@@ -251,6 +251,14 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const ConvParams P) {
     mfma_chunk<CT_TILES, PG, CT, UP, TAPS>(acc, a_base, b_base, P.xs_max, pixoff, wp, NoSideWork());
   }
 
+  if constexpr (!UP) {
+    // whole channel tiles of an encoder-type launch (per-channel scale / bias, no noise): the epilogue without
+    // per-element switches (conv_common.h)
+    if (!P.noise && P.d_bstride == 0 && co0 + CT <= P.cout) {
+      store_tile_rows<CT_TILES, PG>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+      return;
+    }
+  }
   store_tile<CT_TILES, PG, UP>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
@@ -428,6 +436,14 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const
     if (ABLATE < 2) __syncthreads();  // also drains the weight DMA (vmcnt) before anyone reads the other buffer
   }
 
+  if constexpr (!UP) {
+    // whole channel tiles of an encoder-type launch (per-channel scale / bias, no noise): the epilogue without
+    // per-element switches (conv_common.h)
+    if (!P.noise && P.d_bstride == 0 && co0 + CT <= P.cout) {
+      store_tile_rows<CT_TILES, PG>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+      return;
+    }
+  }
   store_tile<CT_TILES, PG, UP>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 

@@ -18,9 +18,9 @@ def label(name):
                 f"{',pre' if pre else ''}{',fuse' if fuse else ''}>")
     if "blur4x4_split8" in name:
         return "blur4x4_split8"
-    me = re.search(r"conv_enc_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)E", name)
+    me = re.search(r"conv_enc_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)E(?:Li(\d)ELi(\d)E)?", name)
     if me:
-        nt, pg, wpx, stride, pre = (int(v) for v in me.groups())
+        nt, pg, wpx, stride, pre = (int(v) for v in me.groups()[:5])
         return f"conv_enc_h<{'64x%d' % (32 * pg * wpx)}{',stride2' if stride == 2 else ''}{',pre' if pre else ''}>"
     name = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     m = re.match(r"(conv_mfma\w*)<(.*)>", name)
