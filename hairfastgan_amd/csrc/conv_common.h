@@ -188,80 +188,84 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
 // store_tile for whole channel tiles (cout % 32 == 0, no noise, !UP): the encoder-type epilogue
 //   v = act( acc * d[co] + bias[co] (+ residual) ) (+ residual),  act in {none, leaky ReLU * scale, PReLU}
 // without per-element switches: the per-channel vectors arrive as 16-byte loads of the lane's 4 consecutive channels,
-// ALL loads (parameters, residual) are issued before the first store (a load behind a store waits for the store's
-// acknowledgement), the activation is one select + multiply (negative slope 1 = identity), and the run-time
-// options are tested per tile, not per element (store_tile spends ~100 cycles per element on them: as long as the
+// the loads of a 32-channel tile (parameters, residual) are issued before its first store (a load behind a store
+// waits for the store's acknowledgement), the activation is one select + multiply (negative slope 1 = identity),
+// and the run-time options are tested per tile, not per element (store_tile spends ~100 cycles per element on them: as long as the
 // whole K loop of a 64-channel layer).  split-K launches store the raw sums.
-template <int CT_TILES, int PG>
-__device__ __forceinline__ void store_tile_rows(const ConvParams &P, const TileGeom &G, const GroupOfs &go,
-                                                f32x16 (&acc)[1][CT_TILES][PG], int co_wave, int wave_pg, int li, int lh,
-                                                int ty0, int tx0, int b0) {
+template <int CT_TILES, int PG, bool RES>
+__device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const TileGeom &G, const GroupOfs &go,
+                                                     f32x16 (&acc)[1][CT_TILES][PG], int co_wave, int wave_pg, int li, int lh,
+                                                     int ty0, int tx0, int b0) {
   const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
   const long long oplane = (long long)P.out_h * P.out_w;
   const bool partial = P.splits > 1;
   const bool prelu = !partial && P.act == ACT_PRELU, lrelu = !partial && P.act == ACT_LRELU;
   const float neg_u = lrelu ? P.alpha : 1.0f, sc = lrelu ? P.scale : 1.0f;
-  const bool has_res = !partial && P.residual != nullptr;
-  const bool res_pre = has_res && P.residual_pre;
-  float4 dm[CT_TILES][4], bs[CT_TILES][4], sl[CT_TILES][4];
-  int bq[PG];
+  const bool res_pre = RES && P.residual_pre;
   long long pofs[PG];
   bool pvs[PG];
 #pragma unroll
   for (int g = 0; g < PG; ++g) {
     const int p = (wave_pg + g) * 32 + li;
     const int px = p & (tw - 1), py = (p >> G.lg_tw) & (th - 1), im = p >> (G.lg_tw + G.lg_th);
-    const int Y = ty0 + py, X = tx0 + px;
-    bq[g] = b0 + im;
-    pvs[g] = (Y < G.y0 + G.dh) && (X < G.x0 + G.dw) && (bq[g] < P.batch);
-    pofs[g] = (long long)bq[g] * P.cout * oplane + (long long)Y * P.out_w + X;
+    const int Y = ty0 + py, X = tx0 + px, b = b0 + im;
+    pvs[g] = (Y < G.y0 + G.dh) && (X < G.x0 + G.dw) && (b < P.batch);
+    pofs[g] = (long long)b * P.cout * oplane + (long long)Y * P.out_w + X;
   }
-  // per-channel vectors (d may be per image: d_bstride != 0 - then of the first pixel group's image; encoder
-  // launches have d_bstride == 0)
+  float *obase = (partial ? P.partial + (long long)blockIdx.z * P.zslab : P.out) + go.o;
+  // one 32-channel tile at a time (register budget: some callers run two blocks per CU): its per-channel vectors
+  // and residual values are loaded, then its PG * 16 values stored
 #pragma unroll
-  for (int ct = 0; ct < CT_TILES; ++ct)
+  for (int ct = 0; ct < CT_TILES; ++ct) {
+    float4 dm[4], bs[4], sl[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c4 = go.c + co_wave + ct * 32 + 8 * q + 4 * lh;
-      dm[ct][q] = (P.d && !partial) ? *reinterpret_cast<const float4 *>(P.d + c4) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-      bs[ct][q] = (P.bias && !partial) ? *reinterpret_cast<const float4 *>(P.bias + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      sl[ct][q] = prelu ? *reinterpret_cast<const float4 *>(P.slope + c4) : make_float4(neg_u, neg_u, neg_u, neg_u);
+      dm[q] = (P.d && !partial) ? *reinterpret_cast<const float4 *>(P.d + c4) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+      bs[q] = (P.bias && !partial) ? *reinterpret_cast<const float4 *>(P.bias + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      sl[q] = prelu ? *reinterpret_cast<const float4 *>(P.slope + c4) : make_float4(neg_u, neg_u, neg_u, neg_u);
     }
-  float rv[PG][CT_TILES][16];
-  if (has_res) {
+    float rv[RES ? PG : 1][16];
+    if (RES) {
 #pragma unroll
-    for (int g = 0; g < PG; ++g)
-#pragma unroll
-      for (int ct = 0; ct < CT_TILES; ++ct)
+      for (int g = 0; g < PG; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          rv[g][ct][r] = pvs[g] ? P.residual[go.o + pofs[g] + (long long)co * oplane] : 0.0f;
+          rv[RES ? g : 0][r] = pvs[g] ? P.residual[go.o + pofs[g] + (long long)co * oplane] : 0.0f;
         }
-  }
-  float *obase = (partial ? P.partial + (long long)blockIdx.z * P.zslab : P.out) + go.o;
+    }
 #pragma unroll
-  for (int g = 0; g < PG; ++g) {
-    if (!pvs[g]) continue;
-#pragma unroll
-    for (int ct = 0; ct < CT_TILES; ++ct)
+    for (int g = 0; g < PG; ++g) {
+      if (!pvs[g]) continue;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float dmv[4] = {dm[ct][q].x, dm[ct][q].y, dm[ct][q].z, dm[ct][q].w};
-        const float bsv[4] = {bs[ct][q].x, bs[ct][q].y, bs[ct][q].z, bs[ct][q].w};
-        const float slv[4] = {sl[ct][q].x, sl[ct][q].y, sl[ct][q].z, sl[ct][q].w};
+        const float dmv[4] = {dm[q].x, dm[q].y, dm[q].z, dm[q].w};
+        const float bsv[4] = {bs[q].x, bs[q].y, bs[q].z, bs[q].w};
+        const float slv[4] = {sl[q].x, sl[q].y, sl[q].z, sl[q].w};
         float *ob = obase + pofs[g] + (long long)(co_wave + ct * 32 + 8 * q + 4 * lh) * oplane;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int r = 4 * q + k;
           float v = fmaf(acc[0][ct][g][r], dmv[k], bsv[k]);
-          if (res_pre) v += rv[g][ct][r];
+          if (RES && res_pre) v += rv[RES ? g : 0][r];
           v = (v > 0.0f ? v : v * slv[k]) * sc;
-          if (has_res && !res_pre) v += rv[g][ct][r];
+          if (RES && !res_pre) v += rv[RES ? g : 0][r];
           HF_STORE_OUT(ob + k * oplane, v);
         }
       }
+    }
   }
+}
+
+template <int CT_TILES, int PG>
+__device__ __forceinline__ void store_tile_rows(const ConvParams &P, const TileGeom &G, const GroupOfs &go,
+                                                f32x16 (&acc)[1][CT_TILES][PG], int co_wave, int wave_pg, int li, int lh,
+                                                int ty0, int tx0, int b0) {
+  if (P.residual && P.splits <= 1)
+    store_tile_rows_impl<CT_TILES, PG, true>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
+  else
+    store_tile_rows_impl<CT_TILES, PG, false>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
 }
 
 inline int ilog2(int v) {
