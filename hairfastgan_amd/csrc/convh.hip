@@ -6,10 +6,12 @@
 //               lo = fp16(v - hi) (22 significant bits together) and the product a*b is
 //               formed as hi*hi + hi*lo + lo*hi - three fp16 MFMAs whose products are exact
 //               in the fp32 accumulator.  The dropped lo*lo term and the 22-bit operands
-//               leave a relative error of ~5e-7 per product, the same class as an fp32
-//               reassociation; the cost is 3/16 of the fp32 MFMA time.
-//               Range: |s*x| and |w| must stay below 65504 (fp16); StyleGAN2 activations
-//               are O(1..1e3).
+//               leave a relative error of 2^-22 per operand (absolute 2^-25 below 2^-3, see
+//               hf_common.h), the same class as an fp32 reassociation; the cost is 3/16 of the
+//               fp32 MFMA time.  Range: weights are pre-scaled by a power of two and styles
+//               normalised to [1, 2) by the producers (split_weights, style.hip), both parts
+//               saturate at +-65504 (values up to 131008 are carried, larger ones clamp and are
+//               counted: hf_f16_overflow_count).
 //   NTERMS = 1  "f16": operands rounded to fp16 (BASELINE.json configs[4]: fp16 MFMA with
 //               fp32 demodulation / accumulation), relative error ~5e-4 per product.
 //
