@@ -396,13 +396,15 @@ int run_enc(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *ws, lo
   const long long blocks256 = (long long)P.batch * groups * hf_cdiv((long long)P.out_h * P.out_w, 256) * (P.cout / 64);
   const long long blocks512 = (long long)P.batch * groups * hf_cdiv((long long)P.out_h * P.out_w, 512) * (P.cout / 64);
   rc = HF_E_INVALID;
-  // hf_debug_set_tuning: bit 2 = never the 512-pixel form, bits 8.. = its minimum block count (0: the default)
-  const int min512 = (g_h_tune >> 8) > 0 ? (g_h_tune >> 8) : 512;
+  // hf_debug_set_tuning: bit 2 = never the 512-pixel form, bits 8-15 = its minimum block count / 8 (0: the default),
+  // bits 16-23 = the minimum block count / 8 of the 256-pixel form
+  const int min512 = ((g_h_tune >> 8) & 255) > 0 ? ((g_h_tune >> 8) & 255) * 8 : 512;
+  const int min256 = ((g_h_tune >> 16) & 255) > 0 ? ((g_h_tune >> 16) & 255) * 8 : 384;
   if (NTERMS == 3 && !(g_h_tune & 4) && blocks512 >= min512) {  // plain fp16 operands: staging-bound, measured slower
     rc = launch_enc<NTERMS, 2, 8, 1, 2, 1>(P, hi, lo, ws, wsn, st, plan_only);
     if (rc == HF_OK && !plan_only) note_path(6, 4);
   }
-  if (rc == HF_E_INVALID && blocks256 >= 384) {
+  if (rc == HF_E_INVALID && blocks256 >= min256) {
     rc = launch_enc<NTERMS, 2, 4, 1>(P, hi, lo, ws, wsn, st, plan_only);
     if (rc == HF_OK && !plan_only) note_path(6, 1);
   }

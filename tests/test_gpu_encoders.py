@@ -170,6 +170,44 @@ def test_conv2d_f16_matrix_cores_encoder_shapes(nterms, tol, B, cin, cout, H, W,
     assert float((y - ref).abs().max()) < tol * scale, float((y - ref).abs().max()) / scale
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W", [(24, 64, 64, 128, 128), (16, 1024, 1024, 64, 64), (24, 256, 256, 32, 32)])
+def test_conv2d_f16_batched_pass_tile_forms(B, cin, cout, H, W):
+    """The shapes of a batched swap (HairFast.swap_batch, 8 triples per pass): the 64 x 512 tile form (2 x 2 MFMA
+    tiles per wave) where it fills the chip - bit-identical to the smaller forms (same K order), on fp32 and
+    pre-split inputs - and the encoder-type epilogue (store_tile_rows) against the exact-fp32 kernel."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = _dev()
+    torch.manual_seed(B + cin)
+    L, st = lib(), stream()
+    x = torch.randn(B, cin, H, W, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+    a, t = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.2
+    g, bsh, slope = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.2, torch.rand(cout, device=dev) * 0.5
+    wt = M.conv_prepare(L, st, w)
+    hi, lo = M.conv_split_weights_f16(L, st, wt)
+    res = torch.randn(B, cout, H, W, device=dev)
+    kw = dict(out_scale=g, bias=bsh, act=M.ACT_PRELU, slope=slope, residual=res)
+    xs = M.split_activation_f16(L, st, x, a, t)
+    blocks512 = B * ((H * W + 511) // 512) * (cout // 64)
+    try:
+        L.hf_debug_set_tuning(4)  # never the 512-pixel form
+        small = M.conv2d_f16(L, st, x, hi, lo, 3, cout, 1, in_scale=a, in_shift=t, **kw)
+        assert L.hf_debug_last_path() in (601, 603)
+        L.hf_debug_set_tuning(0)
+        y = M.conv2d_f16(L, st, x, hi, lo, 3, cout, 1, in_scale=a, in_shift=t, **kw)
+        assert (L.hf_debug_last_path() == 604) == (blocks512 >= 512)
+        ys = M.conv2d_f16(L, st, xs, hi, lo, 3, cout, 1, **kw)
+    finally:
+        L.hf_debug_set_tuning(0)
+    ref = M.conv2d(L, st, x, wt, 3, 1, in_scale=a, in_shift=t, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y, small) and torch.equal(ys, small)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((y - ref).abs().max()) < 5e-6 * scale
+
+
 def test_encoders_precision_modes(golden):
     """The encoder goldens in the other operand modes: exact fp32 MFMA (f32) at the fp32 tolerance,
     fp16 operands (f16) within 2e-2 of the W+ codes (the default f16x3 mode is what every other test runs)."""

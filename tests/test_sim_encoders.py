@@ -245,6 +245,37 @@ def test_conv2d_f16_presplit_input(simlib, stride, B, cin, cout, H, W):
         assert torch.equal(y, ref)
 
 
+def test_conv2d_f16_512_pixel_tile_form(simlib):
+    """The 64 x 512 tile form of csrc/convh_enc.hip (each wave all 64 channels x 64 pixels: the batched swap's
+    layers), forced on a small shape through hf_debug_set_tuning: same K order, so bit-identical to the
+    256-pixel form - on fp32 and pre-split inputs, with BN affines, PReLU and the residual."""
+    torch.manual_seed(31)
+    B, cin, cout, H, W = 2, 32, 128, 32, 64
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    a, t = torch.rand(cin) + 0.5, torch.randn(cin) * 0.2
+    g, bsh, slope = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2, torch.rand(cout) * 0.5
+    wt = M.conv_prepare(simlib, None, w)
+    hi, lo = M.conv_split_weights_f16(simlib, None, wt)
+    res = torch.randn(B, cout, H, W)
+    kw = dict(out_scale=g, bias=bsh, act=M.ACT_PRELU, slope=slope, residual=res)
+    xs = M.split_activation_f16(simlib, None, x, a, t)
+    try:
+        simlib.hf_debug_set_tuning(4)  # never the 512-pixel form
+        ref = M.conv2d_f16(simlib, None, x, hi, lo, 3, cout, 1, in_scale=a, in_shift=t, **kw)
+        assert simlib.hf_debug_last_path() in (601, 603)
+        simlib.hf_debug_set_tuning(1 << 8)  # from 8 blocks of 512 pixels (here: 2 * 4 * 2 = 16)
+        y = M.conv2d_f16(simlib, None, x, hi, lo, 3, cout, 1, in_scale=a, in_shift=t, **kw)
+        assert simlib.hf_debug_last_path() == 604
+        ys = M.conv2d_f16(simlib, None, xs, hi, lo, 3, cout, 1, **kw)
+        assert simlib.hf_debug_last_path() == 604
+    finally:
+        simlib.hf_debug_set_tuning(0)
+    assert torch.equal(y, ref) and torch.equal(ys, ref)
+    want = F.prelu(F.conv2d(x * a.view(1, -1, 1, 1) + t.view(1, -1, 1, 1), w, padding=1) * g.view(1, -1, 1, 1) + bsh.view(1, -1, 1, 1), slope) + res
+    assert maxdiff(y, want) < TOL * max(1.0, float(want.abs().max()))
+
+
 def test_conv2d_f16_split_k_and_grouped_presplit(simlib):
     """Few output tiles + many input channels: split-K over the K stages with the deterministic second pass
     (epilogue incl. PReLU + residual there); grouped launch on pre-split shared / per-group inputs."""
