@@ -27,6 +27,8 @@ and once for (face, color)) are issued as ONE batch-2 forward (`Alignment.rotate
 per-sample results are identical because the kernels share nothing across the batch.
 """
 import argparse
+import contextlib
+import os
 import random
 import sys
 import time
@@ -219,6 +221,14 @@ class Embedding(nn.Module):  # models/Embedding.py:17-117
             self.encoder.dlatent_avg.copy_(fs_dlatent_avg.to(dev))
         self.downsample_512 = BicubicDownSample(factor=2)
         self.downsample_256 = BicubicDownSample(factor=4)
+        self._overlap = os.environ.get("HAIRFAST_EMBED_OVERLAP", "1") != "0"
+        self._side = None  # two HIP side streams, created on first use
+        # Lazily derived weights (prepared / split layouts, folded BatchNorms) are computed on whatever stream first
+        # needs them and then shared by all: the first pass after construction or load_state_dict runs sequentially.
+        self._warmed = False
+        for top in (self.e4e.encoder, self.encoder, self.parsing, self.net.generator):
+            for m in top.modules():  # post hooks fire per (sub)module that is loaded
+                m.register_load_state_dict_post_hook(lambda *_: setattr(self, "_warmed", False))
 
     @staticmethod
     def normalize(x):
@@ -247,14 +257,36 @@ class Embedding(nn.Module):  # models/Embedding.py:17-117
             im_512 = self.downsample_512(image)
             im_256 = self.downsample_256(image)
             im_256_norm = self.normalize(im_256)
+            # The three branches below share nothing but their inputs.  For a single swap (<= 6 images: every kernel
+            # of the encoders is a latency-bound launch that fills a fraction of the chip) the FS-encoder branch and
+            # the parsing branch are ENQUEUED on two side streams so that the GPU overlaps them with e4e; the host
+            # order of the calls - and with it torch's RNG stream - is that of the sequential form: same results.
+            overlap = (self._overlap and self._warmed and image.is_cuda and image.shape[0] <= 6
+                       and not torch.cuda.is_current_stream_capturing())
+            main = torch.cuda.current_stream() if overlap else None
+            if overlap:
+                if self._side is None:
+                    self._side = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+                ready = torch.cuda.Event()
+                ready.record(main)
+                for st_ in self._side:  # a side stream starts after everything enqueued on `main` so far (incl. the
+                    st_.wait_event(ready)  # previous swap's readers of blocks its allocator pool may hand out again)
             latent_W = get_latents(self.e4e, im_256_norm)  # E4E
-            output = self.encoder.test(img=self.normalize(image), return_latent=True)  # FS encoder
-            latent = output.pop()    # [bs, 512, 16, 16]
-            latent_S = output.pop()  # [bs, 18, 512]
-            latent_F, _ = self.net.generator([latent_S], input_is_latent=True, return_latents=False, start_layer=3,
-                                             end_layer=3, layer_in=latent)
-            # BiSeNet: the reference parses the images one by one (:81); the batch is one call here (samples are independent)
-            masks = get_segmentation(self.parsing, self.to_bisenet(im_512))
+            with (torch.cuda.stream(self._side[0]) if overlap else contextlib.nullcontext()):
+                output = self.encoder.test(img=self.normalize(image), return_latent=True)  # FS encoder
+                latent = output.pop()    # [bs, 512, 16, 16]
+                latent_S = output.pop()  # [bs, 18, 512]
+                latent_F, _ = self.net.generator([latent_S], input_is_latent=True, return_latents=False, start_layer=3,
+                                                 end_layer=3, layer_in=latent)
+            with (torch.cuda.stream(self._side[1]) if overlap else contextlib.nullcontext()):
+                # BiSeNet: the reference parses the images one by one (:81); the batch is one call here (samples are independent)
+                masks = get_segmentation(self.parsing, self.to_bisenet(im_512))
+            if overlap:
+                for st_ in self._side:
+                    main.wait_stream(st_)
+                for t_ in (latent_S, latent_F, masks):  # allocated on a side stream, consumed on `main` from here on
+                    t_.record_stream(main)
+            self._warmed = True
             if len(images_to_name) > 1:  # mixing if we change the colour or the shape
                 hair_mask = (masks == 13).float()
                 hair_mask = F.interpolate(hair_mask, size=(32, 32), mode="bicubic")

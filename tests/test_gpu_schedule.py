@@ -115,6 +115,16 @@ def test_hairfast_swap_call_surface():
     assert calls == [(3, 3, 3), (3, 0, 3), (2, 0, 8), (2, 0, 3), (1, 4, 8), (1, 5, 8)], calls
     again = hf.swap(face, shape, color, seed=7)
     assert torch.equal(out, again)
+    # the first pass ran sequentially (lazily derived weights), `again` with the FS-encoder and parsing branches of the
+    # Embedding stage on side streams: same host call order, same RNG stream, same bits - also against the
+    # sequential form forced
+    assert hf.embed._warmed and hf.embed._side is not None
+    hf.embed._overlap = False
+    seq = hf.swap(face, shape, color, seed=7)
+    hf.embed._overlap = True
+    assert torch.equal(out, seq)
+    for _ in range(3):
+        assert torch.equal(hf.swap(face, shape, color, seed=7), out)
     # shape == color: one rotation only, align_color reuses align_shape (hair_swap.py:53-56)
     calls.clear()
     hf.net.generator.forward = spy
