@@ -702,9 +702,8 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     hf_note_overflow(ovf_tile);
   };
 
-  // static issue priority for the second-dispatched half of the block (MI355X_MICROARCH.md, "two waves per SIMD",
-  // item 4: the younger wave of each SIMD loses every VALU arbitration); hf_debug_set_tuning bit 3 (experiment)
-  if ((P.dma_early & 2) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  // (s_setprio 1 for the second-dispatched half of the block - MI355X_MICROARCH.md, "two waves per SIMD", item 4 -
+  // measured no effect on any generator layer)
   int stage = 0;  // LDS buffer = stage & 1, running across tiles
   int trace_n = 0;
   (void)trace_n;
@@ -791,7 +790,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       constexpr int NSLOT = (UP && !PRE) ? 1 : 2;
       // PRE: all DMAs of the next stage in the first tap-step (short K loops: HBM latency exceeds the stage's MFMA
       // time, the copies need the whole stage to land) or spread one per tap-step (long K loops, see DMA_PER_STEP)
-      const bool early = PRE && (P.dma_early & 1);
+      const bool early = PRE && P.dma_early;
       half8 ah[NSLOT][CT_TILES], al[NSLOT][CT_TILES], bh[NSLOT][PG], bl[NSLOT][PG];
       auto fetch_a = [&](int slot, int tap) {
 #pragma unroll
@@ -994,7 +993,7 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
     return HF_E_INVALID;
   if (lds > 160 * 1024) return HF_E_INVALID;
   P.n_tiles = nblocks;
-  P.dma_early = ((g_h_tune & 1) ? 1 : 0) | ((g_h_tune & 8) ? 2 : 0);  // measured (tools/probes/gen_layers.py): spread is 0-8 % faster on every generator layer
+  P.dma_early = (g_h_tune & 1) ? 1 : 0;  // measured (tools/probes/gen_layers.py): spread is 0-8 % faster on every generator layer
   // LDS allows one block per CU: size the grid to the chip and let each block walk its share
   // of the tiles as one pipeline (the tile-to-tile hand-over needs >= 2 stages per tile)
   const int co_tiles = P.cout / CT;
