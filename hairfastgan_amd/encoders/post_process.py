@@ -1,6 +1,9 @@
 """PostProcessModel on the MI355X kernels - host-side mirror of
 models/Encoders.py:106-137 (`PostProcessModel`), :13-32 (`ModulationModule`), :35-57
-(`FeatureiResnet`) and models/Net.py:396-477 (`FeatureEncoderMult(fs_layers=[9])`).
+(`FeatureiResnet`) and models/Net.py:396-477 (`FeatureEncoderMult(fs_layers=[9])`) - and, built from the same
+ModulationModule, the two latent-space models of row f4: `RotateModel` (:60-72, complete) and
+`ClipBlendingModel` (:75-103: its own parameters; the CLIP ViT-B/32 image tower it embeds the two images with is an
+un-vendored dependency of the reference - `clip @ git+...`, requirements.txt:6 - and stays an injected callable).
 
 It sits immediately before the last generator call of a swap (models/Blending.py:66-68):
 `S_final, F_final = post_process(I_1, I_blend_256)`, then `generator([S_final], start_layer=5,
@@ -150,3 +153,61 @@ class PostProcessModel(nn.Module):  # models/Encoders.py:106-137
         cat_f = torch.cat((f_both[:b], f_both[b:]), dim=1)                # [B,1024,64,64]
         final_f = self.to_feature(cat_f)
         return final_s, final_f
+
+
+class RotateModel(nn.Module):  # models/Encoders.py:60-72
+    """W+ rows 0..5 of the shape image rotated towards the pose of the face image (Alignment.py:61):
+    latent_from + 0.1 * five ModulationModules(PixelNorm(latent_from) | latent_to).  15 linear launches + 11 small ones."""
+
+    def __init__(self):
+        super().__init__()
+        self.modulation_module_list = nn.ModuleList([ModulationModule(6, i == 4) for i in range(5)])
+
+    @torch.inference_mode()
+    def forward(self, latent_from, latent_to):
+        require_gpu(latent_from, latent_to)
+        L, st = lib(), stream()
+        latent_from, latent_to = latent_from.contiguous(), latent_to.contiguous()
+        dt = M.pixel_norm_dim1(L, st, latent_from)
+        for mod in self.modulation_module_list:
+            dt = mod(dt, latent_to)
+        return M.axpby(L, st, dt, 0.1, latent_from.reshape(-1), 1.0).reshape(latent_from.shape)  # latent_from + 0.1 * dt
+
+
+class ClipBlendingModel(nn.Module):  # models/Encoders.py:75-103
+    """S rows 6..17 of the blended image (Blending.py:60): latent_face + 0.1 * five ModulationModules(12, inp = 512 * 3,
+    middle = 1024) of PixelNorm(latent_face) | [latent_color, CLIP(target_face), CLIP(hair_color)].
+
+    image_embed: callable [B,3,224,224] (CLIP-normalised) -> [B,512], the reference's `clip_model.encode_image`
+    (clip.load("ViT-B/32")): NOT part of this backend (an external package the reference pip-installs from git);
+    everything else - pooling to 224^2, CLIP normalisation, the modulation stack - is.  State-dict keys as in the
+    reference (`modulation_module_list.*`; its frozen `clip_model.*` entries belong to the injected callable)."""
+
+    CLIP_MEAN, CLIP_STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+
+    def __init__(self, image_embed=None):
+        super().__init__()
+        self.image_embed = image_embed
+        self.modulation_module_list = nn.ModuleList([ModulationModule(12, i == 4, inp=512 * 3, middle=1024) for i in range(5)])
+
+    def get_image_embed(self, image_tensor):  # :91-94
+        if self.image_embed is None:
+            raise NotImplementedError("ClipBlendingModel needs image_embed = the CLIP ViT-B/32 image encoder "
+                                      "(clip_model.encode_image of the reference's un-vendored `clip` package)")
+        x = torch.nn.functional.adaptive_avg_pool2d(image_tensor, (224, 224)) * 0.5 + 0.5
+        mean = torch.tensor(self.CLIP_MEAN, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
+        std = torch.tensor(self.CLIP_STD, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
+        return self.image_embed((x - mean) / std)
+
+    @torch.inference_mode()
+    def forward(self, latent_face, latent_color, target_face, hair_color):
+        require_gpu(latent_face, latent_color)
+        L, st = lib(), stream()
+        embed_face = self.get_image_embed(target_face).float().unsqueeze(1).expand(-1, 12, -1)
+        embed_color = self.get_image_embed(hair_color).float().unsqueeze(1).expand(-1, 12, -1)
+        latent_in = torch.cat((latent_color, embed_face, embed_color), dim=-1).contiguous()
+        latent_face = latent_face.contiguous()
+        dt = M.pixel_norm_dim1(L, st, latent_face)
+        for mod in self.modulation_module_list:
+            dt = mod(dt, latent_in)
+        return M.axpby(L, st, dt, 0.1, latent_face.reshape(-1), 1.0).reshape(latent_face.shape)

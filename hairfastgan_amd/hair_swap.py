@@ -42,7 +42,7 @@ from torch import nn
 
 from . import _marshal as M
 from ._runtime import lib, require_gpu, stream
-from .encoders import Encoder4Editing, FSEncoder, PostProcessModel, get_latents
+from .encoders import ClipBlendingModel, Encoder4Editing, FSEncoder, PostProcessModel, RotateModel, get_latents
 from .face_parsing import BiSeNet, get_segmentation
 from .net import Net
 
@@ -145,7 +145,7 @@ class Stages:
             f"stages=<object providing {what}()> - the reference's own module (INTEGRATION.md) or SyntheticStages")
 
     def rotate(self, w_source_0_6, w_target_0_6):
-        """models/Encoders.py:60-103 RotateModel: ([1,6,512], [1,6,512]) -> [1,6,512]."""
+        """models/Encoders.py:60-72 RotateModel: ([P,6,512], [P,6,512]) -> [P,6,512] (P pairs: 1 or 2 per triple)."""
         self._missing("rotate")
 
     def shape_adaptor(self, mask_target_pose, mask_hair_source):
@@ -160,12 +160,46 @@ class Stages:
         self._missing("sean_inpaint")
 
     def blend(self, s_face_6_18, s_color_6_18, image_face_masked, image_color_masked):
-        """models/Encoders.py ClipBlendingModel: -> S_blend[:, 6:18] [1,12,512]."""
+        """models/Encoders.py:75-103 ClipBlendingModel: ([T,12,512], [T,12,512], [T,3,256,256] x 2) ->
+        S_blend[:, 6:18] [T,12,512] (T triples in one call)."""
         self._missing("blend")
 
     # Not stages any more (built natively, SURVEY.md section 8 rows f1 / f2): PostProcessModel
     # (hairfastgan_amd.encoders.PostProcessModel, owned by Blending) and BiSeNet face parsing / get_segmentation
     # (hairfastgan_amd.face_parsing, owned by HairFast and shared by Embedding and Alignment).
+
+
+class NativeLatentStages(Stages):
+    """`rotate` and `blend` on this backend's own RotateModel / ClipBlendingModel (the two
+    ModulationModule stacks), everything else delegated to `base`.  The CLIP ViT-B/32 image tower inside the blending
+    model remains the caller's (`clip_image_embed`, the reference's `clip_model.encode_image`)."""
+
+    def __init__(self, base, device, rotate_state=None, blend_state=None, clip_image_embed=None):
+        self.base = base
+        self.rotate_model = self.blend_model = None
+        if rotate_state is not None:  # pretrained_models/Rotate/rotate_best.pth ['model_state_dict'] (Alignment.py:36-38)
+            self.rotate_model = RotateModel().eval()
+            self.rotate_model.load_state_dict(rotate_state)
+            self.rotate_model.to(device)
+        if blend_state is not None:   # pretrained_models/Blending/checkpoint.pth ['model_state_dict'] (Blending.py:22-26)
+            self.blend_model = ClipBlendingModel(image_embed=clip_image_embed).eval()
+            own = {k: v for k, v in blend_state.items() if not k.startswith("clip_model.")}  # the frozen tower's entries
+            self.blend_model.load_state_dict(own)
+            self.blend_model.to(device)
+
+    def rotate(self, w_source_0_6, w_target_0_6):
+        return self.rotate_model(w_source_0_6, w_target_0_6) if self.rotate_model is not None else self.base.rotate(w_source_0_6, w_target_0_6)
+
+    def shape_adaptor(self, mask_target_pose, mask_hair_source):
+        return self.base.shape_adaptor(mask_target_pose, mask_hair_source)
+
+    def sean_inpaint(self, images_256, labels, target_mask):
+        return self.base.sean_inpaint(images_256, labels, target_mask)
+
+    def blend(self, s_face_6_18, s_color_6_18, image_face_masked, image_color_masked):
+        if self.blend_model is not None:
+            return self.blend_model(s_face_6_18, s_color_6_18, image_face_masked, image_color_masked)
+        return self.base.blend(s_face_6_18, s_color_6_18, image_face_masked, image_color_masked)
 
 
 class SyntheticStages(Stages):
@@ -320,11 +354,10 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
         todo = [(a, b) for a, b in pairs if name_to_embed[a]["image_256"] is not name_to_embed[b]["image_256"]]
         if not todo:
             return {}
-        lat = []
-        for a, b in todo:
-            w1, w2 = name_to_embed[a]["W"], name_to_embed[b]["W"]
-            lat.append(torch.cat((self.stages.rotate(w2[:, :6], w1[:, :6]), w2[:, 6:]), dim=1))
-        I_rot, _ = self.net.generator([torch.cat(lat, 0)], input_is_latent=True, return_latents=False)
+        w1 = torch.cat([name_to_embed[a]["W"] for a, _ in todo], 0)
+        w2 = torch.cat([name_to_embed[b]["W"] for _, b in todo], 0)
+        lat = torch.cat((self.stages.rotate(w2[:, :6], w1[:, :6]), w2[:, 6:]), dim=1)  # every pair in one Rotate call
+        I_rot, _ = self.net.generator([lat], input_is_latent=True, return_latents=False)
         seg_in = Embedding.to_bisenet(((I_rot + 1) / 2).clip(0, 1))
         masks = get_segmentation(self.parsing, seg_in)  # the 1024^2 images are parsed (:65-67), both in one call
         return {key: (I_rot[k:k + 1], masks[k:k + 1]) for k, key in enumerate(todo)}
@@ -414,7 +447,7 @@ class Blending(nn.Module):  # models/Blending.py:11-82
         emb = [[name_to_embed[k] for k in key] for key in keys]
         mask_de = self.dilate_erosion.hair_from_mask(torch.cat([e[i]["mask"] for e in emb for i in (0, 2)], dim=0))  # [2T,...]
         HM_XD, _ = self.dilate_erosion.mask(torch.cat([a["HM_X"] for a in aligns_color], dim=0))
-        S_blend = []
+        S_blend, todo, args_ = [None] * T, [], []
         for t, (ef, es, ec) in enumerate(emb):
             I_1, I_2, I_3 = ef["image_norm_256"], es["image_norm_256"], ec["image_norm_256"]
             HM_1D = mask_de[0][2 * t].unsqueeze(0)
@@ -422,10 +455,14 @@ class Blending(nn.Module):  # models/Blending.py:11-82
             latent_S_1, latent_S_3 = ef["S"], ec["S"]
             target_mask = (1 - HM_1D) * (1 - HM_3D) * (1 - HM_XD[t:t + 1])
             if I_1 is not I_3 or I_1 is not I_2:
-                S_blend_6_18 = self.stages.blend(latent_S_1[:, 6:], latent_S_3[:, 6:], I_1 * target_mask, I_3 * HM_3E)
-                S_blend.append(torch.cat((latent_S_1[:, :6], S_blend_6_18), dim=1))
+                todo.append(t)
+                args_.append((latent_S_1[:, 6:], latent_S_3[:, 6:], I_1 * target_mask, I_3 * HM_3E))
             else:
-                S_blend.append(latent_S_1)
+                S_blend[t] = latent_S_1
+        if todo:  # the blending encoder once for all triples that need it
+            S_6_18 = self.stages.blend(*(torch.cat([a[j] for a in args_], 0) for j in range(4)))
+            for j, t in enumerate(todo):
+                S_blend[t] = torch.cat((emb[t][0]["S"][:, :6], S_6_18[j:j + 1]), dim=1)
         latent_F_align = torch.cat([a["latent_F_align"] for a in aligns_shape], dim=0)
         I_blend, _ = self.net.generator([torch.cat(S_blend, 0)], input_is_latent=True, return_latents=False, start_layer=4,
                                         end_layer=8, layer_in=latent_F_align)
@@ -447,12 +484,18 @@ class HairFast:
       e4e_state / fs_state (+ e4e_latent_avg / fs_dlatent_avg)  encoder state dicts
       pp_state (+ pp_latent_avg)  PostProcessModel state dict ('model_state_dict' of args.pp_checkpoint)
       bisenet_state   BiSeNet state dict (pretrained_models/BiSeNet/face_parsing_79999_iter.pth)
+      rotate_state    RotateModel state dict ('model_state_dict' of args.rotate_checkpoint): the Rotate stage runs natively
+      blend_state (+ clip_image_embed)  ClipBlendingModel state dict ('model_state_dict' of args.blending_checkpoint) and
+                      the CLIP ViT-B/32 image encoder callable: the blending stage runs natively around that callable
     """
 
     def __init__(self, args, *, stages=None, generator_state=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
-                 fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None, bisenet_state=None):
+                 fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None, bisenet_state=None, rotate_state=None,
+                 blend_state=None, clip_image_embed=None):
         self.args = args
         self.stages = stages or Stages()
+        if rotate_state is not None or blend_state is not None:
+            self.stages = NativeLatentStages(self.stages, args.device, rotate_state, blend_state, clip_image_embed)
         self.net = Net(args, state=generator_state)
         self.parsing = BiSeNet(19).eval()  # pretrained_models/BiSeNet/face_parsing_79999_iter.pth (my_parsing_util.py:77-79)
         if bisenet_state is not None:

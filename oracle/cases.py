@@ -209,6 +209,24 @@ def pp_inputs():
     return src, tgt
 
 
+def latent_model_inputs():
+    """RotateModel / ClipBlendingModel inputs (Alignment.py:61, Blending.py:60): W+ rows [2,6,512] x 2;
+    S rows [2,12,512] x 2 and two masked [2,3,256,256] images in [-1,1]."""
+    w_from = t(synth.pseudo_normal("latent/rot/from", (2, 6, 512)))
+    w_to = t(synth.pseudo_normal("latent/rot/to", (2, 6, 512)))
+    s_face = t(synth.pseudo_normal("latent/blend/face", (2, 12, 512)))
+    s_color = t(synth.pseudo_normal("latent/blend/color", (2, 12, 512)))
+    img_face = (t(synth.pseudo_normal("latent/blend/img_face", (2, 3, 256, 256))) * 0.4).clamp(-1, 1)
+    img_color = (t(synth.pseudo_normal("latent/blend/img_color", (2, 3, 256, 256))) * 0.4).clamp(-1, 1)
+    return w_from, w_to, s_face, s_color, img_face, img_color
+
+
+def fake_clip_embed(x):
+    """Deterministic stand-in for clip_model.encode_image in tests and golden generation ([B,3,224,224] -> [B,512]):
+    the CLIP tower is an un-vendored dependency of the reference; what is pinned is everything around it."""
+    return x.flatten(1)[:, ::294][:, :512].contiguous() * 0.5
+
+
 def bisenet_input(tag):
     """ImageNet-normalised image for BiSeNet / get_segmentation: "512" = the [1,3,512,512] case of
     Embedding.py:81 (a smooth pattern + noise so that the argmax map has regions, not salt and pepper),

@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
     ap.add_argument("--only", default=None,
-                    help="comma list of sections to (re)generate (default all): basic,gen64,gen1024,enc_units,encoders,glue,pp,bisenet")
+                    help="comma list of sections to (re)generate (default all): basic,gen64,gen1024,enc_units,encoders,glue,pp,latent,bisenet")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -414,6 +414,44 @@ def main():
                                maxdiff(torch.from_numpy(g["pp_mod_last"]), PP.modulation_module(P, "to_latent_1.4", xm, em, 18, True)))
         np.savez_compressed(os.path.join(args.out, "postprocess.npz"), **g)
         print("done postprocess", report["pp/s"], report["pp/f"], flush=True)
+
+    # ---------------- (vi-b) RotateModel, ClipBlendingModel around a stand-in CLIP tower (row f4) --------------------
+    if want("latent"):
+        from models import Encoders as ref_enc
+        from oracle import ref_postprocess as PP
+
+        class _Normalize:  # torchvision.transforms.Normalize (the library, stubbed: this container has no torchvision)
+            def __init__(self, mean, std):
+                self.mean, self.std = torch.tensor(mean).view(1, 3, 1, 1), torch.tensor(std).view(1, 3, 1, 1)
+
+            def __call__(self, x):
+                return (x - self.mean) / self.std
+
+        class _FakeClip(torch.nn.Module):  # stands for clip.load("ViT-B/32")[0] (un-vendored dependency)
+            def encode_image(self, x):
+                return C.fake_clip_embed(x)
+
+        ref_enc.T.Normalize = _Normalize
+        ref_enc.T.Compose = lambda ts: (lambda x, _ts=ts: [x := t_(x) for t_ in _ts][-1])
+        ref_enc.clip.load = lambda name, device=None: (_FakeClip(), None)
+        w_from, w_to, s_face, s_color, img_face, img_color = C.latent_model_inputs()
+        rot = ref_enc.RotateModel().eval()
+        shapes = {k_: tuple(v_.shape) for k_, v_ in rot.state_dict().items()}
+        assert shapes == PP.rotate_param_shapes() and list(shapes) == list(PP.rotate_param_shapes()), "RotateModel layout mismatch"
+        Pr = C.params_from_shapes("rotate", shapes)
+        rot.load_state_dict(Pr)
+        r_ref = rot(w_from, w_to)
+        report["latent/rotate"] = maxdiff(r_ref, PP.rotate_model(Pr, w_from, w_to))
+        blend = ref_enc.ClipBlendingModel().eval()
+        shapes = {k_: tuple(v_.shape) for k_, v_ in blend.state_dict().items() if not k_.startswith("clip_model.")}
+        assert shapes == PP.clip_blending_param_shapes() and list(shapes) == list(PP.clip_blending_param_shapes())
+        Pb = C.params_from_shapes("clipblend", shapes)
+        blend.load_state_dict(Pb, strict=False)
+        b_ref = blend(s_face, s_color, img_face, img_color)
+        report["latent/clip_blend"] = maxdiff(b_ref, PP.clip_blending(Pb, s_face, s_color, img_face, img_color, C.fake_clip_embed))
+        report["latent/clip_input"] = maxdiff(blend.transform(blend.face_pool(img_face) * 0.5 + 0.5), PP.clip_image_input(img_face))
+        np.savez_compressed(os.path.join(args.out, "latent_models.npz"), rotate=r_ref.numpy(), clip_blend=b_ref.numpy())
+        print("done latent models", report["latent/rotate"], report["latent/clip_blend"], report["latent/clip_input"], flush=True)
 
     # ---------------- (vii) BiSeNet face parsing + label remap --------------------
     if not args.skip_big and want("bisenet"):

@@ -14,6 +14,12 @@ pinned by oracle/make_golden.py against the imported reference (tests/golden/pos
 oracle_vs_reference.json: bit-identical).  Parameters are a flat dict with the reference's
 state-dict keys (`encoder_face.*`, `to_feature.res_blocks.*`, `to_latent_1.*`, `to_latent_2.*`)
 plus `latent_avg` (a tensor attribute in the reference, loaded from a file).
+
+Also the two latent-space models of SURVEY.md section 8 row f4 that are built from the same ModulationModule:
+  models/Encoders.py:60-72     RotateModel.forward
+  models/Encoders.py:75-103    ClipBlendingModel.forward / get_image_embed (the CLIP image tower itself is an
+                               un-vendored dependency of the reference: a callable here)
+pinned the same way (tests/golden/latent_models.npz).
 """
 import torch
 import torch.nn.functional as F
@@ -141,3 +147,57 @@ def post_process_param_shapes():
                 S[f"{m}.{fn}.3.weight"], S[f"{m}.{fn}.3.bias"] = (512, 512), (512,)
     S["latent_avg"] = (18, 512)
     return S
+
+
+def _modulation_shapes(S, pre, inp=512, middle=512):
+    S[f"{pre}.fc.weight"], S[f"{pre}.fc.bias"] = (512, 512), (512,)
+    for name in ("gamma_function", "beta_function"):
+        S[f"{pre}.{name}.0.weight"], S[f"{pre}.{name}.0.bias"] = (middle, inp), (middle,)
+        S[f"{pre}.{name}.1.weight"], S[f"{pre}.{name}.1.bias"] = (middle,), (middle,)
+        S[f"{pre}.{name}.3.weight"], S[f"{pre}.{name}.3.bias"] = (512, middle), (512,)
+
+
+def rotate_param_shapes():
+    """State-dict key -> shape of RotateModel (reference key order)."""
+    S = {}
+    for i in range(5):
+        _modulation_shapes(S, f"modulation_module_list.{i}")
+    return S
+
+
+def clip_blending_param_shapes():
+    """State-dict key -> shape of ClipBlendingModel's OWN parameters (the frozen `clip_model.*` entries excluded)."""
+    S = {}
+    for i in range(5):
+        _modulation_shapes(S, f"modulation_module_list.{i}", inp=512 * 3, middle=1024)
+    return S
+
+
+def rotate_model(P, latent_from, latent_to):
+    """RotateModel.forward (Encoders.py:66-71): [B,6,512] x 2 -> [B,6,512]."""
+    dt = pixel_norm(latent_from)
+    for i in range(5):
+        dt = modulation_module(P, f"modulation_module_list.{i}", dt, latent_to, 6, i == 4)
+    return latent_from + 0.1 * dt
+
+
+CLIP_MEAN, CLIP_STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_image_input(image):
+    """What ClipBlendingModel.get_image_embed hands to clip_model.encode_image (Encoders.py:91-94):
+    AdaptiveAvgPool2d(224) of the [-1,1] image, mapped to [0,1], CLIP-normalised."""
+    x = F.adaptive_avg_pool2d(image, (224, 224)) * 0.5 + 0.5
+    mean, std = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    return (x - mean) / std
+
+
+def clip_blending(P, latent_face, latent_color, target_face, hair_color, image_embed):
+    """ClipBlendingModel.forward (Encoders.py:96-103) with `image_embed` standing for clip_model.encode_image."""
+    embed_face = image_embed(clip_image_input(target_face)).unsqueeze(1).expand(-1, 12, -1)
+    embed_color = image_embed(clip_image_input(hair_color)).unsqueeze(1).expand(-1, 12, -1)
+    latent_in = torch.cat((latent_color, embed_face, embed_color), dim=-1)
+    dt = pixel_norm(latent_face)
+    for i in range(5):
+        dt = modulation_module(P, f"modulation_module_list.{i}", dt, latent_in, 12, i == 4)
+    return latent_face + 0.1 * dt

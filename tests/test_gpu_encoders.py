@@ -258,6 +258,31 @@ def test_postprocess_vs_reference_golden(golden):
     assert np.allclose(stats, G["pp_f_stats"], rtol=0, atol=REL * max(1.0, abs(G["pp_f_stats"][2]), abs(G["pp_f_stats"][3])))
 
 
+def test_latent_models_vs_reference_golden(golden):
+    """RotateModel (complete) and ClipBlendingModel (its own parameters; the CLIP image tower
+    is an injected callable - here the stand-in the goldens were generated with) on the HIP kernels against the
+    reference's outputs."""
+    from hairfastgan_amd.encoders import ClipBlendingModel, RotateModel
+    from oracle import ref_postprocess as PP
+
+    dev = _dev()
+    G = golden("latent_models.npz")
+    w_from, w_to, s_face, s_color, img_face, img_color = (t.to(dev) for t in C.latent_model_inputs())
+    rot = RotateModel().eval()
+    rot.load_state_dict(C.params_from_shapes("rotate", PP.rotate_param_shapes()))
+    rot.to(dev)
+    y = rot(w_from, w_to)
+    ref = torch.from_numpy(G["rotate"]).to(dev)
+    assert float((y - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    blend = ClipBlendingModel(image_embed=C.fake_clip_embed).eval()
+    blend.load_state_dict(C.params_from_shapes("clipblend", PP.clip_blending_param_shapes()))
+    blend.to(dev)
+    y = blend(s_face, s_color, img_face, img_color)
+    ref = torch.from_numpy(G["clip_blend"]).to(dev)
+    assert float((y - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(rot(w_from, w_to), rot(w_from, w_to))
+
+
 def test_split_k_without_empty_splits():
     """Regression (round 2): 64 channels = 8 K chunks over a plane that asks for 5 splits gave a fifth, EMPTY split whose
     pipelined kernel still prefetched 'its' first chunk - past the end of x (a GPU memory fault when x ends a mapped

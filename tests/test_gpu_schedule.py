@@ -81,7 +81,10 @@ def _hairfast(dev):
     return HairFast(args, stages=SyntheticStages(), generator_state=state,
                     e4e_state=C.params_from_shapes("e4e", E.e4e_param_shapes()),
                     fs_state=C.params_from_shapes("fs", E.fs_param_shapes()),
-                    pp_state=C.params_from_shapes("pp", pp_shapes), bisenet_state=C.bisenet_params())
+                    pp_state=C.params_from_shapes("pp", pp_shapes), bisenet_state=C.bisenet_params(),
+                    rotate_state=C.params_from_shapes("rotate", PP.rotate_param_shapes()),
+                    blend_state=C.params_from_shapes("clipblend", PP.clip_blending_param_shapes()),
+                    clip_image_embed=C.fake_clip_embed)
 
 
 def test_hairfast_swap_call_surface():

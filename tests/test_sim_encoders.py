@@ -348,3 +348,24 @@ def test_postprocess_state_dict_matches_reference_layout():
     want.pop("latent_avg")
     got = {k: tuple(v.shape) for k, v in PostProcessModel().state_dict().items()}
     assert got == want and list(got) == list(want)
+
+
+def test_latent_models_oracle_and_layout(golden):
+    """SURVEY section 8 row f4, the two ModulationModule stacks: the oracle restatements of RotateModel and
+    ClipBlendingModel (around a stand-in image tower) reproduce the reference's golden outputs bit for bit, and the
+    HIP-backed mirrors have the reference's state-dict layout (their kernels: test_postprocess_modulation_module;
+    the complete models against the goldens: tests/test_gpu_encoders.py)."""
+    from hairfastgan_amd.encoders import ClipBlendingModel, RotateModel
+    from oracle import ref_postprocess as PP
+
+    G = golden("latent_models.npz")
+    w_from, w_to, s_face, s_color, img_face, img_color = C.latent_model_inputs()
+    Pr = C.params_from_shapes("rotate", PP.rotate_param_shapes())
+    assert torch.equal(PP.rotate_model(Pr, w_from, w_to), torch.from_numpy(G["rotate"]))
+    Pb = C.params_from_shapes("clipblend", PP.clip_blending_param_shapes())
+    assert torch.equal(PP.clip_blending(Pb, s_face, s_color, img_face, img_color, C.fake_clip_embed), torch.from_numpy(G["clip_blend"]))
+    for cls, shapes in ((RotateModel, PP.rotate_param_shapes()), (ClipBlendingModel, PP.clip_blending_param_shapes())):
+        sd = cls().state_dict()
+        assert {k: tuple(v.shape) for k, v in sd.items()} == shapes and list(sd) == list(shapes)
+    with pytest.raises(NotImplementedError, match="CLIP"):
+        ClipBlendingModel().get_image_embed(img_face)
