@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_encoders.py tests/test_gpu_schedule.py -q -x -k "latent or hairfast or swap" 2>&1 | tail -5
-python bench.py --workload swap256 --triples 32 --warmup 1 --no-kernel-events 2>/dev/null | head -c 200; echo
-python bench.py --workload swap256 --triples 16 --warmup 1 --swap-batch 1 --no-kernel-events 2>/dev/null | head -c 200; echo
+mkdir -p gpurun_out
+python tools/bench_batch.py 2>&1 | grep -v amdgpu | tee gpurun_out/r02z_batch_scaling.txt
+PROBE_BATCH=1 python tools/probes/forward_launches.py 2>&1 | grep -v "amdgpu\|Warn\|warn" | head -24
