@@ -449,11 +449,20 @@ def main():
                                swap_batch_fn=hf.swap_batch if args.swap_batch > 1 else None)
             barrier()
             tp = max_over_ranks(time.perf_counter() - t0)
+            # the same pipeline one swap at a time (the reference's own protocol, utils/time.py): latency of a single swap
+            n_single = args.swap_triples * world
+            t0 = time.perf_counter()
+            parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), n_single, load, device=dev)
+            barrier()
+            ts = max_over_ranks(time.perf_counter() - t0)
             pipeline_info = {"metric": "hair_swap_triples_per_sec", "value": round(n_pipe / tp, 3), "unit": "triples/s",
                              "ms_per_triple_per_gpu": round(tp / (n_pipe / world) * 1e3, 2), "triples": n_pipe,
                              "swap_batch": args.swap_batch,
-                             "workload": "python bench.py --workload swap256 on a bounded sample: host uint8 -> H2D -> HairFast.swap "
-                                         "(SyntheticStages between the hot-path calls) -> uint8 -> gather (BASELINE.json configs[3])"}
+                             "single_swap": {"ms_per_swap": round(ts / (n_single / world) * 1e3, 2), "triples": n_single,
+                                             "note": "one HairFast.swap per triple (no batching across triples)"},
+                             "workload": "python bench.py --workload swap256 on a bounded sample: host uint8 -> H2D -> HairFast.swap / "
+                                         "swap_batch (RotateModel, ClipBlendingModel around a stand-in CLIP tower native; SyntheticStages "
+                                         "for the shape adaptor and SEAN) -> uint8 -> gather (BASELINE.json configs[3])"}
         except Exception as e:
             pipeline_info = {"error": f"{type(e).__name__}: {e}"[:300]}
 

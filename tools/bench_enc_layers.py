@@ -41,7 +41,8 @@ def timeit(fn, iters=10):
 def main():
     dev = torch.device("cuda:0")
     L, st = lib(), stream()
-    print(f"{'layer':24s} {'GFLOP':>7s} | {'f32 us':>8s} {'TF/s':>6s} | {'f16x3 us':>8s} {'TF/s':>6s} | {'pre us':>8s} {'TF/s':>6s} | {'f16 us':>8s} {'TF/s':>6s} | split-K")
+    print("rooflines: fp32 MFMA 157.3 TFLOP/s, f16x3 (3 fp16 MFMAs per product) 838.9, f16 2516.6; `pre` includes the split pass")
+    print(f"{'layer':24s} {'GFLOP':>7s} | {'f32 us':>8s} {'TF/s':>6s} {'%':>3s} | {'f16x3 us':>8s} {'TF/s':>6s} {'%':>3s} | {'pre us':>8s} {'TF/s':>6s} {'%':>3s} | {'f16 us':>8s} {'TF/s':>6s} {'%':>3s} | split-K")
     L.hf_debug_set_tuning(int(os.environ.get("ENC_TUNE", "0")))  # 4 = without the 512-pixel tile form
     mult = int(os.environ.get("ENC_BATCH_MULT", "1"))  # swap_batch: the same layers with `mult` triples per pass
     for label, B, cin, cout, H, W, stride, G in LAYERS:
@@ -62,8 +63,9 @@ def main():
         tp = timeit(lambda: M.conv2d_f16(L, st, M.split_activation_f16(L, st, x), hi, lo, 3, cout, stride, **kw))
         t1 = timeit(lambda: M.conv2d_f16(L, st, x, hi, lo, 1, cout, stride, **kw))
         sk = L.hf_conv2d_f16_workspace_floats(B, cin, cout, H, W, stride, G) // (G * B * cout * oh * ow)
-        print(f"{label:24s} {gf:7.2f} | {t32:8.1f} {gf / t32 * 1e3:6.1f} | {t3:8.1f} {gf / t3 * 1e3:6.1f} | {tp:8.1f} {gf / tp * 1e3:6.1f} | "
-              f"{t1:8.1f} {gf / t1 * 1e3:6.1f} | {sk}", flush=True)
+        tf = lambda t: gf / t * 1e3  # noqa: E731
+        print(f"{label:24s} {gf:7.2f} | {t32:8.1f} {tf(t32):6.1f} {tf(t32) / 1.573:3.0f} | {t3:8.1f} {tf(t3):6.1f} {tf(t3) / 8.389:3.0f} | "
+              f"{tp:8.1f} {tf(tp):6.1f} {tf(tp) / 8.389:3.0f} | {t1:8.1f} {tf(t1):6.1f} {tf(t1) / 25.166:3.0f} | {sk}", flush=True)
 
 
 if __name__ == "__main__":
