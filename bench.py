@@ -90,14 +90,16 @@ def build_hairfast(sd, dev):
     args.device = dev
     pp_shapes = PP.post_process_param_shapes()
     pp_shapes.pop("latent_avg")
-    # RotateModel and ClipBlendingModel run natively; the CLIP image tower inside the latter is
-    # a stand-in projection (the un-vendored `clip` package is not part of this backend); shape adaptor and SEAN synthetic
+    # RotateModel, ClipBlendingModel and the CtrlHair shape adaptor run natively; the CLIP image
+    # tower inside the blending model is a stand-in projection (the un-vendored `clip` package is not part of this
+    # backend); SEAN synthetic
     stand_in_clip = lambda x: x.flatten(1)[:, ::294][:, :512].contiguous() * 0.5  # noqa: E731  [B,3,224,224] -> [B,512]
     return HairFast(args, stages=SyntheticStages(), generator_state={"g_ema": sd, "latent_avg": torch.zeros(512)},
                     e4e_state=synth_state("e4e", E.e4e_param_shapes()), fs_state=synth_state("fs", E.fs_param_shapes()),
                     pp_state=synth_state("pp", pp_shapes), bisenet_state=C.bisenet_params(),
                     rotate_state=synth_state("rotate", PP.rotate_param_shapes()),
-                    blend_state=synth_state("clipblend", PP.clip_blending_param_shapes()), clip_image_embed=stand_in_clip)
+                    blend_state=synth_state("clipblend", PP.clip_blending_param_shapes()), clip_image_embed=stand_in_clip,
+                    shape_state=C.shape_adaptor_params())
 
 
 def cpu_baseline(sd, budget_s=30.0):
@@ -334,7 +336,7 @@ def main():
                               "workload": f"{args.triples} synthetic 1024^2 triples sharded over {world} GPU(s): host uint8 -> H2D -> "
                                           "HairFast.swap (e4e B=3, FS-encoder B=3, gen 3->3 B=3, gen 0->3 B=3, gen 0->8 B=2 [both "
                                           "Alignment rotations batched], e4e B=2, gen 0->3 B=2, gen 4->8 B=1, PostProcess encoder "
-                                          "[774 GFLOP], gen 5->8 B=1, BiSeNet parsing x5, RotateModel, ClipBlendingModel around a stand-in CLIP tower; shape adaptor / SEAN = SyntheticStages) -> uint8 -> "
+                                          "[774 GFLOP], gen 5->8 B=1, BiSeNet parsing x5, RotateModel, ClipBlendingModel around a stand-in CLIP tower, CtrlHair shape adaptor; SEAN = SyntheticStages) -> uint8 -> "
                                           "chunked RCCL all-gather; wall from first H2D to last gather (BASELINE.json configs[3])",
                               "triples": args.triples, "triples_per_gpu": n_local, "parallelism": f"replica x{world}, block-partitioned triples",
                               "weights": "synthetic closed-form (oracle/synth.py)", "conv_precision": precision,
@@ -461,8 +463,8 @@ def main():
                              "single_swap": {"ms_per_swap": round(ts / (n_single / world) * 1e3, 2), "triples": n_single,
                                              "note": "one HairFast.swap per triple (no batching across triples)"},
                              "workload": "python bench.py --workload swap256 on a bounded sample: host uint8 -> H2D -> HairFast.swap / "
-                                         "swap_batch (RotateModel, ClipBlendingModel around a stand-in CLIP tower native; SyntheticStages "
-                                         "for the shape adaptor and SEAN) -> uint8 -> gather (BASELINE.json configs[3])"}
+                                         "swap_batch (RotateModel, ClipBlendingModel around a stand-in CLIP tower, shape adaptor native; SyntheticStages "
+                                         "for SEAN) -> uint8 -> gather (BASELINE.json configs[3])"}
         except Exception as e:
             pipeline_info = {"error": f"{type(e).__name__}: {e}"[:300]}
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "hf_parsing_mask_i64": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _st],
     "hf_layernorm_f32": [_f, _f, _f, _f, _i, _i, _fl, _i, _fl, _st],
     "hf_modulate_f32": [_f, _f, _f, _f, _ll, _i, _fl, _st],
+    "hf_sample_layernorm_f32": [_f, _f, _f, _f, _i, _i, _i, _ll, _fl, _fl, _f, _ll, _st],
     "hf_pixel_norm_dim1_f32": [_f, _f, _i, _i, _i, _st],
     "hf_axpby_bcast_f32": [_f, _f, _fl, _f, _fl, _ll, _ll, _st],
     "hf_add_bcast_f32": [_f, _f, _f, _ll, _ll, _st],
@@ -96,6 +97,8 @@ def bind(cdll):
     cdll.hf_conv2d_workspace_floats.restype = ctypes.c_longlong
     cdll.hf_conv2d_f16_workspace_floats.argtypes = [_i, _i, _i, _i, _i, _i, _i]
     cdll.hf_conv2d_f16_workspace_floats.restype = ctypes.c_longlong
+    cdll.hf_sample_layernorm_workspace_floats.argtypes = [_i, _i, _i]
+    cdll.hf_sample_layernorm_workspace_floats.restype = ctypes.c_longlong
     cdll.hf_f16_overflow_count.argtypes = [_i]
     cdll.hf_f16_overflow_count.restype = ctypes.c_longlong
     cdll.hf_abi_version.argtypes = []

@@ -789,6 +789,22 @@ def layernorm(lib, st, x, dim, gamma=None, beta=None, eps=1e-5, lrelu=False, alp
     return out
 
 
+def sample_layernorm(lib, st, x, gamma=None, beta=None, eps=1e-5, slope=1.0, channels=None):
+    """hf_sample_layernorm_f32: per-sample LayerNorm over C*H*W with the unbiased std and eps added to it, per-channel
+    affine, LeakyReLU(slope) - the CtrlHair shape adaptor's norm.  channels < x.shape[1]: only the first `channels`
+    planes of every sample are normalised and returned (x came out of a conv with a padded channel count)."""
+    x = _c(x)
+    b, c_all = x.shape[0], x.shape[1]
+    c = c_all if channels is None else channels
+    hw = x.numel() // (b * c_all)
+    out = x.new_empty((b, c) + tuple(x.shape[2:]))
+    n = lib.hf_sample_layernorm_workspace_floats(b, c, hw)
+    ws = x.new_empty((max(n, 1),))
+    check(lib, lib.hf_sample_layernorm_f32(_p(out), _p(x), _p(_c(gamma)), _p(_c(beta)), b, c, hw, c_all * hw, float(eps),
+                                           float(slope), _p(ws), n, st), "hf_sample_layernorm_f32")
+    return out
+
+
 def modulate(lib, st, x, gamma, beta, lrelu=False, alpha=0.01):
     x, gamma, beta = _c(x), _c(gamma), _c(beta)
     if gamma.shape != x.shape or beta.shape != x.shape:

@@ -150,7 +150,7 @@ class Stages:
 
     def shape_adaptor(self, mask_target_pose, mask_hair_source):
         """models/CtrlHair/shape_branch/solver.py:248-262 get_hair_face_code + get_new_shape:
-        two long [1,1,256,256] label maps -> long [1,1,256,256] target label map."""
+        two long [P,1,256,256] label maps -> long [P,1,256,256] target label maps (P pairs in one call)."""
         self._missing("shape_adaptor")
 
     def sean_inpaint(self, images_256, labels, target_mask):
@@ -170,13 +170,19 @@ class Stages:
 
 
 class NativeLatentStages(Stages):
-    """`rotate` and `blend` on this backend's own RotateModel / ClipBlendingModel (the two
-    ModulationModule stacks), everything else delegated to `base`.  The CLIP ViT-B/32 image tower inside the blending
+    """`rotate`, `blend` and `shape_adaptor` on this backend's own RotateModel / ClipBlendingModel / CtrlHair mask generator
+     where their state dicts are given, everything else (SEAN) delegated to `base`.  The CLIP ViT-B/32 image tower inside the blending
     model remains the caller's (`clip_image_embed`, the reference's `clip_model.encode_image`)."""
 
-    def __init__(self, base, device, rotate_state=None, blend_state=None, clip_image_embed=None):
+    def __init__(self, base, device, rotate_state=None, blend_state=None, clip_image_embed=None, shape_state=None):
         self.base = base
-        self.rotate_model = self.blend_model = None
+        self.rotate_model = self.blend_model = self.mask_generator = None
+        if shape_state is not None:   # pretrained_models/ShapeAdaptor/mask_generator.pth (Alignment.py:33-35)
+            from .shape_adaptor import MaskGenerator
+
+            self.mask_generator = MaskGenerator().eval()
+            self.mask_generator.load_state_dict(shape_state)
+            self.mask_generator.to(device)
         if rotate_state is not None:  # pretrained_models/Rotate/rotate_best.pth ['model_state_dict'] (Alignment.py:36-38)
             self.rotate_model = RotateModel().eval()
             self.rotate_model.load_state_dict(rotate_state)
@@ -191,6 +197,10 @@ class NativeLatentStages(Stages):
         return self.rotate_model(w_source_0_6, w_target_0_6) if self.rotate_model is not None else self.base.rotate(w_source_0_6, w_target_0_6)
 
     def shape_adaptor(self, mask_target_pose, mask_hair_source):
+        if self.mask_generator is not None:
+            from .shape_adaptor import adapt_shape
+
+            return adapt_shape(self.mask_generator, mask_target_pose, mask_hair_source)
         return self.base.shape_adaptor(mask_target_pose, mask_hair_source)
 
     def sean_inpaint(self, images_256, labels, target_mask):
@@ -350,7 +360,8 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
     def rotate_images(self, pairs, name_to_embed):
         """The `Rotate stage` of shape_module (:58-67) for several (im_name1, im_name2) pairs at once: the
         rotated latents are stacked into ONE generator forward (the reference runs one batch-1 forward
-        per pair).  Returns {(name1, name2): (I_rot [1,3,size,size], rot_mask)}."""
+        per pair), and so is the shape adaptor on their parses (:74-77: one call for all pairs).
+        Returns {(name1, name2): (I_rot [1,3,size,size], rot_mask, target_mask)}."""
         todo = [(a, b) for a, b in pairs if name_to_embed[a]["image_256"] is not name_to_embed[b]["image_256"]]
         if not todo:
             return {}
@@ -360,7 +371,8 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
         I_rot, _ = self.net.generator([lat], input_is_latent=True, return_latents=False)
         seg_in = Embedding.to_bisenet(((I_rot + 1) / 2).clip(0, 1))
         masks = get_segmentation(self.parsing, seg_in)  # the 1024^2 images are parsed (:65-67), both in one call
-        return {key: (I_rot[k:k + 1], masks[k:k + 1]) for k, key in enumerate(todo)}
+        targets = self.stages.shape_adaptor(torch.cat([name_to_embed[a]["mask"] for a, _ in todo], 0), masks)
+        return {key: (I_rot[k:k + 1], masks[k:k + 1], targets[k:k + 1]) for k, key in enumerate(todo)}
 
     @torch.inference_mode()
     def shape_module(self, im_name1, im_name2, name_to_embed, only_target=True, rotated=None, **kwargs):  # :40-99
@@ -370,8 +382,7 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
             rot = (rotated or {}).get((im_name1, im_name2))
             if rot is None:
                 rot = self.rotate_images([(im_name1, im_name2)], name_to_embed)[(im_name1, im_name2)]
-            rot_mask = rot[1]
-            target_mask = self.stages.shape_adaptor(inp_mask1, rot_mask)
+            target_mask = rot[2]
         else:
             target_mask = inp_mask1
         hair_mask_target = (target_mask == 13).to(target_mask.dtype)
@@ -487,15 +498,17 @@ class HairFast:
       rotate_state    RotateModel state dict ('model_state_dict' of args.rotate_checkpoint): the Rotate stage runs natively
       blend_state (+ clip_image_embed)  ClipBlendingModel state dict ('model_state_dict' of args.blending_checkpoint) and
                       the CLIP ViT-B/32 image encoder callable: the blending stage runs natively around that callable
+      shape_state     CtrlHair mask-generator state dict (pretrained_models/ShapeAdaptor/mask_generator.pth): the shape
+                      adaptor runs natively (hairfastgan_amd.shape_adaptor)
     """
 
     def __init__(self, args, *, stages=None, generator_state=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
                  fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None, bisenet_state=None, rotate_state=None,
-                 blend_state=None, clip_image_embed=None):
+                 blend_state=None, clip_image_embed=None, shape_state=None):
         self.args = args
         self.stages = stages or Stages()
-        if rotate_state is not None or blend_state is not None:
-            self.stages = NativeLatentStages(self.stages, args.device, rotate_state, blend_state, clip_image_embed)
+        if rotate_state is not None or blend_state is not None or shape_state is not None:
+            self.stages = NativeLatentStages(self.stages, args.device, rotate_state, blend_state, clip_image_embed, shape_state)
         self.net = Net(args, state=generator_state)
         self.parsing = BiSeNet(19).eval()  # pretrained_models/BiSeNet/face_parsing_79999_iter.pth (my_parsing_util.py:77-79)
         if bisenet_state is not None:

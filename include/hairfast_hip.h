@@ -418,6 +418,16 @@ int hf_parsing_mask_i64(long long *out, const float *logits, const int *remap, i
                         int full_h, int full_w, int out_h, int out_w, void *stream);
 
 /* ---- stencils on either side of the hot path ---- */
+/* LayerNorm of the CtrlHair shape adaptor's Conv2dBlock (models/CtrlHair/my_torchlib/module.py:181-206, norm 'ln'):
+ * per sample, over all channels * hw values: y = (x - mean) / (std_unbiased + eps) * gamma[c] + beta[c], then
+ * LeakyReLU(slope) (slope 1 = no activation; gamma / beta may be NULL).  out: [batch][channels][hw]; x: the same, or
+ * with x_batch_stride (> channels*hw; 0 = dense) elements between samples - the first `channels` planes of a tensor
+ * with more (a conv output whose channel count was padded up to a tile multiple). */
+int hf_sample_layernorm_f32(float *out, const float *x, const float *gamma, const float *beta, int batch, int channels,
+                            int hw, long long x_batch_stride, float eps, float slope, float *workspace,
+                            long long workspace_floats, void *stream);
+/* scratch of hf_sample_layernorm_f32 (per-chunk statistics), in floats */
+long long hf_sample_layernorm_workspace_floats(int batch, int channels, int hw);
 /* BicubicDownSample.forward (utils/bicubic.py:38-75): reflect padding + the separable 4*factor-tap bicubic filter
  * k1d (device, 4*factor floats, normalised; the module's k), stride factor along both axes:
  * x [planes, h, w] -> out [planes, h/factor, w/factor]; h, w multiples of factor (the pipeline: 1024 -> 512 / 256). */

@@ -227,6 +227,49 @@ def fake_clip_embed(x):
     return x.flatten(1)[:, ::294][:, :512].contiguous() * 0.5
 
 
+def shape_masks():
+    """Two pairs of CelebAMask-style label maps, long [2,1,256,256] each (Alignment.py:74-75: the face image's mask and the
+    rotated shape image's mask): background, a skin ellipse with a few facial regions, neck / cloth, and a hair region
+    (label 13) whose outline differs between the two maps and the two pairs."""
+    yy, xx = torch.meshgrid(torch.arange(256, dtype=torch.float32), torch.arange(256, dtype=torch.float32), indexing="ij")
+
+    def one(cx, cy, hair_w, hair_top, tilt):
+        m = torch.zeros(256, 256, dtype=torch.long)
+        m[(yy > 200) & ((xx - cx).abs() < 90)] = 18                                              # cloth
+        m[(yy > 170) & (yy <= 215) & ((xx - cx).abs() < 35)] = 17                                # neck
+        hair = (((xx - cx - tilt * (yy - cy) * 0.2) / hair_w) ** 2 + ((yy - cy + 25) / (cy - hair_top)) ** 2 < 1) & (yy < cy + 60)
+        m[hair] = 13
+        m[((xx - cx) / 52) ** 2 + ((yy - cy) / 70) ** 2 < 1] = 1                                 # skin
+        for lab, ex, ey, rw, rh in ((4, -20, -15, 9, 5), (5, 20, -15, 9, 5), (6, -20, -28, 12, 3), (7, 20, -28, 12, 3),
+                                    (2, 0, 8, 8, 14), (11, 0, 35, 16, 5), (12, 0, 30, 14, 3), (13 - 13 + 10, 0, 38, 12, 3)):
+            m[((xx - cx - ex) / rw) ** 2 + ((yy - cy - ey) / rh) ** 2 < 1] = lab
+        return m
+
+    a = torch.stack([one(128, 120, 75, 25, 0.0), one(120, 125, 85, 35, 0.6)])[:, None]
+    b = torch.stack([one(132, 118, 95, 15, -0.5), one(128, 122, 70, 40, 0.2)])[:, None]
+    return a, b
+
+
+def shape_adaptor_params():
+    """Synthetic parameters of the CtrlHair mask generator: the closed-form fill with Linear weights scaled by
+    1/sqrt(fan_in), LayerNorm gains in [0.25, 1], small shifts, and pseudo-random class-score convs (so that the argmax
+    map has several regions and a spread of top-1 / top-2 margins)."""
+    from . import ref_shape_adaptor as SA
+
+    P = params_from_shapes("shape_adaptor", SA.param_shapes())
+    for k in list(P):
+        if k.endswith(".fc.weight"):
+            P[k] = P[k] / float(P[k].shape[1]) ** 0.5
+        elif k.endswith(".gamma"):
+            P[k] = 0.25 + 0.75 * P[k].abs()
+        elif k.endswith(".beta"):
+            P[k] = P[k] * 0.2
+    for name in ("hair_decoder", "face_decoder"):
+        k = f"{name}.out_layer.conv.weight"
+        P[k] = t(synth.pseudo_normal(f"shape_adaptor/{k}", tuple(P[k].shape))) * 0.3
+    return P
+
+
 def bisenet_input(tag):
     """ImageNet-normalised image for BiSeNet / get_segmentation: "512" = the [1,3,512,512] case of
     Embedding.py:81 (a smooth pattern + noise so that the argmax map has regions, not salt and pepper),

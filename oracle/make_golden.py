@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
     ap.add_argument("--only", default=None,
-                    help="comma list of sections to (re)generate (default all): basic,gen64,gen1024,enc_units,encoders,glue,pp,latent,bisenet")
+                    help="comma list of sections to (re)generate (default all): basic,gen64,gen1024,enc_units,encoders,glue,pp,latent,shape,bisenet")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -452,6 +452,76 @@ def main():
         report["latent/clip_input"] = maxdiff(blend.transform(blend.face_pool(img_face) * 0.5 + 0.5), PP.clip_image_input(img_face))
         np.savez_compressed(os.path.join(args.out, "latent_models.npz"), rotate=r_ref.numpy(), clip_blend=b_ref.numpy())
         print("done latent models", report["latent/rotate"], report["latent/clip_blend"], report["latent/clip_input"], flush=True)
+
+    # ---------------- (vi-c) CtrlHair shape adaptor: the mask generator + get_hair_face_code / get_new_shape (row f4) ----
+    if not args.skip_big and want("shape"):
+        class _AttrDict(dict):  # `addict.Dict` (the library; not installed here): nested dict with attribute access
+            def __init__(self, *a, **k):
+                super().__init__(*a, **k)
+                for k_, v_ in list(self.items()):
+                    if isinstance(v_, dict) and not isinstance(v_, _AttrDict):
+                        self[k_] = _AttrDict(v_)
+
+            __getattr__ = dict.get
+            __setattr__ = dict.__setitem__
+
+        addict_mod = _types.ModuleType("addict")
+        addict_mod.Dict = _AttrDict
+        sys.modules.setdefault("addict", addict_mod)
+        tvt_mod.functional.resize = lambda img, size, interpolation=None: (
+            img if tuple(img.shape[-2:]) == tuple(size) else torch.nn.functional.interpolate(img.float(), size=size, mode="nearest").to(img.dtype))
+        tvt_mod.InterpolationMode = _types.SimpleNamespace(NEAREST="nearest")
+        from models.CtrlHair.shape_branch import shape_util as ref_su
+        from models.CtrlHair.shape_branch.config import cfg as ref_cfg
+        from models.CtrlHair.shape_branch.model import Generator as RefMaskGenerator
+        from oracle import ref_shape_adaptor as SA
+
+        try:
+            from models.CtrlHair.shape_branch.solver import get_hair_face_code as ref_codes, get_new_shape as ref_new_shape
+        except Exception as e:  # the solver module pulls training-only dependencies: compose its two 6-line functions
+            print("solver import failed (", type(e).__name__, e, "): composing get_hair_face_code / get_new_shape from "
+                  "shape_util + the model, as solver.py:248-262 do", flush=True)
+
+            def ref_codes(gen, mask):
+                mb = mask[None, None].long()
+                hair, face = ref_su.split_hair_face(ref_su.mask_label_to_one_hot(mb))
+                return gen.forward_face_encoder(face), gen.forward_hair_encoder(hair, testing=True)
+
+            def ref_new_shape(gen, face_code, hair_code):
+                return ref_su.mask_one_hot_to_label(gen.forward_decode_by_code(hair_code, face_code))[0]
+
+        gen = RefMaskGenerator(ref_cfg).eval()
+        shapes = {k_: tuple(v_.shape) for k_, v_ in gen.state_dict().items()}
+        mine = SA.param_shapes()
+        assert shapes == mine and list(shapes) == list(mine), "mask generator state-dict layout mismatch"
+        Ps = C.shape_adaptor_params()
+        gen.load_state_dict(Ps)
+        m1, m2 = C.shape_masks()
+        g = {}
+        labels, worst_logit, worst_code, flips = [], 0.0, 0.0, 0
+        logit_all = []
+        for b_ in range(m1.shape[0]):  # one pair at a time, as Alignment.py:74-77 calls it
+            face_1, _hair_1 = ref_codes(gen, m1[b_, 0].clone())
+            _face_2, hair_2 = ref_codes(gen, m2[b_, 0].clone())
+            lab = ref_new_shape(gen, face_1, hair_2)
+            prob = gen.forward_decode_by_code(hair_2, face_1)  # softmax over the 19 classes
+            lab_o, logit_o, fc_o, hc_o = SA.adapt_shape(Ps, m1[b_:b_ + 1], m2[b_:b_ + 1])
+            labels.append(lab)
+            logit_all.append(logit_o)
+            worst_code = max(worst_code, maxdiff(face_1, fc_o), maxdiff(hair_2, hc_o))
+            worst_logit = max(worst_logit, maxdiff(prob, torch.softmax(logit_o, dim=1)))
+            flips += int((lab != lab_o[0]).sum())
+            top2 = logit_o[0].topk(2, dim=0).values
+            g[f"margin_{b_}"] = (top2[0] - top2[1]).to(torch.float16).numpy()
+            g[f"face_code_{b_}"], g[f"hair_code_{b_}"] = face_1.numpy(), hair_2.numpy()
+        logit_o = torch.cat(logit_all)
+        report["shape/codes"], report["shape/softmax"], report["shape/label_flips"] = worst_code, worst_logit, float(flips)
+        report.pop("shape/log_softmax", None)
+        g["labels"] = torch.stack(labels).to(torch.uint8).numpy()
+        g["logits_samples"] = strided_samples(logit_o, 2048)
+        g["logits_stats"] = stats(logit_o)
+        np.savez_compressed(os.path.join(args.out, "shape_adaptor.npz"), **g)
+        print("done shape adaptor", worst_code, worst_logit, flips, flush=True)
 
     # ---------------- (vii) BiSeNet face parsing + label remap --------------------
     if not args.skip_big and want("bisenet"):

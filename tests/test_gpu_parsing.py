@@ -113,3 +113,32 @@ def test_generated_image_mask_hip_vs_oracle():
     assert n_small <= max(n, 0)
     print(f"generated 1024^2 image -> mask: {n} of {1024 * 1024} indices differ ({n_small} of 65536 in the 256^2 mask); "
           f"largest margin among them {float(margin[flips].max()) if n else 0.0:.2e} (largest logit {scale:.1f})")
+
+
+def test_shape_adaptor_vs_reference_golden(golden):
+    """the CtrlHair mask generator (get_hair_face_code + get_new_shape, Alignment.py:74-77) on the
+    HIP kernels against the reference's golden codes and label maps: codes to 1e-4, label indices equal wherever the
+    decision is not a near-tie of the two largest logits; both pairs in one batched call and one by one."""
+    from hairfastgan_amd.shape_adaptor import MaskGenerator, adapt_shape, get_hair_face_code, get_new_shape
+
+    dev = torch.device("cuda:0")
+    G = golden("shape_adaptor.npz")
+    gen = MaskGenerator().eval()
+    gen.load_state_dict(C.shape_adaptor_params())
+    gen.to(dev)
+    m1, m2 = (m.to(dev) for m in C.shape_masks())
+    out = adapt_shape(gen, m1, m2)
+    assert out.shape == (2, 1, 256, 256) and out.dtype == torch.int64
+    scale = float(G["logits_stats"][3]) if "logits_stats" in G.files else 1.0
+    for b in range(2):
+        face_code, _ = get_hair_face_code(gen, m1[b, 0])
+        _, hair_code = get_hair_face_code(gen, m2[b, 0])
+        for got, key in ((face_code, f"face_code_{b}"), (hair_code, f"hair_code_{b}")):
+            ref = torch.from_numpy(G[key]).to(dev)
+            assert float((got - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())), key
+        ref_lab = torch.from_numpy(G["labels"][b].astype("int64")).to(dev)
+        margin = torch.from_numpy(G[f"margin_{b}"].astype("float32")).to(dev)
+        for lab in (out[b, 0], get_new_shape(gen, face_code, hair_code)):
+            flips = lab != ref_lab
+            assert float(flips.float().mean()) < 1e-3
+            assert int(flips.sum()) == 0 or float(margin[flips].max()) < 2e-3 * max(1.0, abs(scale)), (int(flips.sum()), float(margin[flips].max()))

@@ -108,3 +108,79 @@ def test_glue_stencils_vs_reference_golden(simlib, golden):
     mask = (C.unit_input("glue/mask", (3, 1, 48, 48)) > 0.3).float()
     d, e = M.dilate_erode(simlib, None, mask, 3)
     assert torch.equal(d, torch.from_numpy(G["dilate3"])) and torch.equal(e, torch.from_numpy(G["erode3"]))
+
+
+def test_shape_adaptor_blocks_and_layout(simlib, monkeypatch, golden):
+    """SURVEY section 8 row f4, the CtrlHair mask generator: (1) the oracle reproduces the reference's golden codes and
+    label map of one pair bit for bit; (2) the HIP-backed mirror has the reference's state-dict layout; (3) its two
+    non-standard blocks on the interpreted kernels - the 4x4 / stride-2 / pad-1 conv as a 3x3 conv of the space-to-depth
+    input, and the per-sample LayerNorm (unbiased std, eps added to it) + LeakyReLU - against torch."""
+    import sys
+
+    from hairfastgan_amd import shape_adaptor as SAP
+    from oracle import ref_shape_adaptor as SA
+
+    G = golden("shape_adaptor.npz")
+    P = C.shape_adaptor_params()
+    m1, m2 = C.shape_masks()
+    lab, logits, fc, hc = SA.adapt_shape(P, m1[:1], m2[:1])
+    assert torch.equal(fc, torch.from_numpy(G["face_code_0"])) and torch.equal(hc, torch.from_numpy(G["hair_code_0"]))
+    assert torch.equal(lab[0].to(torch.uint8), torch.from_numpy(G["labels"][0]))
+    assert len(set(lab.flatten().tolist())) >= 4  # a map with several regions, not one class everywhere
+    gen = SAP.MaskGenerator()
+    sd = gen.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == SA.param_shapes() and list(sd) == list(SA.param_shapes())
+    assert torch.equal(gen.hair_encoder.input_embedding[0], SA.pos_embedding())
+
+    for mod in (sys.modules["hairfastgan_amd.shape_adaptor"], sys.modules["hairfastgan_amd.encoders._fused"]):
+        monkeypatch.setattr(mod, "lib", lambda: simlib)
+        monkeypatch.setattr(mod, "stream", lambda: None)
+        monkeypatch.setattr(mod, "require_gpu", lambda *a: None)
+    torch.manual_seed(4)
+    blk = SAP.Conv2dBlock(5, 24, 4, 2, padding=1, norm="ln", activation="lrelu")
+    x = torch.randn(2, 5, 12, 20)
+    ref = F.conv2d(F.pad(x, (1, 1, 1, 1)), blk.conv.weight, blk.conv.bias, stride=2)
+    flat = ref.reshape(2, -1)
+    ref = (ref - flat.mean(1).view(-1, 1, 1, 1)) / (flat.std(1).view(-1, 1, 1, 1) + 1e-5)
+    ref = F.leaky_relu(ref * blk.norm.gamma.view(1, -1, 1, 1) + blk.norm.beta.view(1, -1, 1, 1), 0.2)
+    ref = ref.detach()
+    with torch.inference_mode():
+        y = blk(x)
+    assert y.shape == ref.shape and float((y - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    # the same layer with its last two input channels declared constant (a MaskEncoder's positional encoding): their
+    # share of the conv is folded into a per-pixel bias at plan time
+    blk._plan = None
+    xc = torch.cat([x[:, :3], x[:1, 3:].expand(2, -1, -1, -1)], 1)
+    with torch.no_grad():
+        refc = F.conv2d(F.pad(xc, (1, 1, 1, 1)), blk.conv.weight, blk.conv.bias, stride=2)
+        flat = refc.reshape(2, -1)
+        refc = (refc - flat.mean(1).view(-1, 1, 1, 1)) / (flat.std(1).view(-1, 1, 1, 1) + 1e-5)
+        refc = F.leaky_relu(refc * blk.norm.gamma.view(1, -1, 1, 1) + blk.norm.beta.view(1, -1, 1, 1), 0.2)
+    with torch.inference_mode():
+        yc = blk(x[:, :3].contiguous(), const_planes=x[:1, 3:].contiguous())
+    assert float((yc - refc).abs().max()) < 2e-5 * max(1.0, float(refc.abs().max()))
+    # deep-layer form: 8x8 input -> patches + GEMM on the 1x1 conv kernel
+    blk8 = SAP.Conv2dBlock(6, 10, 4, 2, padding=1, norm="none", activation="none")
+    x8 = torch.randn(3, 6, 8, 8)
+    with torch.inference_mode():
+        y8 = blk8(x8)
+    with torch.no_grad():
+        r8 = F.conv2d(F.pad(x8, (1, 1, 1, 1)), blk8.conv.weight, blk8.conv.bias, stride=2)
+    assert "gemm" in blk8._plan and y8.shape == r8.shape and float((y8 - r8).abs().max()) < 2e-5
+    # a channel count that is padded up to the fp16 kernel's 64-channel tiles (16 input channels, 24 -> 64 filters)
+    blk16 = SAP.Conv2dBlock(16, 24, 3, 1, padding=1, norm="ln", activation="lrelu")
+    x16 = torch.randn(2, 16, 16, 32)
+    with torch.no_grad():
+        r16 = F.conv2d(x16, blk16.conv.weight, blk16.conv.bias, padding=1)
+        flat = r16.reshape(2, -1)
+        r16 = (r16 - flat.mean(1).view(-1, 1, 1, 1)) / (flat.std(1).view(-1, 1, 1, 1) + 1e-5)
+        r16 = F.leaky_relu(r16 * blk16.norm.gamma.view(1, -1, 1, 1) + blk16.norm.beta.view(1, -1, 1, 1), 0.2)
+    with torch.inference_mode():
+        y16 = blk16(x16)
+    assert blk16._plan["pad_to"] == 64 and y16.shape == r16.shape
+    assert float((y16 - r16).abs().max()) < 2e-5 * max(1.0, float(r16.abs().max()))
+    blk3 = SAP.Conv2dBlock(8, 3, 3, 1, padding=1, norm="none", activation="none")
+    x3 = torch.randn(1, 8, 9, 11)
+    with torch.inference_mode():
+        y3 = blk3(x3)
+    assert float((y3 - F.conv2d(x3, blk3.conv.weight, blk3.conv.bias, padding=1)).abs().max()) < 2e-5
