@@ -38,7 +38,7 @@ using namespace hf_detail;
 
 #define HF_H_BARRIER() hf_barrier_keep_young<0>()
 #ifndef HF_H_ABLATE
-#define HF_H_ABLATE 0  // timing experiments only: 1 no activation loads, 2 no epilogue stores, 4 no weight DMA
+#define HF_H_ABLATE 0  // timing experiments only: 1 no activation loads, 2 no epilogue stores, 4 no weight DMA, 8 no activation DMA
 #endif
 
 #ifdef HF_H_TRACE
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   auto dma_x = [&](int e, int chunk, int bufsel) {
     const int i = tid + e * NT;
     const int kg = i / NPIX;
+    if (HF_H_ABLATE & 8) return;  // timing experiments: no activation DMA
     const bool inside = e_src[e] >= 0;
     int off = inside ? (kg * iplane + e_src[e]) * 16 : 0;
     HF_OPAQUE_I32(off);
@@ -787,7 +788,10 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       // fragments of tap+1 are fetched from LDS while the MFMAs of tap run
       // UP with in-kernel staging: 128 accumulator registers + the staging registers leave no room
       // for a second fragment set
-      constexpr int NSLOT = (UP && !PRE) ? 1 : 2;
+#ifndef HF_H_DEEP_FETCH
+#define HF_H_DEEP_FETCH 0  // experiment: same-resolution kernels fetch the LDS fragments TWO taps ahead (three slots)
+#endif
+      constexpr int NSLOT = (UP && !PRE) ? 1 : ((!UP && HF_H_DEEP_FETCH) ? 3 : 2);
       // PRE: all DMAs of the next stage in the first tap-step (short K loops: HBM latency exceeds the stage's MFMA
       // time, the copies need the whole stage to land) or spread one per tap-step (long K loops, see DMA_PER_STEP)
       const bool early = PRE && P.dma_early;
@@ -810,15 +814,24 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       };
       fetch_a(0, tap_at<UP>(0));
       fetch_b(0, tap_at<UP>(0));
+      if (NSLOT == 3) {
+        fetch_a(1, 1);
+        fetch_b(1, 1);
+      }
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int tap = tap_at<UP>(i);  // the side work below is scheduled by POSITION i
         HF_TRACE_POINT(10 + i);
         const int grp = tap_group<UP>(i);
-        const int sa = (NSLOT == 1) ? 0 : (i & 1), sb = (NSLOT == 1) ? 0 : (grp & 1);
+        const int sa = (NSLOT == 1) ? 0 : (NSLOT == 3 ? i % 3 : (i & 1)), sb = (NSLOT == 1) ? 0 : (NSLOT == 3 ? i % 3 : (grp & 1));
         if (NSLOT == 1) {
           if (i > 0) fetch_a(0, tap);
           if (i > 0 && group_first<UP>(grp) == i) fetch_b(0, tap);
+        } else if (NSLOT == 3) {  // !UP: natural tap order, one fragment pair per tap
+          if (i + 2 < 9) {
+            fetch_a((i + 2) % 3, i + 2);
+            fetch_b((i + 2) % 3, i + 2);
+          }
         } else {
           if (i + 1 < 9) fetch_a(sa ^ 1, tap_at<UP>(i + 1));
           // the next group's activation fragment, as soon as its slot is free (= when this group starts)
