@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-C=$GRAFT_REPO_ROOT/hairfastgan_amd/csrc
-PROBE_TUNE=0 python tools/probes/gen_layers.py > /dev/null 2>&1
-for v in hip ab4 ab12 hip; do echo "== $v"; HAIRFAST_HIP_LIB=$C/libhairfast_$v.so PROBE_TUNE=0 python tools/probes/gen_layers.py 2>&1 | grep "same\|upfu"; done
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -q 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > gpurun_out/r02h_bench.json 2> gpurun_out/r02h_bench.err; python -c "
+import json; d=json.load(open('gpurun_out/r02h_bench.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic_source'][:40], d['cpu_baseline']['value'], d['swap_pipeline']['value'], d['swap_pipeline']['single_swap'])"
