@@ -12,19 +12,24 @@ What runs where:
   reference issues (Embedding.py:51-53,71-90, Alignment.py:63, Blending.py:62,66,68) - runs on the HIP
   library (hairfastgan_amd.encoders, hairfastgan_amd.stylegan2);
 * BiSeNet face parsing + get_segmentation (row f2) likewise (hairfastgan_amd.face_parsing);
-* the networks BETWEEN those calls that SURVEY.md section 8 leaves out of scope (the Rotate encoder,
-  the CtrlHair shape adaptor, SEAN inpainting, the CLIP blending encoder) are `Stages`: named callables injected at construction.
-  With the reference installed they are its own modules (INTEGRATION.md shows the binding);
-  `SyntheticStages` provides shape- and dtype-faithful stand-ins so that the complete call
-  schedule can be executed and timed on a box that has neither the reference nor checkpoints;
+* the networks BETWEEN those calls are `Stages`: named callables injected at construction.
+  Three of the four have native implementations that take over when their state dicts are passed to `HairFast`
+  (`NativeLatentStages`): the Rotate encoder (encoders.RotateModel), the CLIP blending encoder
+  (encoders.ClipBlendingModel - everything but the CLIP ViT-B/32 image tower, which stays a callable) and the
+  CtrlHair shape adaptor (shape_adaptor.MaskGenerator); SEAN inpainting is always a stage.  With the reference
+  installed the stages are its own modules (INTEGRATION.md shows the binding); `SyntheticStages` provides shape- and
+  dtype-faithful stand-ins so that the complete call schedule can be executed and timed on a box that has neither
+  the reference nor checkpoints;
 * the stencils on either side of the path (BicubicDownSample, DilateErosion: row f2) are HIP kernels too;
   the remaining glue (normalisation, mask arithmetic, two small F.interpolate calls) is torch elementwise
   code, as in the reference.
 
-One scheduling change against the reference: the two batch-1
-full generator forwards of `Alignment.shape_module` (Alignment.py:63, once for (face, shape)
-and once for (face, color)) are issued as ONE batch-2 forward (`Alignment.rotate_images`);
-per-sample results are identical because the kernels share nothing across the batch.
+Scheduling changes against the reference, none of which changes a per-sample result
+(frozen weights, independent samples): the two batch-1 full generator forwards of `Alignment.shape_module`
+(Alignment.py:63, once for (face, shape) and once for (face, color)) are issued as ONE batch-2 forward together with
+their parses and shape-adaptor calls (`Alignment.rotate_images`); `HairFast.swap_batch` runs several triples as one
+batched pass over every hot-path call; for a single swap the three independent branches of the Embedding stage are
+enqueued on separate HIP streams.
 """
 import argparse
 import contextlib
