@@ -114,9 +114,16 @@ class Conv2dBlock(nn.Module):  # my_torchlib/module.py:64-131 (pad_type 'zero', 
                 p["gemm"] = M.conv_prepare(L, st, w2.contiguous())
             b, _, h, w_ = x.shape
             cols = F.unfold(x, kernel_size=4, stride=2, padding=1)                     # [B, cin*16, L]
-            cols = cols.permute(1, 0, 2).contiguous().unsqueeze(0)                     # [1, cin*16, B, L]
-            y = M.conv2d(L, st, cols, p["gemm"], 1, 1, bias=self.conv.bias.detach())   # [1, cout, B, L]
-            y = y[0].permute(1, 0, 2).reshape(b, cout, h // 2, w_ // 2).contiguous()
+            if b * cols.shape[2] <= 32:
+                # a single swap: up to 32 patch rows - the weight-streaming GEMV kernel reads the 34 / 134 MB of weights
+                # once per 8 rows at HBM speed (the MFMA GEMM form below needs more rows to pay: 209 -> ~60 us)
+                rows = cols.permute(0, 2, 1).reshape(-1, cols.shape[1])                # [B*L, cin*16]
+                y = M.linear(L, st, rows, self.conv.weight.detach().reshape(cout, -1), self.conv.bias.detach(), 1.0)
+                y = y.reshape(b, -1, cout).permute(0, 2, 1).reshape(b, cout, h // 2, w_ // 2).contiguous()
+            else:
+                cols = cols.permute(1, 0, 2).contiguous().unsqueeze(0)                     # [1, cin*16, B, L]
+                y = M.conv2d(L, st, cols, p["gemm"], 1, 1, bias=self.conv.bias.detach())   # [1, cout, B, L]
+                y = y[0].permute(1, 0, 2).reshape(b, cout, h // 2, w_ // 2).contiguous()
         else:
             y = self._conv(x, p["w"], p["bias"], k)
         if p["const"] is not None:

@@ -167,6 +167,11 @@ def test_shape_adaptor_blocks_and_layout(simlib, monkeypatch, golden):
     with torch.no_grad():
         r8 = F.conv2d(F.pad(x8, (1, 1, 1, 1)), blk8.conv.weight, blk8.conv.bias, stride=2)
     assert "gemm" in blk8._plan and y8.shape == r8.shape and float((y8 - r8).abs().max()) < 2e-5
+    with torch.inference_mode():  # few patch rows (a single swap): the weight-streaming linear kernel
+        y8s = blk8(x8[:1, :, :4, :4].contiguous())
+    with torch.no_grad():
+        r8s = F.conv2d(F.pad(x8[:1, :, :4, :4], (1, 1, 1, 1)), blk8.conv.weight, blk8.conv.bias, stride=2)
+    assert y8s.shape == r8s.shape and float((y8s - r8s).abs().max()) < 2e-5
     # a channel count that is padded up to the fp16 kernel's 64-channel tiles (16 input channels, 24 -> 64 filters)
     blk16 = SAP.Conv2dBlock(16, 24, 3, 1, padding=1, norm="ln", activation="lrelu")
     x16 = torch.randn(2, 16, 16, 32)
