@@ -245,6 +245,61 @@ __global__ __launch_bounds__(256) void linear_kernel(float *__restrict__ out, co
     }
 }
 
+// The same product for LONG rows (in_f >= 4096: the 8192- and 16384-wide Linear layers of the shape adaptor and the
+// e4e / FS style heads): the four waves of a block share kLinRows output rows and split K between them, partial sums
+// meet in LDS in wave order (deterministic).  One wave per row group left half of the chip idle with only 4 KiB of
+// weights in flight per wave (0.85 TB/s on a 134 MB weight matrix); K-split quadruples the waves.
+__global__ __launch_bounds__(256) void linear_kernel_ksplit(float *__restrict__ out, const float *__restrict__ x,
+                                                            long long x_stride, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, int batch, int in_f, int out_f,
+                                                            float scale, float bias_scale, int act, float alpha,
+                                                            float act_scale) {
+  HF_DYN_LDS;
+  float *red = reinterpret_cast<float *>(hf_dyn_lds);  // [4 waves][kLinRows * kLinMaxBatch]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * kLinRows;
+  x += (long long)blockIdx.y * kLinMaxBatch * x_stride;
+  out += (long long)blockIdx.y * kLinMaxBatch * out_f;
+  batch = min(kLinMaxBatch, batch - (int)blockIdx.y * kLinMaxBatch);
+  float acc[kLinRows][kLinMaxBatch];
+#pragma unroll
+  for (int r = 0; r < kLinRows; ++r)
+#pragma unroll
+    for (int b = 0; b < kLinMaxBatch; ++b) acc[r][b] = 0.0f;
+  const int kq = in_f / 4, k_lo = wave * kq, k_hi = wave == 3 ? in_f : k_lo + kq;  // in_f % 16 == 0 (launcher)
+  for (int k = k_lo + lane * 4; k < k_hi; k += 256) {
+    float4 xv[kLinMaxBatch];
+#pragma unroll
+    for (int b = 0; b < kLinMaxBatch; ++b)
+      xv[b] = (b < batch) ? *reinterpret_cast<const float4 *>(x + b * x_stride + k) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < kLinRows; ++r) {
+      const int n = min(n0 + r, out_f - 1);
+      const float4 wv = *reinterpret_cast<const float4 *>(w + (long long)n * in_f + k);
+#pragma unroll
+      for (int b = 0; b < kLinMaxBatch; ++b)
+        acc[r][b] = fmaf(wv.x, xv[b].x, fmaf(wv.y, xv[b].y, fmaf(wv.z, xv[b].z, fmaf(wv.w, xv[b].w, acc[r][b]))));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kLinRows; ++r)
+#pragma unroll
+    for (int b = 0; b < kLinMaxBatch; ++b) {
+      const float v = hf_wave_sum(acc[r][b]);
+      if (lane == 0) red[wave * (kLinRows * kLinMaxBatch) + r * kLinMaxBatch + b] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < kLinRows * kLinMaxBatch) {
+    const int r = threadIdx.x / kLinMaxBatch, b = threadIdx.x % kLinMaxBatch;
+    if (b < batch && n0 + r < out_f) {
+      const int i = r * kLinMaxBatch + b, st = kLinRows * kLinMaxBatch;
+      float y = ((red[i] + red[st + i]) + (red[2 * st + i] + red[3 * st + i])) * scale + (bias ? bias[n0 + r] * bias_scale : 0.0f);
+      if (act) y = hf_lrelu(y, alpha, act_scale);
+      out[(long long)b * out_f + n0 + r] = y;
+    }
+  }
+}
+
 // PixelNorm (models/stylegan2/model.py:16-21): x * rsqrt(mean(x^2, dim 1) + 1e-8); one wave per row
 __global__ __launch_bounds__(256) void pixel_norm_rows(float *__restrict__ out, const float *__restrict__ x, int rows,
                                                        int dim) {
@@ -574,12 +629,22 @@ extern "C" int hf_downscale2x_f32(float *out, const float *x, int planes, int h,
   return hf_launch_status();
 }
 
+static void launch_linear(float *out, const float *x, long long x_stride, const float *w, const float *bias, int batch, int in_f,
+                          int out_f, float scale, float bias_scale, int act, float alpha, float act_scale, hipStream_t st) {
+  if (in_f >= 4096 && (in_f & 15) == 0 && (x_stride & 3) == 0)
+    hipLaunchKernelGGL(linear_kernel_ksplit, dim3(hf_cdiv(out_f, kLinRows), hf_cdiv(batch, kLinMaxBatch)), dim3(256),
+                       4 * kLinRows * kLinMaxBatch * sizeof(float), st, out, x, x_stride, w, bias, batch, in_f, out_f, scale,
+                       bias_scale, act, alpha, act_scale);
+  else
+    hipLaunchKernelGGL(linear_kernel, dim3(hf_cdiv(out_f, 4 * kLinRows), hf_cdiv(batch, kLinMaxBatch)), dim3(256), 0, st, out, x,
+                       x_stride, w, bias, batch, in_f, out_f, scale, bias_scale, act, alpha, act_scale);
+}
+
 extern "C" int hf_linear_f32(float *out, const float *x, long long x_stride, const float *w, const float *bias,
                              int batch, int in_features, int out_features, float scale, void *stream) {
   if (!out || !x || !w || batch <= 0 || batch > 65535 * kLinMaxBatch || in_features <= 0 || out_features <= 0)
     return HF_E_INVALID;
-  hipLaunchKernelGGL(linear_kernel, dim3(hf_cdiv(out_features, 4 * kLinRows), hf_cdiv(batch, kLinMaxBatch)), dim3(256), 0,
-                     (hipStream_t)stream, out, x, x_stride, w, bias, batch, in_features, out_features, scale, 1.0f, 0, 0.0f, 1.0f);
+  launch_linear(out, x, x_stride, w, bias, batch, in_features, out_features, scale, 1.0f, 0, 0.0f, 1.0f, (hipStream_t)stream);
   return hf_launch_status();
 }
 

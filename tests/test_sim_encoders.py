@@ -335,6 +335,8 @@ def test_postprocess_modulation_module(sim_backend, golden):
     assert maxdiff(M.layernorm(simlib, None, a, 18 * 32), F.layer_norm(a, [18, 32])) < 1e-5
     g_, b_ = torch.rand(32) + 0.5, torch.randn(32)
     assert maxdiff(M.layernorm(simlib, None, a, 32, g_, b_, lrelu=True), F.leaky_relu(F.layer_norm(a, [32], g_, b_))) < 1e-5
+    xl, wl4, bl4 = torch.randn(3, 4112), torch.randn(6, 4112) / 64, torch.randn(6)  # long rows: the K-split form (4 waves per row group)
+    assert maxdiff(M.linear(simlib, None, xl, wl4, bl4, 1.0), F.linear(xl, wl4, bl4)) < 2e-5
     rows = torch.randn(19, 40)  # > 8 rows: several row chunks in one launch
     wl, bl = torch.randn(7, 40), torch.randn(7)
     assert maxdiff(M.linear(simlib, None, rows, wl, bl, 1.0), F.linear(rows, wl, bl)) < 1e-5
