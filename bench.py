@@ -29,8 +29,15 @@ timing is weight-independent.  Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline  the CPU oracle (bit-identical restatement of the reference's PyTorch CPU path) timed
                 on this host: batch-1 forwards with the best thread count (value) and with ONE thread
                 (per_core), host core count stated (rank 0, N=1 only).
-For N>1 (torchrun, one rank per GPU over RCCL) the generator workload weak-scales (same per-GPU batch,
-uint8 result images all-gathered asynchronously per step).
+For N>1 (one rank per GPU over RCCL) the generator workload weak-scales (same per-GPU batch, uint8 result
+images all-gathered asynchronously per step).  `python bench.py --gpus N` without a torchrun environment
+re-executes itself as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port <free> bench.py ...` (and refuses when fewer than N GPUs are visible); under torchrun it uses the
+environment it finds and refuses a WORLD_SIZE that differs from --gpus.  The JSON line carries `ranks_observed`
+(an all-reduce of ones over the process group).
+--workload launch-check: the launcher / rank plumbing only (process group, barrier, max-over-ranks clock, the
+  all-gather of a small uint8 tensor per step) - runs under gloo without a GPU; tests/test_parallel_gloo.py
+  uses it to check that `bench.py --gpus 2` really is two ranks.
 """
 import argparse
 import json
@@ -255,13 +262,72 @@ def kernel_report(prof, elapsed, precision):
     return out
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a torchrun environment: become the launcher of N ranks."""
+    import socket
+    import subprocess
+
+    if args.workload != "launch-check":
+        n_vis = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_vis < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {n_vis} GPU(s) visible - refusing to report fewer ranks than asked for")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def launch_check(args):
+    """The N-rank plumbing of this file without the GPU workload (gloo on CPU, RCCL when GPUs are there)."""
+    import torch.distributed as dist
+
+    from hairfastgan_amd import parallel
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    cuda = torch.cuda.is_available()
+    dev = torch.device("cuda", local) if cuda else torch.device("cpu")
+    ones = torch.ones(1, device=dev)
+    if world > 1:
+        dist.all_reduce(ones)
+        dist.barrier()
+    t0 = time.perf_counter()
+    got = None
+    for k in range(args.steps):
+        u8 = torch.full((2, 3, 8, 8), (rank * 16 + k) % 256, dtype=torch.uint8, device=dev)
+        got = parallel.all_gather_images(u8)
+    if world > 1:
+        dist.barrier()
+    sec = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(sec, op=dist.ReduceOp.MAX)
+    ok = got.shape[0] == 2 * world and all(int(got[2 * r, 0, 0, 0]) == (r * 16 + args.steps - 1) % 256 for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "launch_check", "value": int(ones.item()), "unit": "ranks", "n_gpus": world,
+                          "ranks_observed": int(ones.item()), "steps": args.steps, "warmup": 0,
+                          "ms_per_step": round(float(sec.item()) / max(args.steps, 1) * 1e3, 4), "gather_ok": bool(ok),
+                          "backend": dist.get_backend() if world > 1 else None, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                          "config": {"workload": "launcher / process-group check (no GPU work)"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (generator workload)")
-    ap.add_argument("--workload", choices=("generator", "swap256"), default="generator")
+    ap.add_argument("--workload", choices=("generator", "swap256", "launch-check"), default="generator")
     ap.add_argument("--triples", type=int, default=256, help="swap256: triples of the whole job")
     ap.add_argument("--swap-batch", type=int, default=8,
                     help="swap256: triples per batched pass over the hot path (HairFast.swap_batch); 1 = one HairFast.swap per triple")
@@ -274,6 +340,11 @@ def main():
                     help="generator workload: triples per GPU for the secondary hair-swap measurements (0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        self_launch(args, sys.argv[1:])
+    if args.workload == "launch-check":
+        return launch_check(args)
+
     from hairfastgan_amd import _marshal, _runtime, parallel
 
     if args.precision:
@@ -281,9 +352,11 @@ def main():
     precision = _runtime.conv_precision()
 
     rank, world, local = parallel.init_from_env()
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} - refusing to print a line for a different rank count")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if torch.cuda.device_count() <= local:
+        sys.exit(f"bench.py: rank {rank} (local {local}) has no GPU: {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -302,6 +375,13 @@ def main():
         t = torch.tensor([sec], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    ranks_observed = 1
+    if use_dist:
+        t_ranks = torch.ones(1, device=dev)
+        dist.all_reduce(t_ranks)
+        ranks_observed = int(t_ranks.item())
+        assert ranks_observed == world, f"process group reports {ranks_observed} ranks, WORLD_SIZE {world}"
 
     g, sd = build_generator(dev)
 
@@ -326,7 +406,7 @@ def main():
         assert images.shape == (args.triples, 3, 1024, 1024) and images.dtype == torch.uint8
         if rank == 0:
             out = {"metric": "hair_swap_triples_per_sec", "value": round(args.triples / elapsed, 3), "unit": "triples/s",
-                   "n_gpus": world, "steps": args.triples, "warmup": max(1, args.warmup),
+                   "n_gpus": world, "ranks_observed": ranks_observed, "steps": args.triples, "warmup": max(1, args.warmup),
                    "ms_per_step": round(elapsed / args.triples * 1e3 * world, 4), "ms_per_triple_per_gpu": round(elapsed / max(n_local, 1) * 1e3, 3),
                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPES[precision],
                    "data": "synthetic",
@@ -473,7 +553,7 @@ def main():
         value = B * args.steps * world / elapsed
         out = {
             "metric": "stylegan2_generator_fwd_1024_images_per_sec", "value": round(value, 3), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "n_gpus": world, "ranks_observed": ranks_observed, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "ms_per_image": round(ms_step / B, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPES[precision], "data": "synthetic",
             "config": {"workload": "StyleGAN2 1024^2 generator forward (range 0->8), random W+, fresh noise per layer, "

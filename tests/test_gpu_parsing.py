@@ -63,10 +63,13 @@ def test_masks_vs_reference_golden(golden, tag, mode):
     ref_full = torch.from_numpy(G[f"mask_{tag}"].astype(np.int64))
     flips = full[0, 0].cpu() != ref_full
     n = int(flips.sum())
-    assert n == 0 or float(margin[flips].max()) <= 2e-4 * scale + 2e-3, (n, float(margin[flips].max()))  # + fp16 storage of the margins
+    # north_star: "bit-exact segmentation-mask indices".  On the reference's golden inputs every index is reproduced
+    # (observed 0 of 262 144 / 0 of 122 880 in both modes since round 2): assert exactly that, so that a regression
+    # shows; the near-tie margin clause is kept only for the generated-image chain below.
+    assert n == 0, (n, float(margin[flips].max()))
     ref_small = torch.from_numpy(G[f"mask256_{tag}"].astype(np.int64))
     n_small = int((small[0, 0].cpu() != ref_small).sum())
-    assert n_small <= n
+    assert n_small == 0
     assert tuple(small.shape) == (1, 1, 256, 256) and small.dtype == torch.int64
     print(f"bisenet {tag} {mode}: {n} of {H * W} full-resolution indices differ from the reference ({n_small} of 65536 in the "
           f"256^2 mask), all with top-1/top-2 margin <= {float(margin[flips].max()) if n else 0.0:.2e} (largest logit {scale:.1f}); "

@@ -210,6 +210,64 @@ def test_swap_many_forced_rccl_single_rank():
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_swap_many_256_triples_batch8_forced_rccl():
+    """BASELINE.json configs[3] at its own size on one GPU: 256 synthetic triples, 8 per batched pass, through
+    parallel.swap_many with RCCL initialised (HF_FORCE_DIST=1, world 1): shape / dtype / order of the gathered
+    uint8 images, and bit-equality of three groups (first, one in the middle, the ragged... last) with direct
+    HairFast.swap_batch calls on the same triples.  Noise strengths are zero so that separate calls are comparable
+    (they draw different noise otherwise).  Group g holds the pool rotated by g, so a result in the wrong slot shows."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, time, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from hairfastgan_amd import parallel\n"
+        "import torch.distributed as dist\n"
+        "rank, world, local = parallel.init_from_env()\n"
+        "assert dist.is_initialized() and dist.get_backend() == 'nccl'\n"
+        "sys.path.insert(0, os.path.join(sys.path[0], 'tests'))\n"
+        "from test_gpu_schedule import _hairfast\n"
+        "dev = torch.device('cuda', local)\n"
+        "hf = _hairfast(dev)\n"
+        "with torch.no_grad():\n"
+        "    for name, p in hf.net.generator.named_parameters():\n"
+        "        if name.endswith('noise.weight'):\n"
+        "            p.zero_()\n"
+        "pool = []\n"
+        "for t in range(8):\n"
+        "    g = torch.Generator().manual_seed(100 + t)\n"
+        "    pool.append(tuple(torch.randint(0, 256, (3, 1024, 1024), dtype=torch.uint8, generator=g).pin_memory() for _ in range(3)))\n"
+        "N = 256\n"
+        "load = lambda i: pool[(i + i // 8) % 8]\n"
+        "hf.swap_batch([tuple(t.to(dev) for t in load(i)) for i in range(8)])\n"
+        "torch.cuda.synchronize(); t0 = time.perf_counter()\n"
+        "imgs, n = parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), N, load, device=dev, batch=8, swap_batch_fn=hf.swap_batch)\n"
+        "torch.cuda.synchronize(); sec = time.perf_counter() - t0\n"
+        "assert n == N and imgs.shape == (N, 3, 1024, 1024) and imgs.dtype == torch.uint8\n"
+        "for g0 in (0, 15, 31):\n"
+        "    direct = hf.swap_batch([tuple(t.to(dev) for t in load(8 * g0 + j)) for j in range(8)])\n"
+        "    for j in range(8):\n"
+        "        assert torch.equal(imgs[8 * g0 + j], parallel.to_uint8_image(direct[j] * 2 - 1)), (g0, j)\n"
+        "# the same triple in another slot of another group: same image up to batch-position effects (none expected)\n"
+        "worst = 0.0\n"
+        "for i in range(8, N):\n"
+        "    j = (i + i // 8) % 8\n"
+        "    d = (imgs[i].float() - imgs[j].float()).abs()\n"
+        "    worst = max(worst, float(d.mean()))\n"
+        "assert worst < 0.05, worst\n"
+        "assert not torch.equal(imgs[0], imgs[1])\n"
+        "print('SWAP256_OK %.2f s, %.1f triples/s, worst mean |diff| between slots %.4f levels' % (sec, N / sec, worst))\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    env = dict(os.environ, HF_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "SWAP256_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    print(r.stdout.strip().splitlines()[-1])
+
+
 def test_glue_stencils_vs_reference_golden(golden):
     """BicubicDownSample / DilateErosion on the GPU against golden vectors from the reference's classes (incl. the
     pipeline's own setting: 5 rounds on 256^2 masks)."""

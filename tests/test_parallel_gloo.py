@@ -125,3 +125,31 @@ def test_swap_many_single_process():
     got, n = parallel.swap_many(None, 7, lambda i: tuple(torch.full((3, 2, 2), 10 * i, dtype=torch.uint8) for _ in range(3)), chunk=5, batch=3,
                                 swap_batch_fn=lambda ts: (sizes.append(len(ts)), [t[0].float() / 255.0 for t in ts])[1])
     assert n == 7 and got[:, 0, 0, 0].tolist() == [0, 10, 20, 30, 40, 50, 60] and sizes == [3, 2, 2]
+
+
+def test_bench_gpus2_self_launches_two_ranks():
+    """`python bench.py --gpus 2` without a torchrun environment re-executes itself under torch.distributed.run
+    with two ranks (here: gloo, the launcher / process-group workload that needs no GPU) and rank 0 prints ONE
+    JSON line carrying the rank count the process group observed."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "launch-check", "--steps", "3"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["ranks_observed"] == 2 and doc["gather_ok"] and doc["backend"] == "gloo"
+    # a WORLD_SIZE that contradicts --gpus is refused, not silently reported as a different job
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "launch-check"],
+                        env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in r2.stderr
+    if not torch.cuda.is_available():  # and the GPU workloads refuse to run with fewer GPUs than ranks
+        r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                            text=True, timeout=300)
+        assert r3.returncode != 0 and "GPU(s) visible" in r3.stderr
