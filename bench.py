@@ -97,16 +97,15 @@ def build_hairfast(sd, dev):
     args.device = dev
     pp_shapes = PP.post_process_param_shapes()
     pp_shapes.pop("latent_avg")
-    # RotateModel, ClipBlendingModel and the CtrlHair shape adaptor run natively; the CLIP image
-    # tower inside the blending model is a stand-in projection (the un-vendored `clip` package is not part of this
-    # backend); SEAN synthetic
+    # RotateModel, ClipBlendingModel, the CtrlHair shape adaptor and SEAN run natively; the CLIP
+    # image tower inside the blending model is a stand-in projection (the un-vendored `clip` package)
     stand_in_clip = lambda x: x.flatten(1)[:, ::294][:, :512].contiguous() * 0.5  # noqa: E731  [B,3,224,224] -> [B,512]
     return HairFast(args, stages=SyntheticStages(), generator_state={"g_ema": sd, "latent_avg": torch.zeros(512)},
                     e4e_state=synth_state("e4e", E.e4e_param_shapes()), fs_state=synth_state("fs", E.fs_param_shapes()),
                     pp_state=synth_state("pp", pp_shapes), bisenet_state=C.bisenet_params(),
                     rotate_state=synth_state("rotate", PP.rotate_param_shapes()),
                     blend_state=synth_state("clipblend", PP.clip_blending_param_shapes()), clip_image_embed=stand_in_clip,
-                    shape_state=C.shape_adaptor_params())
+                    shape_state=C.shape_adaptor_params(), sean_state=C.sean_params(), sean_mean_codes=C.sean_mean_codes())
 
 
 def cpu_baseline(sd, budget_s=30.0):

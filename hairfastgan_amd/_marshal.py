@@ -837,3 +837,60 @@ def add_bcast(lib, st, a, bvec):
     out = torch.empty_like(a)
     check(lib, lib.hf_add_bcast_f32(_p(out), _p(a), _p(bvec), a.numel(), bvec.numel(), st), "hf_add_bcast_f32")
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# SEAN (csrc/sean.hip)
+# ----------------------------------------------------------------------------------------
+def label_conv3x3(lib, st, labels, table, bias, channels, batch=None, cols_per_sample=0, group=1, relu=False):
+    """hf_label_conv3x3_f32: 3x3 conv of a per-label-constant input as nine table lookups per output.
+    labels int32 [B/group, H, W]; table [9*channels, table_cols] -> [B, channels, H, W]."""
+    if labels.dtype != torch.int32 or not labels.is_contiguous():
+        raise TypeError("labels must be contiguous int32 [B/group, H, W]")
+    table = _c(table)
+    nb, h, w = labels.shape
+    b = nb * group if batch is None else batch
+    if table.shape[0] != 9 * channels or (cols_per_sample and table.shape[1] < b * cols_per_sample):
+        raise ValueError(f"table {tuple(table.shape)} does not fit {channels} channels / {b} samples")
+    out = table.new_empty((b, channels, h, w))
+    check(lib, lib.hf_label_conv3x3_f32(_p(out), _p(labels), _p(table), _p(_c(bias)), b, channels, h, w, table.shape[1],
+                                        cols_per_sample, group, 1 if relu else 0, st), "hf_label_conv3x3_f32")
+    return out
+
+
+def ace_modulate(lib, st, x, noise, noise_var, bn_scale, bn_shift, avg, sp, blend, group=1, slope=1.0):
+    """hf_ace_modulate_f32: the tail of ACE.forward; x [B,C,H,W], noise [B,H,W] | None, avg [B,2C,H,W] | None,
+    sp [B/group,2C,H,W], blend = device tensor (blending_gamma, blending_beta)."""
+    x, sp = _c(x), _c(sp)
+    b, c, h, w = x.shape
+    if tuple(sp.shape) != (b // group, 2 * c, h, w) or (avg is not None and tuple(avg.shape) != (b, 2 * c, h, w)):
+        raise ValueError("sp / avg must be [B/group | B, 2C, H, W]")
+    if noise is not None and noise.numel() != b * h * w:
+        raise ValueError("noise must be [B, H, W]")
+    out = torch.empty_like(x)
+    check(lib, lib.hf_ace_modulate_f32(_p(out), _p(x), _p(_c(noise)), _p(_c(noise_var)), _p(_c(bn_scale)), _p(_c(bn_shift)),
+                                       _p(_c(avg)), _p(sp), _p(_c(blend)), b, c, h * w, group, float(slope), st),
+          "hf_ace_modulate_f32")
+    return out
+
+
+def region_mean(lib, st, x, labels, crop=0, act_tanh=False):
+    """hf_region_mean_f32: per-label mean of (tanh of) x [B,C,H+2*crop,W+2*crop] over its interior, labels int32
+    [B,H,W] -> [B,19,C]."""
+    x = _c(x)
+    b, c, hp, wp = x.shape
+    h, w = hp - 2 * crop, wp - 2 * crop
+    if labels.dtype != torch.int32 or tuple(labels.shape) != (b, h, w) or not labels.is_contiguous():
+        raise TypeError("labels must be contiguous int32 [B, H, W] of the cropped size")
+    out = x.new_empty((b, 19, c))
+    base = x.data_ptr() + 4 * (crop * wp + crop)
+    check(lib, lib.hf_region_mean_f32(_p(out), base, _p(labels), b, c, h, w, 19, c * hp * wp, hp * wp, wp, 1 if act_tanh else 0, st),
+          "hf_region_mean_f32")
+    return out
+
+
+def tanh(lib, st, x):
+    x = _c(x)
+    out = torch.empty_like(x)
+    check(lib, lib.hf_tanh_f32(_p(out), _p(x), x.numel(), st), "hf_tanh_f32")
+    return out

@@ -1,0 +1,182 @@
+// sean.hip - kernels of the SEAN inpainting stage (models/sean_codes/models/networks/{generator,architecture,
+// normalization}.py).  The dense 3x3 convolutions run on the library's conv kernels
+// (csrc/convh_enc.hip / modconv.hip); what is here is what makes SEAN's normalisation cheap on this machine:
+//
+//  * A 3x3 convolution whose input is PIECEWISE CONSTANT per segmentation label - SPADE's mlp_shared on the one-hot
+//    map (normalization.py:246-252), ACE's conv_gamma / conv_beta on `middle_avg` (the per-region style vector
+//    broadcast over the region, :117-160), the generator's `fc` on the down-sampled one-hot map (generator.py:75-76) -
+//    is a sum of nine table entries: out[c, p] = bias[c] + sum_tap T[tap, c, label(p + tap)], T = W_tap . v_label.
+//    ACE's two 512 -> C convolutions (2 x 77 GFLOP at 128^2 for one image) become a 19-row GEMM (the table) plus nine
+//    gathers per output element.
+//  * ACE's tail in one pass: noise, inference BatchNorm, the gamma / beta blend, (1 + gamma) * x + beta, LeakyReLU.
+//  * The style encoder's per-region average pooling (architecture.py:187-205) with the final tanh folded in.
+#include "hf_common.h"
+
+constexpr int kSeanLabels = 19;
+
+// out[b, c, y, x] = act( bias[c] + sum_{tap=(ky,kx)} table[(tap*C + c) * tcols + col0(b) + label[b / group, y+ky-1, x+kx-1]] )
+// taps outside the image contribute nothing (zero padding).  table: [9*C][tcols]; col0(b) = b * cols_per_sample.
+__global__ __launch_bounds__(256) void label_conv3x3(float *__restrict__ out, const int *__restrict__ labels,
+                                                     const float *__restrict__ table, const float *__restrict__ bias, int C,
+                                                     int H, int W, int tcols, int cols_per_sample, int group, int act,
+                                                     int cchunk) {
+  const int hw = H * W;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  const int b = blockIdx.z;
+  const int y = p / W, x = p - y * W;
+  const int *lb = labels + (long long)(b / group) * hw;
+  int col[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    col[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? b * cols_per_sample + lb[yy * W + xx] : -1;
+  }
+  const int c0 = blockIdx.y * cchunk, c1 = min(C, c0 + cchunk);
+  float *o = out + ((long long)b * C + c0) * hw + p;
+  for (int c = c0; c < c1; ++c, o += hw) {
+    float acc = bias ? bias[c] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      if (col[t] >= 0) acc += table[((long long)t * C + c) * tcols + col[t]];
+    *o = act ? fmaxf(acc, 0.0f) : acc;
+  }
+}
+
+extern "C" int hf_label_conv3x3_f32(float *out, const int *labels, const float *table, const float *bias, int batch,
+                                    int channels, int h, int w, int table_cols, int cols_per_sample, int group, int relu,
+                                    void *stream) {
+  if (!out || !labels || !table || batch <= 0 || channels <= 0 || h <= 0 || w <= 0 || table_cols <= 0 || group <= 0 ||
+      cols_per_sample < 0 || batch > 65535)
+    return HF_E_INVALID;
+  const int hw = h * w;
+  // enough blocks to fill the chip, at least 8 channels per thread to amortise the nine label loads
+  int cchunk = channels;
+  while (cchunk > 8 && (long long)hf_cdiv(hw, 256) * hf_cdiv(channels, cchunk) * batch < 1024) cchunk = (cchunk + 1) / 2;
+  hipLaunchKernelGGL(label_conv3x3, dim3(hf_cdiv(hw, 256), hf_cdiv(channels, cchunk), batch), dim3(256), 0,
+                     (hipStream_t)stream, out, labels, table, bias, channels, h, w, table_cols, cols_per_sample, group,
+                     relu ? 1 : 0, cchunk);
+  return hf_launch_status();
+}
+
+// ACE.forward's tail (normalization.py:106-107, 164-178):
+//   n   = ((x + r[b,p] * noise_var[c]) - mean[c]) * rsqrt(var[c] + eps)            as n = (x + r*nv) * bn_scale + bn_shift
+//   g   = a_g * avg[b, c] + (1 - a_g) * sp[b / group, c],     a_g = sigmoid(blend[0])    (avg NULL: g = sp)
+//   bt  = a_b * avg[b, C + c] + (1 - a_b) * sp[b / group, C + c], a_b = sigmoid(blend[1])
+//   out = lrelu_slope( n * (1 + g) + bt )                                           (slope 1: no activation)
+// avg / sp: [*, 2C, H, W] (gamma planes first, then beta planes).
+__global__ __launch_bounds__(256) void ace_modulate(float *__restrict__ out, const float *__restrict__ x,
+                                                    const float *__restrict__ r, const float *__restrict__ noise_var,
+                                                    const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
+                                                    const float *__restrict__ avg, const float *__restrict__ sp,
+                                                    const float *__restrict__ blend, int C, int hw4, int group, float slope) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw4) return;
+  const long long plane = (long long)hw4;  // in float4 units
+  const float4 xv = reinterpret_cast<const float4 *>(x)[((long long)b * C + c) * plane + i];
+  float4 rv = make_float4(0, 0, 0, 0);
+  const float nv = noise_var ? noise_var[c] : 0.0f;
+  if (r) rv = reinterpret_cast<const float4 *>(r)[(long long)b * plane + i];
+  const float sc = bn_scale[c], sh = bn_shift[c];
+  const long long sb = (long long)(b / group) * 2 * C;
+  const float4 gs = reinterpret_cast<const float4 *>(sp)[(sb + c) * plane + i];
+  const float4 bs = reinterpret_cast<const float4 *>(sp)[(sb + C + c) * plane + i];
+  float4 g = gs, bt = bs;
+  if (avg) {
+    const float ag = 1.0f / (1.0f + expf(-blend[0])), ab = 1.0f / (1.0f + expf(-blend[1]));
+    const float4 ga = reinterpret_cast<const float4 *>(avg)[((long long)b * 2 * C + c) * plane + i];
+    const float4 ba = reinterpret_cast<const float4 *>(avg)[((long long)b * 2 * C + C + c) * plane + i];
+    g = make_float4(ag * ga.x + (1.0f - ag) * gs.x, ag * ga.y + (1.0f - ag) * gs.y, ag * ga.z + (1.0f - ag) * gs.z,
+                    ag * ga.w + (1.0f - ag) * gs.w);
+    bt = make_float4(ab * ba.x + (1.0f - ab) * bs.x, ab * ba.y + (1.0f - ab) * bs.y, ab * ba.z + (1.0f - ab) * bs.z,
+                     ab * ba.w + (1.0f - ab) * bs.w);
+  }
+  float4 o;
+  o.x = ((xv.x + rv.x * nv) * sc + sh) * (1.0f + g.x) + bt.x;
+  o.y = ((xv.y + rv.y * nv) * sc + sh) * (1.0f + g.y) + bt.y;
+  o.z = ((xv.z + rv.z * nv) * sc + sh) * (1.0f + g.z) + bt.z;
+  o.w = ((xv.w + rv.w * nv) * sc + sh) * (1.0f + g.w) + bt.w;
+  o.x = o.x > 0.0f ? o.x : o.x * slope;
+  o.y = o.y > 0.0f ? o.y : o.y * slope;
+  o.z = o.z > 0.0f ? o.z : o.z * slope;
+  o.w = o.w > 0.0f ? o.w : o.w * slope;
+  reinterpret_cast<float4 *>(out)[((long long)b * C + c) * plane + i] = o;
+}
+
+extern "C" int hf_ace_modulate_f32(float *out, const float *x, const float *noise, const float *noise_var,
+                                   const float *bn_scale, const float *bn_shift, const float *avg, const float *sp,
+                                   const float *blend, int batch, int channels, int hw, int group, float slope, void *stream) {
+  if (!out || !x || !bn_scale || !bn_shift || !sp || batch <= 0 || channels <= 0 || hw <= 0 || (hw & 3) || group <= 0 ||
+      (avg && !blend) || batch > 65535 || channels > 65535)
+    return HF_E_INVALID;
+  hipLaunchKernelGGL(ace_modulate, dim3(hf_cdiv(hw / 4, 256), channels, batch), dim3(256), 0, (hipStream_t)stream, out, x, noise,
+                     noise_var, bn_scale, bn_shift, avg, sp, blend, channels, hw / 4, group, slope);
+  return hf_launch_status();
+}
+
+// Zencoder's region pooling (architecture.py:187-205): out[b, l, c] = mean of act(x[b, c, p]) over the pixels p whose
+// label is l, 0 when the label does not occur.  One block per (c, b); every thread keeps the 19 partial sums of its
+// pixels in registers (compile-time label loop: no dynamic register indexing), waves reduce by shuffles, the four wave
+// results are added in wave order: deterministic.  x rows are `pitch` floats apart, planes `plane_stride` (a view into
+// a larger tensor: the conv output computed on the reflection-padded plane).  act: 0 none, 1 tanh.
+__global__ __launch_bounds__(256) void region_mean(float *__restrict__ out, const float *__restrict__ x,
+                                                   const int *__restrict__ labels, int C, int H, int W, long long batch_stride,
+                                                   long long plane_stride, int pitch, int act) {
+  HF_DYN_LDS;
+  float *red = reinterpret_cast<float *>(hf_dyn_lds);  // [4 waves][2 * kSeanLabels]
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float *xp = x + (long long)b * batch_stride + (long long)c * plane_stride;
+  const int *lb = labels + (long long)b * H * W;
+  float s[kSeanLabels], n[kSeanLabels];
+#pragma unroll
+  for (int l = 0; l < kSeanLabels; ++l) s[l] = n[l] = 0.0f;
+  for (int i = threadIdx.x; i < H * W; i += 256) {
+    const int yy = i / W, xx = i - yy * W;
+    float v = xp[(long long)yy * pitch + xx];
+    if (act == 1) v = tanhf(v);
+    const int lab = lb[i];
+#pragma unroll
+    for (int l = 0; l < kSeanLabels; ++l) {
+      s[l] += lab == l ? v : 0.0f;
+      n[l] += lab == l ? 1.0f : 0.0f;
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int l = 0; l < kSeanLabels; ++l) {
+    const float sv = hf_wave_sum(s[l]), nv = hf_wave_sum(n[l]);
+    if (lane == 0) {
+      red[wave * 2 * kSeanLabels + l] = sv;
+      red[wave * 2 * kSeanLabels + kSeanLabels + l] = nv;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kSeanLabels) {
+    const int l = threadIdx.x, st = 2 * kSeanLabels;
+    const float tot = (red[l] + red[st + l]) + (red[2 * st + l] + red[3 * st + l]);
+    const float cnt = (red[kSeanLabels + l] + red[st + kSeanLabels + l]) + (red[2 * st + kSeanLabels + l] + red[3 * st + kSeanLabels + l]);
+    out[((long long)b * kSeanLabels + l) * C + c] = cnt > 0.0f ? tot / cnt : 0.0f;
+  }
+}
+
+extern "C" int hf_region_mean_f32(float *out, const float *x, const int *labels, int batch, int channels, int h, int w,
+                                  int n_labels, long long batch_stride, long long plane_stride, int pitch, int act, void *stream) {
+  if (!out || !x || !labels || batch <= 0 || channels <= 0 || h <= 0 || w <= 0 || n_labels != kSeanLabels || pitch < w ||
+      batch > 65535 || (act != 0 && act != 1))
+    return HF_E_INVALID;
+  hipLaunchKernelGGL(region_mean, dim3(channels, batch), dim3(256), 4 * 2 * kSeanLabels * sizeof(float), (hipStream_t)stream, out,
+                     x, labels, channels, h, w, batch_stride, plane_stride, pitch, act);
+  return hf_launch_status();
+}
+
+__global__ __launch_bounds__(256) void tanh_kernel(float *__restrict__ out, const float *__restrict__ x, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = tanhf(x[i]);
+}
+
+extern "C" int hf_tanh_f32(float *out, const float *x, long long n, void *stream) {
+  if (!out || !x || n <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(tanh_kernel, dim3(hf_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, x, n);
+  return hf_launch_status();
+}

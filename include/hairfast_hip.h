@@ -457,6 +457,46 @@ int hf_axpby_bcast_f32(float *out, const float *a, float alpha, const float *b, 
 /* out[i] = a[i] + b[i % b_period] */
 int hf_add_bcast_f32(float *out, const float *a, const float *b, long long n, long long b_period, void *stream);
 
+/* ===========================================================================
+ * SEAN inpainting stage: encode_sean / decode_sean of
+ * models/sean_codes/models/pix2pix_model.py:299-325 around SPADEGenerator (networks/generator.py:72-110),
+ * SPADEResnetBlock / Zencoder (networks/architecture.py) and ACE / SPADE (networks/normalization.py).  Its dense 3x3
+ * convolutions are hf_conv2d_f32 / hf_conv2d_f16_f32; the entry points below are the label-driven parts.  csrc/sean.hip.
+ * =========================================================================== */
+/* 3x3 convolution (zero pad 1) of an input that is constant per segmentation label, as a table lookup:
+ *   out[b,c,y,x] = act( bias[c] + sum_{ky,kx} table[((ky*3+kx)*channels + c) * table_cols
+ *                                                   + b*cols_per_sample + labels[b/group, y+ky-1, x+kx-1]] )
+ * table [9*channels][table_cols] holds W[c, :, ky, kx] . v_label for every label's input vector v_label:
+ *   - one-hot label maps (SPADE's mlp_shared, normalization.py:246-252; SPADEGenerator.fc, generator.py:75-76):
+ *     table = the conv weight itself re-laid out, cols_per_sample = 0;
+ *   - ACE's conv_gamma / conv_beta on `middle_avg` (normalization.py:117-162: relu(fc_mu_j(style code j)) broadcast
+ *     over region j): table = a [19*batch]-column GEMM of the weights with the per-sample region vectors,
+ *     cols_per_sample = 19.
+ * labels: int32 [batch/group, h, w] (group consecutive samples share a label map - the two decodes of a pair,
+ * models/Alignment.py:130-131); relu != 0 applies ReLU; bias may be NULL. */
+int hf_label_conv3x3_f32(float *out, const int *labels, const float *table, const float *bias, int batch, int channels,
+                         int h, int w, int table_cols, int cols_per_sample, int group, int relu, void *stream);
+/* The tail of ACE.forward (normalization.py:103-107, 164-185) in one pass:
+ *   n   = (x + noise[b,p] * noise_var[c]) * bn_scale[c] + bn_shift[c]      (the eval-mode SynchronizedBatchNorm2d as an
+ *                                                                           affine: hf_bn_fold_f32 with gamma 1, beta 0)
+ *   g   = sigmoid(blend[0]) * avg[b,c]   + (1 - sigmoid(blend[0])) * sp[b/group, c]
+ *   bt  = sigmoid(blend[1]) * avg[b,C+c] + (1 - sigmoid(blend[1])) * sp[b/group, C+c]     (avg NULL: g, bt = sp's)
+ *   out = LeakyReLU_slope( n * (1 + g) + bt )                                (slope 1 = none; SPADEResnetBlock.actvn)
+ * x, out [batch,channels,hw]; noise [batch,hw] or NULL (ACE draws randn(B,W,H,1) and transposes: the caller's layout
+ * choice); avg [batch,2*channels,hw], sp [batch/group,2*channels,hw]: gamma planes then beta planes; blend: DEVICE
+ * pointer to (blending_gamma, blending_beta); hw % 4 == 0. */
+int hf_ace_modulate_f32(float *out, const float *x, const float *noise, const float *noise_var, const float *bn_scale,
+                        const float *bn_shift, const float *avg, const float *sp, const float *blend, int batch,
+                        int channels, int hw, int group, float slope, void *stream);
+/* Zencoder's per-region average pooling (architecture.py:187-205): out[b,l,c] = mean over {p : labels[b,p] == l} of
+ * act(x[b,c,p]), 0 for labels that do not occur; act 1 = tanh (the encoder's last layer, :177), 0 = none.
+ * x is a strided view: sample stride batch_stride, plane stride plane_stride, row pitch `pitch` (floats).
+ * labels int32 [batch,h,w]; n_labels must be 19.  out [batch,19,channels]. */
+int hf_region_mean_f32(float *out, const float *x, const int *labels, int batch, int channels, int h, int w, int n_labels,
+                       long long batch_stride, long long plane_stride, int pitch, int act, void *stream);
+/* out = tanh(x), n elements (SPADEGenerator.forward's last line, generator.py:109). */
+int hf_tanh_f32(float *out, const float *x, long long n, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Tuning / debugging hook (no reference counterpart): force the tile
  * configuration hf_modconv3x3_f32 / hf_modconv3x3_up_f32 dispatch to

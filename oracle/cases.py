@@ -296,3 +296,67 @@ def bisenet_params():
         k = f"{name}.conv_out.weight"
         P[k] = t(synth.pseudo_normal(f"bisenet/{k}", tuple(P[k].shape))) * 0.5
     return P
+
+
+# ------------------------------------------------------------------------------------
+# SEAN inpainting (oracle/ref_sean.py)
+# ------------------------------------------------------------------------------------
+def sean_params(cfg=None):
+    """Synthetic Pix2PixModel(SEAN_OPT) parameters: the closed-form fill with (i) spectral-norm triples whose u is one
+    power-iteration step from a random unit v, times a gain that keeps the activations O(1) through the seven blocks
+    (sigma = gain * |W v| > 0, computed in float64 so that every machine rounds to the same fp32 values; a random W has
+    |W v| ~ its spectral norm / (1 + sqrt(n/m)), which would amplify 3x per conv), (ii) fc_mu weights scaled by
+    1/sqrt(512), (iii) small ACE noise strengths, (iv) a conv_img gain that leaves the final tanh unsaturated."""
+    from . import ref_sean as SN
+
+    shapes = SN.sean_param_shapes(cfg=cfg or SN.DEFAULT)
+    P = {}
+    for k, shp in shapes.items():
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf == "weight_orig":
+            fan_in = shp[1] * shp[2] * shp[3]
+            P[k] = t(synth.unit_uniform(k, shp) * np.float32(0.7 / np.sqrt(fan_in)))
+        elif leaf == "weight_v":
+            v = synth.pseudo_normal(k, shp).astype(np.float64)
+            P[k] = t((v / np.linalg.norm(v)).astype(np.float32))
+        elif leaf == "weight_u":
+            continue  # below, from W and v
+        elif ".fc_mu" in k and leaf == "weight":
+            P[k] = t(synth.unit_uniform(k, shp) * np.float32(1.0 / np.sqrt(shp[1])))
+        elif leaf == "noise_var":
+            P[k] = t(np.float32(0.1) * synth.unit_uniform(k, shp))
+        elif leaf == "num_batches_tracked":
+            P[k] = torch.zeros((), dtype=torch.int64)
+        else:
+            P[k] = t(synth.fill_value(k, shp))
+    for k in shapes:
+        if k.endswith("weight_u"):
+            pre = k[:-len("weight_u")]
+            w = P[pre + "weight_orig"].numpy().astype(np.float64)
+            wv = w.reshape(w.shape[0], -1) @ P[pre + "weight_v"].numpy().astype(np.float64)
+            gain = 6.0 if ".conv_1." in k else (3.0 if ".conv_0." in k else 1.5)
+            P[k] = t((gain * wv / np.linalg.norm(wv)).astype(np.float32))
+    P["netG.conv_img.weight"] = P["netG.conv_img.weight"] * 0.5
+    return {k: P[k] for k in shapes}
+
+
+def sean_mean_codes():
+    """Stand-in for the per-label median style codes (models/sean_codes/styles_test/mean_style_code/median/*/ACE.npy)."""
+    return t(synth.pseudo_normal("sean/mean_codes", (19, 512))) * 0.5
+
+
+def sean_inputs():
+    """One pair as Alignment.align_images hands it to SEAN (Alignment.py:123-131): images [2,3,256,256] in [0,1], their label
+    maps long [2,1,256,256] (the second one lacks a few labels, so decode_sean's median-code rule is exercised), the
+    target label map [1,1,256,256], and the explicit ACE noise of the two decodes (18 draws [1,W,H,1] each)."""
+    from . import ref_sean as SN
+
+    images = t(synth.uniform01("sean/images", (2, 3, 256, 256)))
+    m1, m2 = shape_masks()
+    labels = torch.stack([m1[0], m2[0]])
+    labels[1][labels[1] == 2] = 1
+    labels[1][labels[1] == 18] = 0
+    target = m1[1:2].clone()
+    noise = [[t(synth.pseudo_normal(f"sean/noise/{d}/{i}", (1, r, r, 1))) for i, (_b, _a, _c, r) in enumerate(SN.ace_call_order())]
+             for d in range(2)]
+    return images, labels, target, noise

@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
     ap.add_argument("--only", default=None,
-                    help="comma list of sections to (re)generate (default all): basic,gen64,gen1024,enc_units,encoders,glue,pp,latent,shape,bisenet")
+                    help="comma list of sections to (re)generate (default all): basic,gen64,gen1024,enc_units,encoders,glue,pp,latent,shape,bisenet,sean")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -560,6 +560,78 @@ def main():
             g[f"margin_{tag}"] = (top2[0] - top2[1]).to(torch.float16).numpy()  # top-1 minus top-2 logit per pixel
         np.savez_compressed(os.path.join(args.out, "bisenet.npz"), **g)
         print("done bisenet", {k_: v_ for k_, v_ in report.items() if k_.startswith("bisenet")}, flush=True)
+
+    # ---------------- (viii) SEAN inpainting: encode_sean / decode_sean around the real SPADEGenerator (row f4) ----------
+    if not args.skip_big and want("sean"):
+        import copy as _copy
+
+        for m in ("cv2", "dill", "PIL", "PIL.Image"):  # imported by models/sean_codes/util/util.py, unused on this path
+            if m not in sys.modules:
+                try:
+                    __import__(m)
+                except Exception:
+                    sys.modules[m] = _types.ModuleType(m)
+        from models.sean_codes.models import pix2pix_model as ref_pm
+        from models.sean_codes.models.networks import normalization as ref_norm
+        from models.sean_codes.models.networks.generator import SPADEGenerator
+        from oracle import ref_sean as SN
+
+        opt = _copy.copy(ref_pm.SEAN_OPT)
+        opt.gpu_ids = []                                              # use_gpu() False: FloatTensor = torch.FloatTensor
+        model = ref_pm.Pix2PixModel.__new__(ref_pm.Pix2PixModel)      # the constructor reads checkpoint files
+        torch.nn.Module.__init__(model)
+        model.opt = opt
+        model.FloatTensor, model.ByteTensor = torch.FloatTensor, torch.ByteTensor
+        model.netG, model.netD, model.netE = SPADEGenerator(opt), None, None
+        model.eval()
+        shapes = {k_: tuple(v_.shape) for k_, v_ in model.state_dict().items()}
+        mine = SN.sean_param_shapes()
+        assert shapes == mine and list(shapes) == list(mine), "SEAN state-dict layout mismatch"
+        Ps = C.sean_params()
+        model.load_state_dict(Ps)
+        mean_codes = C.sean_mean_codes()
+        images, labels, target, noise = C.sean_inputs()
+
+        class _TorchWithNoise:  # ACE.forward draws torch.randn(..., device='cuda') (normalization.py:106): explicit draws
+            def __init__(self):
+                self.queue = []
+
+            def __getattr__(self, name):
+                return getattr(torch, name)
+
+            def randn(self, *shape, device=None):
+                r = self.queue.pop(0)
+                assert tuple(r.shape) == tuple(shape), (tuple(r.shape), shape)
+                return r
+
+        shim = _TorchWithNoise()
+        ref_norm.torch = shim
+        ref_pm.load_average_feature = lambda: {str(i): {"ACE": mean_codes[i].clone()} for i in range(19)}
+        codes_ref = ref_pm.encode_sean(model, images.clone(), labels.clone())
+        codes_o = SN.encode_sean(Ps, images, labels)
+        report["sean/codes"] = maxdiff(codes_ref, codes_o)
+        g = {"codes": codes_ref.numpy()}
+        gens = []
+        for d in range(2):
+            shim.queue = [n.clone() for n in noise[d]]
+            gen_ref = ref_pm.decode_sean(model, codes_ref[d].unsqueeze(0), target.clone())   # [3,256,256]
+            assert not shim.queue
+            taps = {}
+            gen_o = SN.spade_generator(Ps, SN.one_hot(target), SN.merge_codes(codes_o[d:d + 1], mean_codes), noise[d], taps=taps)
+            report[f"sean/decode{d}"] = maxdiff(gen_ref, gen_o[0])
+            gens.append(gen_ref)
+            g[f"gen{d}_stats"] = stats(gen_ref)
+            g[f"gen{d}_samples"] = strided_samples(gen_ref, 2048)
+            g[f"gen{d}_crop"] = gen_ref[:, 96:160, 96:160].numpy().copy()
+            g[f"gen{d}_corner"] = gen_ref[:, :32, :32].numpy().copy()
+            for nm, v in taps.items():  # oracle-side taps (the oracle equals the reference on the outputs above)
+                g[f"gen{d}_tap_{nm}"] = np.concatenate([stats(v), strided_samples(v, 64).astype(np.float64)])
+        both = SN.sean_inpaint(Ps, images, labels, target, mean_codes, noise[0], noise[1])
+        report["sean/inpaint"] = max(maxdiff(both[0], gens[0]), maxdiff(both[1], gens[1]))
+        ref_norm.torch = torch
+        np.savez_compressed(os.path.join(args.out, "sean.npz"), **g)
+        print("done sean", {k_: v_ for k_, v_ in report.items() if k_.startswith("sean")},
+              {k_: g[k_] for k_ in g if k_.endswith("_stats")}, flush=True)
 
     worst = max(report.values())
     with open(rep_path, "w") as f:

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
                                     "hf_f16_overflow_count", "hf_conv2d_f16_workspace_floats",
                                     "hf_sample_layernorm_workspace_floats"} == declared
     bound = _lib.bind(lib)
-    assert bound.hf_abi_version() == 7
+    assert bound.hf_abi_version() == 8
     assert bound.hf_strerror(-1) == b"invalid argument"
 
 
