@@ -9,7 +9,7 @@
   callers do (noise=None, models/stylegan2/model.py:289-291).  value = images/s.
 --workload swap256 (BASELINE.json configs[3]): `--triples` (default 256) synthetic 1024^2 triples,
   block-partitioned over the ranks; every triple goes host uint8 -> H2D -> HairFast.swap (the complete
-  call schedule of hair_swap.py:38-61 with SyntheticStages standing in for the out-of-scope networks)
+  call schedule of hair_swap.py:38-61; every network runs natively, incl. SEAN and the CLIP ViT-B/32 image tower)
   -> uint8 -> chunked RCCL all-gather; wall clock from the first H2D to the completion of the last
   gather.  value = triples/s (strong scaling: total work fixed).  --steps / --warmup count triples
   per rank are ignored: the workload is the whole set; --warmup triples are run untimed first.
@@ -87,8 +87,8 @@ def build_generator(dev):
 
 
 def build_hairfast(sd, dev):
-    """HairFast(args) on synthetic weights with SyntheticStages for the out-of-scope networks."""
-    from hairfastgan_amd.hair_swap import HairFast, SyntheticStages, get_parser
+    """HairFast(args) on synthetic weights; no stand-in stages (the default `Stages` raise if anything were missing)."""
+    from hairfastgan_amd.hair_swap import HairFast, get_parser
     from oracle import cases as C
     from oracle import ref_encoders as E
     from oracle import ref_postprocess as PP
@@ -97,21 +97,21 @@ def build_hairfast(sd, dev):
     args.device = dev
     pp_shapes = PP.post_process_param_shapes()
     pp_shapes.pop("latent_avg")
-    # RotateModel, ClipBlendingModel, the CtrlHair shape adaptor and SEAN run natively; the CLIP
-    # image tower inside the blending model is a stand-in projection (the un-vendored `clip` package)
-    stand_in_clip = lambda x: x.flatten(1)[:, ::294][:, :512].contiguous() * 0.5  # noqa: E731  [B,3,224,224] -> [B,512]
-    return HairFast(args, stages=SyntheticStages(), generator_state={"g_ema": sd, "latent_avg": torch.zeros(512)},
+    # every network of a swap runs natively: RotateModel, ClipBlendingModel with its CLIP
+    # ViT-B/32 image tower, the CtrlHair shape adaptor, SEAN
+    return HairFast(args, generator_state={"g_ema": sd, "latent_avg": torch.zeros(512)},
                     e4e_state=synth_state("e4e", E.e4e_param_shapes()), fs_state=synth_state("fs", E.fs_param_shapes()),
                     pp_state=synth_state("pp", pp_shapes), bisenet_state=C.bisenet_params(),
                     rotate_state=synth_state("rotate", PP.rotate_param_shapes()),
-                    blend_state=synth_state("clipblend", PP.clip_blending_param_shapes()), clip_image_embed=stand_in_clip,
+                    blend_state=synth_state("clipblend", PP.clip_blending_param_shapes()), clip_state=C.clip_params(),
                     shape_state=C.shape_adaptor_params(), sean_state=C.sean_params(), sean_mean_codes=C.sean_mean_codes())
 
 
 def cpu_baseline(sd, budget_s=30.0):
-    """Oracle forward (generator 0->8, batch 1, explicit noise) timed on this host: with all cores
-    (only up to 64: very wide hosts oversubscribe ATen's grouped convs) and with 32 threads - the
-    faster is `value` - and with ONE thread (`per_core`, a single forward: ~10-20 s)."""
+    """Oracle forward (generator 0->8, batch 1, explicit noise) timed on this host with 32, 64, 128 and ALL
+    hardware threads (all host cores, stated; the fastest is `value`, every count tried is listed) and
+    with ONE thread (`per_core`, a single forward: ~10-20 s).  Bounded: thread counts are tried in ascending
+    order until the budget is spent."""
     from oracle import cases as C
     from oracle import ref_stylegan2 as O
 
@@ -119,8 +119,10 @@ def cpu_baseline(sd, budget_s=30.0):
     lat, nz, _ = C.generator_inputs(1024, 1, 0)
     tried = {}
     t_start = time.time()
-    counts = {min(ncpu, 32)} | ({ncpu} if ncpu <= 64 else set())
-    for threads in sorted(counts, reverse=True):
+    counts = {c for c in (32, 64, 128) if c <= ncpu} | {ncpu}
+    for threads in sorted(counts):
+        if tried and (time.time() - t_start) > budget_s:
+            break  # bounded sample: the remaining (larger) thread counts are listed as not tried
         torch.set_num_threads(threads)
         times = []
         with torch.inference_mode():
@@ -148,7 +150,8 @@ def cpu_baseline(sd, budget_s=30.0):
             "sample": f"oracle (CPU restatement, bit-identical to the reference's PyTorch CPU path) generator "
                       f"0->8, batch 1, explicit noise; median of {n} timed forwards after 1 warm-up, torch "
                       f"{torch.__version__}; thread counts tried: "
-                      + ", ".join(f"{k}T={v[0] * 1e3:.0f}ms" for k, v in sorted(tried.items()))}
+                      + ", ".join(f"{k}T={v[0] * 1e3:.0f}ms" for k, v in sorted(tried.items()))
+                      + "".join(f", {k}T=not tried (budget)" for k in sorted(counts) if k not in tried)}
 
 
 def pmc_profile(kernel):
@@ -247,6 +250,20 @@ def kernel_report(prof, elapsed, precision):
                            "avg_launch_ms": round(d[1] / d[2] * 1e3, 4), "launches": d[2],
                            "flops_per_launch_avg": d[0] / d[2], "peak_note": peak_note,
                            "mfma_busy_pmc": busy, "mfma_busy_pmc_source": f"{PMC_PROFILE} (tag {tag})" if busy is not None else None}
+    # every MFMA kernel family of the timed region against its own roof (progress on the non-dominant ones - the fused
+    # upsampling StyledConv, the 1024^2 layer, the 4^2-32^2 tower - shows here)
+    fam_roof = {}
+    for k, v in sorted(mfma.items(), key=lambda kv: -kv[1][1]):
+        if k.startswith("conv_mfma_h") or k.startswith("conv_enc_h") or k.startswith("gemm_h"):
+            terms = 3 if precision == "f16x3" else 1
+            pk = PEAK_F16_MFMA_TFLOPS / terms
+        else:
+            pk = PEAK_FP32_MFMA_TFLOPS
+        a = v[0] / v[1] / 1e12
+        fam_roof[k] = {"achieved": round(a, 2), "peak": round(pk, 1), "frac": round(a / pk, 4), "avg_launch_ms": round(v[1] / v[2] * 1e3, 4),
+                       "launches": v[2], "share_of_timed_region": round(v[1] / elapsed, 4)}
+    if fam_roof:
+        out["roofline_families"] = {"bound": "mfma", "unit": "TFLOP/s", "kernels": fam_roof}
     hbm = {k: v for k, v in agg.items() if v[3] > 0 and v[0] == 0}
     if hbm:
         dom = max(hbm, key=lambda k: hbm[k][1])
@@ -415,7 +432,7 @@ def main():
                               "workload": f"{args.triples} synthetic 1024^2 triples sharded over {world} GPU(s): host uint8 -> H2D -> "
                                           "HairFast.swap (e4e B=3, FS-encoder B=3, gen 3->3 B=3, gen 0->3 B=3, gen 0->8 B=2 [both "
                                           "Alignment rotations batched], e4e B=2, gen 0->3 B=2, gen 4->8 B=1, PostProcess encoder "
-                                          "[774 GFLOP], gen 5->8 B=1, BiSeNet parsing x5, RotateModel, ClipBlendingModel around a stand-in CLIP tower, CtrlHair shape adaptor; SEAN = SyntheticStages) -> uint8 -> "
+                                          "[774 GFLOP], gen 5->8 B=1, BiSeNet parsing x5, RotateModel, ClipBlendingModel incl. its CLIP ViT-B/32 image tower, CtrlHair shape adaptor, SEAN encode + 2 decodes - all native) -> uint8 -> "
                                           "chunked RCCL all-gather; wall from first H2D to last gather (BASELINE.json configs[3])",
                               "triples": args.triples, "triples_per_gpu": n_local, "parallelism": f"replica x{world}, block-partitioned triples",
                               "weights": "synthetic closed-form (oracle/synth.py)", "conv_precision": precision,
@@ -470,7 +487,7 @@ def main():
 
     # comparison runs (outside the timed region): the same forward with every conv on the exact-fp32
     # MFMA, and BASELINE.json configs[4] (fp16 operands, batch 16)
-    def alt_run(mode, batch):
+    def alt_run(mode, batch, events=None):
         prev = _runtime.set_conv_precision(mode)
         lat = torch.randn(batch, 18, 512, device=dev)
         try:
@@ -478,20 +495,26 @@ def main():
                 for _ in range(2):
                     g([lat], input_is_latent=True)
                 torch.cuda.synchronize()
+                _marshal.PROFILE = events
                 t1 = time.perf_counter()
                 for _ in range(args.steps):
                     g([lat], input_is_latent=True)
                 torch.cuda.synchronize()
                 return time.perf_counter() - t1
         finally:
+            _marshal.PROFILE = None
             _runtime.set_conv_precision(prev)
 
     exact_f32 = f16_mode = None
     if world == 1 and not args.no_exact_f32:
         if precision != "f32":
-            e32 = alt_run("f32", B)
+            ev32 = None if args.no_kernel_events else []
+            e32 = alt_run("f32", B, ev32)
             exact_f32 = {"value": round(B * args.steps / e32, 3), "unit": "images/s", "ms_per_step": round(e32 / args.steps * 1e3, 4),
-                         "note": "same forward, HAIRFAST_CONV_PRECISION=f32 (v_mfma_f32_32x32x2_f32 only)"}
+                         "note": "same forward, HAIRFAST_CONV_PRECISION=f32 (v_mfma_f32_32x32x2_f32 only): the fallback headline "
+                                 "should the fp16 split ever clamp on a trained checkpoint"}
+            if ev32:
+                exact_f32["roofline"] = kernel_report(ev32, e32, "f32").get("roofline")
         e16 = alt_run("f16", 16)
         f16_mode = {"value": round(16 * args.steps / e16, 3), "unit": "images/s", "ms_per_step": round(e16 / args.steps * 1e3, 4),
                     "batch": 16, "note": "BASELINE.json configs[4]: fp16 conv operands (HAIRFAST_CONV_PRECISION=f16; the hand-over "
@@ -542,8 +565,8 @@ def main():
                              "single_swap": {"ms_per_swap": round(ts / (n_single / world) * 1e3, 2), "triples": n_single,
                                              "note": "one HairFast.swap per triple (no batching across triples)"},
                              "workload": "python bench.py --workload swap256 on a bounded sample: host uint8 -> H2D -> HairFast.swap / "
-                                         "swap_batch (RotateModel, ClipBlendingModel around a stand-in CLIP tower, shape adaptor native; SyntheticStages "
-                                         "for SEAN) -> uint8 -> gather (BASELINE.json configs[3])"}
+                                         "swap_batch (every network native, no stand-ins: SEAN, CLIP ViT-B/32 tower, shape adaptor, RotateModel, "
+                                         "PostProcess, BiSeNet) -> uint8 -> gather; a BOUNDED SAMPLE of BASELINE.json configs[3] (synthetic weights)"}
         except Exception as e:
             pipeline_info = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -561,6 +584,9 @@ def main():
                        "weights": "synthetic closed-form (oracle/synth.py)", "conv_precision": precision},
             "algorithmic_tflops_whole_forward": round(value * GFLOP_PER_IMAGE / 1e3 / world, 2),
             "f16_split_clamped_elements": overflow,
+            "timing_note": ("every conv / streaming launch of the timed region is bracketed by a pair of HIP events (the per-kernel "
+                            "durations of `roofline`): the headline includes that overhead (about 0.3 ms per step; --no-kernel-events "
+                            "measures without it)") if prof else "no per-kernel events in the timed region",
         }
         if gather_note:
             out["config"]["gather"] = gather_note

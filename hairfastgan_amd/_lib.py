@@ -72,6 +72,9 @@ SIGNATURES = {
     "hf_ace_modulate_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _st],
     "hf_region_mean_f32": [_f, _f, _f, _i, _i, _i, _i, _i, _ll, _ll, _i, _i, _st],
     "hf_tanh_f32": [_f, _f, _ll, _st],
+    "hf_channel_layernorm_f32": [_f, _f, _f, _f, _i, _ll, _fl, _st],
+    "hf_mha_small_f32": [_f, _f, _i, _i, _i, _i, _st],
+    "hf_quick_gelu_f32": [_f, _f, _ll, _st],
     "hf_debug_set_dispatch": [_i, _i],
     "hf_debug_last_path": [],
     "hf_debug_set_persistent_blocks": [_i],

@@ -894,3 +894,35 @@ def tanh(lib, st, x):
     out = torch.empty_like(x)
     check(lib, lib.hf_tanh_f32(_p(out), _p(x), x.numel(), st), "hf_tanh_f32")
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# CLIP ViT image tower (csrc/vit.hip): feature-major activations [C, T]
+# ----------------------------------------------------------------------------------------
+def channel_layernorm(lib, st, x, gamma, beta, eps=1e-5):
+    """LayerNorm over the feature axis of x [C, ...tokens] or [1, C, ...tokens] (the NCHW view the 1x1-conv GEMMs use)."""
+    x = _c(x)
+    c = x.shape[1] if (x.ndim == 4 and x.shape[0] == 1) else x.shape[0]
+    out = torch.empty_like(x)
+    check(lib, lib.hf_channel_layernorm_f32(_p(out), _p(x), _p(_c(gamma)), _p(_c(beta)), c, x.numel() // c, float(eps), st),
+          "hf_channel_layernorm_f32")
+    return out
+
+
+def mha_small(lib, st, qkv, images, seq, heads):
+    """qkv [3E, images*seq] (or [1, 3E, images, seq]) feature-major -> attention output [E, images*seq] (same form)."""
+    qkv = _c(qkv)
+    lead = 1 if (qkv.ndim == 4 and qkv.shape[0] == 1) else 0
+    e = qkv.shape[lead] // 3
+    if qkv.numel() != 3 * e * images * seq:
+        raise ValueError("qkv must be [3E, images*seq]")
+    out = qkv.new_empty(tuple(qkv.shape[:lead]) + (e,) + tuple(qkv.shape[lead + 1:]))
+    check(lib, lib.hf_mha_small_f32(_p(out), _p(qkv), images, seq, heads, e // heads, st), "hf_mha_small_f32")
+    return out
+
+
+def quick_gelu(lib, st, x):
+    x = _c(x)
+    out = torch.empty_like(x)
+    check(lib, lib.hf_quick_gelu_f32(_p(out), _p(x), x.numel(), st), "hf_quick_gelu_f32")
+    return out

@@ -1,0 +1,123 @@
+// vit.hip - the small operators of the CLIP ViT-B/32 image tower (models/Encoders.py:75-90: `clip_model.encode_image`;
+// OpenAI CLIP clip/model.py VisionTransformer / ResidualAttentionBlock / QuickGELU / LayerNorm).  The linear layers are
+// the library's 1x1-conv GEMMs on FEATURE-MAJOR activations x[feature][token] (an NCHW tensor whose "pixels" are the
+// tokens); these kernels work on the same layout so that nothing is transposed between layers.
+#include "hf_common.h"
+
+// LayerNorm over the FEATURE axis of x [C][T] (per token t: mean / biased variance over c, eps inside the sqrt),
+// affine gamma / beta [C].  One block per 64 consecutive tokens: lane = token (coalesced rows), the four waves split
+// the features and meet in LDS in wave order (deterministic).  Two passes over x (L2-resident: C*64*4 bytes per block).
+__global__ __launch_bounds__(256) void channel_layernorm(float *__restrict__ out, const float *__restrict__ x,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         int C, long long T, float eps) {
+  HF_DYN_LDS;
+  float *red = reinterpret_cast<float *>(hf_dyn_lds);  // [2][4][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long t = (long long)blockIdx.x * 64 + lane;
+  const bool ok = t < T;
+  float s = 0.0f;
+  for (int c = wave; c < C; c += 4) s += ok ? x[(long long)c * T + t] : 0.0f;
+  red[wave * 64 + lane] = s;
+  __syncthreads();
+  const float mean = ((red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane])) / (float)C;
+  float v = 0.0f;
+  for (int c = wave; c < C; c += 4) {
+    const float d = ok ? x[(long long)c * T + t] - mean : 0.0f;
+    v = fmaf(d, d, v);
+  }
+  red[256 + wave * 64 + lane] = v;
+  __syncthreads();
+  const float inv = rsqrtf(((red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane])) / (float)C + eps);
+  if (!ok) return;
+  for (int c = wave; c < C; c += 4) {
+    const float y = (x[(long long)c * T + t] - mean) * inv;
+    out[(long long)c * T + t] = gamma ? fmaf(y, gamma[c], beta ? beta[c] : 0.0f) : y;
+  }
+}
+
+extern "C" int hf_channel_layernorm_f32(float *out, const float *x, const float *gamma, const float *beta, int channels,
+                                        long long tokens, float eps, void *stream) {
+  if (!out || !x || channels <= 0 || tokens <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(channel_layernorm, dim3(hf_cdiv(tokens, 64)), dim3(256), 2 * 4 * 64 * sizeof(float), (hipStream_t)stream, out,
+                     x, gamma, beta, channels, tokens, eps);
+  return hf_launch_status();
+}
+
+// Multi-head self-attention of short sequences (nn.MultiheadAttention of ResidualAttentionBlock, no mask):
+// qkv [3*E][T] feature-major (rows 0..E-1 = q, E..2E-1 = k, 2E..3E-1 = v; T = images * seq tokens, image-major),
+// out [E][T]:  out[h*D + d][b*seq + i] = sum_j softmax_j(q_i . k_j / sqrt(D)) v_j[d].
+// One block per (head, image); q, k, v of the head (feature-major, as they arrive: [D][sp]) and the TRANSPOSED score
+// matrix sT[j][i] live in LDS - every inner-loop access is then either consecutive across the lanes or a broadcast.
+// seq <= 64, D = 64: (3*64 + seq) * sp * 4 bytes <= 64 KiB.
+constexpr int kMhaMaxSeq = 64, kMhaDim = 64;
+__global__ __launch_bounds__(256) void mha_small(float *__restrict__ out, const float *__restrict__ qkv, int E, long long T,
+                                                 int seq, int sp, float scale) {
+  HF_DYN_LDS;
+  float *q = reinterpret_cast<float *>(hf_dyn_lds);       // [D][sp]
+  float *k = q + kMhaDim * sp;
+  float *v = k + kMhaDim * sp;
+  float *s = v + kMhaDim * sp;                             // [seq (j)][sp (i)]
+  const int head = blockIdx.x, img = blockIdx.y;
+  const long long t0 = (long long)img * seq;
+  for (int i = threadIdx.x; i < kMhaDim * seq; i += 256) {  // coalesced over tokens
+    const int d = i / seq, j = i - d * seq;
+    const long long row = (long long)head * kMhaDim + d;
+    q[d * sp + j] = qkv[row * T + t0 + j] * scale;
+    k[d * sp + j] = qkv[(row + E) * T + t0 + j];
+    v[d * sp + j] = qkv[(row + 2 * E) * T + t0 + j];
+  }
+  __syncthreads();
+  for (int ij = threadIdx.x; ij < seq * seq; ij += 256) {
+    const int i = ij / seq, j = ij - i * seq;
+    float acc = 0.0f;
+#pragma unroll 16
+    for (int d = 0; d < kMhaDim; ++d) acc = fmaf(q[d * sp + i], k[d * sp + j], acc);
+    s[j * sp + i] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < seq) {  // softmax of row i (seq <= 64 values: one thread per row)
+    const int i = threadIdx.x;
+    float m = s[i];
+    for (int j = 1; j < seq; ++j) m = fmaxf(m, s[j * sp + i]);
+    float z = 0.0f;
+    for (int j = 0; j < seq; ++j) {
+      const float e = expf(s[j * sp + i] - m);
+      s[j * sp + i] = e;
+      z += e;
+    }
+    const float inv = 1.0f / z;
+    for (int j = 0; j < seq; ++j) s[j * sp + i] *= inv;
+  }
+  __syncthreads();
+  for (int id = threadIdx.x; id < kMhaDim * seq; id += 256) {  // coalesced stores over tokens
+    const int d = id / seq, i = id - d * seq;
+    float acc = 0.0f;
+    for (int j = 0; j < seq; ++j) acc = fmaf(s[j * sp + i], v[d * sp + j], acc);
+    out[((long long)head * kMhaDim + d) * T + t0 + i] = acc;
+  }
+}
+
+extern "C" int hf_mha_small_f32(float *out, const float *qkv, int images, int seq, int heads, int head_dim, void *stream) {
+  if (!out || !qkv || images <= 0 || images > 65535 || seq <= 0 || seq > kMhaMaxSeq || heads <= 0 || head_dim != kMhaDim)
+    return HF_E_INVALID;
+  const int sp = (seq + 3) & ~3;
+  const size_t lds = (size_t)(3 * kMhaDim + seq) * sp * sizeof(float);
+  hipLaunchKernelGGL(mha_small, dim3(heads, images), dim3(256), lds, (hipStream_t)stream, out, qkv, heads * head_dim,
+                     (long long)images * seq, seq, sp, 1.0f / sqrtf((float)head_dim));
+  return hf_launch_status();
+}
+
+// QuickGELU (clip/model.py: x * sigmoid(1.702 x)), n elements
+__global__ __launch_bounds__(256) void quick_gelu(float *__restrict__ out, const float *__restrict__ x, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float v = x[i];
+    out[i] = v / (1.0f + expf(-1.702f * v));
+  }
+}
+
+extern "C" int hf_quick_gelu_f32(float *out, const float *x, long long n, void *stream) {
+  if (!out || !x || n <= 0) return HF_E_INVALID;
+  hipLaunchKernelGGL(quick_gelu, dim3(hf_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, x, n);
+  return hf_launch_status();
+}

@@ -180,9 +180,17 @@ class NativeLatentStages(Stages):
     model remains the caller's (`clip_image_embed`, the reference's `clip_model.encode_image`)."""
 
     def __init__(self, base, device, rotate_state=None, blend_state=None, clip_image_embed=None, shape_state=None,
-                 sean_state=None, sean_mean_codes=None):
+                 sean_state=None, sean_mean_codes=None, clip_state=None):
         self.base = base
-        self.rotate_model = self.blend_model = self.mask_generator = self.sean_model = None
+        self.rotate_model = self.blend_model = self.mask_generator = self.sean_model = self.clip_tower = None
+        if clip_state is not None:    # clip.load("ViT-B/32") (models/Encoders.py:79): the OpenAI model's state dict
+            from .clip_vit import ClipImageTower
+
+            self.clip_tower = ClipImageTower().eval()
+            self.clip_tower.load_clip_state_dict(clip_state)
+            self.clip_tower.to(device)
+            if clip_image_embed is None:
+                clip_image_embed = self.clip_tower.encode_image
         if sean_state is not None:    # pretrained_models/sean_checkpoints/CelebA-HQ_pretrained/latest_net_G.pth (Alignment.py:29-30)
             from .sean import SeanModel
 
@@ -530,6 +538,9 @@ class HairFast:
                       the CLIP ViT-B/32 image encoder callable: the blending stage runs natively around that callable
       shape_state     CtrlHair mask-generator state dict (pretrained_models/ShapeAdaptor/mask_generator.pth): the shape
                       adaptor runs natively (hairfastgan_amd.shape_adaptor)
+      clip_state      state dict of the OpenAI CLIP ViT-B/32 model (its `visual.*` entries; what clip.load("ViT-B/32") holds,
+                      models/Encoders.py:79): the image tower inside the blending model runs natively (hairfastgan_amd.clip_vit)
+                      instead of through `clip_image_embed`
       sean_state (+ sean_mean_codes)  SEAN generator state dict (pretrained_models/sean_checkpoints/CelebA-HQ_pretrained/
                       latest_net_G.pth) and the [19,512] per-label median style codes
                       (models/sean_codes/styles_test/mean_style_code/median/<label>/ACE.npy): SEAN inpainting runs natively
@@ -538,12 +549,13 @@ class HairFast:
 
     def __init__(self, args, *, stages=None, generator_state=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
                  fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None, bisenet_state=None, rotate_state=None,
-                 blend_state=None, clip_image_embed=None, shape_state=None, sean_state=None, sean_mean_codes=None):
+                 blend_state=None, clip_image_embed=None, shape_state=None, sean_state=None, sean_mean_codes=None,
+                 clip_state=None):
         self.args = args
         self.stages = stages or Stages()
         if any(s_ is not None for s_ in (rotate_state, blend_state, shape_state, sean_state)):
             self.stages = NativeLatentStages(self.stages, args.device, rotate_state, blend_state, clip_image_embed, shape_state,
-                                             sean_state, sean_mean_codes)
+                                             sean_state, sean_mean_codes, clip_state)
         self.net = Net(args, state=generator_state)
         self.parsing = BiSeNet(19).eval()  # pretrained_models/BiSeNet/face_parsing_79999_iter.pth (my_parsing_util.py:77-79)
         if bisenet_state is not None:

@@ -226,6 +226,8 @@ class SPADEGenerator(FrozenPlanMixin, nn.Module):  # generator.py:14-110, num_up
             setattr(self, name, SPADEResnetBlock(fin, fout, rgb, style, hidden))
         self.conv_img = nn.Conv2d(ngf, 3, 3, padding=1)
         self._plan = None
+        # tests: callable(d, sizes) -> list of the 18 ACE noise tensors [d, r, r] instead of fresh torch.randn draws
+        self.noise_source = None
 
     def blocks(self):
         return [getattr(self, name) for name, *_ in self.BLOCKS]
@@ -267,6 +269,12 @@ class SPADEGenerator(FrozenPlanMixin, nn.Module):  # generator.py:14-110, num_up
         mu = M.conv2d(L, st, xg, p["mu_w"], 1, 1, bias=p["mu_b"], act=M.ACT_LRELU, alpha=0.0, groups=n_st * N_LABELS, x_shared=False)
         mu = mu.reshape(n_st, N_LABELS, d, STYLE_LEN).permute(0, 3, 2, 1).contiguous()            # [15, 512, D, 19]
         aces = [a for blk in self.blocks() for a in blk.aces()]
+        if noise is None and self.noise_source is not None:
+            res_, sizes_ = S // 32, []
+            for i, blk in enumerate(self.blocks()):
+                res_ = res_ * 2 if i in self.UP_BEFORE else res_
+                sizes_ += [res_] * len(blk.aces())
+            noise = self.noise_source(d, sizes_)
         if noise is None:
             sizes = []
             res = S // 32

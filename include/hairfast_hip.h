@@ -497,6 +497,25 @@ int hf_region_mean_f32(float *out, const float *x, const int *labels, int batch,
 /* out = tanh(x), n elements (SPADEGenerator.forward's last line, generator.py:109). */
 int hf_tanh_f32(float *out, const float *x, long long n, void *stream);
 
+/* ===========================================================================
+ * CLIP ViT-B/32 image tower: `self.clip_model.encode_image(...)` of ClipBlendingModel
+ * (models/Encoders.py:75-90; the un-vendored dependency `clip @ git+https://github.com/openai/CLIP@a1d0717`,
+ * requirements.txt:6 - clip/model.py VisionTransformer, ResidualAttentionBlock, QuickGELU, LayerNorm).  The linear
+ * layers run as 1x1-conv GEMMs (hf_conv2d_f32, k = 1) on FEATURE-MAJOR activations x[feature][token]; the entry
+ * points below are the operators between them, on the same layout.  csrc/vit.hip.
+ * =========================================================================== */
+/* LayerNorm over the feature axis of x [channels][tokens] (per token: biased variance, eps inside the sqrt), affine
+ * gamma / beta [channels] (both may be NULL).  clip/model.py LayerNorm (an nn.LayerNorm evaluated in fp32). */
+int hf_channel_layernorm_f32(float *out, const float *x, const float *gamma, const float *beta, int channels,
+                             long long tokens, float eps, void *stream);
+/* Self-attention core of nn.MultiheadAttention (ResidualAttentionBlock.attention, no mask) for short sequences:
+ * qkv [3*E][T] = the in_proj output, feature-major (rows 0..E-1 q, E..2E-1 k, 2E..3E-1 v), E = heads*head_dim,
+ * T = images*seq (image-major); out [E][T]: per (image, head) softmax(q k^T / sqrt(head_dim)) v, heads concatenated
+ * along the feature axis (the input of out_proj).  seq <= 64, head_dim == 64. */
+int hf_mha_small_f32(float *out, const float *qkv, int images, int seq, int heads, int head_dim, void *stream);
+/* QuickGELU: out = x * sigmoid(1.702 x) (clip/model.py QuickGELU), n elements. */
+int hf_quick_gelu_f32(float *out, const float *x, long long n, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Tuning / debugging hook (no reference counterpart): force the tile
  * configuration hf_modconv3x3_f32 / hf_modconv3x3_up_f32 dispatch to

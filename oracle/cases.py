@@ -360,3 +360,56 @@ def sean_inputs():
     noise = [[t(synth.pseudo_normal(f"sean/noise/{d}/{i}", (1, r, r, 1))) for i, (_b, _a, _c, r) in enumerate(SN.ace_call_order())]
              for d in range(2)]
     return images, labels, target, noise
+
+
+# ------------------------------------------------------------------------------------
+# CLIP ViT image tower (oracle/ref_clip.py)
+# ------------------------------------------------------------------------------------
+def clip_params(tag="clip", **sizes):
+    """Synthetic `visual.*` parameters of the CLIP image tower: matrices scaled by 1/sqrt(fan_in), LayerNorm gains in
+    [0.5, 1.5], small biases / embeddings."""
+    from . import ref_clip as RC
+
+    P = {}
+    for k, shp in RC.clip_visual_param_shapes(**sizes).items():
+        leaf = k.rsplit(".", 1)[-1]
+        if len(shp) == 2 and leaf != "positional_embedding":
+            P[k] = t(synth.unit_uniform(f"{tag}.{k}", shp)) * (1.0 / shp[-1 if leaf != "proj" else 0] ** 0.5)
+        elif len(shp) == 4:
+            P[k] = t(synth.unit_uniform(f"{tag}.{k}", shp)) * (1.0 / (shp[1] * shp[2] * shp[3]) ** 0.5)
+        elif "ln_" in k and leaf == "weight":
+            P[k] = 0.5 + t(synth.uniform01(f"{tag}.{k}", shp))
+        else:
+            P[k] = t(synth.unit_uniform(f"{tag}.{k}", shp)) * 0.2
+    return P
+
+
+# ------------------------------------------------------------------------------------
+# one complete swap (oracle/make_pipeline_golden.py, tests/test_gpu_pipeline.py)
+# ------------------------------------------------------------------------------------
+def pipeline_images():
+    """face / shape / color: three uint8 [3,1024,1024] images - smooth patterns plus noise (so that the synthetic BiSeNet
+    yields maps with regions; after ImageNet normalisation the pattern has the amplitude of bisenet_input)."""
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 1024), torch.linspace(-1, 1, 1024), indexing="ij")
+    out = []
+    for k, (a, b, c) in enumerate(((3.0, 1.0, 2.0), (2.5, -1.5, 3.0), (3.5, 0.5, -2.5))):
+        base = torch.stack([torch.sin(a * xx + b * yy), torch.cos(c * yy - b * xx), torch.sin(a * xx * yy + c)])
+        img = 0.5 + 0.33 * base + 0.07 * t(synth.pseudo_normal(f"pipeline/img/{k}", (3, 1024, 1024)))
+        out.append((img.clamp(0, 1) * 255).round().to(torch.uint8))
+    return tuple(out)
+
+
+def pipeline_sean_noise(k, r):
+    """The k-th ACE noise draw of the swap's SEAN decodes (decode = k // 18, ACE = k % 18), natural [1, H, W] order."""
+    return t(synth.pseudo_normal(f"pipeline/sean_noise/{k}", (1, r, r)))
+
+
+def pipeline_bisenet_params():
+    """bisenet_params() with the class-score rows of 'nose' (BiSeNet class 10) and 'hair' (17) exchanged: the synthetic
+    network then labels about a third of every image as hair (CelebA index 13), so that the swap's hair-mask algebra,
+    mixing and F-space alignment are exercised (with the plain synthetic parameters no pixel is hair)."""
+    P = dict(bisenet_params())
+    w = P["conv_out.conv_out.weight"].clone()
+    w[[10, 17]] = w[[17, 10]]
+    P["conv_out.conv_out.weight"] = w
+    return P

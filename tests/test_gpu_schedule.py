@@ -84,7 +84,7 @@ def _hairfast(dev):
                     pp_state=C.params_from_shapes("pp", pp_shapes), bisenet_state=C.bisenet_params(),
                     rotate_state=C.params_from_shapes("rotate", PP.rotate_param_shapes()),
                     blend_state=C.params_from_shapes("clipblend", PP.clip_blending_param_shapes()),
-                    clip_image_embed=C.fake_clip_embed, shape_state=C.shape_adaptor_params(),
+                    clip_state=C.clip_params(), shape_state=C.shape_adaptor_params(),
                     sean_state=C.sean_params(), sean_mean_codes=C.sean_mean_codes())
 
 

@@ -1,0 +1,149 @@
+"""CPU tests of the CLIP ViT image tower (parity UNPINNED against the reference - the `clip`
+package is an un-vendored dependency): the oracle restatement against an assembly of torch's own nn.MultiheadAttention /
+nn.LayerNorm / nn.Conv2d modules in the published ViT arrangement, the product's state-dict layout, and - kernel sources
+interpreted by tests/hipsim - the HIP-path tower on a scaled-down configuration against the oracle."""
+import sys
+
+import pytest
+import torch
+from torch import nn
+
+from hairfastgan_amd import _marshal as M
+from oracle import cases as C
+from oracle import ref_clip as RC
+from oracle import synth
+
+SMALL = dict(width=128, layers=2, patch=16, res=64, out_dim=32)
+
+
+def _params(shapes, tag):
+    P = C.clip_params(tag, **SMALL)
+    assert {k: tuple(v.shape) for k, v in P.items()} == shapes
+    return P
+
+
+class _TorchViT(nn.Module):
+    """The published VisionTransformer assembled from torch's own modules (what clip/model.py does)."""
+
+    def __init__(self, width, layers, heads, patch, res, out_dim):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, width, patch, patch, bias=False)
+        self.class_embedding = nn.Parameter(torch.zeros(width))
+        self.positional_embedding = nn.Parameter(torch.zeros((res // patch) ** 2 + 1, width))
+        self.ln_pre, self.ln_post = nn.LayerNorm(width), nn.LayerNorm(width)
+        self.blocks = nn.ModuleList()
+        for _ in range(layers):
+            b = nn.Module()
+            b.attn, b.ln_1, b.ln_2 = nn.MultiheadAttention(width, heads), nn.LayerNorm(width), nn.LayerNorm(width)
+            b.c_fc, b.c_proj = nn.Linear(width, 4 * width), nn.Linear(4 * width, width)
+            self.blocks.append(b)
+        self.proj = nn.Parameter(torch.zeros(width, out_dim))
+
+    def load(self, P):
+        g = lambda k: P["visual." + k]  # noqa: E731
+        with torch.no_grad():
+            self.conv1.weight.copy_(g("conv1.weight"))
+            self.class_embedding.copy_(g("class_embedding"))
+            self.positional_embedding.copy_(g("positional_embedding"))
+            self.proj.copy_(g("proj"))
+            for nm in ("ln_pre", "ln_post"):
+                getattr(self, nm).weight.copy_(g(f"{nm}.weight"))
+                getattr(self, nm).bias.copy_(g(f"{nm}.bias"))
+            for i, b in enumerate(self.blocks):
+                p = f"transformer.resblocks.{i}"
+                b.attn.in_proj_weight.copy_(g(f"{p}.attn.in_proj_weight"))
+                b.attn.in_proj_bias.copy_(g(f"{p}.attn.in_proj_bias"))
+                b.attn.out_proj.weight.copy_(g(f"{p}.attn.out_proj.weight"))
+                b.attn.out_proj.bias.copy_(g(f"{p}.attn.out_proj.bias"))
+                for nm in ("ln_1", "ln_2"):
+                    getattr(b, nm).weight.copy_(g(f"{p}.{nm}.weight"))
+                    getattr(b, nm).bias.copy_(g(f"{p}.{nm}.bias"))
+                b.c_fc.weight.copy_(g(f"{p}.mlp.c_fc.weight"))
+                b.c_fc.bias.copy_(g(f"{p}.mlp.c_fc.bias"))
+                b.c_proj.weight.copy_(g(f"{p}.mlp.c_proj.weight"))
+                b.c_proj.bias.copy_(g(f"{p}.mlp.c_proj.bias"))
+        return self.eval()
+
+    def forward(self, x):
+        x = self.conv1(x)
+        x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+        x = torch.cat([self.class_embedding + torch.zeros(x.shape[0], 1, x.shape[-1]), x], dim=1) + self.positional_embedding
+        x = self.ln_pre(x).permute(1, 0, 2)
+        for b in self.blocks:
+            h = b.ln_1(x)
+            x = x + b.attn(h, h, h, need_weights=False)[0]
+            h = b.c_fc(b.ln_2(x))
+            x = x + b.c_proj(h * torch.sigmoid(1.702 * h))
+        return self.ln_post(x.permute(1, 0, 2)[:, 0, :]) @ self.proj
+
+
+def test_oracle_equals_torch_module_assembly():
+    shapes = RC.clip_visual_param_shapes(**SMALL)
+    P = _params(shapes, "clip_small")
+    img = C.t(synth.pseudo_normal("clip_small/img", (3, 3, 64, 64)))
+    with torch.no_grad():
+        want = _TorchViT(128, 2, 2, 16, 64, 32).load(P)(img)
+        got = RC.encode_image(P, img, heads=2)
+    assert got.shape == (3, 32) and float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_state_dict_layout():
+    from hairfastgan_amd.clip_vit import ClipImageTower
+
+    with torch.device("meta"):
+        m = ClipImageTower()
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    want = RC.clip_visual_param_shapes()
+    assert mine == want and list(mine) == list(want)
+    assert sum(int(torch.tensor(v).prod()) for v in want.values()) == 87_849_216  # ViT-B/32 image tower
+
+
+def test_vit_operators(simlib):
+    torch.manual_seed(0)
+    x = torch.randn(24, 3, 50)  # [C, images, seq] feature-major
+    g, b = torch.rand(24) + 0.5, torch.randn(24)
+    want = torch.nn.functional.layer_norm(x.permute(1, 2, 0), (24,), g, b, 1e-5).permute(2, 0, 1)
+    assert float((M.channel_layernorm(simlib, None, x, g, b) - want).abs().max()) < 2e-6
+    qkv = torch.randn(3 * 128, 2 * 17)
+    mha = nn.MultiheadAttention(128, 2, bias=False)
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(torch.eye(128).repeat(3, 1))
+        mha.out_proj.weight.copy_(torch.eye(128))
+    got = M.mha_small(simlib, None, qkv, 2, 17, 2)
+    q, k, v = (t.reshape(128, 2, 17).permute(2, 1, 0) for t in qkv.chunk(3, 0))  # [L, B, E]
+    with torch.no_grad():
+        want = torch.nn.functional.multi_head_attention_forward(
+            q, k, v, 128, 2, None, None, None, None, False, 0.0, torch.eye(128), None, use_separate_proj_weight=True,
+            q_proj_weight=torch.eye(128), k_proj_weight=torch.eye(128), v_proj_weight=torch.eye(128), need_weights=False)[0]
+    assert float((got.reshape(128, 2, 17).permute(2, 1, 0) - want).abs().max()) < 2e-6
+    y = torch.randn(1000)
+    assert float((M.quick_gelu(simlib, None, y) - y * torch.sigmoid(1.702 * y)).abs().max()) < 1e-6
+
+
+@pytest.fixture()
+def sim_clip(simlib, monkeypatch):
+    import hairfastgan_amd.clip_vit  # noqa: F401
+
+    for n in ("hairfastgan_amd.clip_vit",):
+        mod = sys.modules[n]
+        monkeypatch.setattr(mod, "lib", lambda: simlib)
+        monkeypatch.setattr(mod, "stream", lambda: None)
+        monkeypatch.setattr(mod, "require_gpu", lambda *a: None)
+    return simlib
+
+
+def test_small_tower_vs_oracle(sim_clip):
+    from hairfastgan_amd.clip_vit import ClipImageTower
+
+    shapes = RC.clip_visual_param_shapes(**SMALL)
+    P = _params(shapes, "clip_small")
+    m = ClipImageTower(input_resolution=64, patch_size=16, width=128, layers=2, heads=2, output_dim=32).eval()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes
+    m.load_clip_state_dict({"clip_model." + k: v for k, v in P.items()} | {"clip_model.transformer.dummy": torch.zeros(1)})
+    img = C.t(synth.pseudo_normal("clip_small/img", (3, 3, 64, 64)))
+    taps, taps_o = {}, {}
+    got = m.encode_image(img) if False else m.visual(img, taps=taps)
+    want = RC.encode_image(P, img, heads=2, taps=taps_o)
+    for i in taps_o:  # oracle taps are [L, B, width]
+        assert float((taps[i][0].permute(2, 1, 0) - taps_o[i]).abs().max()) < 1e-4, i
+    assert got.shape == (3, 32) and float((got - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
