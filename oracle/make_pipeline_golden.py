@@ -238,9 +238,13 @@ def main():
     targets = []
     new_shape = ref_al.get_new_shape
 
+    margins = []
+
     def recorded_new_shape(gen_, face, hair):
         m = new_shape(gen_, face, hair)
         targets.append(m.clone())
+        top2 = gen_.forward_decode_by_code(hair, face)[0].log().topk(2, dim=0).values   # softmax output -> log-probabilities
+        margins.append((top2[0] - top2[1]).clone())                                     # = top-1 minus top-2 logit
         return m
 
     ref_al.get_new_shape = recorded_new_shape
@@ -326,6 +330,7 @@ def main():
     assert len(parses) == 5 and len(targets) == 2 and len(sean_out) == 2, (len(parses), len(targets), len(sean_out))
     g["rot_mask_shape"], g["rot_mask_color"] = parses[3][0, 0].to(torch.uint8).numpy(), parses[4][0, 0].to(torch.uint8).numpy()
     g["target_mask_shape"], g["target_mask_color"] = targets[0].to(torch.uint8).numpy(), targets[1].to(torch.uint8).numpy()
+    g["target_margin_shape"], g["target_margin_color"] = margins[0].to(torch.float16).numpy(), margins[1].to(torch.float16).numpy()
     g["HM_X_shape"] = np.packbits(align_shape["HM_X"][0, 0].numpy().astype(np.uint8))
     g["HM_X_color"] = np.packbits(align_color["HM_X"][0, 0].numpy().astype(np.uint8))
     for d in range(2):

@@ -141,36 +141,79 @@ def test_hairfast_swap_call_surface():
         hf.swap(face, shape, color, align=True)
 
 
+def _recorded(hf, fn):
+    """Run fn() with the intermediates of every stage recorded: embeddings, parses, shape-adaptor label maps, SEAN
+    renderings, align results, generator calls."""
+    import hairfastgan_amd.hair_swap as HS
+
+    rec = {"parses": [], "targets": [], "sean": [], "embed": None, "align": [], "calls": []}
+    seg, adaptor, sean = HS.get_segmentation, hf.stages.shape_adaptor, hf.stages.sean_inpaint_pairs
+    emb, alb, gen_fwd = hf.embed.embedding_images, hf.align.align_images_batch, hf.net.generator.forward
+
+    def spy(styles, **kw):
+        out = gen_fwd(styles, **kw)
+        rec["calls"].append({"sig": (styles[0].shape[0], kw.get("start_layer", 0), kw.get("end_layer", 8)), "latent": styles[0],
+                             "layer_in": kw.get("layer_in"), "out": out[0]})
+        return out
+
+    HS.get_segmentation = lambda net, x, **kw: (rec["parses"].append(seg(net, x, **kw)) or rec["parses"][-1])
+    hf.stages.shape_adaptor = lambda a, b: (rec["targets"].append(adaptor(a, b)) or rec["targets"][-1])
+    hf.stages.sean_inpaint_pairs = lambda *a: (rec["sean"].append(sean(*a)) or rec["sean"][-1])
+    hf.embed.embedding_images = lambda *a, **k: (rec.__setitem__("embed", emb(*a, **k)) or rec["embed"])
+    hf.align.align_images_batch = lambda *a, **k: (rec["align"].append(alb(*a, **k)) or rec["align"][-1])
+    hf.net.generator.forward = spy
+    try:
+        rec["result"] = fn()
+    finally:
+        HS.get_segmentation = seg
+        hf.stages.shape_adaptor, hf.stages.sean_inpaint_pairs = adaptor, sean
+        hf.embed.embedding_images, hf.align.align_images_batch, hf.net.generator.forward = emb, alb, gen_fwd
+    return rec
+
+
 def test_swap_batch_equals_single_swaps():
-    """HairFast.swap_batch: two triples as ONE batched pass (every hot-path call with the batch of both triples)
-    give the images of two separate swaps.  Noise strengths are zeroed (the batched and the single calls draw
-    different noise otherwise); what remains are summation-order differences of batch-dependent tile plans -
-    and, rarely, a parsing-mask index that flips on a near-tie of the synthetic BiSeNet."""
+    """HairFast.swap_batch: two triples as ONE batched pass (every hot-path call with the batch of both triples) against
+    two separate swaps, STAGE BY STAGE: latents and feature maps at the fp32 tolerance (what remains between the two forms
+    are summation-order differences of batch-dependent tile plans), every segmentation mask index equal (counted
+    separately; a near-tie flip would show here, not hide in an image-level bound), final images at 1e-4.  Noise strengths
+    are zeroed (the batched and the single calls draw different noise otherwise)."""
     dev = torch.device("cuda:0")
     hf = _hairfast(dev)
     with torch.no_grad():
         for name, p in hf.net.generator.named_parameters():
             if name.endswith("noise.weight"):
                 p.zero_()
+    hf.stages.sean_model.netG.noise_source = lambda d, sizes: [torch.zeros(d, r, r, device=dev) for r in sizes]
     g = torch.Generator().manual_seed(5)
     triples = [tuple(torch.randint(0, 256, (3, 1024, 1024), dtype=torch.uint8, generator=g).to(dev) for _ in range(3)) for _ in range(2)]
-    calls = []
-    gen_fwd = hf.net.generator.forward
+    both = _recorded(hf, lambda: hf.swap_batch(triples, seed=3))
+    assert [c["sig"] for c in both["calls"]] == [(6, 3, 3), (6, 0, 3), (4, 0, 8), (4, 0, 3), (2, 4, 8), (2, 5, 8)]
+    assert len(both["result"]) == 2
 
-    def spy(styles, **kw):
-        calls.append((styles[0].shape[0], kw.get("start_layer", 0), kw.get("end_layer", 8)))
-        return gen_fwd(styles, **kw)
+    def close(a, b, what, tol=1e-4):
+        err, scale = float((a - b).abs().max()), max(1.0, float(b.abs().max()))
+        assert err <= tol * scale, (what, err, scale)
 
-    hf.net.generator.forward = spy
-    both = hf.swap_batch(triples, seed=3)
-    hf.net.generator.forward = gen_fwd
-    assert calls == [(6, 3, 3), (6, 0, 3), (4, 0, 8), (4, 0, 3), (2, 4, 8), (2, 5, 8)], calls
-    assert len(both) == 2
+    flips = {}
     for t, triple in enumerate(triples):
-        one = hf.swap(*triple, seed=3)
-        assert both[t].shape == one.shape == (3, 1024, 1024)
-        diff = (both[t] - one).abs()
-        assert float((diff > 1e-2).float().mean()) < 1e-3, (t, float(diff.max()), float((diff > 1e-2).float().mean()))
+        one = _recorded(hf, lambda: hf.swap(*triple, seed=3))
+        for n in ("face", "shape", "color"):
+            eb, es = both["embed"][(t, n)], one["embed"][n]
+            for k in ("W", "S", "F"):
+                close(eb[k], es[k], f"triple {t} {n} {k}")
+            flips[f"{t}/mask_{n}"] = int((eb["mask"] != es["mask"]).sum())
+        flips[f"{t}/rot_masks"] = int((both["parses"][1][2 * t:2 * t + 2] != one["parses"][1]).sum())
+        flips[f"{t}/target_masks"] = int((both["targets"][0][2 * t:2 * t + 2] != one["targets"][0]).sum())
+        close(both["calls"][2]["latent"][2 * t:2 * t + 2], one["calls"][2]["latent"], f"triple {t} rotated latents")
+        close(both["sean"][0][2 * t:2 * t + 2], one["sean"][0], f"triple {t} SEAN renderings")
+        close(both["align"][0][t]["latent_F_align"], one["align"][0][0]["latent_F_align"], f"triple {t} latent_F_align")
+        assert torch.equal(both["align"][0][t]["HM_X"], one["align"][0][0]["HM_X"])
+        for ci, what in ((4, "S_blend / I_blend"), (5, "S_final / I_final")):
+            close(both["calls"][ci]["latent"][t:t + 1], one["calls"][ci]["latent"], f"triple {t} {what} latent")
+            close(both["calls"][ci]["layer_in"][t:t + 1], one["calls"][ci]["layer_in"], f"triple {t} {what} layer_in")
+        close(both["result"][t], one["result"], f"triple {t} final image")
+    print("swap_batch vs single swaps, mask index differences:", flips)
+    assert all(v == 0 for v in flips.values()), flips
     # a triple that repeats an image takes the single path (the reference's shortcuts), the other one the batched path
     mixed = hf.swap_batch([triples[0], (triples[1][0], triples[1][1], triples[1][1].clone())], seed=3)
     assert len(mixed) == 2 and all(torch.isfinite(m).all() for m in mixed)
