@@ -559,20 +559,56 @@ def conv2d_f16_supported(cin, cout, h, w, k, stride):
 
 
 def conv_split_weights_f16(lib, st, wt):
-    """Prepared conv weights [9,cin,cout] or [G,9,cin,cout] -> (hi, lo) fp16 blobs in the layout
-    hf_conv2d_f16_f32 takes: per group [9*cin*cout halves | 16-byte trailer] (hi) and 9*cin*cout halves (lo)."""
+    """Prepared conv weights [taps,cin,cout] or [G,taps,cin,cout] (taps 9 or 1) -> (hi, lo) fp16 blobs in the layout
+    hf_conv2d_f16_f32 / hf_conv1x1_f16_f32 take: per group [taps*cin*cout halves | 16-byte trailer] (hi) and
+    taps*cin*cout halves (lo)."""
     wt = _c(wt)
     w4 = wt if wt.ndim == 4 else wt.unsqueeze(0)
     g, taps, cin, cout = w4.shape
-    if taps != 9 or cin % 16:
-        raise ValueError(f"f16 MFMA path needs 3x3 weights with cin % 16 == 0; got {tuple(wt.shape)}")
-    n = 9 * cin * cout
+    if taps not in (9, 1) or cin % 16:
+        raise ValueError(f"f16 MFMA path needs 3x3 or 1x1 weights with cin % 16 == 0; got {tuple(wt.shape)}")
+    n = taps * cin * cout
     hi = torch.empty(g * (n + 8), dtype=torch.float16, device=wt.device)
     lo = torch.empty(g * n, dtype=torch.float16, device=wt.device)
     for i in range(g):
-        check(lib, lib.hf_conv_split_weights_f16(hi[i * (n + 8):].data_ptr(), lo[i * n:].data_ptr(), w4[i].data_ptr(), cin, cout, st),
-              "hf_conv_split_weights_f16")
+        check(lib, lib.hf_conv_split_weights_f16_taps(hi[i * (n + 8):].data_ptr(), lo[i * n:].data_ptr(), w4[i].data_ptr(), cin, cout,
+                                                     taps, st), "hf_conv_split_weights_f16_taps")
     return hi, lo
+
+
+def conv1x1_f16_supported(cin, cout):
+    """Shapes hf_conv1x1_f16_f32 takes (include/hairfast_hip.h)."""
+    return cin % 32 == 0 and cout % 64 == 0
+
+
+def conv1x1_f16(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None, in_shift=None, out_scale=None, bias=None,
+                act=ACT_NONE, slope=None, alpha=0.0, residual=None, groups=1, x_shared=True):
+    """hf_conv1x1_f16_f32: a 1x1 conv / Linear layer as a GEMM on the fp16 matrix cores; argument meaning as conv2d()."""
+    x = _c(x)
+    if groups > 1 and not x_shared:
+        g_, b, cin, h, w = x.shape
+        if g_ != groups:
+            raise ValueError("x must be [groups, B, cin, H, W]")
+        x_gstride = b * cin * h * w
+    else:
+        b, cin, h, w = x.shape
+        x_gstride = 0
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    out = x.new_empty((groups, b, cout, oh, ow) if groups > 1 else (b, cout, oh, ow))
+    if residual is not None:
+        residual = _c(residual)
+        if tuple(residual.shape) != tuple(out.shape):
+            raise ValueError(f"residual {tuple(residual.shape)} != output {tuple(out.shape)}")
+    n = lib.hf_conv1x1_f16_workspace_floats(b, cin, cout, h, w, stride, groups)
+    ws = x.new_empty((n,)) if n > 0 else None
+    code = _launch_profiled(
+        lib, 2.0 * cin * cout * oh * ow * b * groups,
+        lambda: lib.hf_conv1x1_f16_f32(_p(out), _p(x), _p(wt_hi), _p(wt_lo), nterms, _p(_c(in_scale)), _p(_c(in_shift)),
+                                       _p(_c(out_scale)), _p(_c(bias)), act, _p(_c(slope)), float(alpha), _p(residual), b, cin, cout,
+                                       h, w, stride, groups, x_gstride, _p(ws), max(n, 0), st),
+        label="gemm_h")
+    check(lib, code, "hf_conv1x1_f16_f32")
+    return out
 
 
 def split_activation_f16(lib, st, x, in_scale=None, in_shift=None, want_lo=True):

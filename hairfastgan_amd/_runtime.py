@@ -47,14 +47,49 @@ def stream():
 #   "f16"              plain fp16 operands (nterms 1): BASELINE.json configs[4]'s fp16 mode,
 #                      ~5e-4 relative error per product.
 # Layers whose shape the fp16 kernels do not take run the fp32 kernels in every mode.
-CONV_PRECISIONS = ("f16x3", "f32", "f16")
+#   "auto"             f16x3 with a safety net: the forward (Generator.forward, HairFast.swap / swap_batch) is followed by a
+#                      read of the library's clamp counter (hf_f16_overflow_count: elements the fp16 split had to
+#                      saturate, |s*x| > 131008 or NaN) and RE-RUN on the exact fp32 kernels when it is not zero.  Two
+#                      device synchronisations per guarded call; not usable inside a hipGraph capture (there it runs
+#                      unguarded f16x3).  For the first runs on a new checkpoint (tools/check_checkpoint.py).
+CONV_PRECISIONS = ("f16x3", "f32", "f16", "auto")
 _conv_precision = os.environ.get("HAIRFAST_CONV_PRECISION", "f16x3")
 if _conv_precision not in CONV_PRECISIONS:
     raise ValueError(f"HAIRFAST_CONV_PRECISION must be one of {CONV_PRECISIONS}, got {_conv_precision!r}")
+_auto_depth = 0        # > 0 inside a guarded call (nested guards do nothing)
+auto_reruns = 0        # how many guarded calls were repeated in f32 (diagnostics, tests)
 
 
 def conv_precision():
+    """The mode the kernels run in now: "auto" is f16x3 (or f32 during a re-run)."""
+    return "f16x3" if _conv_precision == "auto" else _conv_precision
+
+
+def configured_conv_precision():
     return _conv_precision
+
+
+def run_guarded(fn):
+    """Mode "auto": fn() on the f16x3 kernels; if the fp16 split clamped anything meanwhile, fn() again on the exact
+    fp32 kernels (fn must be repeatable: same inputs, explicit or re-seeded noise).  Any other mode: fn()."""
+    global _conv_precision, _auto_depth, auto_reruns
+    if _conv_precision != "auto" or _auto_depth > 0 or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        return fn()
+    L = lib()
+    _auto_depth += 1
+    try:
+        L.hf_f16_overflow_count(1)          # synchronises; clears the counter
+        out = fn()
+        if int(L.hf_f16_overflow_count(0)) > 0:
+            _conv_precision = "f32"
+            try:
+                out = fn()
+                auto_reruns += 1
+            finally:
+                _conv_precision = "auto"
+        return out
+    finally:
+        _auto_depth -= 1
 
 
 def set_conv_precision(mode):

@@ -10,8 +10,9 @@ against the reference (see oracle/ref_clip.py), tested against a torch restateme
 torch's nn.MultiheadAttention / nn.LayerNorm.
 
 Layout: activations are FEATURE-MAJOR, x[feature][token] with token = image * 50 + position - an NCHW tensor
-[1, C, images, 50] whose pixels are the tokens - so that every Linear is a 1x1-conv GEMM of the library's conv kernel
-(weights streamed once per call, bias / residual in its epilogue) and nothing is transposed between layers; LayerNorm,
+[1, C, images, 50] whose pixels are the tokens - so that every Linear is a 1x1-conv GEMM on the fp16 matrix cores
+(hf_conv1x1_f16_f32, csrc/gemm_h.hip, in the process-wide operand mode: f16x3 = fp32-class; weights streamed once per
+call, split-K when the token count is small, bias / residual in its epilogue) and nothing is transposed between layers; LayerNorm,
 the 12-head attention core and QuickGELU are kernels on the same layout (csrc/vit.hip).  The patch embedding (a
 32x32 / stride-32 convolution) is the same GEMM on unfolded patches.  fp32 tensors and accumulation (the reference runs
 this tower in fp16).
@@ -21,7 +22,7 @@ from torch import nn
 
 from . import _marshal as M
 from ._runtime import lib, require_gpu, stream
-from .encoders._fused import FrozenPlanMixin
+from .encoders._fused import FrozenPlanMixin, PreparedConv, conv
 
 
 class _Attention(nn.Module):  # nn.MultiheadAttention's parameter layout
@@ -49,17 +50,17 @@ class ResidualAttentionBlock(nn.Module):  # clip/model.py ResidualAttentionBlock
         """x [1, width, images, seq] feature-major."""
         L, st = lib(), stream()
         if self._plan is None:
-            prep = lambda w: M.conv_prepare(L, st, w.detach().reshape(w.shape[0], w.shape[1], 1, 1).contiguous())  # noqa: E731
+            prep = lambda w: PreparedConv(M.conv_prepare(L, st, w.detach().reshape(w.shape[0], w.shape[1], 1, 1).contiguous()), 1)  # noqa: E731
             self._plan = {"qkv": prep(self.attn.in_proj_weight), "out": prep(self.attn.out_proj.weight),
                           "fc": prep(self.mlp.c_fc.weight), "proj": prep(self.mlp.c_proj.weight)}
         p = self._plan
         h = M.channel_layernorm(L, st, x, self.ln_1.weight.detach(), self.ln_1.bias.detach(), self.ln_1.eps)
-        qkv = M.conv2d(L, st, h, p["qkv"], 1, 1, bias=self.attn.in_proj_bias.detach())
+        qkv = conv(h, p["qkv"], 1, 1, bias=self.attn.in_proj_bias.detach())
         a = M.mha_small(L, st, qkv, images, seq, self.heads)
-        x = M.conv2d(L, st, a, p["out"], 1, 1, bias=self.attn.out_proj.bias.detach(), residual=x)
+        x = conv(a, p["out"], 1, 1, bias=self.attn.out_proj.bias.detach(), residual=x)
         h = M.channel_layernorm(L, st, x, self.ln_2.weight.detach(), self.ln_2.bias.detach(), self.ln_2.eps)
-        h = M.quick_gelu(L, st, M.conv2d(L, st, h, p["fc"], 1, 1, bias=self.mlp.c_fc.bias.detach()))
-        return M.conv2d(L, st, h, p["proj"], 1, 1, bias=self.mlp.c_proj.bias.detach(), residual=x)
+        h = M.quick_gelu(L, st, conv(h, p["fc"], 1, 1, bias=self.mlp.c_fc.bias.detach()))
+        return conv(h, p["proj"], 1, 1, bias=self.mlp.c_proj.bias.detach(), residual=x)
 
 
 class _Transformer(nn.Module):
@@ -94,14 +95,14 @@ class VisionTransformer(FrozenPlanMixin, nn.Module):  # clip/model.py VisionTran
             raise ValueError(f"the tower takes {self.input_resolution}^2 images")
         if self._plan is None:
             w = self.conv1.weight.detach().reshape(wd, 3 * ps * ps, 1, 1).contiguous()
-            self._plan = {"embed": M.conv_prepare(L, st, w),
-                          "proj": M.conv_prepare(L, st, self.proj.detach().t().reshape(self.output_dim, wd, 1, 1).contiguous())}
+            self._plan = {"embed": PreparedConv(M.conv_prepare(L, st, w), 1),
+                          "proj": PreparedConv(M.conv_prepare(L, st, self.proj.detach().t().reshape(self.output_dim, wd, 1, 1).contiguous()), 1)}
         p = self._plan
         g = r // ps
         seq = g * g + 1
         # patches, feature-major: [1, 3*ps*ps, B, g*g] (glue: a re-layout of the input image)
         cols = image.float().reshape(b, 3, g, ps, g, ps).permute(1, 3, 5, 0, 2, 4).reshape(1, 3 * ps * ps, b, g * g).contiguous()
-        emb = M.conv2d(L, st, cols, p["embed"], 1, 1)                                    # [1, width, B, g*g]
+        emb = conv(cols, p["embed"], 1, 1)                                               # [1, width, B, g*g]
         x = emb.new_empty((1, wd, b, seq))
         x[0, :, :, 0] = self.class_embedding.detach()[:, None]
         x[0, :, :, 1:] = emb[0]
@@ -113,7 +114,7 @@ class VisionTransformer(FrozenPlanMixin, nn.Module):  # clip/model.py VisionTran
                 taps[i] = x
         cls = x[:, :, :, 0:1].contiguous()                                               # [1, width, B, 1]
         cls = M.channel_layernorm(L, st, cls, self.ln_post.weight.detach(), self.ln_post.bias.detach(), self.ln_post.eps)
-        out = M.conv2d(L, st, cls, p["proj"], 1, 1)                                      # [1, out_dim, B, 1]
+        out = conv(cls, p["proj"], 1, 1)                                                 # [1, out_dim, B, 1]
         return out[0, :, :, 0].t().contiguous()
 
 

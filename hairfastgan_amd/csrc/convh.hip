@@ -935,8 +935,8 @@ __device__ __forceinline__ int weight_prescale_log2(unsigned int absmax_bits) {
   return k > 120 ? 120 : (k < -120 ? -120 : k);
 }
 __global__ __launch_bounds__(256) void split_weights(_Float16 *__restrict__ wth, _Float16 *__restrict__ wtl,
-                                                     const float *__restrict__ wt, int cin, int cout) {
-  const long long n = 9LL * cin * cout;
+                                                     const float *__restrict__ wt, int cin, int cout, int taps) {
+  const long long n = (long long)taps * cin * cout;
   unsigned int *trailer = reinterpret_cast<unsigned int *>(wth + n);
   const int k = weight_prescale_log2(trailer[1]);
   const float up = __uint_as_float((unsigned int)(127 + k) << 23);
@@ -947,7 +947,7 @@ __global__ __launch_bounds__(256) void split_weights(_Float16 *__restrict__ wth,
     const int co = (int)(i % cout);
     const long long r = i / cout;
     const int ci = (int)(r % cin), tap = (int)(r / cin);
-    const long long dst = ((((long long)(ci / 16) * 9 + tap) * 2 + (ci % 16) / 8) * cout + co) * 8 + (ci % 8);
+    const long long dst = ((((long long)(ci / 16) * taps + tap) * 2 + (ci % 16) / 8) * cout + co) * 8 + (ci % 8);
     _Float16 h, l;
     hf_split_f16(wt[i] * up, h, l, ovf);
     wth[dst] = h;
@@ -1102,15 +1102,19 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
 }  // namespace hf_detail
 
 extern "C" int hf_conv_split_weights_f16(void *wt_hi, void *wt_lo, const float *wt, int cin, int cout, void *stream) {
-  if (!wt_hi || !wt || cin <= 0 || cout <= 0 || (cin % 16)) return HF_E_INVALID;
-  long long n = 9LL * cin * cout;
+  return hf_conv_split_weights_f16_taps(wt_hi, wt_lo, wt, cin, cout, 9, stream);
+}
+
+extern "C" int hf_conv_split_weights_f16_taps(void *wt_hi, void *wt_lo, const float *wt, int cin, int cout, int taps, void *stream) {
+  if (!wt_hi || !wt || cin <= 0 || cout <= 0 || (cin % 16) || (taps != 9 && taps != 1)) return HF_E_INVALID;
+  long long n = (long long)taps * cin * cout;
   long long g = (n + 255) / 256;
   if (g > 4096) g = 4096;
   unsigned int *trailer = reinterpret_cast<unsigned int *>(static_cast<_Float16 *>(wt_hi) + n);
   hipLaunchKernelGGL(split_weights_clear, dim3(1), dim3(64), 0, (hipStream_t)stream, trailer);
   hipLaunchKernelGGL(split_weights_absmax, dim3((int)(g > 512 ? 512 : g)), dim3(256), 0, (hipStream_t)stream, trailer, wt, n);
   hipLaunchKernelGGL(split_weights, dim3((int)g), dim3(256), 0, (hipStream_t)stream, static_cast<_Float16 *>(wt_hi),
-                     static_cast<_Float16 *>(wt_lo), wt, cin, cout);
+                     static_cast<_Float16 *>(wt_lo), wt, cin, cout, taps);
   return hf_launch_status();
 }
 

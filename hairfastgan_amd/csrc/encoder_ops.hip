@@ -15,6 +15,8 @@
 //   hf_downscale2x_f32           F.interpolate(scale_factor=0.5, 'bilinear') (trainer.py:61-64)
 //   hf_linear_f32                nn.Linear / EqualLinear heads (weight-bandwidth bound GEMV batch)
 //   hf_add_bcast_f32             w0 + delta_i, + latent_avg (psp_encoders.py:199, model_utils.py:9-13)
+#include <cstdint>
+
 #include "hf_common.h"
 
 namespace {
@@ -204,7 +206,8 @@ __global__ __launch_bounds__(256) void linear_kernel(float *__restrict__ out, co
   for (int r = 0; r < kLinRows; ++r)
 #pragma unroll
     for (int b = 0; b < kLinMaxBatch; ++b) acc[r][b] = 0.0f;
-  const bool vec = (in_f & 3) == 0 && (x_stride & 3) == 0;
+  const bool vec = (in_f & 3) == 0 && (x_stride & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0;
   if (vec) {
     for (int k = lane * 4; k < in_f; k += 256) {
       float4 xv[kLinMaxBatch];
@@ -631,7 +634,10 @@ extern "C" int hf_downscale2x_f32(float *out, const float *x, int planes, int h,
 
 static void launch_linear(float *out, const float *x, long long x_stride, const float *w, const float *bias, int batch, int in_f,
                           int out_f, float scale, float bias_scale, int act, float alpha, float act_scale, hipStream_t st) {
-  if (in_f >= 4096 && (in_f & 15) == 0 && (x_stride & 3) == 0)
+  // the K-split form issues 16-byte loads of x and w: base pointers must be 16-byte aligned too (a view with a storage
+  // offset - x[:, 1:] re-strided, a weight slice - takes the scalar-tolerant kernel below)
+  const bool aligned16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+  if (in_f >= 4096 && (in_f & 15) == 0 && (x_stride & 3) == 0 && aligned16)
     hipLaunchKernelGGL(linear_kernel_ksplit, dim3(hf_cdiv(out_f, kLinRows), hf_cdiv(batch, kLinMaxBatch)), dim3(256),
                        4 * kLinRows * kLinMaxBatch * sizeof(float), st, out, x, x_stride, w, bias, batch, in_f, out_f, scale,
                        bias_scale, act, alpha, act_scale);

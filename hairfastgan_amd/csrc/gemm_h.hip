@@ -1,0 +1,284 @@
+// gemm_h.hip - 1x1 convolutions / Linear layers as GEMMs on the fp16 matrix cores (v_mfma_f32_32x32x16_f16).
+//
+// Same arithmetic contract as hf_conv2d_f32 with k = 1 (csrc/modconv.hip):
+//   y[b,co,p] = act( out_scale[co] * sum_ci W[co,ci] * (in_scale[ci]*x[b,ci,p'] + in_shift[ci]) + bias[co] ) + residual
+// (p' = the stride-1 / stride-2 source pixel of output pixel p) in the operand modes of csrc/convh.hip: nterms 3 = fp32
+// operands split into fp16 (hi, lo) pairs, hi*hi + hi*lo + lo*hi in the fp32 accumulator (fp32-class accuracy), nterms 1
+// = operands rounded to fp16.  Reference operators: the 1x1 shortcut / downsample convolutions of the encoders
+// (models/encoder4editing/models/encoders/helpers.py:99-103, models/FeatureStyleEncoder/arcface/iresnet.py:17-19,
+// BiSeNet's 1x1 convs, model.py:13-29), SEAN's conv_s (networks/architecture.py:50, 88-92), and - on feature-major
+// activations x[feature][token], an NCHW tensor whose pixels are the tokens - every nn.Linear of the CLIP ViT-B/32 image
+// tower (clip/model.py: in_proj / out_proj / c_fc / c_proj / the patch embedding / proj) and SEAN's per-label table GEMM.
+//
+// Structure: one block = 64 output channels x PT = 64*PG pixels (of one image, or of 2^n whole small images), 4 waves =
+// 2 (channels) x 2 (pixels), each 1 x PG MFMA tiles; K loop in stages of 32 input channels, double-buffered in LDS:
+// weights by LDS-DMA from [cin/16][kgroup 2][cout][8 halves] hi (+ lo) (hf_conv_split_weights_f16 with taps = 1,
+// pre-scaled by 2^k, un-scaled in the epilogue), activations through registers (8 coalesced plane loads per
+// (pixel, 8-channel block) item, affine, saturating split, one 16-byte LDS write per part) loaded one stage ahead.
+// Small grids split K over blockIdx.z (deterministic second pass: splitk_reduce of modconv.hip).
+#define HF_WANT_F16_SPLIT
+#include "conv_common.h"
+
+using namespace hf_detail;
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr int KH = 16;   // input channels per MFMA k-step
+constexpr int KS = 32;   // input channels per LDS stage
+
+template <int NTERMS, int PG>
+__global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
+                                                 const _Float16 *__restrict__ wtl_all) {
+  constexpr int NT = 256, CT = 64, PT = 64 * PG;
+  constexpr int NPART = (NTERMS == 3) ? 2 : 1;
+  constexpr int W_UNITS = (KS / 8) * CT;        // 16-byte units of one weight part per stage: [chunk 2][kg 2][64 co]
+  constexpr int X_UNITS = (KS / 8) * PT;        // [kblock 4][PT pixels]
+  constexpr int BUF_UNITS = NPART * (W_UNITS + X_UNITS);
+  constexpr int OFF_WL = W_UNITS, OFF_XH = NPART * W_UNITS, OFF_XL = NPART * W_UNITS + X_UNITS;
+  constexpr int XE = X_UNITS / NT;              // staging items per thread and stage (PG)
+  constexpr int N_WPIECE = NPART * W_UNITS / 64;  // 1 KiB DMA pieces per stage (4 or 8)
+  constexpr int ND = N_WPIECE / 4;              // per wave
+
+  HF_DYN_LDS;
+  half8 *lds = reinterpret_cast<half8 *>(hf_dyn_lds);  // [2][BUF_UNITS]
+  const GroupOfs go = group_offsets(P);
+  const int grp = (P.groups > 1) ? (int)blockIdx.y / P.co_tiles : 0;
+  const long long wn = (long long)P.cin * P.cout;
+  const _Float16 *wth = wth_all + (long long)grp * (wn + 8);  // [weights | 16-byte trailer] per group
+  const _Float16 *wtl = wtl_all ? wtl_all + (long long)grp * wn : nullptr;
+  const float w_unscale = *reinterpret_cast<const float *>(wth + wn);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wave_co = (wave >> 1) * 32, wave_pg = (wave & 1) * PG;
+  const int co0 = go.co_tile * CT;
+
+  // ---- tile: PT flat OUTPUT pixels (the epilogue sees every image as a 1 x (oh*ow) plane) ----
+  const TileGeom G = P.g[0];
+  const int oplane = P.out_h * P.out_w;  // = G.dw
+  int t = blockIdx.x;
+  const int tx = t % G.tiles_x;
+  const int b0 = (t / G.tiles_x) << G.lg_nb;
+  const int tx0 = tx << G.lg_tw;
+  const long long iplane = (long long)P.h * P.w;
+  const float *xb = P.x + go.x;
+
+  // staging items (stage invariant): element offset of the source pixel inside image 0's channel 0 plane (+ image
+  // offset), -1 = outside (zero)
+  long long e_src[XE];
+#pragma unroll
+  for (int e = 0; e < XE; ++e) {
+    const int i = tid + e * NT;
+    const int px = i % PT;  // i / PT = kblock
+    const int pp = px & ((1 << G.lg_tw) - 1), im = px >> G.lg_tw;
+    const int p = tx0 + pp, b = b0 + im;
+    e_src[e] = -1;
+    if (p < oplane && b < P.batch) {
+      const int oy = p / P.out_wv, ox = p - oy * P.out_wv;  // out_wv: the true output width (out_w is the flat plane)
+      e_src[e] = (long long)b * P.cin * iplane + (long long)(oy * P.stride) * P.w + ox * P.stride;
+    }
+  }
+
+  const int nstages_all = P.cin / KS;
+  const int s_begin = (P.splits > 1) ? (int)blockIdx.z * P.chunks_per_split : 0;
+  const int s_end = (P.splits > 1) ? min(nstages_all, s_begin + P.chunks_per_split) : nstages_all;
+
+  const unsigned lds_addr0 = hf_lds_addr(lds);
+  auto dma_w = [&](int stage, int bufsel) {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      const int pc = wave + j * 4;  // piece: (part, chunk-in-stage, kg)
+      const int part = pc / (W_UNITS / 64), q = pc % (W_UNITS / 64);  // q = chunk*2 + kg
+      const _Float16 *src = (part ? wtl : wth) + ((long long)(stage * (KS / KH) * 2 + q) * P.cout + co0) * 8;
+      hf_glds16_raw_s(src, (unsigned)lane * 16u, lds_addr0 + (unsigned)(bufsel * BUF_UNITS + part * W_UNITS + q * 64) * 16u);
+    }
+  };
+  float xr[XE][8];
+  auto load_x = [&](int stage) {
+#pragma unroll
+    for (int e = 0; e < XE; ++e) {
+      const int kb = (tid + e * NT) / PT;
+      const float *src = xb + (e_src[e] >= 0 ? e_src[e] : 0) + (long long)(stage * KS + kb * 8) * iplane;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) xr[e][k] = src[(long long)k * iplane];
+    }
+  };
+  auto convert_x = [&](int stage, half8 *buf) {
+    bool ovf = false;
+#pragma unroll
+    for (int e = 0; e < XE; ++e) {
+      const int i = tid + e * NT;
+      const int kb = i / PT;
+      half8 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int ci = stage * KS + kb * 8 + k;
+        float v = xr[e][k];
+        if (P.s) v *= P.s[ci];
+        if (P.t) v += P.t[ci];
+        if (e_src[e] < 0) v = 0.0f;
+        _Float16 hv, lv;
+        hf_split_f16(v, hv, lv, ovf);
+        hi[k] = hv;
+        lo[k] = lv;
+      }
+      buf[OFF_XH + i] = hi;
+      if (NTERMS == 3) buf[OFF_XL + i] = lo;
+    }
+    hf_note_overflow(ovf);
+  };
+
+  f32x16 acc[1][1][PG];
+#pragma unroll
+  for (int g = 0; g < PG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][g][r] = 0.0f;
+
+  if (s_begin < s_end) {
+    dma_w(s_begin, 0);
+    load_x(s_begin);
+    convert_x(s_begin, lds);
+  }
+  hf_barrier_keep_young<0>();
+  for (int s = s_begin; s < s_end; ++s) {
+    const int cb = (s - s_begin) & 1;
+    half8 *buf = lds + cb * BUF_UNITS, *nbuf = lds + (cb ^ 1) * BUF_UNITS;
+    const bool more = s + 1 < s_end;
+    if (more) {
+      dma_w(s + 1, cb ^ 1);
+      load_x(s + 1);
+    }
+#pragma unroll
+    for (int cs = 0; cs < KS / KH; ++cs) {
+      const half8 ah = buf[(cs * 2 + lh) * CT + wave_co + li];
+      half8 al;
+      if (NTERMS == 3) al = buf[OFF_WL + (cs * 2 + lh) * CT + wave_co + li];
+#pragma unroll
+      for (int g = 0; g < PG; ++g) {
+        const int u = (cs * 2 + lh) * PT + (wave_pg + g) * 32 + li;
+        const half8 bh = buf[OFF_XH + u];
+        acc[0][0][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0][0][g], 0, 0, 0);
+        if (NTERMS == 3) {
+          const half8 bl = buf[OFF_XL + u];
+          acc[0][0][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[0][0][g], 0, 0, 0);
+          acc[0][0][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[0][0][g], 0, 0, 0);
+        }
+      }
+    }
+    if (more) convert_x(s + 1, nbuf);
+    hf_barrier_keep_young<0>();
+  }
+  // epilogue: the weights' power-of-two pre-scale comes out here (exact); split-K launches store raw sums * 2^-k
+#pragma unroll
+  for (int g = 0; g < PG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][g][r] *= w_unscale;
+  store_tile_rows<1, PG>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, 0, tx0, b0);
+}
+
+template <int NTERMS, int PG>
+int launch_gemm(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_t st) {
+  constexpr int PT = 64 * PG;
+  const int oplane = P.out_h * P.out_w;
+  TileGeom g{};
+  g.y0 = 0; g.x0 = 0; g.dh = 1; g.dw = oplane;
+  int tw = PT, nb = 1;
+  if (oplane < PT && (oplane & (oplane - 1)) == 0) {  // small power-of-two planes: several whole images per tile
+    tw = oplane;
+    nb = PT / oplane;
+    if (nb > pow2_ceil(P.batch)) nb = pow2_ceil(P.batch);
+  }
+  g.lg_tw = ilog2(tw); g.lg_th = 0; g.lg_nb = ilog2(nb);
+  g.tiles_x = hf_cdiv(oplane, tw); g.tiles_y = 1; g.tiles_b = hf_cdiv(P.batch, nb);
+  g.first_block = 0;
+  P.g[0] = g;
+  P.n_geom = 1;
+  const int nblocks = g.tiles_x * g.tiles_b;
+  constexpr int NPART = (NTERMS == 3) ? 2 : 1;
+  const size_t lds = (size_t)2 * NPART * ((KS / 8) * 64 + (KS / 8) * PT) * 16;
+  dim3 grid(nblocks, P.co_tiles * max(1, P.groups), P.splits);
+  if (grid.y > 65535 || grid.z > 65535) return HF_E_INVALID;
+  hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG>), grid, dim3(256), lds, st, P, wth, wtl);
+  return hf_launch_status();
+}
+
+}  // namespace
+
+// Scratch of hf_conv1x1_f16_f32 in floats (0 = none): small grids split K.
+static int gemm_splits(int batch, int cin, int cout, int oplane, int groups) {
+  const int pt = oplane * (long long)batch <= 128 || oplane <= 128 ? 128 : 256;
+  int tw = pt, nb = 1;
+  if (oplane < pt && (oplane & (oplane - 1)) == 0) {
+    tw = oplane;
+    nb = pt / oplane;
+    if (nb > pow2_ceil(batch)) nb = pow2_ceil(batch);
+  }
+  const long long blocks = (long long)hf_cdiv(oplane, tw) * hf_cdiv(batch, nb) * (cout / 64) * (groups > 1 ? groups : 1);
+  const int stages = cin / KS;
+  int sk = 1;
+  if (blocks < 256 && stages >= 4) {
+    sk = (int)((512 + blocks - 1) / blocks);     // ~2 blocks per CU
+    if (sk > stages / 2) sk = stages / 2;        // at least two stages per split (the pipeline's prologue)
+    if (sk < 1) sk = 1;
+  }
+  return sk;
+}
+
+extern "C" long long hf_conv1x1_f16_workspace_floats(int batch, int cin, int cout, int h, int w, int stride, int groups) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2) || (cin % KS) || (cout % 64)) return 0;
+  const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
+  const int sk = gemm_splits(batch, cin, cout, oh * ow, groups);
+  return sk > 1 ? (long long)sk * (groups > 1 ? groups : 1) * batch * cout * oh * ow : 0;
+}
+
+extern "C" int hf_conv1x1_f16_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
+                                  const float *in_scale, const float *in_shift, const float *out_scale, const float *bias,
+                                  int act, const float *slope, float alpha, const float *residual, int batch, int cin,
+                                  int cout, int h, int w, int stride, int groups, long long x_group_stride,
+                                  float *workspace, long long workspace_floats, void *stream) {
+  const int act_kind = act & ~HF_ACT_RESIDUAL_FIRST;
+  if (!out || !x || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (nterms != 1 && nterms != 3) ||
+      (nterms == 3 && !wt_lo) || (stride != 1 && stride != 2) || (cin % KS) || (cout % 64) || act_kind < 0 || act_kind > 2 ||
+      (act_kind == ACT_PRELU && !slope) || groups < 1 || (groups > 1 && (in_scale || in_shift)))
+    return HF_E_INVALID;
+  ConvParams P{};
+  P.out = out; P.x = x; P.s = in_scale; P.t = in_shift; P.d = out_scale; P.bias = bias; P.slope = slope;
+  P.residual = residual; P.residual_pre = (act & HF_ACT_RESIDUAL_FIRST) ? 1 : 0;
+  P.s_bstride = 0; P.d_bstride = 0;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w;
+  P.stride = stride;
+  const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
+  // the epilogue (store_tile_rows) addresses an image's output as a 1 x (oh*ow) plane: out_w is the flat plane size,
+  // the kernel recovers (oy, ox) with the true output width kept in out_wv
+  P.out_h = 1; P.out_w = oh * ow; P.out_wv = ow;
+  P.act = act_kind; P.alpha = alpha; P.scale = 1.0f;
+  P.groups = groups; P.co_tiles = cout / 64; P.x_gstride = x_group_stride; P.wt_gstride = 0;
+  if ((long long)batch * cin * h * w >= (1LL << 40)) return HF_E_INVALID;
+  const int oplane = oh * ow;
+  const int sk = gemm_splits(batch, cin, cout, oplane, groups);
+  P.splits = sk;
+  if (sk > 1) {
+    const long long slab = (long long)(groups > 1 ? groups : 1) * batch * cout * oplane;
+    if (!workspace || workspace_floats < sk * slab) return HF_E_WORKSPACE;
+    const int stages = cin / KS;
+    P.chunks_per_split = (stages + sk - 1) / sk;
+    P.splits = (stages + P.chunks_per_split - 1) / P.chunks_per_split;  // no empty split
+    P.partial = workspace;
+    P.zslab = slab;
+  }
+  const _Float16 *hi = static_cast<const _Float16 *>(wt_hi), *lo = static_cast<const _Float16 *>(wt_lo);
+  const bool small = (long long)oplane * batch <= 128 || oplane <= 128;
+  int rc;
+  if (small) rc = (nterms == 3) ? launch_gemm<3, 2>(P, hi, lo, (hipStream_t)stream) : launch_gemm<1, 2>(P, hi, lo, (hipStream_t)stream);
+  else rc = (nterms == 3) ? launch_gemm<3, 4>(P, hi, lo, (hipStream_t)stream) : launch_gemm<1, 4>(P, hi, lo, (hipStream_t)stream);
+  if (rc != HF_OK) return rc;
+  note_path(7, small ? 1 : 2);
+  if (P.splits > 1) {
+    P.out_h = 1; P.out_w = oplane;
+    return launch_splitk_reduce(P, true, (hipStream_t)stream);
+  }
+  return HF_OK;
+}
+
+extern "C" unsigned long long hf_f16_overflow_count_gemm(int reset) { return hf_f16_overflow_read_tu(reset); }

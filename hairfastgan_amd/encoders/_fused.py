@@ -66,6 +66,8 @@ def prep_conv(conv):
 # up to 88 (group, channel-tile) block columns; "all" = also every conv with >= 8 block columns per input tile
 # (512+ output channels: the deep encoder stages, PostProcess's 512-1024 channel trunk); "none".  Tuning knob.
 PRESPLIT = os.environ.get("HAIRFAST_ENC_PRESPLIT", "all")
+# 1x1 convolutions / Linear layers on the fp16 matrix cores (csrc/gemm_h.hip) instead of the fp32-MFMA general kernel
+USE_GEMM_H = os.environ.get("HAIRFAST_GEMM_H", "1") != "0"
 
 
 def conv(x, w, k, stride=1, presplit=False, **kw):
@@ -75,6 +77,9 @@ def conv(x, w, k, stride=1, presplit=False, **kw):
     presplit: this conv's input is shared by many block columns - convert it once (see PRESPLIT)."""
     mode = conv_precision()
     h, wd = x.shape[-2], x.shape[-1]
+    if mode != "f32" and k == 1 and USE_GEMM_H and M.conv1x1_f16_supported(w.cin, w.cout):
+        hi, lo = w.f16()
+        return M.conv1x1_f16(lib(), stream(), x, hi, lo, 3 if mode == "f16x3" else 1, w.cout, stride, **kw)
     if mode != "f32" and M.conv2d_f16_supported(w.cin, w.cout, h, wd, k, stride):
         hi, lo = w.f16()
         nterms = 3 if mode == "f16x3" else 1

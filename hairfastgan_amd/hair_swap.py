@@ -46,7 +46,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _marshal as M
-from ._runtime import lib, require_gpu, stream
+from ._runtime import lib, require_gpu, run_guarded, stream
 from .encoders import ClipBlendingModel, Encoder4Editing, FSEncoder, PostProcessModel, RotateModel, get_latents
 from .face_parsing import BiSeNet, get_segmentation
 from .net import Net
@@ -547,11 +547,31 @@ class HairFast:
                       (hairfastgan_amd.sean)
     """
 
+    @staticmethod
+    def _as_tensor(img, cache=None):
+        """torch.Tensor [3,H,W] (uint8 or float in [0,1]), numpy HWC uint8 array, or the path of a .npy array (image
+        decoding libraries are not part of this backend)."""
+        if isinstance(img, np.ndarray):
+            return torch.from_numpy(img).permute(2, 0, 1) if img.ndim == 3 and img.shape[-1] == 3 else torch.from_numpy(img)
+        if isinstance(img, (Path, str)):
+            cache = cache if cache is not None else {}
+            if img not in cache:
+                arr = np.load(str(img))
+                cache[img] = torch.from_numpy(arr).permute(2, 0, 1) if arr.shape[-1] == 3 else torch.from_numpy(arr)
+            return cache[img]
+        if not isinstance(img, torch.Tensor):
+            raise TypeError(f"Unsupported image format {type(img)}")
+        return img
+
     def __init__(self, args, *, stages=None, generator_state=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
                  fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None, bisenet_state=None, rotate_state=None,
                  blend_state=None, clip_image_embed=None, shape_state=None, sean_state=None, sean_mean_codes=None,
                  clip_state=None):
         self.args = args
+        if getattr(args, "save_all", False):
+            raise NotImplementedError(
+                "--save_all (intermediate images / latents written by the reference's utils/save_utils.py, Embedding.py:94-108, "
+                "Alignment.py:84-93, 159-179, Blending.py:70-78) is not implemented by this backend: nothing would be written")
         self.stages = stages or Stages()
         if any(s_ is not None for s_ in (rotate_state, blend_state, shape_state, sean_state)):
             self.stages = NativeLatentStages(self.stages, args.device, rotate_state, blend_state, clip_image_embed, shape_state,
@@ -601,19 +621,16 @@ class HairFast:
 
     def swap(self, face_img, shape_img, color_img, benchmark=False, align=False, seed=None, exp_name=None, **kwargs):
         """hair_swap.py:63-103.  Images: torch.Tensor [3,H,W] (uint8 or float in [0,1]), numpy HWC
-        uint8 arrays, or file paths of .npy arrays (image decoding libraries are not part of this backend)."""
-        images, cache = [], {}
-        for img in (face_img, shape_img, color_img):
-            if isinstance(img, np.ndarray):
-                img = torch.from_numpy(img).permute(2, 0, 1) if img.ndim == 3 and img.shape[-1] == 3 else torch.from_numpy(img)
-            elif isinstance(img, (Path, str)):
-                if img not in cache:
-                    arr = np.load(str(img))
-                    cache[img] = torch.from_numpy(arr).permute(2, 0, 1) if arr.shape[-1] == 3 else torch.from_numpy(arr)
-                img = cache[img]
-            elif not isinstance(img, torch.Tensor):
-                raise TypeError(f"Unsupported image format {type(img)}")
-            images.append(img)
+        uint8 arrays, or file paths of .npy arrays (image decoding libraries are not part of this backend).
+
+        Randomness: `seed` (default 3407, utils/seed.py:19) makes a swap reproducible on THIS backend; it does not
+        reproduce a seeded run of the reference sample for sample: the per-layer noise of a generator forward is one draw
+        here (17 in the reference), the FS encoder's discarded generator forward (trainer.py:295, which only advances the
+        RNG) is not run, SEAN's 18 ACE noise maps per decode are one draw, and hipRAND's Philox walk differs from cuRAND's
+        in any case.  Bit-level comparisons with the reference therefore inject the noise explicitly
+        (Generator.forward(noise= / randomize_noise=False), SPADEGenerator.noise_source; tests/test_gpu_pipeline.py)."""
+        cache = {}
+        images = [self._as_tensor(img, cache) for img in (face_img, shape_img, color_img)]
         if align:
             raise NotImplementedError("align=True needs the reference's dlib face aligner (utils/shape_predictor.py): out of scope")
         images = equal_replacer(images)
@@ -621,7 +638,13 @@ class HairFast:
         if benchmark:  # utils/time.py:15-37
             torch.cuda.current_stream().synchronize()
             t0 = time.time()
-        final_image = self._swap_from_tensors(*images, exp_name=exp_name, **kwargs)
+        seed_ = 3407 if seed is None else seed
+
+        def run():  # HAIRFAST_CONV_PRECISION=auto: the whole swap again on the fp32 kernels if the fp16 split clamped
+            set_seed(seed_)
+            return self._swap_from_tensors(*images, exp_name=exp_name, **kwargs)
+
+        final_image = run_guarded(run)
         if benchmark:
             torch.cuda.current_stream().synchronize()
             self._times.append(time.time() - t0)
@@ -636,27 +659,26 @@ class HairFast:
         "batched HairFast swap").  triples: sequence of (face, shape, color) with the image forms `swap` takes
         (tensors / arrays).  Returns a list of [3, size, size] images in [0, 1], one per triple, equal to what
         `swap` returns for each triple given the same per-layer noise."""
-        prepared = []
-        for triple in triples:
-            imgs = []
-            for img in triple:
-                if isinstance(img, np.ndarray):
-                    img = torch.from_numpy(img).permute(2, 0, 1) if img.ndim == 3 and img.shape[-1] == 3 else torch.from_numpy(img)
-                elif not isinstance(img, torch.Tensor):
-                    raise TypeError(f"Unsupported image format {type(img)}")
-                imgs.append(img)
-            prepared.append(tuple(equal_replacer(imgs)))
+        cache = {}
+        prepared = [tuple(equal_replacer([self._as_tensor(img, cache) for img in triple])) for triple in triples]
         set_seed(3407 if seed is None else seed)
         # a triple that repeats an image takes the reference's shortcuts (no mixing / no second Rotate): one by one
         plain = [t for t, tr in enumerate(prepared) if len({id(x) for x in tr}) == 3]
         out = [None] * len(prepared)
-        if plain:
-            for t, img in zip(plain, self._swap_batch_from_tensors([prepared[t] for t in plain], **kwargs)):
-                out[t] = img
-        for t, tr in enumerate(prepared):
-            if out[t] is None:
-                out[t] = self._swap_from_tensors(*tr, **kwargs)
-        return out
+        seed_ = 3407 if seed is None else seed
+
+        def run():
+            set_seed(seed_)
+            res = [None] * len(prepared)
+            if plain:
+                for t, img in zip(plain, self._swap_batch_from_tensors([prepared[t] for t in plain], **kwargs)):
+                    res[t] = img
+            for t, tr in enumerate(prepared):
+                if res[t] is None:
+                    res[t] = self._swap_from_tensors(*tr, **kwargs)
+            return res
+
+        return run_guarded(run)
 
 
 # ---------------------------------------------------------------------------------------------

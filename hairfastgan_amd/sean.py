@@ -101,7 +101,7 @@ class ACE(nn.Module):  # normalization.py:70-208
                 # the table GEMM: rows (tap, gamma|beta channel), K = 512 style features -> a 1x1 "conv" over 19*B pixels
                 w = torch.cat([self.conv_gamma.weight.detach(), self.conv_beta.weight.detach()], 0)      # [2C, 512, 3, 3]
                 w = w.permute(2, 3, 0, 1).reshape(9 * 2 * c, STYLE_LEN, 1, 1).contiguous()
-                p["w_table"] = M.conv_prepare(L, st, w)
+                p["w_table"] = PreparedConv(M.conv_prepare(L, st, w), 1)
                 p["b_avg"] = torch.cat([self.conv_gamma.bias.detach(), self.conv_beta.bias.detach()]).contiguous()
             self._plan = p
         return self._plan
@@ -123,7 +123,7 @@ class ACE(nn.Module):  # normalization.py:70-208
         sp = conv(actv, p["w_gb"], 3, 1, bias=p["b_gb"])                                              # [D/group,2C,H,W]
         avg = None
         if self.use_rgb:
-            table = M.conv2d(L, st, mu, p["w_table"], 1, 1)                                           # [1, 9*2C, D, 19]
+            table = conv(mu, p["w_table"], 1, 1)                                                      # [1, 9*2C, D, 19]
             avg = M.label_conv3x3(L, st, labels, table.reshape(9 * 2 * c, d * N_LABELS), p["b_avg"], 2 * c, batch=d,
                                   cols_per_sample=N_LABELS, group=group)
         return M.ace_modulate(L, st, x, noise, p["noise_var"], p["bn"][0], p["bn"][1], avg, sp, p["blend"] if avg is not None else None,
@@ -243,7 +243,7 @@ class SPADEGenerator(FrozenPlanMixin, nn.Module):  # generator.py:14-110, num_up
             ws, bs = zip(*[a.fc_mu_weights() for a in styled])
             self._plan = {
                 "t_fc": self.fc.weight.detach().permute(2, 3, 0, 1).reshape(9 * 16 * self.ngf, N_LABELS).contiguous(),
-                "mu_w": torch.cat(ws, 0).unsqueeze(1).contiguous(),   # [15*19, 1, 512, 512] grouped 1x1 conv weights
+                "mu_w": PreparedConv(torch.cat(ws, 0).unsqueeze(1).contiguous(), 1),  # [15*19, 1, 512, 512] grouped 1x1 conv weights
                 "mu_b": torch.cat(bs, 0).contiguous(),                # [15*19, 512]
                 "n_styled": len(styled),
                 "w_img": PreparedConv(M.conv_prepare(L, st, self.conv_img.weight.detach()), 3)}
@@ -266,7 +266,7 @@ class SPADEGenerator(FrozenPlanMixin, nn.Module):  # generator.py:14-110, num_up
         n_st = p["n_styled"]
         xg = codes.permute(1, 0, 2).reshape(1, N_LABELS, d, STYLE_LEN).expand(n_st, -1, -1, -1)
         xg = xg.reshape(n_st * N_LABELS, d, STYLE_LEN, 1, 1).contiguous()
-        mu = M.conv2d(L, st, xg, p["mu_w"], 1, 1, bias=p["mu_b"], act=M.ACT_LRELU, alpha=0.0, groups=n_st * N_LABELS, x_shared=False)
+        mu = conv(xg, p["mu_w"], 1, 1, bias=p["mu_b"], act=M.ACT_LRELU, alpha=0.0, groups=n_st * N_LABELS, x_shared=False)
         mu = mu.reshape(n_st, N_LABELS, d, STYLE_LEN).permute(0, 3, 2, 1).contiguous()            # [15, 512, D, 19]
         aces = [a for blk in self.blocks() for a in blk.aces()]
         if noise is None and self.noise_source is not None:

@@ -99,7 +99,9 @@ class Conv2dBlock(nn.Module):  # my_torchlib/module.py:64-131 (pad_type 'zero', 
             bias = self.conv.bias.detach()
             if pad_to != cout:
                 bias = torch.cat([bias, bias.new_zeros(pad_to - cout)])
-            plan = {"w": prep(w[:, :n_var]), "bias": bias.contiguous(), "pad_to": pad_to, "const": None}
+            # the conv-path weights are built on first use: the two deepest encoder layers (512 -> 1024 @ 8x8, 1024 -> 2048
+            # @ 4x4) always take the patch-GEMM / GEMV branch below and never need their 75 + 302 MB space-to-depth form
+            plan = {"w": None, "make_w": lambda: prep(w[:, :n_var]), "bias": bias.contiguous(), "pad_to": pad_to, "const": None}
             if const_planes is not None:  # conv of the constant planes (no bias: the variable part carries it)
                 plan["const"] = self._conv(const_planes, prep(w[:, n_var:]), None, k)[:, :cout].contiguous()
             self._plan = plan
@@ -109,11 +111,11 @@ class Conv2dBlock(nn.Module):  # my_torchlib/module.py:64-131 (pad_type 'zero', 
             # product over cin*16 values - a GEMM [B*L, cin*16] x [cin*16, cout] whose cost is streaming the weights
             # once.  Patches by F.unfold (glue, a few KB), the product on the 1x1 conv kernel; the space-to-depth form
             # would stream 2.25x the weights (its zero taps) through the general 3x3 path: 0.95 ms per layer at batch 16.
-            if "gemm" not in p:
-                w2 = self.conv.weight.detach().reshape(cout, -1, 1, 1)
-                p["gemm"] = M.conv_prepare(L, st, w2.contiguous())
             b, _, h, w_ = x.shape
             cols = F.unfold(x, kernel_size=4, stride=2, padding=1)                     # [B, cin*16, L]
+            if b * cols.shape[2] > 32 and "gemm" not in p:  # the MFMA-GEMM form's weights: only when that branch runs
+                w2 = self.conv.weight.detach().reshape(cout, -1, 1, 1)
+                p["gemm"] = M.conv_prepare(L, st, w2.contiguous())
             if b * cols.shape[2] <= 32:
                 # a single swap: up to 32 patch rows - the weight-streaming GEMV kernel reads the 34 / 134 MB of weights
                 # once per 8 rows at HBM speed (the MFMA GEMM form below needs more rows to pay: 209 -> ~60 us)
@@ -125,6 +127,8 @@ class Conv2dBlock(nn.Module):  # my_torchlib/module.py:64-131 (pad_type 'zero', 
                 y = M.conv2d(L, st, cols, p["gemm"], 1, 1, bias=self.conv.bias.detach())   # [1, cout, B, L]
                 y = y[0].permute(1, 0, 2).reshape(b, cout, h // 2, w_ // 2).contiguous()
         else:
+            if p["w"] is None:
+                p["w"] = p.pop("make_w")()
             y = self._conv(x, p["w"], p["bias"], k)
         if p["const"] is not None:
             y = M.add_bcast(L, st, y, p["const"].reshape(-1)) if p["pad_to"] == cout else y[:, :cout] + p["const"]

@@ -25,7 +25,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from .. import _marshal as M
-from .._runtime import conv_precision, lib, require_gpu, stream
+from .._runtime import conv_precision, lib, require_gpu, run_guarded, stream
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 
 
@@ -476,14 +476,18 @@ class Generator(nn.Module):  # :368-565
             latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
 
-        styled = self._batch_styles(latent)
         if layer_in is None or tuple(layer_in.shape[-2:]) == (2 ** (start_layer + 1),) * 2:  # standard pyramid sizes only
             noise = self._draw_noise(noise, latent, start_layer, end_layer)
-        try:
-            return self._run_layers(latent, noise, layer_in, skip, start_layer, end_layer, return_latents)
-        finally:
-            for conv in styled:
-                conv._coeffs = None
+
+        def run():  # HAIRFAST_CONV_PRECISION=auto: repeated on the fp32 kernels (same latent, same noise) if the split clamped
+            styled = self._batch_styles(latent)
+            try:
+                return self._run_layers(latent, noise, layer_in, skip, start_layer, end_layer, return_latents)
+            finally:
+                for conv in styled:
+                    conv._coeffs = None
+
+        return run_guarded(run)
 
     def _draw_noise(self, noise, latent, start_layer, end_layer):
         """randomize_noise: the fresh N(0,1) maps of every layer that will run, from ONE normal_() launch on torch's

@@ -163,6 +163,9 @@ int hf_style_batch_f32(float *out, const float *latent, long long lat_bstride, l
  * anything else returns HF_E_INVALID and the caller uses hf_modconv3x3_f32.
  */
 int hf_conv_split_weights_f16(void *wt_hi, void *wt_lo, const float *wt, int cin, int cout, void *stream);
+/* The same for `taps` in {9, 1}: prepared weights [taps][cin][cout] -> [cin/16][tap][2][cout][8] fp16 hi / lo (+ the
+ * 16-byte trailer behind hi).  taps = 1: the weights of hf_conv1x1_f16_f32 (from hf_conv_prepare_f32 with k = 1). */
+int hf_conv_split_weights_f16_taps(void *wt_hi, void *wt_lo, const float *wt, int cin, int cout, int taps, void *stream);
 /* Elements the fp16 split had to clamp (|v| > 131008 or NaN) since the last reset, summed over
  * all kernels of the library.  SYNCHRONOUS (copies a device counter; do not call inside a stream
  * capture).  A non-zero value means a tensor left the fp16-pair range: re-run with the exact
@@ -352,6 +355,22 @@ int hf_conv2d_f16_f32(float *out, const float *x, const void *x_hi, const void *
                       const float *residual, int batch, int cin, int cout, int h, int w, int stride, int groups,
                       long long x_group_stride, float *workspace, long long workspace_floats, void *stream);
 long long hf_conv2d_f16_workspace_floats(int batch, int cin, int cout, int h, int w, int stride, int groups);
+/* hf_conv2d_f32 for k = 1 on the fp16 matrix cores (csrc/gemm_h.hip): a GEMM over the pixels,
+ *   y = act( out_scale[co] * sum_ci W[co,ci] * (in_scale[ci]*x + in_shift[ci]) + bias[co] ) + residual,
+ * stride in {1, 2} (the source pixel of output (oy, ox) is (oy*stride, ox*stride)), operand modes as hf_conv2d_f16_f32.
+ * Replaces the 1x1 shortcut / downsample convolutions of the encoders (helpers.py:99-103, iresnet.py:17-19), BiSeNet's
+ * and SEAN's 1x1 convs (architecture.py:50), and - on feature-major activations x[feature][token], i.e. NCHW with the
+ * tokens as pixels - the nn.Linear layers of the CLIP image tower (clip/model.py) and SEAN's per-label table GEMM.
+ * wt_hi / wt_lo: hf_conv_split_weights_f16_taps(taps = 1) of the prepared [1][cin][cout] weights; per group a
+ * self-contained [cin*cout halves | 16-byte trailer] (hi) and cin*cout halves (lo).  cin % 32 == 0, cout % 64 == 0,
+ * otherwise HF_E_INVALID (callers use hf_conv2d_f32).  groups > 1 as in hf_conv2d_f32 (in_scale / in_shift NULL).
+ * workspace: hf_conv1x1_f16_workspace_floats() floats (small grids split K; 0 -> may be NULL). */
+int hf_conv1x1_f16_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
+                       const float *in_scale, const float *in_shift, const float *out_scale, const float *bias, int act,
+                       const float *slope, float alpha, const float *residual, int batch, int cin, int cout, int h, int w,
+                       int stride, int groups, long long x_group_stride, float *workspace, long long workspace_floats,
+                       void *stream);
+long long hf_conv1x1_f16_workspace_floats(int batch, int cin, int cout, int h, int w, int stride, int groups);
 /* in_scale[c]*x + in_shift[c] (NULL = identity) split into fp16 pairs hi = fp16(v), lo = fp16(v - hi)
  * (saturating, hf_f16_overflow_count) and K-blocked: out_hi / out_lo [images][channels/8][h][w][8];
  * x [images][channels][h][w] fp32, channels % 8 == 0.  out_lo may be NULL (nterms 1 consumer).

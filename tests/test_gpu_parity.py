@@ -849,3 +849,37 @@ def test_modconv_up_fused_blur(shape):
         full = O.fused_leaky_relu(O.modulated_conv2d(x.cpu(), sty.cpu(), wgt.cpu(), mw.cpu(), mb.cpu(), True, True)
                                   + nw.cpu() * nz.cpu(), bias.cpu())
         assert float((y.cpu() - full).abs().max()) < 1e-5 * scale
+
+
+def test_auto_precision_reruns_clamped_forward_in_f32():
+    """HAIRFAST_CONV_PRECISION=auto (the real-checkpoint safety net): a forward whose activations leave the fp16-pair
+    range (|s*x| > 131008: the split saturates and counts) is repeated on the exact fp32 kernels - the result equals the
+    f32 mode's bit for bit; a forward that stays in range is not repeated and equals the f16x3 mode's."""
+    from hairfastgan_amd import _runtime
+    from hairfastgan_amd.stylegan2.model import Generator
+
+    dev = _dev()
+    g = Generator(64, 512, 2).eval()
+    shapes = {k: tuple(v.shape) for k, v in g.state_dict().items()}
+    g.load_state_dict(C.generator_params(shapes))
+    g = g.to(dev)
+    lat, nz, _ = C.generator_inputs(64, 2, 0)
+    lat, nz = lat.to(dev), [n.to(dev) for n in nz]
+
+    def run(mode):
+        prev = _runtime.set_conv_precision(mode)
+        try:
+            with torch.inference_mode():
+                return g([lat], input_is_latent=True, noise=nz)[0]
+        finally:
+            _runtime.set_conv_precision(prev)
+
+    n0 = _runtime.auto_reruns
+    assert torch.equal(run("auto"), run("f16x3")) and _runtime.auto_reruns == n0          # in range: one pass
+    with torch.no_grad():
+        g.input.input.mul_(1e7)                                                            # learned constant far out of range
+    y32, y16, ya = run("f32"), run("f16x3"), run("auto")
+    assert _runtime.auto_reruns == n0 + 1
+    assert torch.equal(ya, y32)
+    assert not torch.equal(y16, y32)
+    assert _runtime.configured_conv_precision() != "auto" and _runtime.conv_precision() in ("f16x3", "f32", "f16")

@@ -124,7 +124,9 @@ def test_vit_operators(simlib):
 def sim_clip(simlib, monkeypatch):
     import hairfastgan_amd.clip_vit  # noqa: F401
 
-    for n in ("hairfastgan_amd.clip_vit",):
+    import hairfastgan_amd.encoders  # noqa: F401
+
+    for n in ("hairfastgan_amd.clip_vit", "hairfastgan_amd.encoders._fused"):
         mod = sys.modules[n]
         monkeypatch.setattr(mod, "lib", lambda: simlib)
         monkeypatch.setattr(mod, "stream", lambda: None)
