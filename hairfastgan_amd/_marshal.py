@@ -488,7 +488,7 @@ def torgb(lib, st, x, wt, s, bias, skip, up_kernel):
 # ----------------------------------------------------------------------------------------
 # encoders
 # ----------------------------------------------------------------------------------------
-ACT_NONE, ACT_LRELU, ACT_PRELU = 0, 1, 2
+ACT_NONE, ACT_LRELU, ACT_PRELU, ACT_QGELU = 0, 1, 2, 3
 ACT_RESIDUAL_FIRST = 16  # OR-ed into act: residual added before the activation (HF_ACT_RESIDUAL_FIRST)
 
 
@@ -889,8 +889,10 @@ def label_conv3x3(lib, st, labels, table, bias, channels, batch=None, cols_per_s
     if table.shape[0] != 9 * channels or (cols_per_sample and table.shape[1] < b * cols_per_sample):
         raise ValueError(f"table {tuple(table.shape)} does not fit {channels} channels / {b} samples")
     out = table.new_empty((b, channels, h, w))
+    # interior fast path (one lookup of the tap sum instead of nine) where planes are large enough to have interiors
+    tsum = table.new_empty((channels, table.shape[1])) if h * w >= 1024 else None
     check(lib, lib.hf_label_conv3x3_f32(_p(out), _p(labels), _p(table), _p(_c(bias)), b, channels, h, w, table.shape[1],
-                                        cols_per_sample, group, 1 if relu else 0, st), "hf_label_conv3x3_f32")
+                                        cols_per_sample, group, 1 if relu else 0, _p(tsum), st), "hf_label_conv3x3_f32")
     return out
 
 

@@ -59,7 +59,7 @@ class ResidualAttentionBlock(nn.Module):  # clip/model.py ResidualAttentionBlock
         a = M.mha_small(L, st, qkv, images, seq, self.heads)
         x = conv(a, p["out"], 1, 1, bias=self.attn.out_proj.bias.detach(), residual=x)
         h = M.channel_layernorm(L, st, x, self.ln_2.weight.detach(), self.ln_2.bias.detach(), self.ln_2.eps)
-        h = M.quick_gelu(L, st, conv(h, p["fc"], 1, 1, bias=self.mlp.c_fc.bias.detach()))
+        h = conv(h, p["fc"], 1, 1, bias=self.mlp.c_fc.bias.detach(), act=M.ACT_QGELU)  # QuickGELU in the GEMM's epilogue
         return conv(h, p["proj"], 1, 1, bias=self.mlp.c_proj.bias.detach(), residual=x)
 
 

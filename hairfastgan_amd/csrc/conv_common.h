@@ -22,7 +22,7 @@ constexpr int KC = 8;             // input channels per LDS stage (4 MFMA k-step
 constexpr int kThreads = 256;     // general kernel: 4 waves
 constexpr int kMaxElemPerCi = 4;  // general kernel: halo-tile elements per thread per channel
 
-enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_PRELU = 2 };
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_PRELU = 2, ACT_QGELU = 3 };  // QGELU: x * sigmoid(1.702 x) (CLIP's QuickGELU)
 
 struct TileGeom {
   int y0, x0;      // origin of this tile family in the OUTPUT pixel domain
@@ -105,6 +105,7 @@ __device__ __forceinline__ GroupOfs group_offsets(const ConvParams &P) {
 __device__ __forceinline__ float apply_act(float v, int act, float alpha, float scale, float slope) {
   if (act == ACT_LRELU) return hf_lrelu(v, alpha, scale);
   if (act == ACT_PRELU) return v > 0.0f ? v : v * slope;
+  if (act == ACT_QGELU) return v / (1.0f + expf(-1.702f * v));
   return v;
 }
 
@@ -199,7 +200,7 @@ __device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const 
   const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
   const long long oplane = (long long)P.out_h * P.out_w;
   const bool partial = P.splits > 1;
-  const bool prelu = !partial && P.act == ACT_PRELU, lrelu = !partial && P.act == ACT_LRELU;
+  const bool prelu = !partial && P.act == ACT_PRELU, lrelu = !partial && P.act == ACT_LRELU, qgelu = !partial && P.act == ACT_QGELU;
   const float neg_u = lrelu ? P.alpha : 1.0f, sc = lrelu ? P.scale : 1.0f;
   const bool res_pre = RES && P.residual_pre;
   long long pofs[PG];
@@ -250,6 +251,7 @@ __device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const 
           float v = fmaf(acc[0][ct][g][r], dmv[k], bsv[k]);
           if (RES && res_pre) v += rv[RES ? g : 0][r];
           v = (v > 0.0f ? v : v * slv[k]) * sc;
+          if (qgelu) v = v / (1.0f + expf(-1.702f * v));  // uniform branch (per launch)
           if (RES && !res_pre) v += rv[RES ? g : 0][r];
           HF_STORE_OUT(ob + k * oplane, v);
         }

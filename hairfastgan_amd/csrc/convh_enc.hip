@@ -457,7 +457,7 @@ static int enc_fill(ConvParams &P, float *out, const float *x, const void *x_hi,
     return HF_E_INVALID;
   P.residual_pre = (act & HF_ACT_RESIDUAL_FIRST) ? 1 : 0;
   act &= ~HF_ACT_RESIDUAL_FIRST;
-  if (act < ACT_NONE || act > ACT_PRELU || (act == ACT_PRELU && !slope)) return HF_E_INVALID;
+  if (act < ACT_NONE || act > ACT_QGELU || (act == ACT_PRELU && !slope)) return HF_E_INVALID;
   if (groups > 1 && (in_scale || in_shift)) return HF_E_INVALID;  // grouped form: plain conv + epilogue (as hf_conv2d_f32)
   if (x_hi && (in_scale || in_shift)) return HF_E_INVALID;        // pre-split input: the affine went into the split
   P.out = out; P.x = x; P.xh = x_hi; P.xl = x_lo; P.s = in_scale; P.t = in_shift; P.d = out_scale; P.bias = bias;

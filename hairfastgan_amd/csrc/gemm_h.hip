@@ -239,7 +239,7 @@ extern "C" int hf_conv1x1_f16_f32(float *out, const float *x, const void *wt_hi,
                                   float *workspace, long long workspace_floats, void *stream) {
   const int act_kind = act & ~HF_ACT_RESIDUAL_FIRST;
   if (!out || !x || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (nterms != 1 && nterms != 3) ||
-      (nterms == 3 && !wt_lo) || (stride != 1 && stride != 2) || (cin % KS) || (cout % 64) || act_kind < 0 || act_kind > 2 ||
+      (nterms == 3 && !wt_lo) || (stride != 1 && stride != 2) || (cin % KS) || (cout % 64) || act_kind < 0 || act_kind > ACT_QGELU ||
       (act_kind == ACT_PRELU && !slope) || groups < 1 || (groups > 1 && (in_scale || in_shift)))
     return HF_E_INVALID;
   ConvParams P{};

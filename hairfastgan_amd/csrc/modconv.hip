@@ -952,7 +952,7 @@ extern "C" int hf_conv2d_f32(float *out, const float *x, const float *wt, const 
     return HF_E_INVALID;
   const int residual_pre = (act & HF_ACT_RESIDUAL_FIRST) ? 1 : 0;  // residual added BEFORE the activation (ResNet BasicBlock)
   act &= ~HF_ACT_RESIDUAL_FIRST;
-  if (act < ACT_NONE || act > ACT_PRELU || (act == ACT_PRELU && !slope)) return HF_E_INVALID;
+  if (act < ACT_NONE || act > ACT_QGELU || (act == ACT_PRELU && !slope)) return HF_E_INVALID;
   if (groups > 1 && (in_scale || in_shift)) return HF_E_INVALID;  // grouped form: plain conv + epilogue
   ConvParams P{};
   P.residual_pre = residual_pre;

@@ -14,38 +14,69 @@
 
 constexpr int kSeanLabels = 19;
 
+#ifndef HF_WAVE_ANY_DEFINED
+#define HF_WAVE_ANY_DEFINED
+__device__ __forceinline__ bool hf_wave_any(bool p) { return __any((int)p) != 0; }
+#endif
+
 // out[b, c, y, x] = act( bias[c] + sum_{tap=(ky,kx)} table[(tap*C + c) * tcols + col0(b) + label[b / group, y+ky-1, x+kx-1]] )
 // taps outside the image contribute nothing (zero padding).  table: [9*C][tcols]; col0(b) = b * cols_per_sample.
+// tsum [C][tcols] = sum over the nine taps of table (NULL = off): a pixel whose 3x3 neighbourhood lies inside the image
+// and carries ONE label - the interior of a region, most pixels at the high resolutions - needs one lookup instead of nine;
+// a wave takes that path when all of its 64 pixels qualify.  (The interior sum is the table's taps added in a fixed order
+// by the caller, the general path adds them in tap order: the two paths differ by an fp32 reassociation.)
 __global__ __launch_bounds__(256) void label_conv3x3(float *__restrict__ out, const int *__restrict__ labels,
-                                                     const float *__restrict__ table, const float *__restrict__ bias, int C,
-                                                     int H, int W, int tcols, int cols_per_sample, int group, int act,
-                                                     int cchunk) {
+                                                     const float *__restrict__ table, const float *__restrict__ tsum,
+                                                     const float *__restrict__ bias, int C, int H, int W, int tcols,
+                                                     int cols_per_sample, int group, int act, int cchunk) {
   const int hw = H * W;
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= hw) return;
+  const bool live = p < hw;
   const int b = blockIdx.z;
-  const int y = p / W, x = p - y * W;
+  const int pc = live ? p : hw - 1;
+  const int y = pc / W, x = pc - y * W;
   const int *lb = labels + (long long)(b / group) * hw;
   int col[9];
+  bool uniform = tsum != nullptr;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-    col[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? b * cols_per_sample + lb[yy * W + xx] : -1;
+    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    col[t] = in ? b * cols_per_sample + lb[yy * W + xx] : -1;
   }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) uniform = uniform && col[t] == col[4];
   const int c0 = blockIdx.y * cchunk, c1 = min(C, c0 + cchunk);
-  float *o = out + ((long long)b * C + c0) * hw + p;
+  float *o = out + ((long long)b * C + c0) * hw + pc;
+  if (!hf_wave_any(!uniform)) {
+    for (int c = c0; c < c1; ++c, o += hw) {
+      const float acc = (bias ? bias[c] : 0.0f) + tsum[(long long)c * tcols + col[4]];
+      if (live) *o = act ? fmaxf(acc, 0.0f) : acc;
+    }
+    return;
+  }
   for (int c = c0; c < c1; ++c, o += hw) {
     float acc = bias ? bias[c] : 0.0f;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
       if (col[t] >= 0) acc += table[((long long)t * C + c) * tcols + col[t]];
-    *o = act ? fmaxf(acc, 0.0f) : acc;
+    if (live) *o = act ? fmaxf(acc, 0.0f) : acc;
   }
+}
+
+// tsum[c][j] = sum_tap table[tap*C + c][j]  (taps added in order 0..8)
+__global__ __launch_bounds__(256) void label_table_sum(float *__restrict__ tsum, const float *__restrict__ table, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc += table[(long long)t * n + i];
+  tsum[i] = acc;
 }
 
 extern "C" int hf_label_conv3x3_f32(float *out, const int *labels, const float *table, const float *bias, int batch,
                                     int channels, int h, int w, int table_cols, int cols_per_sample, int group, int relu,
-                                    void *stream) {
+                                    float *tap_sum_scratch, void *stream) {
   if (!out || !labels || !table || batch <= 0 || channels <= 0 || h <= 0 || w <= 0 || table_cols <= 0 || group <= 0 ||
       cols_per_sample < 0 || batch > 65535)
     return HF_E_INVALID;
@@ -53,9 +84,13 @@ extern "C" int hf_label_conv3x3_f32(float *out, const int *labels, const float *
   // enough blocks to fill the chip, at least 8 channels per thread to amortise the nine label loads
   int cchunk = channels;
   while (cchunk > 8 && (long long)hf_cdiv(hw, 256) * hf_cdiv(channels, cchunk) * batch < 1024) cchunk = (cchunk + 1) / 2;
+  if (tap_sum_scratch) {
+    const long long n = (long long)channels * table_cols;
+    hipLaunchKernelGGL(label_table_sum, dim3(hf_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, tap_sum_scratch, table, n);
+  }
   hipLaunchKernelGGL(label_conv3x3, dim3(hf_cdiv(hw, 256), hf_cdiv(channels, cchunk), batch), dim3(256), 0,
-                     (hipStream_t)stream, out, labels, table, bias, channels, h, w, table_cols, cols_per_sample, group,
-                     relu ? 1 : 0, cchunk);
+                     (hipStream_t)stream, out, labels, table, tap_sum_scratch, bias, channels, h, w, table_cols,
+                     cols_per_sample, group, relu ? 1 : 0, cchunk);
   return hf_launch_status();
 }
 

@@ -5,41 +5,82 @@
 #include "hf_common.h"
 
 // LayerNorm over the FEATURE axis of x [C][T] (per token t: mean / biased variance over c, eps inside the sqrt),
-// affine gamma / beta [C].  One block per 64 consecutive tokens: lane = token (coalesced rows), the four waves split
-// the features and meet in LDS in wave order (deterministic).  Two passes over x (L2-resident: C*64*4 bytes per block).
-__global__ __launch_bounds__(256) void channel_layernorm(float *__restrict__ out, const float *__restrict__ x,
-                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                         int C, long long T, float eps) {
+// affine gamma / beta [C].  One block per 64 consecutive tokens, 16 waves: lane = token (coalesced rows), wave w owns the
+// features w, w+16, ... and keeps them IN REGISTERS (one pass over x; all loads of a thread are independent and in
+// flight together - the first version walked the 768 features of a token with 4 waves, one dependent-latency load
+// after the other: 115 us per call on 100 tokens, 12 % of a swap).  The wave partials meet in LDS and are added in wave
+// order (deterministic).  C <= 16 * kLnMaxV; wider inputs take the re-reading form below.
+constexpr int kLnWaves = 16, kLnMaxV = 64;
+__global__ __launch_bounds__(64 * kLnWaves) void channel_layernorm(float *__restrict__ out, const float *__restrict__ x,
+                                                                   const float *__restrict__ gamma,
+                                                                   const float *__restrict__ beta, int C, long long T,
+                                                                   float eps) {
   HF_DYN_LDS;
-  float *red = reinterpret_cast<float *>(hf_dyn_lds);  // [2][4][64]
+  float *red = reinterpret_cast<float *>(hf_dyn_lds);  // [2][16 waves][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long t = (long long)blockIdx.x * 64 + lane;
   const bool ok = t < T;
+  const bool in_regs = C <= kLnWaves * kLnMaxV;
+  float v[kLnMaxV];
   float s = 0.0f;
-  for (int c = wave; c < C; c += 4) s += ok ? x[(long long)c * T + t] : 0.0f;
+  if (in_regs) {
+#pragma unroll
+    for (int i = 0; i < kLnMaxV; ++i) {
+      const int c = wave + i * kLnWaves;
+      v[i] = (ok && c < C) ? x[(long long)c * T + t] : 0.0f;
+      s += v[i];
+    }
+  } else {
+    for (int c = wave; c < C; c += kLnWaves) s += ok ? x[(long long)c * T + t] : 0.0f;
+  }
   red[wave * 64 + lane] = s;
   __syncthreads();
-  const float mean = ((red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane])) / (float)C;
-  float v = 0.0f;
-  for (int c = wave; c < C; c += 4) {
-    const float d = ok ? x[(long long)c * T + t] - mean : 0.0f;
-    v = fmaf(d, d, v);
+  float tot = 0.0f;
+#pragma unroll
+  for (int w = 0; w < kLnWaves; ++w) tot += red[w * 64 + lane];
+  const float mean = tot / (float)C;
+  float q = 0.0f;
+  if (in_regs) {
+#pragma unroll
+    for (int i = 0; i < kLnMaxV; ++i) {
+      const float d = (wave + i * kLnWaves < C) ? v[i] - mean : 0.0f;
+      q = fmaf(d, d, q);
+    }
+  } else {
+    for (int c = wave; c < C; c += kLnWaves) {
+      const float d = ok ? x[(long long)c * T + t] - mean : 0.0f;
+      q = fmaf(d, d, q);
+    }
   }
-  red[256 + wave * 64 + lane] = v;
+  red[(kLnWaves + wave) * 64 + lane] = q;
   __syncthreads();
-  const float inv = rsqrtf(((red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane])) / (float)C + eps);
+  float qt = 0.0f;
+#pragma unroll
+  for (int w = 0; w < kLnWaves; ++w) qt += red[(kLnWaves + w) * 64 + lane];
+  const float inv = rsqrtf(qt / (float)C + eps);
   if (!ok) return;
-  for (int c = wave; c < C; c += 4) {
-    const float y = (x[(long long)c * T + t] - mean) * inv;
-    out[(long long)c * T + t] = gamma ? fmaf(y, gamma[c], beta ? beta[c] : 0.0f) : y;
+  if (in_regs) {
+#pragma unroll
+    for (int i = 0; i < kLnMaxV; ++i) {
+      const int c = wave + i * kLnWaves;
+      if (c < C) {
+        const float y = (v[i] - mean) * inv;
+        out[(long long)c * T + t] = gamma ? fmaf(y, gamma[c], beta ? beta[c] : 0.0f) : y;
+      }
+    }
+  } else {
+    for (int c = wave; c < C; c += kLnWaves) {
+      const float y = (x[(long long)c * T + t] - mean) * inv;
+      out[(long long)c * T + t] = gamma ? fmaf(y, gamma[c], beta ? beta[c] : 0.0f) : y;
+    }
   }
 }
 
 extern "C" int hf_channel_layernorm_f32(float *out, const float *x, const float *gamma, const float *beta, int channels,
                                         long long tokens, float eps, void *stream) {
   if (!out || !x || channels <= 0 || tokens <= 0) return HF_E_INVALID;
-  hipLaunchKernelGGL(channel_layernorm, dim3(hf_cdiv(tokens, 64)), dim3(256), 2 * 4 * 64 * sizeof(float), (hipStream_t)stream, out,
-                     x, gamma, beta, channels, tokens, eps);
+  hipLaunchKernelGGL(channel_layernorm, dim3(hf_cdiv(tokens, 64)), dim3(64 * kLnWaves), 2 * kLnWaves * 64 * sizeof(float),
+                     (hipStream_t)stream, out, x, gamma, beta, channels, tokens, eps);
   return hf_launch_status();
 }
 

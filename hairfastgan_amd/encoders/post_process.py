@@ -203,8 +203,12 @@ class ClipBlendingModel(nn.Module):  # models/Encoders.py:75-103
     def forward(self, latent_face, latent_color, target_face, hair_color):
         require_gpu(latent_face, latent_color)
         L, st = lib(), stream()
-        embed_face = self.get_image_embed(target_face).float().unsqueeze(1).expand(-1, 12, -1)
-        embed_color = self.get_image_embed(hair_color).float().unsqueeze(1).expand(-1, 12, -1)
+        # both images of every triple through the tower in ONE call (rows are independent: clip/model.py has no
+        # cross-sample operation; the reference calls encode_image twice, Encoders.py:97-98)
+        n = target_face.shape[0]
+        embed = self.get_image_embed(torch.cat([target_face, hair_color], 0)).float()
+        embed_face = embed[:n].unsqueeze(1).expand(-1, 12, -1)
+        embed_color = embed[n:].unsqueeze(1).expand(-1, 12, -1)
         latent_in = torch.cat((latent_color, embed_face, embed_color), dim=-1).contiguous()
         latent_face = latent_face.contiguous()
         dt = M.pixel_norm_dim1(L, st, latent_face)

@@ -313,7 +313,7 @@ int hf_bn_fold_f32(float *scale, float *shift, const float *gamma, const float *
  *   in_scale / in_shift : the BatchNorm BEFORE the conv (applied to real pixels only, the zero
  *                          padding stays zero - which is why it cannot be folded into the weights);
  *   out_scale / bias    : the BatchNorm AFTER the conv (and/or the conv's own bias);
- *   act                 : 0 none, 1 LeakyReLU(alpha), 2 PReLU(slope[co]);
+ *   act                 : 0 none, 1 LeakyReLU(alpha), 2 PReLU(slope[co]), 3 QuickGELU x*sigmoid(1.702x) (CLIP's MLP);
  *   residual            : [batch,cout,oh,ow] added last (IBasicBlock's `out += identity`).
  * Any of the pointers may be NULL.  k in {1,3,7} (7: ungrouped), stride in {1,2}; oh = (h-1)/stride + 1.
  * Replaces: nn.Conv2d + BatchNorm2d + PReLU/LeakyReLU (+ add) chains of
@@ -492,9 +492,13 @@ int hf_add_bcast_f32(float *out, const float *a, const float *b, long long n, lo
  *     over region j): table = a [19*batch]-column GEMM of the weights with the per-sample region vectors,
  *     cols_per_sample = 19.
  * labels: int32 [batch/group, h, w] (group consecutive samples share a label map - the two decodes of a pair,
- * models/Alignment.py:130-131); relu != 0 applies ReLU; bias may be NULL. */
+ * models/Alignment.py:130-131); relu != 0 applies ReLU; bias may be NULL.
+ * tap_sum_scratch: NULL, or channels*table_cols floats of scratch: the sum of the nine taps is computed first and pixels
+ * whose whole 3x3 neighbourhood carries one label (the interior of a region) take ONE lookup instead of nine - worth it
+ * from ~32x32 planes upward. */
 int hf_label_conv3x3_f32(float *out, const int *labels, const float *table, const float *bias, int batch, int channels,
-                         int h, int w, int table_cols, int cols_per_sample, int group, int relu, void *stream);
+                         int h, int w, int table_cols, int cols_per_sample, int group, int relu, float *tap_sum_scratch,
+                         void *stream);
 /* The tail of ACE.forward (normalization.py:103-107, 164-185) in one pass:
  *   n   = (x + noise[b,p] * noise_var[c]) * bn_scale[c] + bn_shift[c]      (the eval-mode SynchronizedBatchNorm2d as an
  *                                                                           affine: hf_bn_fold_f32 with gamma 1, beta 0)

@@ -52,6 +52,15 @@ def test_label_conv_and_ace_tail(simlib):
     for s in range(4):
         mid = vec[s][labels[s // 2].long()].permute(2, 0, 1)[None]  # [1,5,H,W]
         assert float((ya[s:s + 1] - F.conv2d(mid, wg, bg, padding=1)).abs().max()) < 1e-4
+    # a plane large enough for the interior fast path (one lookup of the tap sum where a wave's 64 pixels all have a
+    # single-label neighbourhood): blocks of one label with ragged borders -> both paths inside one launch
+    big = torch.zeros(1, 32, 40, dtype=torch.int32)
+    big[0, :, 20:] = 7
+    big[0, 25:, :13] = 3
+    big[0, 5, 5] = 11
+    yb = M.label_conv3x3(simlib, None, big, table, b, 6, relu=False)
+    ohb = F.one_hot(big.long(), 19).permute(0, 3, 1, 2).float()
+    assert float((yb - F.conv2d(ohb, w, b, padding=1)).abs().max()) < 2e-5
     # ACE tail
     x, r = torch.randn(4, 4, 9, 12), torch.randn(4, 9, 12)
     nv, sc, sh = torch.randn(4) * 0.1, torch.rand(4) + 0.5, torch.randn(4)
