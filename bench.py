@@ -217,8 +217,10 @@ def make_triple_loader(n_pool=8):
     return lambda i: pool[i % n_pool]
 
 
-def kernel_report(prof, elapsed, precision):
-    """Aggregate the HIP-event brackets of the timed region: per-kernel table + the two rooflines."""
+def kernel_report(prof, elapsed, precision, sampled=1.0):
+    """Aggregate the HIP-event brackets of the timed region: per-kernel table + the two rooflines.
+    sampled: fraction of the region's steps whose launches were bracketed (shares are scaled by it)."""
+    elapsed = elapsed * sampled
     agg = {}
     for label, flops, e0, e1, nbytes in prof:
         a = agg.setdefault(label, [0.0, 0.0, 0, 0.0])
@@ -357,6 +359,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the fp32-MFMA comparison run (profiling)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="generator workload: bracket the launches of every N-th timed step with HIP events (1 = every step)")
     ap.add_argument("--swap-triples", type=int, default=4,
                     help="generator workload: triples per GPU for the secondary hair-swap measurements (0 = skip)")
     args = ap.parse_args()
@@ -479,15 +483,19 @@ def main():
         pending[1].wait()
     barrier()
     prof = None if args.no_kernel_events else []
-    _marshal.PROFILE = prof
+    every = max(1, args.event_every)
+    n_bracketed = len(range(0, args.steps, every))
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        # per-kernel HIP events (the `roofline` durations) on every `every`-th step of the timed region: an event pair costs
+        # ~8 us of serialised stream time, 41 pairs per forward = 0.3 ms - bracketing every step cost 6 % of the headline
+        _marshal.PROFILE = prof if (prof is not None and i % every == 0) else None
         step()
+    _marshal.PROFILE = None
     if pending is not None:
         pending[1].wait()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
-    _marshal.PROFILE = None
     overflow = _marshal.f16_overflow_count(_runtime.lib())
 
     # comparison runs (outside the timed region): the same forward with every conv on the exact-fp32
@@ -589,16 +597,16 @@ def main():
                        "weights": "synthetic closed-form (oracle/synth.py)", "conv_precision": precision},
             "algorithmic_tflops_whole_forward": round(value * GFLOP_PER_IMAGE / 1e3 / world, 2),
             "f16_split_clamped_elements": overflow,
-            "timing_note": ("every conv / streaming launch of the timed region is bracketed by a pair of HIP events (the per-kernel "
-                            "durations of `roofline`): the headline includes that overhead (about 0.3 ms per step; --no-kernel-events "
-                            "measures without it)") if prof else "no per-kernel events in the timed region",
+            "timing_note": (f"the conv / streaming launches of every {every}th step of the timed region ({n_bracketed} of {args.steps} steps) "
+                            "are bracketed by pairs of HIP events (the per-kernel durations of `roofline`); a bracketed step costs about "
+                            "0.3 ms more, which the headline includes (--no-kernel-events measures without any)") if prof else "no per-kernel events in the timed region",
         }
         if gather_note:
             out["config"]["gather"] = gather_note
         elif use_dist:
             out["config"]["gather"] = "async RCCL all_gather_into_tensor of uint8 images, one per step"
         if prof:
-            out.update(kernel_report(prof, elapsed, precision))
+            out.update(kernel_report(prof, elapsed, precision, n_bracketed / args.steps))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         if exact_f32 is not None:

@@ -248,8 +248,12 @@ def split_weights_unscale(wt_hi):
     return float(flat[n:n + 2].view(torch.float32)[0])
 
 
-def modconv3x3_f16_supported(cin, cout, h, w):
-    """Shapes hf_modconv3x3_f16_f32 takes (include/hairfast_hip.h)."""
+def modconv3x3_f16_supported(cin, cout, h, w, batch=None):
+    """Shapes hf_modconv3x3_f16_f32 takes (include/hairfast_hip.h).  batch given: also whether it PAYS - a launch of
+    fewer than 2048 pixels in total (a batch-1 32^2 layer: 4 tiles x 8 channel tiles) leaves the chip to 32 blocks that
+    each walk the whole K loop (94 us); the fp32 kernels split K over the CUs instead (70 us; tools/probes/tower.py)."""
+    if batch is not None and batch * h * w < 2048:
+        return False
     return cin % 16 == 0 and w >= 32 and (h >= 8 if cout % 64 == 0 else (cout % 32 == 0 and h >= 16))
 
 
@@ -344,8 +348,11 @@ def modconv3x3_f16_pre(lib, st, act, wt_hi, wt_lo, nterms, d, noise, noise_w, bi
     return res[0] if len(res) == 1 else tuple(res)
 
 
-def modconv3x3_up_f16_supported(cin, cout, h, w):
-    """Shapes hf_modconv3x3_up_f16_f32 takes (include/hairfast_hip.h)."""
+def modconv3x3_up_f16_supported(cin, cout, h, w, batch=None):
+    """Shapes hf_modconv3x3_up_f16_f32 takes (include/hairfast_hip.h); batch: see modconv3x3_f16_supported (a batch-1
+    16^2 -> 32^2 layer: 84 us on the fp32 split-K kernels, 106 us here)."""
+    if batch is not None and batch * h * w < 512:
+        return False
     return cin % 16 == 0 and cout % 32 == 0 and h * w >= (256 if cout % 64 == 0 else 512) and min(h, w) >= 2
 
 

@@ -172,8 +172,8 @@ class ModulatedConv2d(nn.Module):  # :183-279
         """3x3 same-resolution modulated conv (+ fused noise/bias/lrelu epilogue) on the matrix
         cores the process-wide mode selects (_runtime.conv_precision).  rgb: see fuses_torgb."""
         mode = conv_precision()
-        _, cin, h, w = input.shape
-        if mode != "f32" and M.modconv3x3_f16_supported(cin, self.out_channel, h, w):
+        b_, cin, h, w = input.shape
+        if mode != "f32" and M.modconv3x3_f16_supported(cin, self.out_channel, h, w, batch=b_):
             hi, lo = self.prepared_f16()
             return M.modconv3x3_f16(lib(), stream(), input, hi, lo, 3 if mode == "f16x3" else 1, s, d, noise,
                                     noise_w, bias, alpha, scale, rgb=rgb)
@@ -214,7 +214,7 @@ class ModulatedConv2d(nn.Module):  # :183-279
                 return M.modconv3x3_up_fused(lib(), stream(), input, hi, lo, s, d, fac, noise, noise_w, bias, alpha, scale,
                                              split_for=None if split_for is None else split_for[1])
         f16 = None
-        if mode != "f32" and M.modconv3x3_up_f16_supported(cin, self.out_channel, h, w):
+        if mode != "f32" and M.modconv3x3_up_f16_supported(cin, self.out_channel, h, w, batch=input.shape[0]):
             hi, lo = self.prepared_f16()
             f16 = (hi, lo, 3 if mode == "f16x3" else 1)
         return M.modconv3x3_up(lib(), stream(), input, wt, s, d, self.blur.kernel, noise, noise_w, bias, alpha, scale,
@@ -566,7 +566,8 @@ class Generator(nn.Module):  # :368-565
                 cmid, csame = conv_up.conv.out_channel, conv_same.conv.out_channel
                 h2, w2 = 2 * src.shape[2], 2 * src.shape[3]
                 fast_mode = conv_precision() != "f32"
-                if (fast_mode and cmid % 16 == 0 and M.modconv3x3_f16_supported(cmid, csame, h2, w2)
+                nb_ = src.shape[0]
+                if (fast_mode and cmid % 16 == 0 and M.modconv3x3_f16_supported(cmid, csame, h2, w2, batch=nb_)
                         and not _observed(conv_up, conv_same)):
                     # fast path: activations travel between the convs pre-modulated, split into fp16
                     # pairs and K-blocked (M.SplitActivation) - conv_up's blur pass writes conv_same's
@@ -581,9 +582,9 @@ class Generator(nn.Module):  # :368-565
                     s_up = None
                     if not is_last and nb <= end_layer:
                         nup, nsame = self.convs[2 * nb - 2], self.convs[2 * nb - 1]
-                        if (csame % 16 == 0 and M.modconv3x3_up_f16_supported(csame, nup.conv.out_channel, h2, w2)
+                        if (csame % 16 == 0 and M.modconv3x3_up_f16_supported(csame, nup.conv.out_channel, h2, w2, batch=nb_)
                                 and nup.conv.out_channel % 16 == 0
-                                and M.modconv3x3_f16_supported(nup.conv.out_channel, nsame.conv.out_channel, 2 * h2, 2 * w2)
+                                and M.modconv3x3_f16_supported(nup.conv.out_channel, nsame.conv.out_channel, 2 * h2, 2 * w2, batch=nb_)
                                 and not _observed(nup, nsame)):
                             up_coeffs = nup.conv.style_coefficients(latent[:, i + 2])
                             s_up = up_coeffs[1]

@@ -453,7 +453,7 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
 
     dev = _dev()
     g, shapes, size, _, _ = _gpu_generator("g1024", dev)
-    lat, nz, _ = C.generator_inputs(size, 1, 0)
+    lat, nz, _ = C.generator_inputs(size, 2, 0)  # batch 2: the smallest batch whose 32^2 layers take the fp16-core kernels
     lat, nz = lat.to(dev), [n.to(dev) for n in nz]
     fused, plain_rgb, presplit = [], [], []
     real_conv, real_rgb, real_pre = M.modconv3x3_f16, M.torgb, M.modconv3x3_f16_pre
@@ -502,14 +502,20 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
         assert up_pre == [32, 64] and up_fused == [128, 256, 512]
         # finishing passes on the raw slabs (8, 4, 2, 1, 1 slabs of 3 channels); the layers below 64^2 run the stand-alone ToRGB
         assert plain_rgb == [512, 512, 512, 512, 24, 12, 6, 3, 3], plain_rgb
+        # batch 1: the 32^2 block (1024 pixels per launch: 32 blocks that would each walk the whole K loop) stays on the
+        # fp32 split-K kernels (M.modconv3x3_f16_supported(batch=)), the hand-over chain starts at 64^2
+        fused.clear(); presplit.clear(); up_pre.clear(); up_fused.clear(); plain_rgb.clear()
+        g([lat[:1]], input_is_latent=True, noise=nz)
+        assert presplit == [64, 128, 256, 512, 1024] and up_pre == [64] and up_fused == [128, 256, 512], (presplit, up_pre)
         # module API: forward_rgb's explicit (out, raw) pair finished by ToRGB.finish equals the stand-alone ToRGB
         x32 = torch.randn(1, 32, 1024, 1024, device=dev)
-        out, raw = g.convs[15].forward_rgb(x32, lat[:, 16], nz[16], g.to_rgbs[7].coefficients(lat[:, 17]))
+        l1 = lat[:1]
+        out, raw = g.convs[15].forward_rgb(x32, l1[:, 16], nz[16], g.to_rgbs[7].coefficients(l1[:, 17]))
         a = g.to_rgbs[7].finish(raw, None)
-        b = g.to_rgbs[7](out, lat[:, 17])
+        b = g.to_rgbs[7](out, l1[:, 17])
         assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
-        assert torch.equal(out, g.convs[15](x32, lat[:, 16], noise=nz[16])) and not hasattr(out, "_hf_fused_rgb")
-    assert y.shape == (1, 3, 1024, 1024)
+        assert torch.equal(out, g.convs[15](x32, l1[:, 16], noise=nz[16])) and not hasattr(out, "_hf_fused_rgb")
+    assert y.shape == (2, 3, 1024, 1024)
 
 
 @pytest.mark.parametrize("mode,bar", [("f16", 1e-4), ("f32", 1e-8)])
