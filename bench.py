@@ -572,11 +572,28 @@ def main():
             parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), n_single, load, device=dev)
             barrier()
             ts = max_over_ranks(time.perf_counter() - t0)
+            # ... and the whole swap as one hipGraph replay (HairFast.swap_graphed): the same kernels without the host's launch gaps
+            graph_info = None
+            try:
+                dev_triples = [tuple(t.to(dev) for t in load(i)) for i in range(2)]
+                with torch.inference_mode():
+                    hf.swap_graphed(*dev_triples[0])
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(n_single):
+                        hf.swap_graphed(*dev_triples[i % 2])
+                    torch.cuda.synchronize()
+                    tg = time.perf_counter() - t0
+                graph_info = {"ms_per_swap": round(tg / n_single * 1e3, 2), "triples": n_single,
+                              "note": "HairFast.swap_graphed: one hipGraph replay per swap, images resident on the GPU"}
+            except Exception as e:
+                graph_info = {"error": f"{type(e).__name__}: {e}"[:300]}
             pipeline_info = {"metric": "hair_swap_triples_per_sec", "value": round(n_pipe / tp, 3), "unit": "triples/s",
                              "ms_per_triple_per_gpu": round(tp / (n_pipe / world) * 1e3, 2), "triples": n_pipe,
                              "swap_batch": args.swap_batch,
                              "single_swap": {"ms_per_swap": round(ts / (n_single / world) * 1e3, 2), "triples": n_single,
                                              "note": "one HairFast.swap per triple (no batching across triples)"},
+                             "single_swap_graph": graph_info,
                              "workload": "python bench.py --workload swap256 on a bounded sample: host uint8 -> H2D -> HairFast.swap / "
                                          "swap_batch (every network native, no stand-ins: SEAN, CLIP ViT-B/32 tower, shape adaptor, RotateModel, "
                                          "PostProcess, BiSeNet) -> uint8 -> gather; a BOUNDED SAMPLE of BASELINE.json configs[3] (synthetic weights)"}

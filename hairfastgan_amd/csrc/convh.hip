@@ -730,6 +730,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
 #pragma unroll
       for (int k = 0; k < 4; ++k) nzf[g][k] = 0.0f;
     }
+    HF_TRACE_POINT(7);  // tile geometry done
     // the block's next tile, and its image's s into the other slot (read only after
     // the barriers of this tile's first nchunks-1 stages; nchunks >= 2)
     const int t_next = t_cur + gridDim.x;
@@ -747,6 +748,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
         load_s(nxt.b0, sl_slot);
       }
     }
+    HF_TRACE_POINT(8);  // next tile located
 
     // one chunk = 9 tap-steps; side work spread over the steps: step 0 issues the activation
     // loads of the next stage into registers, steps 0-2 its weight DMAs, the last steps convert

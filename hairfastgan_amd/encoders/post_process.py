@@ -195,8 +195,12 @@ class ClipBlendingModel(nn.Module):  # models/Encoders.py:75-103
             raise NotImplementedError("ClipBlendingModel needs image_embed = the CLIP ViT-B/32 image encoder "
                                       "(clip_model.encode_image of the reference's un-vendored `clip` package)")
         x = torch.nn.functional.adaptive_avg_pool2d(image_tensor, (224, 224)) * 0.5 + 0.5
-        mean = torch.tensor(self.CLIP_MEAN, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
-        std = torch.tensor(self.CLIP_STD, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
+        key = (x.device, x.dtype)
+        if self.__dict__.get("_norm_key") != key:  # created once (no host-to-device copy per call / inside a hipGraph capture)
+            self.__dict__["_norm"] = (torch.tensor(self.CLIP_MEAN, device=x.device, dtype=x.dtype).view(1, 3, 1, 1),
+                                      torch.tensor(self.CLIP_STD, device=x.device, dtype=x.dtype).view(1, 3, 1, 1))
+            self.__dict__["_norm_key"] = key
+        mean, std = self.__dict__["_norm"]
         return self.image_embed((x - mean) / std)
 
     @torch.inference_mode()

@@ -43,10 +43,13 @@ class GraphRunner:
     def __call__(self, *inputs):
         if len(inputs) != len(self.static_in):
             raise ValueError("argument count differs from the captured call")
-        for dst, src in zip(self.static_in, inputs):
-            if dst.shape != src.shape:
-                raise ValueError(f"shape {tuple(src.shape)} differs from the captured {tuple(dst.shape)}")
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src)
-        self.graph.replay()
+        # inference mode like the capture: the graph's RNG bookkeeping (philox offset of the draws recorded inside) is an
+        # inference tensor that replay() updates in place
+        with torch.inference_mode():
+            for dst, src in zip(self.static_in, inputs):
+                if dst.shape != src.shape:
+                    raise ValueError(f"shape {tuple(src.shape)} differs from the captured {tuple(dst.shape)}")
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+            self.graph.replay()
         return self.static_out

@@ -240,7 +240,7 @@ def mask_label_to_one_hot(img):  # shape_util.py:6-14: [B,1,H,W] labels (255 = n
 
 
 def split_hair_face(mask):  # shape_util.py:23-26
-    return mask[:, [HAIR_IDX]], torch.cat([mask[:, :HAIR_IDX], mask[:, HAIR_IDX + 1:]], dim=1)
+    return mask[:, HAIR_IDX:HAIR_IDX + 1], torch.cat([mask[:, :HAIR_IDX], mask[:, HAIR_IDX + 1:]], dim=1)  # (a list index would upload an index tensor: illegal in a hipGraph capture)
 
 
 @torch.inference_mode()

@@ -225,6 +225,30 @@ def test_swap_batch_equals_single_swaps():
     assert len(mixed) == 2 and all(torch.isfinite(m).all() for m in mixed)
 
 
+def test_swap_graphed_equals_eager_swap():
+    """HairFast.swap_graphed: the whole swap as ONE hipGraph replay gives the eager swap's image bit for bit (noise
+    strengths zero: the two forms draw their noise from different points of the RNG stream), also on new inputs through
+    the same captured graph, and repeated images fall back to the eager path."""
+    dev = torch.device("cuda:0")
+    hf = _hairfast(dev)
+    with torch.no_grad():
+        for name, p in hf.net.generator.named_parameters():
+            if name.endswith("noise.weight"):
+                p.zero_()
+    hf.stages.sean_model.netG.noise_source = lambda d, sizes: [torch.zeros(d, r, r, device=dev) for r in sizes]
+    a, b, c = (im.to(dev) for im in C.pipeline_images())
+    eager = hf.swap(a, b, c, seed=5)
+    graphed = hf.swap_graphed(a, b, c, seed=5)
+    assert graphed.shape == (3, 1024, 1024) and torch.equal(graphed, eager)
+    eager2 = hf.swap(c, a, b, seed=5)
+    graphed2 = hf.swap_graphed(c, a, b, seed=5)      # a replay of the graph captured above on other images
+    assert torch.equal(graphed2, eager2) and not torch.equal(graphed2, graphed)
+    assert torch.equal(graphed, eager)                # results are copies, not the graph's static buffer
+    assert len(hf._swap_graphs) == 1
+    same = hf.swap_graphed(a, b, b.clone(), seed=5)   # shape == color: the reference's shortcut path, eager
+    assert torch.equal(same, hf.swap(a, b, b.clone(), seed=5)) and len(hf._swap_graphs) == 1
+
+
 def test_swap_many_forced_rccl_single_rank():
     """BASELINE configs[3] code path with RCCL actually initialised on the hardware (world size 1,
     HF_FORCE_DIST=1): sharding, H2D prefetch stream, uint8 conversion and the chunked all-gather."""

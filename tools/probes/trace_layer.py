@@ -35,7 +35,7 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (8 * 512))()
 L.hf_debug_read_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 print("rc", L.hf_debug_read_trace(buf, 8 * 512))
-names = {1: "tile", 2: "mfma_done", 3: "barrier_done", 4: "epilogue_issued", 5: "pre_convert", 6: "post_convert"}
+names = {1: "tile", 2: "mfma_done", 3: "barrier_done", 4: "epilogue_issued", 5: "pre_convert", 6: "post_convert", 7: "geom_done", 8: "next_located"}
 import collections
 for wave in (0, 5):
     ev = [(buf[wave * 512 + i] >> 56, buf[wave * 512 + i] & ((1 << 56) - 1)) for i in range(512)]
