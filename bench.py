@@ -250,8 +250,11 @@ def kernel_report(prof, elapsed, precision, sampled=1.0):
         else:
             peak, peak_note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA peak"
         traffic, busy, tag = pmc_profile(dom)
+        alg_bytes = d[3] / d[2] if d[3] > 0 else None
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1),
                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                           "algorithmic_bytes_per_launch": None if alg_bytes is None else round(alg_bytes),
+                           "traffic_over_algorithmic": None if (traffic is None or not alg_bytes) else round(traffic / alg_bytes, 3),
                            "traffic_source": (f"{PMC_PROFILE} (tag {tag}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                               f"bench, replayed - NOT measured in this run") if traffic is not None else None,
                            "avg_launch_ms": round(d[1] / d[2] * 1e3, 4), "launches": d[2],
@@ -271,7 +274,7 @@ def kernel_report(prof, elapsed, precision, sampled=1.0):
                        "launches": v[2], "share_of_timed_region": round(v[1] / elapsed, 4)}
     if fam_roof:
         out["roofline_families"] = {"bound": "mfma", "unit": "TFLOP/s", "kernels": fam_roof}
-    hbm = {k: v for k, v in agg.items() if v[3] > 0 and v[0] == 0}
+    hbm = {k: v for k, v in agg.items() if v[3] > 0 and v[0] == 0}  # streaming kernels (no MFMA work)
     if hbm:
         dom = max(hbm, key=lambda k: hbm[k][1])
         d = hbm[dom]

@@ -334,11 +334,15 @@ def modconv3x3_f16_pre(lib, st, act, wt_hi, wt_lo, nterms, d, noise, noise_w, bi
         s_next = _c(split_for)
         sh = torch.empty((b, cout // 8, h, w, 8), dtype=torch.float16, device=dev)
         sl = torch.empty_like(sh) if nterms == 3 else None  # plain fp16 consumer: no lo part
+    # algorithmic HBM bytes (bench.py: traffic / algorithmic): the split input once, every output form once, the weights once
+    nparts = 2 if nterms == 3 else 1
+    nb = (float(b) * h * w * (2.0 * nparts * cin + (4.0 * cout if want_out else 0.0) + (2.0 * nparts * cout if split_for is not None else 0.0)
+                              + (12.0 * torgb_slabs(cout) if rgb is not None else 0.0)) + 2.0 * nparts * 9 * cin * cout)
     code = _launch_profiled(
         lib, 2.0 * cin * cout * 9 * h * w * b,
         lambda: lib.hf_modconv3x3_f16_pre_f32(_p(out), _p(act.hi), _p(act.lo), _p(wt_hi), _p(wt_lo), nterms, _p(d), _p(noise),
                                               _p(noise_w), nbs, _p(bias), b, cin, cout, h, w, alpha, scale, _p(raw),
-                                              _p(rgb_wt), _p(rgb_s), _p(sh), _p(sl), _p(s_next), st))
+                                              _p(rgb_wt), _p(rgb_s), _p(sh), _p(sl), _p(s_next), st), nbytes=nb)
     check(lib, code, "hf_modconv3x3_f16_pre_f32")
     res = [out]
     if rgb is not None:
@@ -466,12 +470,13 @@ def modconv3x3_up_fused(lib, st, x, wt_hi, wt_lo, s, d, factors, noise, noise_w,
     else:
         out = torch.empty((b, cout, 2 * h, 2 * w), dtype=torch.float32, device=dev)
     kx, ky = factors
+    nb_alg = float(b) * (4.0 * cin * h * w + 4.0 * cout * 4 * h * w + 4.0 * 4 * h * w) + 4.0 * 9 * cin * cout  # input, output, noise, weights
     code = _launch_profiled(
         lib, 2.0 * cin * cout * 9 * h * w * b,
         lambda: lib.hf_modconv3x3_up_blur_f16_f32(_p(out), _p(sh), _p(sl), None if pre else _p(x), _p(x.hi) if pre else None,
                                                   _p(x.lo) if pre else None, _p(wt_hi), _p(wt_lo), None if pre else _p(s), _p(d),
                                                   kx, ky, _p(noise), _p(_c(noise_w)), nbs, _p(_c(bias)), _p(s_next), b, cin, cout,
-                                                  h, w, alpha, scale, st))
+                                                  h, w, alpha, scale, st), nbytes=nb_alg)
     check(lib, code, "hf_modconv3x3_up_blur_f16_f32")
     return out if split_for is None else SplitActivation(sh, sl, None)
 
