@@ -31,7 +31,8 @@ SIGNATURES = {
     "hf_modconv3x3_f32": [_f, _f, _f, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _f, _ll, _st],
     "hf_conv_split_weights_f16": [_f, _f, _f, _i, _i, _st],
     "hf_conv_split_weights_f16_taps": [_f, _f, _f, _i, _i, _i, _st],
-    "hf_conv1x1_f16_f32": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _ll, _f, _ll, _st],
+    "hf_modconv3x3_small_f16_f32": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _i, _i, _f, _ll, _st],
+    "hf_conv1x1_f16_f32": [_f, _f, _f, _f, _f, _f, _i, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _ll, _f, _ll, _st],
     "hf_modconv3x3_f16_f32": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _st],
     "hf_modconv3x3_f16_rgb_f32": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _f, _f, _f, _st],
     "hf_modconv3x3_f16_pre_f32": [_f, _f, _f, _f, _f, _i, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _f, _f, _f, _f, _f, _f, _st],
@@ -49,6 +50,7 @@ SIGNATURES = {
     "hf_conv2d_f32": [_f, _f, _f, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _f, _ll, _st],
     "hf_conv2d_f16_f32": [_f, _f, _f, _f, _f, _f, _i, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _ll, _f, _ll, _st],
     "hf_split_activation_f16": [_f, _f, _f, _f, _f, _ll, _i, _i, _i, _st],
+    "hf_split_activation_mod_f16": [_f, _f, _f, _f, _ll, _i, _i, _i, _st],
     "hf_plane_mean_f32": [_f, _f, _i, _i, _st],
     "hf_se_gate_f32": [_f, _f, _f, _f, _i, _i, _i, _st],
     "hf_scale_shortcut_add_f32": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _st],
@@ -106,6 +108,8 @@ def bind(cdll):
     cdll.hf_conv2d_workspace_floats.restype = ctypes.c_longlong
     cdll.hf_conv2d_f16_workspace_floats.argtypes = [_i, _i, _i, _i, _i, _i, _i]
     cdll.hf_conv2d_f16_workspace_floats.restype = ctypes.c_longlong
+    cdll.hf_modconv3x3_small_workspace_floats.argtypes = [_i, _i, _i, _i, _i]
+    cdll.hf_modconv3x3_small_workspace_floats.restype = ctypes.c_longlong
     cdll.hf_conv1x1_f16_workspace_floats.argtypes = [_i, _i, _i, _i, _i, _i, _i]
     cdll.hf_conv1x1_f16_workspace_floats.restype = ctypes.c_longlong
     cdll.hf_sample_layernorm_workspace_floats.argtypes = [_i, _i, _i]

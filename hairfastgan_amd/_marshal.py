@@ -352,6 +352,54 @@ def modconv3x3_f16_pre(lib, st, act, wt_hi, wt_lo, nterms, d, noise, noise_w, bi
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def split_weights_small(lib, st, wt):
+    """Prepared weights wt [9, cin, cout] -> the (hi, lo) blobs hf_modconv3x3_small_f16_f32 takes: the nine taps as the
+    rows of ONE 1x1 GEMM, [1][cin][tap*cout + co], split by hf_conv_split_weights_f16_taps(taps = 1)."""
+    taps, cin, cout = wt.shape
+    w1 = _c(wt).permute(1, 0, 2).reshape(1, cin, taps * cout).contiguous()
+    return conv_split_weights_f16(lib, st, w1)
+
+
+def modconv3x3_small_supported(cin, cout, h, w, batch, upsample=False):
+    """Shapes hf_modconv3x3_small_f16_f32 takes AND pays for (tools/probes/tower.py, 512 -> 512 channels, batch 1 / 3 / 8):
+    same resolution: 256 < batch*h*w <= 2048 pixels per launch (below, the three launches of the tap-GEMM form cost more than
+    the fp32 split-K kernel's two; above, the tiled fp16-core conv fills the chip) - 8^2 at batch 8: 43 -> 30 us, 16^2: 98 ->
+    81 us, 32^2 at batch 1: 70 -> 56 us; transposed: inputs up to 8^2 at any batch (4 -> 8: 72 -> 56 us, 8 -> 16: 141 -> 58 us
+    at batch 8; 62 -> 38 / 68 -> 43 us at batch 1) and 16^2 inputs up to 1024 pixels per launch (batch 3: 110 -> 88 us)."""
+    if cin % 32 or cout % 64 or h * w > 1024:
+        return False
+    n = batch * h * w
+    if upsample:
+        return h * w <= 64 or (h * w <= 256 and n <= 1024)
+    return 256 < n <= 2048
+
+
+def modconv3x3_small(lib, st, x, w9, nterms, s, d, noise, noise_w, bias, cout, alpha=0.2, scale=SQRT2, upsample=False):
+    """hf_modconv3x3_small_f16_f32.  upsample: returns the (2h+1) x pitch intermediate [B,cout,2h+1,pitch] (demodulated)."""
+    x = _c(x)
+    b, cin, h, w = x.shape
+    hi, lo = w9
+    n = lib.hf_modconv3x3_small_workspace_floats(b, cin, cout, h, w)
+    ws = x.new_empty((max(n, 1),))
+    if upsample:
+        pitch = lib.hf_modconv_up_pitch(w)
+        out = x.new_empty((b, cout, 2 * h + 1, pitch))
+        noise = bias = noise_w = None
+        nbs = 0
+    else:
+        pitch = 0
+        out = x.new_empty((b, cout, h, w))
+        noise, nbs = _noise_args(noise, b, h * w)
+    code = _launch_profiled(
+        lib, 2.0 * cin * cout * 9 * h * w * b,
+        lambda: lib.hf_modconv3x3_small_f16_f32(_p(out), _p(x), _p(hi), _p(lo), nterms, _p(_c(s)), _p(_c(d)), _p(noise),
+                                                _p(_c(noise_w)), nbs, _p(_c(bias)), b, cin, cout, h, w, alpha, scale,
+                                                1 if upsample else 0, pitch, _p(ws), n, st),
+        label="gemm_h tap-GEMM (small planes)")
+    check(lib, code, "hf_modconv3x3_small_f16_f32")
+    return out
+
+
 def modconv3x3_up_f16_supported(cin, cout, h, w, batch=None):
     """Shapes hf_modconv3x3_up_f16_f32 takes (include/hairfast_hip.h); batch: see modconv3x3_f16_supported (a batch-1
     16^2 -> 32^2 layer: 84 us on the fp32 split-K kernels, 106 us here)."""
@@ -371,19 +419,25 @@ class SplitActivation:
 
 
 def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha=0.2, scale=SQRT2, f16=None,
-                  split_for=None):
+                  split_for=None, small=None):
     """conv_transpose(stride 2) -> [B,cout,2h+1,2w+1] scratch -> blur+noise+bias+act -> [B,cout,2h,2w].
     f16 = (wt_hi, wt_lo, nterms): part 1 on the fp16 matrix cores (hf_modconv3x3_up_f16_f32).
     split_for = (key, s_next [B,cout]): part 2 writes a SplitActivation for the conv whose modulation
-    is s_next instead of the fp32 tensor (hf_blur_noise_bias_act_split_f16)."""
+    is s_next instead of the fp32 tensor (hf_blur_noise_bias_act_split_f16).
+    small = (w9, nterms): part 1 as the small-plane tap-GEMM (hf_modconv3x3_small_f16_f32, upsample form)."""
     pre = isinstance(x, SplitActivation)
     if not pre:
         x = _c(x)
     b, cin, h, w = x.shape
     cout = wt.shape[2]
     pitch = lib.hf_modconv_up_pitch(w)  # rows padded to a multiple of 4 floats (aligned 16 B loads in the blur)
-    tmp = torch.empty((b, cout, 2 * h + 1, pitch), dtype=torch.float32, device=(x.hi if pre else x).device)
-    if pre:  # pre-split input (modulation already applied by the producer): hf_modconv3x3_up_f16_pre_f32
+    if small is not None and not pre:
+        tmp = modconv3x3_small(lib, st, x, small[0], small[1], s, d, None, None, None, cout, upsample=True)
+    else:
+        tmp = torch.empty((b, cout, 2 * h + 1, pitch), dtype=torch.float32, device=(x.hi if pre else x).device)
+    if small is not None and not pre:
+        pass
+    elif pre:  # pre-split input (modulation already applied by the producer): hf_modconv3x3_up_f16_pre_f32
         hi, lo, nterms = f16
         code = _launch_profiled(
             lib, 2.0 * cin * cout * 9 * h * w * b,
@@ -595,9 +649,18 @@ def conv1x1_f16_supported(cin, cout):
 
 def conv1x1_f16(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None, in_shift=None, out_scale=None, bias=None,
                 act=ACT_NONE, slope=None, alpha=0.0, residual=None, groups=1, x_shared=True):
-    """hf_conv1x1_f16_f32: a 1x1 conv / Linear layer as a GEMM on the fp16 matrix cores; argument meaning as conv2d()."""
-    x = _c(x)
-    if groups > 1 and not x_shared:
+    """hf_conv1x1_f16_f32: a 1x1 conv / Linear layer as a GEMM on the fp16 matrix cores; argument meaning as conv2d().
+    x may be a SplitActivation (stride 1, no groups, affine already applied)."""
+    pre = isinstance(x, SplitActivation)
+    if pre:
+        b, cin, h, w = x.shape
+        x_gstride = 0
+        proto = x.hi
+    else:
+        x = proto = _c(x)
+    if pre:
+        pass
+    elif groups > 1 and not x_shared:
         g_, b, cin, h, w = x.shape
         if g_ != groups:
             raise ValueError("x must be [groups, B, cin, H, W]")
@@ -606,16 +669,17 @@ def conv1x1_f16(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None,
         b, cin, h, w = x.shape
         x_gstride = 0
     oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
-    out = x.new_empty((groups, b, cout, oh, ow) if groups > 1 else (b, cout, oh, ow))
+    out = torch.empty((groups, b, cout, oh, ow) if groups > 1 else (b, cout, oh, ow), dtype=torch.float32, device=proto.device)
     if residual is not None:
         residual = _c(residual)
         if tuple(residual.shape) != tuple(out.shape):
             raise ValueError(f"residual {tuple(residual.shape)} != output {tuple(out.shape)}")
     n = lib.hf_conv1x1_f16_workspace_floats(b, cin, cout, h, w, stride, groups)
-    ws = x.new_empty((n,)) if n > 0 else None
+    ws = torch.empty((n,), dtype=torch.float32, device=proto.device) if n > 0 else None
     code = _launch_profiled(
         lib, 2.0 * cin * cout * oh * ow * b * groups,
-        lambda: lib.hf_conv1x1_f16_f32(_p(out), _p(x), _p(wt_hi), _p(wt_lo), nterms, _p(_c(in_scale)), _p(_c(in_shift)),
+        lambda: lib.hf_conv1x1_f16_f32(_p(out), None if pre else _p(x), _p(x.hi) if pre else None, _p(x.lo) if pre else None,
+                                       _p(wt_hi), _p(wt_lo), nterms, _p(_c(in_scale)), _p(_c(in_shift)),
                                        _p(_c(out_scale)), _p(_c(bias)), act, _p(_c(slope)), float(alpha), _p(residual), b, cin, cout,
                                        h, w, stride, groups, x_gstride, _p(ws), max(n, 0), st),
         label="gemm_h")

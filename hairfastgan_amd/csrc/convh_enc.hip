@@ -420,7 +420,7 @@ int run_enc(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *ws, lo
 __global__ __launch_bounds__(256) void split_activation(half8 *__restrict__ hi, half8 *__restrict__ lo,
                                                         const float *__restrict__ x, const float *__restrict__ s,
                                                         const float *__restrict__ t, int channels, long long plane,
-                                                        long long total) {
+                                                        long long total, int s_istride) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   const int cblocks = channels >> 3;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void split_activation(half8 *__restrict__ hi, 
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int c = cb * 8 + k;
-      const float v = fmaf(src[k * plane], s ? s[c] : 1.0f, t ? t[c] : 0.0f);
+      const float v = fmaf(src[k * plane], s ? s[im * s_istride + c] : 1.0f, t ? t[c] : 0.0f);
       _Float16 hv, lv;
       hf_split_f16(v, hv, lv, ovf);
       h8[k] = hv;
@@ -503,6 +503,19 @@ extern "C" int hf_split_activation_f16(void *out_hi, void *out_lo, const float *
   long long g = (total + 255) / 256;
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(split_activation, dim3((int)g), dim3(256), 0, (hipStream_t)stream, static_cast<half8 *>(out_hi),
-                     static_cast<half8 *>(out_lo), x, in_scale, in_shift, channels, plane, total);
+                     static_cast<half8 *>(out_lo), x, in_scale, in_shift, channels, plane, total, 0);
+  return hf_launch_status();
+}
+
+// hf_split_activation_f16 with a PER-IMAGE scale s[image][channel] (the modulation of a ModulatedConv2d applied to its
+// input, models/stylegan2/model.py:241-248) instead of the per-channel affine
+extern "C" int hf_split_activation_mod_f16(void *out_hi, void *out_lo, const float *x, const float *scale, long long images,
+                                           int channels, int h, int w, void *stream) {
+  if (!out_hi || !x || images <= 0 || channels <= 0 || (channels & 7) || h <= 0 || w <= 0) return HF_E_INVALID;
+  const long long plane = (long long)h * w, total = images * (channels >> 3) * plane;
+  long long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(split_activation, dim3((int)g), dim3(256), 0, (hipStream_t)stream, static_cast<half8 *>(out_hi),
+                     static_cast<half8 *>(out_lo), x, scale, (const float *)nullptr, channels, plane, total, scale ? channels : 0);
   return hf_launch_status();
 }

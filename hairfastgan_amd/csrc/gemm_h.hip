@@ -27,7 +27,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KH = 16;   // input channels per MFMA k-step
 constexpr int KS = 32;   // input channels per LDS stage
 
-template <int NTERMS, int PG>
+// PRE: the activations arrive already transformed, split into fp16 (hi, lo) and K-blocked ([image][cin/8][h*w][8 halves]:
+// hf_split_activation_f16 / hf_split_activation_mod_f16; ConvParams::xh / xl) and are staged by LDS-DMA like the weights -
+// an input shared by many output-channel tiles (the tap-GEMM's 72, the CLIP MLP's 48) is converted once, not once per block.
+template <int NTERMS, int PG, bool PRE>
 __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
                                                  const _Float16 *__restrict__ wtl_all) {
   constexpr int NT = 256, CT = 64, PT = 64 * PG;
@@ -62,11 +65,13 @@ __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Floa
   const int b0 = (t / G.tiles_x) << G.lg_nb;
   const int tx0 = tx << G.lg_tw;
   const long long iplane = (long long)P.h * P.w;
-  const float *xb = P.x + go.x;
+  const float *xb = PRE ? nullptr : P.x + go.x;
 
   // staging items (stage invariant): element offset of the source pixel inside image 0's channel 0 plane (+ image
   // offset), -1 = outside (zero)
   long long e_src[XE];
+  long long e_unit[XE];  // PRE: 16-byte unit of the pixel in channel block 0 of its image
+  int e_sofs[XE];  // offset of the item's image inside in_scale (s_bstride != 0: a per-image scale, the modulation)
 #pragma unroll
   for (int e = 0; e < XE; ++e) {
     const int i = tid + e * NT;
@@ -74,9 +79,12 @@ __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Floa
     const int pp = px & ((1 << G.lg_tw) - 1), im = px >> G.lg_tw;
     const int p = tx0 + pp, b = b0 + im;
     e_src[e] = -1;
+    e_unit[e] = 0;
+    e_sofs[e] = (b < P.batch ? b : 0) * P.s_bstride;
     if (p < oplane && b < P.batch) {
       const int oy = p / P.out_wv, ox = p - oy * P.out_wv;  // out_wv: the true output width (out_w is the flat plane)
       e_src[e] = (long long)b * P.cin * iplane + (long long)(oy * P.stride) * P.w + ox * P.stride;
+      e_unit[e] = (long long)b * (P.cin >> 3) * iplane + p;
     }
   }
 
@@ -94,17 +102,34 @@ __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Floa
       hf_glds16_raw_s(src, (unsigned)lane * 16u, lds_addr0 + (unsigned)(bufsel * BUF_UNITS + part * W_UNITS + q * 64) * 16u);
     }
   };
-  float xr[XE][8];
+  // PRE: one 16-byte unit per lane and item straight into LDS (stride 1: e_src is b*cin*plane + p -> unit (b*cin/8 + kblock)*plane + p);
+  // items outside the image are masked out of the DMA and stay zero (filled once below)
+  auto dma_x = [&](int stage, int bufsel) {
+#pragma unroll
+    for (int e = 0; e < XE; ++e) {
+      const int i = tid + e * NT;
+      const int kb = i / PT;
+      const bool inside = e_src[e] >= 0;
+      const long long unit = e_unit[e] + (long long)(stage * (KS / 8) + kb) * iplane;
+      const unsigned off = (unsigned)(unit * 16);
+      const unsigned dst = lds_addr0 + (unsigned)(bufsel * BUF_UNITS + OFF_XH + (i - lane)) * 16u;
+      hf_glds16_raw_s_if(inside, P.xh, off, dst);
+      if (NTERMS == 3) hf_glds16_raw_s_if(inside, P.xl, off, dst + (unsigned)X_UNITS * 16u);
+    }
+  };
+  float xr[PRE ? 1 : XE][8];
   auto load_x = [&](int stage) {
+    if (PRE) return;
 #pragma unroll
     for (int e = 0; e < XE; ++e) {
       const int kb = (tid + e * NT) / PT;
       const float *src = xb + (e_src[e] >= 0 ? e_src[e] : 0) + (long long)(stage * KS + kb * 8) * iplane;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) xr[e][k] = src[(long long)k * iplane];
+      for (int k = 0; k < 8; ++k) xr[PRE ? 0 : e][k] = src[(long long)k * iplane];
     }
   };
   auto convert_x = [&](int stage, half8 *buf) {
+    if (PRE) return;
     bool ovf = false;
 #pragma unroll
     for (int e = 0; e < XE; ++e) {
@@ -114,9 +139,8 @@ __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Floa
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int ci = stage * KS + kb * 8 + k;
-        float v = xr[e][k];
-        if (P.s) v *= P.s[ci];
-        if (P.t) v += P.t[ci];
+        float v = xr[PRE ? 0 : e][k];
+        v = fmaf(v, P.s ? P.s[e_sofs[e] + ci] : 1.0f, P.t ? P.t[ci] : 0.0f);  // as hf_split_activation_f16 rounds it
         if (e_src[e] < 0) v = 0.0f;
         _Float16 hv, lv;
         hf_split_f16(v, hv, lv, ovf);
@@ -135,8 +159,24 @@ __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Floa
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][g][r] = 0.0f;
 
+  if (PRE) {  // items outside the image: zero in both buffers, once (the masked DMA never touches them)
+    half8 z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.0f;
+#pragma unroll
+    for (int e = 0; e < XE; ++e)
+      if (e_src[e] < 0) {
+        const int i = tid + e * NT;
+#pragma unroll
+        for (int bsel = 0; bsel < 2; ++bsel) {
+          lds[bsel * BUF_UNITS + OFF_XH + i] = z;
+          if (NTERMS == 3) lds[bsel * BUF_UNITS + OFF_XL + i] = z;
+        }
+      }
+  }
   if (s_begin < s_end) {
     dma_w(s_begin, 0);
+    if (PRE) dma_x(s_begin, 0);
     load_x(s_begin);
     convert_x(s_begin, lds);
   }
@@ -147,6 +187,7 @@ __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Floa
     const bool more = s + 1 < s_end;
     if (more) {
       dma_w(s + 1, cb ^ 1);
+      if (PRE) dma_x(s + 1, cb ^ 1);
       load_x(s + 1);
     }
 #pragma unroll
@@ -199,7 +240,14 @@ int launch_gemm(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStre
   const size_t lds = (size_t)2 * NPART * ((KS / 8) * 64 + (KS / 8) * PT) * 16;
   dim3 grid(nblocks, P.co_tiles * max(1, P.groups), P.splits);
   if (grid.y > 65535 || grid.z > 65535) return HF_E_INVALID;
-  hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG>), grid, dim3(256), lds, st, P, wth, wtl);
+  if (P.xh) {
+    if (P.stride != 1 || P.s || P.t || (NTERMS == 3 && !P.xl) || P.groups > 1 ||
+        (long long)P.batch * P.cin * P.h * P.w * 2 >= (1LL << 32))
+      return HF_E_INVALID;  // 32-bit unit offsets; the affine went into the split
+    hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, true>), grid, dim3(256), lds, st, P, wth, wtl);
+  } else {
+    hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, false>), grid, dim3(256), lds, st, P, wth, wtl);
+  }
   return hf_launch_status();
 }
 
@@ -232,18 +280,19 @@ extern "C" long long hf_conv1x1_f16_workspace_floats(int batch, int cin, int cou
   return sk > 1 ? (long long)sk * (groups > 1 ? groups : 1) * batch * cout * oh * ow : 0;
 }
 
-extern "C" int hf_conv1x1_f16_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
-                                  const float *in_scale, const float *in_shift, const float *out_scale, const float *bias,
+extern "C" int hf_conv1x1_f16_f32(float *out, const float *x, const void *x_hi, const void *x_lo, const void *wt_hi,
+                                  const void *wt_lo, int nterms, const float *in_scale, const float *in_shift, const float *out_scale, const float *bias,
                                   int act, const float *slope, float alpha, const float *residual, int batch, int cin,
                                   int cout, int h, int w, int stride, int groups, long long x_group_stride,
                                   float *workspace, long long workspace_floats, void *stream) {
   const int act_kind = act & ~HF_ACT_RESIDUAL_FIRST;
-  if (!out || !x || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (nterms != 1 && nterms != 3) ||
+  if (!out || (!x && !x_hi) || !wt_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (nterms != 1 && nterms != 3) ||
       (nterms == 3 && !wt_lo) || (stride != 1 && stride != 2) || (cin % KS) || (cout % 64) || act_kind < 0 || act_kind > ACT_QGELU ||
-      (act_kind == ACT_PRELU && !slope) || groups < 1 || (groups > 1 && (in_scale || in_shift)))
+      (act_kind == ACT_PRELU && !slope) || groups < 1 || (groups > 1 && (in_scale || in_shift)) ||
+      (x_hi && (in_scale || in_shift || stride != 1 || groups > 1 || (nterms == 3 && !x_lo))))
     return HF_E_INVALID;
   ConvParams P{};
-  P.out = out; P.x = x; P.s = in_scale; P.t = in_shift; P.d = out_scale; P.bias = bias; P.slope = slope;
+  P.out = out; P.x = x; P.xh = x_hi; P.xl = x_lo; P.s = in_scale; P.t = in_shift; P.d = out_scale; P.bias = bias; P.slope = slope;
   P.residual = residual; P.residual_pre = (act & HF_ACT_RESIDUAL_FIRST) ? 1 : 0;
   P.s_bstride = 0; P.d_bstride = 0;
   P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w;
@@ -279,6 +328,139 @@ extern "C" int hf_conv1x1_f16_f32(float *out, const float *x, const void *wt_hi,
     return launch_splitk_reduce(P, true, (hipStream_t)stream);
   }
   return HF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small-plane modulated 3x3 convolutions (the generator's 4^2 .. 16^2 tower: 512 -> 512 channels, 128 .. 2048 pixels per
+// batch of 8): the nine taps as ONE 1x1 GEMM with M = 9*cout - y_tap[b, co, p] = sum_ci wt[tap][ci][co] * s[b,ci] x[b,ci,p],
+// no shifts, no halo, no im2col - followed by a combine pass that adds the taps at their shifted positions (and the
+// split-K partials, in a fixed order) and applies the layer's tail:
+//   same resolution (ModulatedConv2d.forward, models/stylegan2/model.py:238-250, 273-277 + StyledConv's noise / bias /
+//     leaky ReLU, :337-343):     out[y, x]  = act( d * sum_{ky,kx} y_(ky,kx)[y+ky-1, x+kx-1] + noise + bias )
+//   transposed, stride 2 (:252-262, F.conv_transpose2d): tmp[2y+ky, 2x+kx] += d * y_(ky,kx)[y, x]  (gathered per output),
+//     the (2h+1) x pitch intermediate hf_blur_noise_bias_act_* consume.
+// The layers are weight-bound (9.4 MB per layer, 0.6 - 10 GFLOP): the GEMM spreads (tap, channel tile, K split) over the
+// whole chip - the tiled conv kernels give a 16^2 layer at batch 8 only 64 blocks that each walk all of K.
+__global__ __launch_bounds__(256) void small_combine(float *__restrict__ out, const float *__restrict__ y, int splits,
+                                                     long long zslab, const float *__restrict__ d,
+                                                     const float *__restrict__ noise, const float *__restrict__ noise_w,
+                                                     long long noise_bstride, const float *__restrict__ bias, int batch,
+                                                     int cout, int h, int w, int up, int out_h, int out_pitch, int out_wv,
+                                                     float alpha, float scale) {
+  const long long oplane = (long long)out_h * out_pitch, iplane = (long long)h * w;
+  const long long total = (long long)batch * cout * oplane;
+  const long long stride = (long long)gridDim.x * 256;
+  const float nw = noise ? noise_w[0] : 0.0f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int ox = (int)(i % out_pitch);
+    long long r = i / out_pitch;
+    const int oy = (int)(r % out_h);
+    r /= out_h;
+    const int co = (int)(r % cout), b = (int)(r / cout);
+    if (ox >= out_wv) continue;  // pitch padding of the transposed conv's intermediate
+    float acc = 0.0f;
+    const float *yb = y + ((long long)b * 9 * cout + co) * iplane;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        int sy, sx;
+        bool ok;
+        if (up) {
+          const int ty = oy - ky, tx = ox - kx;
+          ok = ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) && (ty >> 1) < h && (tx >> 1) < w;
+          sy = ty >> 1;
+          sx = tx >> 1;
+        } else {
+          sy = oy + ky - 1;
+          sx = ox + kx - 1;
+          ok = sy >= 0 && sy < h && sx >= 0 && sx < w;
+        }
+        if (ok) {
+          const float *src = yb + (long long)(ky * 3 + kx) * cout * iplane + (long long)sy * w + sx;
+          float v = 0.0f;
+          for (int z = 0; z < splits; ++z) v += src[(long long)z * zslab];
+          acc += v;
+        }
+      }
+    float v = acc * (d ? d[(long long)b * cout + co] : 1.0f);
+    if (!up) {
+      if (noise) v = fmaf(nw, noise[(long long)b * noise_bstride + (long long)oy * out_pitch + ox], v);
+      if (bias) v = hf_lrelu(v + bias[co], alpha, scale);
+    }
+    out[i] = v;
+  }
+}
+
+extern "C" int hf_split_activation_mod_f16(void *out_hi, void *out_lo, const float *x, const float *scale, long long images,
+                                           int channels, int h, int w, void *stream);
+
+static int small_gemm(ConvParams &P, const void *w9_hi, const void *w9_lo, int nterms, const float *x, const float *s,
+                      int batch, int cin, int cout, int h, int w, float *workspace, long long workspace_floats,
+                      hipStream_t st) {
+  P = ConvParams{};
+  // the modulated input, split once for all 9*cout/64 channel tiles: hi (+ lo) behind the tap slabs in the workspace
+  const long long split_floats = (long long)batch * cin * h * w / 2;  // halves -> floats, per part
+  {
+    const int sk0 = gemm_splits(batch, cin, 9 * cout, h * w, 1);
+    const long long need = (long long)sk0 * batch * 9 * cout * h * w + 2 * split_floats;
+    if (!workspace || workspace_floats < need) return HF_E_WORKSPACE;
+    float *xs_hi = workspace + (long long)sk0 * batch * 9 * cout * h * w, *xs_lo = xs_hi + split_floats;
+    const int rc = hf_split_activation_mod_f16(xs_hi, nterms == 3 ? xs_lo : nullptr, x, s, batch, cin, h, w, st);
+    if (rc != HF_OK) return rc;
+    P.xh = xs_hi;
+    P.xl = nterms == 3 ? xs_lo : nullptr;
+  }
+  P.x = x; P.s = nullptr; P.s_bstride = 0; P.d_bstride = 0;
+  P.batch = batch; P.cin = cin; P.cout = 9 * cout; P.h = h; P.w = w; P.stride = 1;
+  P.out_h = 1; P.out_w = h * w; P.out_wv = w;
+  P.act = ACT_NONE; P.scale = 1.0f;
+  P.groups = 1; P.co_tiles = 9 * cout / 64;
+  const int oplane = h * w;
+  int sk = gemm_splits(batch, cin, 9 * cout, oplane, 1);
+  const int stages = cin / KS;
+  P.chunks_per_split = (stages + sk - 1) / sk;
+  sk = (stages + P.chunks_per_split - 1) / P.chunks_per_split;
+  P.splits = sk;
+  const long long slab = (long long)batch * 9 * cout * oplane;
+  if (!workspace || workspace_floats < (long long)sk * slab) return HF_E_WORKSPACE;
+  // the GEMM always stores through the split-K path (raw sums into the workspace, one slab per split)
+  P.partial = workspace;
+  P.zslab = slab;
+  P.out = workspace;
+  if (sk == 1) P.splits = 1;  // one slab, written by the ordinary epilogue (no scale / bias / activation set)
+  const _Float16 *hi = static_cast<const _Float16 *>(w9_hi), *lo = static_cast<const _Float16 *>(w9_lo);
+  const bool small = (long long)oplane * batch <= 128 || oplane <= 128;
+  if (small) return (nterms == 3) ? launch_gemm<3, 2>(P, hi, lo, st) : launch_gemm<1, 2>(P, hi, lo, st);
+  return (nterms == 3) ? launch_gemm<3, 4>(P, hi, lo, st) : launch_gemm<1, 4>(P, hi, lo, st);
+}
+
+extern "C" long long hf_modconv3x3_small_workspace_floats(int batch, int cin, int cout, int h, int w) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (cin % KS) || (cout % 64)) return 0;
+  const int sk = gemm_splits(batch, cin, 9 * cout, h * w, 1);
+  return (long long)sk * batch * 9 * cout * h * w + (long long)batch * cin * h * w;  // tap slabs + the split input (hi, lo)
+}
+
+extern "C" int hf_modconv3x3_small_f16_f32(float *out, const float *x, const void *w9_hi, const void *w9_lo, int nterms,
+                                           const float *s, const float *d, const float *noise, const float *noise_w,
+                                           long long noise_bstride, const float *bias, int batch, int cin, int cout, int h,
+                                           int w, float alpha, float scale, int upsample, int tmp_pitch, float *workspace,
+                                           long long workspace_floats, void *stream) {
+  if (!out || !x || !w9_hi || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (nterms != 1 && nterms != 3) ||
+      (nterms == 3 && !w9_lo) || (cin % KS) || (cout % 64) || (noise && !noise_w) || h * w > 1024 ||
+      (upsample && (tmp_pitch < 2 * w + 1 || noise || bias)))
+    return HF_E_INVALID;
+  ConvParams P;
+  const int rc = small_gemm(P, w9_hi, w9_lo, nterms, x, s, batch, cin, cout, h, w, workspace, workspace_floats, (hipStream_t)stream);
+  if (rc != HF_OK) return rc;
+  const int out_h = upsample ? 2 * h + 1 : h, pitch = upsample ? tmp_pitch : w, wv = upsample ? 2 * w + 1 : w;
+  const long long total = (long long)batch * cout * out_h * pitch;
+  long long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(small_combine, dim3((int)g), dim3(256), 0, (hipStream_t)stream, out, workspace, P.splits, P.zslab, d, noise,
+                     noise_w, noise_bstride, bias, batch, cout, h, w, upsample ? 1 : 0, out_h, pitch, wv, alpha, scale);
+  note_path(7, upsample ? 4 : 3);
+  return hf_launch_status();
 }
 
 extern "C" unsigned long long hf_f16_overflow_count_gemm(int reset) { return hf_f16_overflow_read_tu(reset); }

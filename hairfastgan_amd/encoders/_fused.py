@@ -79,7 +79,13 @@ def conv(x, w, k, stride=1, presplit=False, **kw):
     h, wd = x.shape[-2], x.shape[-1]
     if mode != "f32" and k == 1 and USE_GEMM_H and M.conv1x1_f16_supported(w.cin, w.cout):
         hi, lo = w.f16()
-        return M.conv1x1_f16(lib(), stream(), x, hi, lo, 3 if mode == "f16x3" else 1, w.cout, stride, **kw)
+        nterms = 3 if mode == "f16x3" else 1
+        # one input feeding >= 8 output-channel tiles over enough pixels: convert it once (hf_split_activation_f16), the
+        # GEMM then stages it by LDS-DMA instead of converting it in every block column
+        if (PRESPLIT == "all" and stride == 1 and kw.get("groups", 1) == 1 and w.cout // 64 >= 8
+                and x.shape[0] * h * wd >= 512 and w.cin % 8 == 0):
+            x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None), want_lo=nterms == 3)
+        return M.conv1x1_f16(lib(), stream(), x, hi, lo, nterms, w.cout, stride, **kw)
     if mode != "f32" and M.conv2d_f16_supported(w.cin, w.cout, h, wd, k, stride):
         hi, lo = w.f16()
         nterms = 3 if mode == "f16x3" else 1

@@ -168,11 +168,24 @@ class ModulatedConv2d(nn.Module):  # :183-279
             self._prep_f16 = (key, hi, lo)
         return self._prep_f16[1], self._prep_f16[2]
 
+    def prepared_small(self):
+        """(hi, lo) of the prepared weight as the rows of ONE 1x1 GEMM, [cin][tap*cout + co] (M.split_weights_small; cached)."""
+        wt, _ = self.prepared()
+        key = self._prep[0]
+        cached = self.__dict__.get("_prep_small")
+        if cached is None or cached[0] != key:
+            cached = self.__dict__["_prep_small"] = (key, M.split_weights_small(lib(), stream(), wt))
+        return cached[1]
+
     def conv_same_res(self, input, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=math.sqrt(2), rgb=None):
         """3x3 same-resolution modulated conv (+ fused noise/bias/lrelu epilogue) on the matrix
         cores the process-wide mode selects (_runtime.conv_precision).  rgb: see fuses_torgb."""
         mode = conv_precision()
         b_, cin, h, w = input.shape
+        if mode != "f32" and rgb is None and M.modconv3x3_small_supported(cin, self.out_channel, h, w, b_):
+            # small planes (the 4^2 - 32^2 tower at small batch): nine taps as one GEMM over the whole chip + a combine pass
+            return M.modconv3x3_small(lib(), stream(), input, self.prepared_small(), 3 if mode == "f16x3" else 1, s, d, noise,
+                                      noise_w, bias, self.out_channel, alpha, scale)
         if mode != "f32" and M.modconv3x3_f16_supported(cin, self.out_channel, h, w, batch=b_):
             hi, lo = self.prepared_f16()
             return M.modconv3x3_f16(lib(), stream(), input, hi, lo, 3 if mode == "f16x3" else 1, s, d, noise,
@@ -213,12 +226,15 @@ class ModulatedConv2d(nn.Module):  # :183-279
                 hi, lo = self.prepared_f16()
                 return M.modconv3x3_up_fused(lib(), stream(), input, hi, lo, s, d, fac, noise, noise_w, bias, alpha, scale,
                                              split_for=None if split_for is None else split_for[1])
-        f16 = None
-        if mode != "f32" and M.modconv3x3_up_f16_supported(cin, self.out_channel, h, w, batch=input.shape[0]):
+        f16 = small = None
+        if (mode != "f32" and not isinstance(input, M.SplitActivation)
+                and M.modconv3x3_small_supported(cin, self.out_channel, h, w, input.shape[0], upsample=True)):
+            small = (self.prepared_small(), 3 if mode == "f16x3" else 1)  # small planes: the nine taps as one GEMM
+        elif mode != "f32" and M.modconv3x3_up_f16_supported(cin, self.out_channel, h, w, batch=input.shape[0]):
             hi, lo = self.prepared_f16()
             f16 = (hi, lo, 3 if mode == "f16x3" else 1)
         return M.modconv3x3_up(lib(), stream(), input, wt, s, d, self.blur.kernel, noise, noise_w, bias, alpha, scale,
-                               f16=f16, split_for=split_for)
+                               f16=f16, split_for=split_for, small=small)
 
     def style_coefficients(self, style):
         """s[b,ci] (EqualLinear :241) and d[b,co] (:244-246; None when demodulate=False).  With

@@ -364,19 +364,42 @@ long long hf_conv2d_f16_workspace_floats(int batch, int cin, int cout, int h, in
  * wt_hi / wt_lo: hf_conv_split_weights_f16_taps(taps = 1) of the prepared [1][cin][cout] weights; per group a
  * self-contained [cin*cout halves | 16-byte trailer] (hi) and cin*cout halves (lo).  cin % 32 == 0, cout % 64 == 0,
  * otherwise HF_E_INVALID (callers use hf_conv2d_f32).  groups > 1 as in hf_conv2d_f32 (in_scale / in_shift NULL).
+ * x_hi / x_lo (NULL = off; stride 1, groups 1, no in_scale / in_shift): the input pre-split by hf_split_activation_f16
+ * ([images][cin/8][h*w][8] fp16), staged by LDS-DMA - worth it when one input feeds many 64-channel output tiles.
  * workspace: hf_conv1x1_f16_workspace_floats() floats (small grids split K; 0 -> may be NULL). */
-int hf_conv1x1_f16_f32(float *out, const float *x, const void *wt_hi, const void *wt_lo, int nterms,
-                       const float *in_scale, const float *in_shift, const float *out_scale, const float *bias, int act,
+int hf_conv1x1_f16_f32(float *out, const float *x, const void *x_hi, const void *x_lo, const void *wt_hi,
+                       const void *wt_lo, int nterms, const float *in_scale, const float *in_shift, const float *out_scale, const float *bias, int act,
                        const float *slope, float alpha, const float *residual, int batch, int cin, int cout, int h, int w,
                        int stride, int groups, long long x_group_stride, float *workspace, long long workspace_floats,
                        void *stream);
 long long hf_conv1x1_f16_workspace_floats(int batch, int cin, int cout, int h, int w, int stride, int groups);
+/* Small-plane modulated 3x3 convolution (h*w <= 1024; the generator's 4^2 .. 16^2 layers) on the fp16 matrix cores:
+ * the nine taps as one 1x1 GEMM with 9*cout output rows over the modulated input (no halo, no shifts), then a combine
+ * pass that adds the taps at their shifted positions - and the split-K partials - in a fixed order and applies the tail.
+ *   upsample == 0: hf_modconv3x3_f32's contract (ModulatedConv2d.forward same-resolution branch, model.py:238-250,
+ *     273-277, + noise / bias / leaky ReLU of StyledConv.forward :337-343): out [batch,cout,h,w];
+ *   upsample != 0: hf_modconv3x3_up_f32's (F.conv_transpose2d stride 2, model.py:252-262): out = the demodulated
+ *     [batch,cout,2h+1,tmp_pitch] intermediate for hf_blur_noise_bias_act_*; noise / bias must be NULL.
+ * w9_hi / w9_lo: hf_conv_split_weights_f16_taps(taps = 1, cin, 9*cout) of the prepared weights re-laid out
+ * [1][cin][tap*cout + co] (from hf_modconv_prepare_f32's wt[tap][ci][co]).  cin % 32 == 0, cout % 64 == 0.
+ * workspace: hf_modconv3x3_small_workspace_floats() floats (the per-tap products, one slab per K split). */
+int hf_modconv3x3_small_f16_f32(float *out, const float *x, const void *w9_hi, const void *w9_lo, int nterms, const float *s,
+                                const float *d, const float *noise, const float *noise_w, long long noise_bstride,
+                                const float *bias, int batch, int cin, int cout, int h, int w, float alpha, float scale,
+                                int upsample, int tmp_pitch, float *workspace, long long workspace_floats, void *stream);
+long long hf_modconv3x3_small_workspace_floats(int batch, int cin, int cout, int h, int w);
 /* in_scale[c]*x + in_shift[c] (NULL = identity) split into fp16 pairs hi = fp16(v), lo = fp16(v - hi)
  * (saturating, hf_f16_overflow_count) and K-blocked: out_hi / out_lo [images][channels/8][h][w][8];
  * x [images][channels][h][w] fp32, channels % 8 == 0.  out_lo may be NULL (nterms 1 consumer).
  * The producer-side form of the conversion hf_conv2d_f16_f32 otherwise does per block while staging. */
 int hf_split_activation_f16(void *out_hi, void *out_lo, const float *x, const float *in_scale, const float *in_shift,
                             long long images, int channels, int h, int w, void *stream);
+
+/* hf_split_activation_f16 with a per-IMAGE scale: scale[image][channel] * x (NULL = 1) - the modulation s of a
+ * ModulatedConv2d applied to its input (models/stylegan2/model.py:241-248) - for the pre-split consumers
+ * (hf_conv1x1_f16_f32's x_hi / x_lo; used inside hf_modconv3x3_small_f16_f32). */
+int hf_split_activation_mod_f16(void *out_hi, void *out_lo, const float *x, const float *scale, long long images,
+                                int channels, int h, int w, void *stream);
 
 /* out[p] = mean of plane p (AdaptiveAvgPool2d(1) of SEModule, helpers.py:60,68). */
 int hf_plane_mean_f32(float *out, const float *x, int planes, int hw, void *stream);

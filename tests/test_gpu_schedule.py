@@ -215,10 +215,12 @@ def test_swap_batch_equals_single_swaps():
             close(both["calls"][ci]["layer_in"][t:t + 1], one["calls"][ci]["layer_in"], f"triple {t} {what} layer_in")
         close(both["result"][t], one["result"], f"triple {t} final image")
     print("swap_batch vs single swaps, mask index differences:", flips)
-    # BiSeNet masks: equal.  The shape adaptor's label maps (an argmax over 19 scores of a 2048-wide bottleneck decoder)
-    # may differ in a handful of near-tie pixels between the two batch sizes (different split-K plans): counted, bounded,
-    # and - by teacher forcing above - kept out of the later stages' comparisons.
-    assert all(v == 0 for k, v in flips.items() if "target" not in k), flips
+    # BiSeNet masks of the INPUT images: equal.  The masks of the GENERATED (rotated) images and the shape adaptor's label
+    # maps are argmaxes downstream of kernels whose tile / split-K plans depend on the batch size (a batch-4 and a batch-2
+    # generator forward take different small-plane kernels): a handful of near-tie pixels may differ - counted, bounded,
+    # and, by teacher forcing above, kept out of the later stages' comparisons.
+    assert all(v == 0 for k, v in flips.items() if "/mask_" in k), flips
+    assert all(v <= 4 for k, v in flips.items() if "rot_masks" in k), flips
     assert all(v <= 8 for k, v in flips.items() if "target" in k), flips
     # a triple that repeats an image takes the single path (the reference's shortcuts), the other one the batched path
     mixed = hf.swap_batch([triples[0], (triples[1][0], triples[1][1], triples[1][1].clone())], seed=3)

@@ -37,7 +37,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert set(_lib.SIGNATURES) | {"hf_strerror", "hf_abi_version", "hf_modconv_workspace_floats", "hf_conv2d_workspace_floats",
                                     "hf_f16_overflow_count", "hf_conv2d_f16_workspace_floats",
-                                    "hf_sample_layernorm_workspace_floats", "hf_conv1x1_f16_workspace_floats"} == declared
+                                    "hf_sample_layernorm_workspace_floats", "hf_conv1x1_f16_workspace_floats",
+                                    "hf_modconv3x3_small_workspace_floats"} == declared
     bound = _lib.bind(lib)
     assert bound.hf_abi_version() == 8
     assert bound.hf_strerror(-1) == b"invalid argument"

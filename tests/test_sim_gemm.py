@@ -74,3 +74,35 @@ def test_conv1x1_split_k_and_groups(simlib):
     y = M.conv1x1_f16(simlib, None, xs, hi, lo, 3, 64, groups=2)
     for g in range(2):
         assert float((y[g] - F.conv2d(xs, wg2[g])).abs().max()) < 2e-5 * 3
+
+
+def test_conv1x1_presplit_input_and_small_plane_modconv(simlib):
+    """Pre-split input (hf_split_activation_f16 -> LDS-DMA staging) gives the register-staged GEMM's result bit for bit;
+    the small-plane modulated 3x3 conv built on it (nine taps as one GEMM + combine pass) equals the fp32 kernels, same
+    resolution and transposed, power-of-two and odd planes."""
+    torch.manual_seed(2)
+    x = torch.randn(2, 64, 6, 10)
+    w, b = torch.randn(128, 64, 1, 1) * 0.1, torch.randn(128)
+    isc, ish = torch.rand(64) + 0.5, torch.randn(64) * 0.1
+    hi, lo = _prep(simlib, w)
+    plain = M.conv1x1_f16(simlib, None, x, hi, lo, 3, 128, in_scale=isc, in_shift=ish, bias=b)
+    xs = M.split_activation_f16(simlib, None, x, isc, ish)
+    pre = M.conv1x1_f16(simlib, None, xs, hi, lo, 3, 128, bias=b)
+    assert torch.equal(plain, pre)
+    for (B, cin, cout, h, ww) in [(3, 32, 64, 4, 4), (2, 32, 64, 5, 7), (1, 32, 64, 16, 16)]:
+        xx, wgt = torch.randn(B, cin, h, ww), torch.randn(1, cout, cin, 3, 3)
+        s, d = torch.rand(B, cin) + 0.5, torch.rand(B, cout) + 0.5
+        nz, nw, bias = torch.randn(B, 1, h, ww), torch.tensor([0.3]), torch.randn(cout)
+        wt, _ = M.prepare_weights(simlib, None, wgt)
+        w9 = M.split_weights_small(simlib, None, wt)
+        y = M.modconv3x3_small(simlib, None, xx, w9, 3, s, d, nz, nw, bias, cout)
+        ref = M.modconv3x3(simlib, None, xx, wt, s, d, nz, nw, bias)
+        assert float((y - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+        t = M.modconv3x3_small(simlib, None, xx, w9, 3, s, d, None, None, None, cout, upsample=True)
+        pitch = simlib.hf_modconv_up_pitch(ww)
+        tr = torch.zeros(B, cout, 2 * h + 1, pitch)
+        n = simlib.hf_modconv_workspace_floats(B, cin, cout, h, ww, 1)
+        ws = torch.empty(max(n, 1))
+        assert simlib.hf_modconv3x3_up_f32(tr.data_ptr(), xx.data_ptr(), wt.data_ptr(), s.data_ptr(), d.data_ptr(), B, cin, cout, h, ww,
+                                           pitch, ws.data_ptr() if n > 0 else None, n, None) == 0
+        assert float((t[..., :2 * ww + 1] - tr[..., :2 * ww + 1]).abs().max()) < 2e-5 * max(1.0, float(tr.abs().max()))

@@ -111,8 +111,8 @@ def test_styled_conv_precision_modes(sim_backend, simlib, mode, tol):
 
     m = sim_backend
     torch.manual_seed(4)
-    x = torch.randn(4, 32, 16, 32)  # 2048 pixels per launch: the smallest launch the fp16-core kernels are dispatched for
-    w = torch.randn(4, 24)
+    x = torch.randn(5, 32, 16, 32)  # 2560 pixels per launch: above the small-plane forms (fp32 split-K / tap-GEMM up to 2048)
+    w = torch.randn(5, 24)
     prev = _runtime.set_conv_precision(mode)
     try:
         for up in (False, True):
@@ -120,7 +120,7 @@ def test_styled_conv_precision_modes(sim_backend, simlib, mode, tol):
             sc.noise.weight.data.fill_(0.3)
             sc.activate.bias.data.normal_()
             oh, ow = (32, 64) if up else (16, 32)
-            nz = torch.randn(4, 1, oh, ow)
+            nz = torch.randn(5, 1, oh, ow)
             with torch.inference_mode():
                 y = sc(x, w, noise=nz)
             fam = simlib.hf_debug_last_path() // 100

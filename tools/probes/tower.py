@@ -40,6 +40,13 @@ for B in (8, 1, 3):
             line += f" | f16x3 {t16:7.1f} us ({fl / t16 * 1e-6:6.1f} TF/s, rel err {err:.1e}, path {L.hf_debug_last_path()})"
         except Exception as e:
             line += f" | f16x3 n/a"
+        if M.modconv3x3_small_supported(c, c, h, h) or h <= 32:
+            w9 = M.split_weights_small(L, st, wt)
+            ys = M.modconv3x3_small(L, st, x, w9, 3, s, d, nz, nw, bias, c)
+            ref = M.modconv3x3(L, st, x, wt, s, d, nz, nw, bias)
+            err = float((ys - ref).abs().max() / ref.abs().max())
+            ts = timeit(lambda: M.modconv3x3_small(L, st, x, w9, 3, s, d, nz, nw, bias, c))
+            line += f" | tap-GEMM {ts:7.1f} us (rel err {err:.1e})"
         print(line, flush=True)
         if h < 32:
             tu = timeit(lambda: M.modconv3x3_up(L, st, x, wt, s, d, k4, nz2, nw, bias))
@@ -47,4 +54,15 @@ for B in (8, 1, 3):
             if M.modconv3x3_up_f16_supported(c, c, h, h):
                 tu16 = timeit(lambda: M.modconv3x3_up(L, st, x, wt, s, d, k4, nz2, nw, bias, f16=(hi, lo, 3)))
                 line += f" | f16x3 {tu16:7.1f} us"
+            def up_small():
+                tmp = M.modconv3x3_small(L, st, x, w9, 3, s, d, None, None, None, c, upsample=True)
+                out = tmp.new_empty((B, c, 2 * h, 2 * h))
+                from hairfastgan_amd._lib import check
+                check(L, L.hf_blur_noise_bias_act_f32(out.data_ptr(), tmp.data_ptr(), k4.data_ptr(), nz2.data_ptr(), nw.data_ptr(),
+                                                      4 * h * h, bias.data_ptr(), B, c, 2 * h + 1, 2 * h + 1, tmp.shape[3], 0.2, 2 ** 0.5, st), "blur")
+                return out
+            ref = M.modconv3x3_up(L, st, x, wt, s, d, k4, nz2, nw, bias)
+            err = float((up_small() - ref).abs().max() / ref.abs().max())
+            tus = timeit(up_small)
+            line += f" | tap-GEMM+blur {tus:7.1f} us (rel err {err:.1e})"
             print(line, flush=True)
