@@ -59,6 +59,62 @@ __global__ __launch_bounds__(256) void torgb_kernel(float *__restrict__ out, con
   }
 
   const int sh = h >> 1, sw = w >> 1;
+  if constexpr (VEC == 4) {
+    if (skip && (w & 3) == 0) {
+      // The four pixels of the thread share a row and start at a multiple of 4: their 2x2 taps of the zero-insert
+      // upsampler (pad (2,1), 4x4 true convolution: only taps with the parity of (y, x) hit non-zero samples) read skip
+      // rows iy0, iy1 and columns c-1 .. c+2 (c = x0/2): 8 loads per channel instead of 16, the 16 kernel taps once
+      // per thread, no per-pixel division.  Same products in the same order as the per-pixel form below.
+      float kk[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) kk[i] = kernel4x4[i];
+      const int y = p0 / w, x0 = p0 - y * w, cc = x0 >> 1;
+      const int ky0 = y & 1, ky1 = ky0 + 2;
+      const int iy0 = (y + ky0 - 2) >> 1, iy1 = (y + ky1 - 2) >> 1;
+      float kr[2][4];  // the two kernel rows (3 - ky) this output row uses: selected once, indexed by constants below
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kr[a][j] = ky0 ? kk[(3 - (1 + 2 * a)) * 4 + j] : kk[(3 - 2 * a) * 4 + j];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float bc = bias ? bias[c] : 0.0f;
+        const float *sp = skip + ((long long)b * 3 + c) * sh * sw;
+        float sv[2][4];  // rows iy0 / iy1, columns cc-1 .. cc+2 (0 outside the plane)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int iy = a ? iy1 : iy0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ix = cc - 1 + j;
+            sv[a][j] = (iy >= 0 && iy < sh && ix >= 0 && ix < sw) ? sp[iy * sw + ix] : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float r = acc[c][v] + bc;
+          float up = 0.0f;
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const int iy = a ? iy1 : iy0;
+            if (iy < 0 || iy >= sh) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int kx = (v & 1) + 2 * e;            // xx & 1 == v & 1 (x0 is even)
+              const int j = ((v + kx - 2) >> 1) + 1;     // compile-time column of sv: ix = (x0 + v + kx - 2) / 2 = cc - 1 + j
+              const int ix = cc - 1 + j;
+              if (ix < 0 || ix >= sw) continue;
+              up = fmaf(sv[a][j], kr[a][3 - kx], up);
+            }
+          }
+          acc[c][v] = r + up;
+        }
+        float *o = out + ((long long)b * 3 + c) * hw + p0;
+        *reinterpret_cast<float4 *>(o) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float bc = bias ? bias[c] : 0.0f;
