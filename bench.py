@@ -575,6 +575,27 @@ def main():
             parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), n_single, load, device=dev)
             barrier()
             ts = max_over_ranks(time.perf_counter() - t0)
+            # where a batched pass spends its time: event marks at the stage boundaries of one swap_batch call
+            stage_ms = None
+            try:
+                from hairfastgan_amd import hair_swap as HS
+
+                trip = [tuple(t.to(dev) for t in load(i)) for i in range(args.swap_batch)]
+                with torch.inference_mode():
+                    HS.STAGE_MARKS = marks = []
+                    hf.swap_batch(trip)
+                    HS.STAGE_MARKS = None
+                torch.cuda.synchronize()
+                stage_ms = {}
+                for (_, e0), (lab, e1) in zip(marks[:-1], marks[1:]):
+                    stage_ms[lab] = round(stage_ms.get(lab, 0.0) + e0.elapsed_time(e1) / max(1, args.swap_batch), 3)
+            except Exception as e:
+                stage_ms = {"error": f"{type(e).__name__}: {e}"[:200]}
+            finally:
+                try:
+                    HS.STAGE_MARKS = None
+                except Exception:
+                    pass
             # ... and the whole swap as one hipGraph replay (HairFast.swap_graphed): the same kernels without the host's launch gaps
             graph_info = None
             try:
@@ -597,6 +618,7 @@ def main():
                              "single_swap": {"ms_per_swap": round(ts / (n_single / world) * 1e3, 2), "triples": n_single,
                                              "note": "one HairFast.swap per triple (no batching across triples)"},
                              "single_swap_graph": graph_info,
+                             "stage_ms_per_triple": stage_ms,
                              "workload": "python bench.py --workload swap256 on a bounded sample: host uint8 -> H2D -> HairFast.swap / "
                                          "swap_batch (every network native, no stand-ins: SEAN, CLIP ViT-B/32 tower, shape adaptor, RotateModel, "
                                          "PostProcess, BiSeNet) -> uint8 -> gather; a BOUNDED SAMPLE of BASELINE.json configs[3] (synthetic weights)"}

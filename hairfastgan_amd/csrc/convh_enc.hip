@@ -360,15 +360,17 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
   P.chunks_per_split = hf_cdiv(P.cin / KH, P.splits);
   P.splits = hf_cdiv(P.cin / KH, P.chunks_per_split);  // no empty split
   P.zslab = (long long)groups * P.batch * P.cout * P.out_h * P.out_w;
+  // the checks that can still reject this tile form come BEFORE the plan-only return: the workspace query must plan with
+  // the form the launch will take
+  dim3 grid(geom_blocks(G), P.co_tiles * groups, P.splits);
+  if (grid.y > 65535) return HF_E_INVALID;
+  const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float);
+  if (lds > 160 * 1024) return HF_E_INVALID;
   if (plan_only) return HF_OK;
   if (P.splits > 1) {
     if (!workspace || workspace_floats < P.splits * P.zslab) return HF_E_WORKSPACE;
     P.partial = workspace;
   }
-  dim3 grid(geom_blocks(G), P.co_tiles * groups, P.splits);
-  if (grid.y > 65535) return HF_E_INVALID;
-  const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float);
-  if (lds > 160 * 1024) return HF_E_INVALID;
   if (P.xh) {
     if ((long long)2 * P.h * P.w * 16 >= (1LL << 31) || (NTERMS == 3 && !P.xl)) return HF_E_INVALID;
     hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, true, CT_TILES, WAVES_CO>), grid, dim3(NT), lds, st, P, wth, wtl);
@@ -476,8 +478,13 @@ extern "C" long long hf_conv2d_f16_workspace_floats(int batch, int cin, int cout
   if (enc_fill(P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0.0f, nullptr, batch,
                cin, cout, h, w, stride, groups, 0) != HF_OK)
     return 0;
-  if (run_enc<3>(P, nullptr, nullptr, nullptr, 0, nullptr, true) != HF_OK) return 0;
-  return P.splits > 1 ? P.splits * P.zslab : 0;
+  // both operand modes (their tile forms can differ: nterms 1 never takes the 512-pixel form): the larger plan
+  long long need = 0;
+  if (run_enc<3>(P, nullptr, nullptr, nullptr, 0, nullptr, true) == HF_OK && P.splits > 1) need = P.splits * P.zslab;
+  ConvParams Q = P;
+  if (run_enc<1>(Q, nullptr, nullptr, nullptr, 0, nullptr, true) == HF_OK && Q.splits > 1 && Q.splits * Q.zslab > need)
+    need = Q.splits * Q.zslab;
+  return need;
 }
 
 extern "C" int hf_conv2d_f16_f32(float *out, const float *x, const void *x_hi, const void *x_lo, const void *wt_hi,

@@ -75,6 +75,15 @@ def get_parser():
 # glue (torch ops, as in the reference)
 # ---------------------------------------------------------------------------------------------
 _CONSTS = {}
+# bench.py / profiling: a list that receives (label, event) marks at the stage boundaries of a swap (None = off)
+STAGE_MARKS = None
+
+
+def _mark(label):
+    if STAGE_MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        STAGE_MARKS.append((label, ev))
 
 
 def _const(values, like):
@@ -461,10 +470,12 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
                 labels = torch.cat([inp_mask1, inp_mask2], dim=0)
                 sean += list(self.stages.sean_inpaint(images, labels, target_mask))  # SEAN for inpaint (per pair)
             masks.append(torch.cat([1 - (1 - hair_mask1) * (1 - hair_mask_target), hair_mask_target, hair_mask2 * hair_mask_target], 0))
+        _mark("align: shape module, masks")
         if batched_sean is not None:  # SEAN for inpaint: every pair in one batched pass (hairfastgan_amd.sean)
             sean = batched_sean(torch.cat([e["image_256"] for _, e1, e2, _m in work for e in (e1, e2)], dim=0),
                                 torch.cat([m_ for _, _e1, _e2, m in work for m_ in (m[0], m[2])], dim=0),
                                 torch.cat([m[4] for _, _e1, _e2, m in work], dim=0))
+        _mark("align: SEAN encode + decodes")
         enc_F = self.latent_encoder(sean)["F"]                                   # e4e batch 2P + generator 0->3
         dilate, erosion = self.dilate_erosion.mask(torch.cat(masks, 0))          # [3P, 1, 256, 256] each
         free_mask = torch.stack([dilate[0::3], erosion[1::3], erosion[2::3]], dim=1).reshape(-1, *dilate.shape[1:])
@@ -518,19 +529,24 @@ class Blending(nn.Module):  # models/Blending.py:11-82
                 args_.append((latent_S_1[:, 6:], latent_S_3[:, 6:], I_1 * target_mask, I_3 * HM_3E))
             else:
                 S_blend[t] = latent_S_1
+        _mark("blend: masks")
         if todo:  # the blending encoder once for all triples that need it
             S_6_18 = self.stages.blend(*(torch.cat([a[j] for a in args_], 0) for j in range(4)))
+            _mark("blend: ClipBlendingModel incl. CLIP tower")
             for j, t in enumerate(todo):
                 S_blend[t] = torch.cat((emb[t][0]["S"][:, :6], S_6_18[j:j + 1]), dim=1)
         latent_F_align = torch.cat([a["latent_F_align"] for a in aligns_shape], dim=0)
         I_blend, _ = self.net.generator([torch.cat(S_blend, 0)], input_is_latent=True, return_latents=False, start_layer=4,
                                         end_layer=8, layer_in=latent_F_align)
         I_blend_256 = self.downsample_256(I_blend)
+        _mark("blend: generator 4->8")
         I_1_all = torch.cat([e[0]["image_norm_256"] for e in emb], dim=0)
         S_final, F_final = self.post_process(I_1_all, I_blend_256)  # Post Process (native: encoders/post_process.py)
+        _mark("blend: PostProcessModel")
         I_final, _ = self.net.generator([S_final], input_is_latent=True, return_latents=False, start_layer=5, end_layer=8,
                                         layer_in=F_final)
         out = ((I_final + 1) / 2).clip(0, 1)
+        _mark("blend: generator 5->8")
         return [out[t] for t in range(T)]
 
 
@@ -614,18 +630,22 @@ class HairFast:
         key = (lambda t, n: (t, n)) if T > 1 else (lambda t, n: n)
         if T > 1:
             kwargs = dict(kwargs, batch_size=max(self.args.batch_size, len(images_to_name)))
+        _mark("start")
         name_to_embed = self.embed.embedding_images(images_to_name, **kwargs)  # Embedding stage
+        _mark("embedding: e4e, FS encoder, BiSeNet, generator 3->3 / 0->3")
         kwargs.pop("batch_size", None)
         same = [triple[1] is triple[2] for triple in triples]                  # shape is color
         pairs = []
         for t in range(T):
             pairs += [(key(t, "face"), key(t, "shape"))] + ([] if same[t] else [(key(t, "face"), key(t, "color"))])
         rotated = self.align.rotate_images(pairs, name_to_embed)               # every Rotate forward as one batch
+        _mark("rotate: RotateModel, generator 0->8, BiSeNet @1024, shape adaptor")
         aligns_shape = self.align.align_images_batch([(key(t, "face"), key(t, "shape")) for t in range(T)], name_to_embed,
                                                      rotated=rotated, **kwargs)
         aligns_color = [aligns_shape[t] if same[t] else
                         self.align.shape_module(key(t, "face"), key(t, "color"), name_to_embed, rotated=rotated, **kwargs)
                         for t in range(T)]
+        _mark("align: e4e of the SEAN renderings, generator 0->3, F alignment")
         return self.blend.blend_images_batch(aligns_shape, aligns_color, name_to_embed,
                                              [tuple(key(t, n) for n in ("face", "shape", "color")) for t in range(T)], **kwargs)
 
