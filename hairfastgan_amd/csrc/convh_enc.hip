@@ -387,8 +387,11 @@ template <int NTERMS>
 int run_enc(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *ws, long long wsn, hipStream_t st, bool plan_only) {
   int rc;
   if (P.stride == 2) {
-    // 64 co x 128 output px (the halo of a stride-2 tile is 4x its output): 4 waves
-    rc = launch_enc<NTERMS, 2, 2, 2>(P, hi, lo, ws, wsn, st, plan_only);
+    // 64 co x 128 output px (the halo of a stride-2 tile is 4x its output: a 256-pixel tile does not fit twice in LDS).
+    // Eight waves of 1 x 1 MFMA tiles: two waves per SIMD hide the stage latencies, which is worth more here than the
+    // 1 instead of 1.33 LDS fragment reads per MFMA of four 1 x 2 waves (tools/probes/stride2.py: 10-25% faster from
+    // 64@256^2 to the 11-group style heads, 30-35% on the register-staged path; same accumulation order, equal bits)
+    rc = launch_enc<NTERMS, 1, 4, 2>(P, hi, lo, ws, wsn, st, plan_only);
     if (rc == HF_OK && !plan_only) note_path(6, 2);
     return rc;
   }
