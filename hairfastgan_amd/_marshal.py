@@ -374,6 +374,12 @@ def modconv3x3_small_supported(cin, cout, h, w, batch, upsample=False):
     return 256 < n <= 2048
 
 
+def conv3x3_small_supported(cin, cout, h, w, batch):
+    """Plain (unmodulated) 3x3 convs worth the tap-GEMM form: planes the tiled fp16 kernel does not take, weights of 1 MB
+    and more (below, the fp32 split-K kernel's two launches win), at most 4096 pixels per launch."""
+    return cin % 32 == 0 and cout % 64 == 0 and h * w <= 256 and batch * h * w <= 4096 and cin * cout >= 512 * 512
+
+
 def modconv3x3_small(lib, st, x, w9, nterms, s, d, noise, noise_w, bias, cout, alpha=0.2, scale=SQRT2, upsample=False):
     """hf_modconv3x3_small_f16_f32.  upsample: returns the (2h+1) x pitch intermediate [B,cout,2h+1,pitch] (demodulated)."""
     x = _c(x)
@@ -986,6 +992,29 @@ def ace_modulate(lib, st, x, noise, noise_var, bn_scale, bn_shift, avg, sp, blen
                                        _p(_c(avg)), _p(sp), _p(_c(blend)), b, c, h * w, group, float(slope), st),
           "hf_ace_modulate_f32")
     return out
+
+
+def ace_modulate_table(lib, st, x, noise, noise_var, bn_scale, bn_shift, labels, table, avg_bias, sp, blend, group=1, slope=1.0):
+    """hf_ace_modulate_table_f32: label_conv3x3(labels, table, avg_bias, 2C, batch=B, cols_per_sample=19, group) fused into
+    ace_modulate (the [B,2C,H,W] avg planes never exist).  table [9*2C, >= B*19]; labels int32 [B/group,H,W]."""
+    x, sp, table = _c(x), _c(sp), _c(table)
+    b, c, h, w = x.shape
+    if labels.dtype != torch.int32 or not labels.is_contiguous() or tuple(labels.shape) != (b // group, h, w):
+        raise TypeError("labels must be contiguous int32 [B/group, H, W]")
+    if tuple(sp.shape) != (b // group, 2 * c, h, w) or table.shape[0] != 9 * 2 * c or table.shape[1] < b * 19:
+        raise ValueError("sp must be [B/group, 2C, H, W] and table [9*2C, >= 19*B]")
+    if noise is not None and noise.numel() != b * h * w:
+        raise ValueError("noise must be [B, H, W]")
+    out = torch.empty_like(x)
+    check(lib, lib.hf_ace_modulate_table_f32(_p(out), _p(x), _p(_c(noise)), _p(_c(noise_var)), _p(_c(bn_scale)), _p(_c(bn_shift)),
+                                             _p(labels), _p(table), _p(_c(avg_bias)), _p(sp), _p(_c(blend)), b, c, h, w,
+                                             table.shape[1], 19, group, float(slope), 1 if h * w >= 1024 else 0, st),
+          "hf_ace_modulate_table_f32")
+    return out
+
+
+def ace_modulate_table_supported(h, w):
+    return w % 4 == 0 and h * w >= 1024
 
 
 def region_mean(lib, st, x, labels, crop=0, act_tanh=False):

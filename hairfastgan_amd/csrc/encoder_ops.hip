@@ -682,11 +682,13 @@ extern "C" int hf_layernorm_f32(float *out, const float *x, const float *gamma, 
 
 // MUNIT-style LayerNorm of the CtrlHair shape adaptor (models/CtrlHair/my_torchlib/module.py:181-206): per SAMPLE
 // mean and UNBIASED standard deviation over all C*H*W values, y = (x - mean) / (std + eps) * gamma[c] + beta[c], then
-// LeakyReLU(slope) (slope 1 = none).  Two launches: (1) one block per (sample, chunk of 16384 values) computes the
-// chunk's (mean, M2 = sum of squared deviations from it); (2) every block of the apply pass merges the chunk statistics
-// of its sample in chunk order (Chan's pairwise update: exact counts, fixed order - deterministic) and normalises its
-// slice.  (A single block per sample took 370 us on a 32 x 128^2 activation.)
+// LeakyReLU(slope) (slope 1 = none).  Three launches: (1) one block per (sample, chunk of 16384 values) computes the
+// chunk's (mean, M2 = sum of squared deviations from it), its values read once and held in registers; (2) one thread per
+// sample merges the chunk statistics in chunk order (Chan's pairwise update: exact counts, fixed order - deterministic);
+// (3) the apply pass normalises.  (A single block per sample took 370 us on a 32 x 128^2 activation.)
 constexpr int kLnChunk = 16384;
+// VEC = 4: 16-byte loads (the launcher checks n % 4 == 0 and the alignment of x and of the sample stride)
+template <int VEC>
 __global__ __launch_bounds__(256) void sample_ln_partial(float *__restrict__ stats, const float *__restrict__ x, long long n,
                                                          long long x_bstride, int nchunks) {
   HF_DYN_LDS;
@@ -695,16 +697,37 @@ __global__ __launch_bounds__(256) void sample_ln_partial(float *__restrict__ sta
   const long long lo = (long long)k * kLnChunk, hi = lo + kLnChunk < n ? lo + kLnChunk : n;
   const float *xb = x + (long long)b * x_bstride;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the thread's values stay in registers between the two passes (a chunk is 64 values per thread)
+  constexpr int PER = kLnChunk / 256;
+  float v[PER];
   float s = 0.0f;
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) s += xb[i];
+  if (VEC == 4) {
+#pragma unroll
+    for (int j = 0; j < PER / 4; ++j) {
+      const long long i = lo + ((long long)j * 256 + threadIdx.x) * 4;
+      float4 q = make_float4(0, 0, 0, 0);
+      if (i < hi) q = *reinterpret_cast<const float4 *>(xb + i);
+      v[4 * j] = q.x, v[4 * j + 1] = q.y, v[4 * j + 2] = q.z, v[4 * j + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const long long i = lo + (long long)j * 256 + threadIdx.x;
+      v[j] = i < hi ? xb[i] : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) s += v[j];
   s = hf_wave_sum(s);
   if (lane == 0) red[wave] = s;
   __syncthreads();
   const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(hi - lo);
   float q = 0.0f;
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-    const float d = xb[i] - mean;
-    q = fmaf(d, d, q);
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const long long i = VEC == 4 ? lo + ((long long)(j / 4) * 256 + threadIdx.x) * 4 + (j & 3) : lo + (long long)j * 256 + threadIdx.x;
+    const float d = v[j] - mean;
+    if (i < hi) q = fmaf(d, d, q);
   }
   q = hf_wave_sum(q);
   if (lane == 0) red[4 + wave] = q;
@@ -714,12 +737,13 @@ __global__ __launch_bounds__(256) void sample_ln_partial(float *__restrict__ sta
     stats[((long long)b * nchunks + k) * 2 + 1] = (red[4] + red[5]) + (red[6] + red[7]);
   }
 }
-__global__ __launch_bounds__(256) void sample_ln_apply(float *__restrict__ out, const float *__restrict__ x,
-                                                       const float *__restrict__ stats, const float *__restrict__ gamma,
-                                                       const float *__restrict__ beta, long long n, long long x_bstride, int hw,
-                                                       int nchunks, float eps, float slope) {
-  const int b = blockIdx.y;
-  // merge the chunk statistics (every thread the same sequence: no communication needed)
+// the chunk statistics of a sample merged in chunk order -> (mean, 1 / (std + eps)) in final[b]; one thread per sample
+// (every block of the apply pass used to repeat this merge: 256 dependent updates, each with a division, in front of
+// four values per thread - three quarters of the pass at 64 x 256^2)
+__global__ void sample_ln_merge(float *__restrict__ final, const float *__restrict__ stats, long long n, int nchunks, int batch,
+                                float eps) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
   float mean = 0.0f, m2 = 0.0f, cnt = 0.0f;
   for (int k = 0; k < nchunks; ++k) {
     const long long lo = (long long)k * kLnChunk;
@@ -730,21 +754,43 @@ __global__ __launch_bounds__(256) void sample_ln_apply(float *__restrict__ out, 
     m2 += qk + delta * delta * (cnt * nk / tot);
     cnt = tot;
   }
-  const float inv = 1.0f / (sqrtf(m2 / (float)(n - 1)) + eps);
+  final[2 * b] = mean;
+  final[2 * b + 1] = 1.0f / (sqrtf(m2 / (float)(n - 1)) + eps);
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void sample_ln_apply(float *__restrict__ out, const float *__restrict__ x,
+                                                       const float *__restrict__ final, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, long long n, long long x_bstride, int hw,
+                                                       float slope) {
+  const int b = blockIdx.y;
+  const float mean = final[2 * b], inv = final[2 * b + 1];
   const float *xb = x + (long long)b * x_bstride;
   float *ob = out + (long long)b * n;
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const int c = (int)(i / hw);
-    float y = (xb[i] - mean) * inv;
-    if (gamma) y = fmaf(y, gamma[c], beta ? beta[c] : 0.0f);
-    ob[i] = y > 0.0f ? y : y * slope;
+  const long long stride = (long long)gridDim.x * 256 * VEC;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC; i < n; i += stride) {
+    const int c = (int)(i / hw);  // VEC == 4: hw % 4 == 0, the four values share the channel
+    const float g = gamma ? gamma[c] : 1.0f, bt = (gamma && beta) ? beta[c] : 0.0f;
+    if (VEC == 4) {
+      const float4 q = *reinterpret_cast<const float4 *>(xb + i);
+      float y[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = (y[j] - mean) * inv;
+        if (gamma) y[j] = fmaf(y[j], g, bt);
+        y[j] = y[j] > 0.0f ? y[j] : y[j] * slope;
+      }
+      *reinterpret_cast<float4 *>(ob + i) = make_float4(y[0], y[1], y[2], y[3]);
+    } else {
+      float y = (xb[i] - mean) * inv;
+      if (gamma) y = fmaf(y, g, bt);
+      ob[i] = y > 0.0f ? y : y * slope;
+    }
   }
 }
 
 extern "C" long long hf_sample_layernorm_workspace_floats(int batch, int channels, int hw) {
   const long long n = (long long)channels * hw;
-  return batch <= 0 || n <= 0 ? 0 : 2LL * batch * ((n + kLnChunk - 1) / kLnChunk);
+  return batch <= 0 || n <= 0 ? 0 : 2LL * batch * ((n + kLnChunk - 1) / kLnChunk + 1);
 }
 
 extern "C" int hf_sample_layernorm_f32(float *out, const float *x, const float *gamma, const float *beta, int batch, int channels,
@@ -754,13 +800,17 @@ extern "C" int hf_sample_layernorm_f32(float *out, const float *x, const float *
   if (x_batch_stride == 0) x_batch_stride = n;
   if (!out || !x || batch <= 0 || channels <= 0 || hw <= 0 || n < 2 || batch > 65535 || x_batch_stride < n) return HF_E_INVALID;
   const int nchunks = (int)((n + kLnChunk - 1) / kLnChunk);
-  if (!workspace || workspace_floats < 2LL * batch * nchunks) return HF_E_WORKSPACE;
-  hipLaunchKernelGGL(sample_ln_partial, dim3(nchunks, batch), dim3(256), 8 * sizeof(float), (hipStream_t)stream, workspace, x, n,
-                     x_batch_stride, nchunks);
-  long long blocks = (n + 1023) / 1024;  // 4 values per thread
+  if (!workspace || workspace_floats < 2LL * batch * (nchunks + 1)) return HF_E_WORKSPACE;
+  float *final = workspace + 2LL * batch * nchunks;
+  const bool vec = (hw & 3) == 0 && (x_batch_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  hipStream_t st = (hipStream_t)stream;
+  long long blocks = (n + 4095) / 4096;  // 16 values per thread
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(sample_ln_apply, dim3((int)blocks, batch), dim3(256), 0, (hipStream_t)stream, out, x, workspace, gamma, beta, n,
-                     x_batch_stride, hw, nchunks, eps, slope);
+  if (vec) hipLaunchKernelGGL(sample_ln_partial<4>, dim3(nchunks, batch), dim3(256), 8 * sizeof(float), st, workspace, x, n, x_batch_stride, nchunks);
+  else hipLaunchKernelGGL(sample_ln_partial<1>, dim3(nchunks, batch), dim3(256), 8 * sizeof(float), st, workspace, x, n, x_batch_stride, nchunks);
+  hipLaunchKernelGGL(sample_ln_merge, dim3(hf_cdiv(batch, 64)), dim3(64), 0, st, final, workspace, n, nchunks, batch, eps);
+  if (vec) hipLaunchKernelGGL(sample_ln_apply<4>, dim3((int)blocks, batch), dim3(256), 0, st, out, x, final, gamma, beta, n, x_batch_stride, hw, slope);
+  else hipLaunchKernelGGL(sample_ln_apply<1>, dim3((int)blocks, batch), dim3(256), 0, st, out, x, final, gamma, beta, n, x_batch_stride, hw, slope);
   return hf_launch_status();
 }
 

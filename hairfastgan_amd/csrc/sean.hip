@@ -74,6 +74,119 @@ __global__ __launch_bounds__(256) void label_table_sum(float *__restrict__ tsum,
   tsum[i] = acc;
 }
 
+// ---- four pixels per thread, tables in LDS (planes of >= 1024 pixels, W % 4 == 0, <= 32 labels) ----------------------
+// The per-pixel form above is bound by its gathers (one L2 lookup and one 256-byte store per wave and channel: 0.2 TB/s
+// of output at 128^2 x 512 channels); here a block first copies the nine tap tables of its channel chunk and of ITS
+// sample's columns into LDS (and adds them up, taps 0..8 in order, for the interior path), a thread then owns four
+// consecutive pixels of a row and writes 16 bytes per channel.  The interior / general choice is made PER PIXEL (a
+// pixel's value does not depend on which pixels share its wave): interior = bias + tap sum, general = bias + taps in
+// order; waves without a general pixel skip that arithmetic.
+constexpr int kLabelMax = 32;
+
+// labels of rows y-1..y+1, columns x-1..x+4 around the thread's four pixels (x % 4 == 0): -1 outside the image,
+// clamped to [0, nl) inside
+__device__ __forceinline__ void label_window(int (&lab)[3][6], const int *__restrict__ lb, int y, int x, int H, int W, int nl) {
+  auto in_range = [nl](int v) { return min(max(v, 0), nl - 1); };
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int yy = y + r - 1;
+    if (yy >= 0 && yy < H) {
+      const int *row = lb + (long long)yy * W + x;
+      const int4 c = *reinterpret_cast<const int4 *>(row);
+      lab[r][0] = x > 0 ? in_range(row[-1]) : -1;
+      lab[r][1] = in_range(c.x);
+      lab[r][2] = in_range(c.y);
+      lab[r][3] = in_range(c.z);
+      lab[r][4] = in_range(c.w);
+      lab[r][5] = x + 4 < W ? in_range(row[4]) : -1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) lab[r][j] = -1;
+    }
+  }
+}
+
+// does pixel j's 3x3 neighbourhood lie inside the image and carry one label
+__device__ __forceinline__ bool label_interior(const int (&lab)[3][6], int j) {
+  bool u = true;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u = u && lab[r][j + k] == lab[1][j + 1];
+  return u;
+}
+
+// LDS tables of `rows` table rows per tap: tl[(tap*rows + i)*nl + label] and ts[i*nl + label] = their sum over the taps
+// (0 + tap 0 + ... + tap 8, the order of label_table_sum).  row_of(i) = the table row (channel) of local row i.
+template <class RowOf>
+__device__ __forceinline__ void stage_label_tables(float *tl, float *ts, const float *__restrict__ table, int C, int tcols, int col0,
+                                                   int nl, int rows, RowOf row_of) {
+  for (int i = threadIdx.x; i < 9 * rows * nl; i += 256) {
+    const int t = i / (rows * nl), rem = i - t * rows * nl;
+    const int r = rem / nl, l = rem - r * nl;
+    tl[i] = table[((long long)t * C + row_of(r)) * tcols + col0 + l];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < rows * nl; i += 256) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc += tl[t * rows * nl + i];
+    ts[i] = acc;
+  }
+  __syncthreads();
+}
+
+// value of local table row i at the thread's four pixels: bias + (interior ? tap sum : taps in order)
+__device__ __forceinline__ void label_lookup4(float (&v)[4], const float *tl, const float *ts, int rows, int nl, int i, float bias,
+                                              const int (&lab)[3][6], const bool (&inner)[4], bool any_general) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = bias + ts[i * nl + lab[1][j + 1]];
+  if (any_general) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = bias;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int l = lab[t / 3][j + t % 3];
+        if (l >= 0) acc += tl[(t * rows + i) * nl + l];
+      }
+      if (!inner[j]) v[j] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void label_conv3x3_v4(float *__restrict__ out, const int *__restrict__ labels,
+                                                        const float *__restrict__ table, const float *__restrict__ bias, int C,
+                                                        int H, int W, int tcols, int cols_per_sample, int group, int act,
+                                                        int cchunk, int nl, int interior) {
+  HF_DYN_LDS;
+  float *tl = reinterpret_cast<float *>(hf_dyn_lds);  // [9][nc][nl]
+  const int b = blockIdx.z, c0 = blockIdx.y * cchunk, nc = min(cchunk, C - c0);
+  float *ts = tl + 9 * cchunk * nl;                   // [nc][nl]
+  stage_label_tables(tl, ts, table, C, tcols, b * cols_per_sample, nl, nc, [&](int r) { return c0 + r; });
+  const int hw = H * W;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool live = p < hw;
+  const int pc = live ? p : 0;
+  const int y = pc / W, x = pc - y * W;
+  int lab[3][6];
+  label_window(lab, labels + (long long)(b / group) * hw, y, x, H, W, nl);
+  bool inner[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) inner[j] = interior && label_interior(lab, j);
+  const bool any_general = hf_wave_any(live && !(inner[0] && inner[1] && inner[2] && inner[3]));
+  float *o = out + ((long long)b * C + c0) * hw + pc;
+  for (int c = 0; c < nc; ++c, o += hw) {
+    float v[4];
+    label_lookup4(v, tl, ts, nc, nl, c, bias ? bias[c0 + c] : 0.0f, lab, inner, any_general);
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+    }
+    if (live) *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 extern "C" int hf_label_conv3x3_f32(float *out, const int *labels, const float *table, const float *bias, int batch,
                                     int channels, int h, int w, int table_cols, int cols_per_sample, int group, int relu,
                                     float *tap_sum_scratch, void *stream) {
@@ -81,6 +194,17 @@ extern "C" int hf_label_conv3x3_f32(float *out, const int *labels, const float *
       cols_per_sample < 0 || batch > 65535)
     return HF_E_INVALID;
   const int hw = h * w;
+  const int nl = cols_per_sample > 0 ? cols_per_sample : table_cols;  // labels per sample
+  if (hw >= 1024 && (w & 3) == 0 && nl <= kLabelMax) {
+    // channel chunk: enough blocks to fill the chip, tables of a block <= 10 * 64 * 32 floats (80 KiB)
+    int cchunk = min(channels, 64);
+    while (cchunk > 8 && (long long)hf_cdiv(hw, 1024) * hf_cdiv(channels, cchunk) * batch < 1024) cchunk = (cchunk + 1) / 2;
+    const size_t lds = (size_t)10 * cchunk * nl * sizeof(float);
+    hipLaunchKernelGGL(label_conv3x3_v4, dim3(hf_cdiv(hw, 1024), hf_cdiv(channels, cchunk), batch), dim3(256), lds,
+                       (hipStream_t)stream, out, labels, table, bias, channels, h, w, table_cols, cols_per_sample, group,
+                       relu ? 1 : 0, cchunk, nl, tap_sum_scratch ? 1 : 0);
+    return hf_launch_status();
+  }
   // enough blocks to fill the chip, at least 8 channels per thread to amortise the nine label loads
   int cchunk = channels;
   while (cchunk > 8 && (long long)hf_cdiv(hw, 256) * hf_cdiv(channels, cchunk) * batch < 1024) cchunk = (cchunk + 1) / 2;
@@ -147,6 +271,80 @@ extern "C" int hf_ace_modulate_f32(float *out, const float *x, const float *nois
     return HF_E_INVALID;
   hipLaunchKernelGGL(ace_modulate, dim3(hf_cdiv(hw / 4, 256), channels, batch), dim3(256), 0, (hipStream_t)stream, out, x, noise,
                      noise_var, bn_scale, bn_shift, avg, sp, blend, channels, hw / 4, group, slope);
+  return hf_launch_status();
+}
+
+// The same tail with ACE's `avg` planes (conv_gamma / conv_beta of the per-region style map) formed IN the kernel from
+// their lookup table instead of read from a [B, 2C, H, W] tensor: avg[b, c, p] = avg_bias[c] + the label_conv3x3 of
+// table rows c (gamma) / C + c (beta), columns b*labels.. (see label_conv3x3_v4 - same LDS tables, same interior /
+// general arithmetic per pixel, so the result equals hf_label_conv3x3_f32 followed by hf_ace_modulate_f32 bit for bit).
+// Saves writing and re-reading 2C planes per sample (at 128^2 x 256 channels x 8 samples: 2 x 268 MB).
+// Block = 1024 pixels (four per thread) x `cchunk` channels of one sample.
+__global__ __launch_bounds__(256) void ace_modulate_table(float *__restrict__ out, const float *__restrict__ x,
+                                                          const float *__restrict__ r, const float *__restrict__ noise_var,
+                                                          const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
+                                                          const int *__restrict__ labels, const float *__restrict__ table,
+                                                          const float *__restrict__ avg_bias, const float *__restrict__ sp,
+                                                          const float *__restrict__ blend, int C, int H, int W, int tcols, int nl,
+                                                          int group, float slope, int cchunk, int interior) {
+  HF_DYN_LDS;
+  float *tl = reinterpret_cast<float *>(hf_dyn_lds);  // [9][2*nc][nl]: local row 2*i = gamma of channel c0+i, 2*i+1 = beta
+  const int b = blockIdx.z, c0 = blockIdx.y * cchunk, nc = min(cchunk, C - c0);
+  float *ts = tl + 9 * 2 * cchunk * nl;
+  stage_label_tables(tl, ts, table, 2 * C, tcols, b * nl, nl, 2 * nc, [&](int i) { return (i & 1) * C + c0 + (i >> 1); });
+  const int hw = H * W;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool live = p < hw;
+  const int pc = live ? p : 0;
+  const int y = pc / W, xx = pc - y * W;
+  int lab[3][6];
+  label_window(lab, labels + (long long)(b / group) * hw, y, xx, H, W, nl);
+  bool inner[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) inner[j] = interior && label_interior(lab, j);
+  const bool any_general = hf_wave_any(live && !(inner[0] && inner[1] && inner[2] && inner[3]));
+  const float ag = 1.0f / (1.0f + expf(-blend[0])), ab = 1.0f / (1.0f + expf(-blend[1]));
+  float4 rv = make_float4(0, 0, 0, 0);
+  if (r) rv = *reinterpret_cast<const float4 *>(r + (long long)b * hw + pc);
+  const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+  const long long sb = (long long)(b / group) * 2 * C;
+  for (int i = 0; i < nc; ++i) {
+    const int c = c0 + i;
+    float ga[4], ba[4];
+    label_lookup4(ga, tl, ts, 2 * nc, nl, 2 * i, avg_bias ? avg_bias[c] : 0.0f, lab, inner, any_general);
+    label_lookup4(ba, tl, ts, 2 * nc, nl, 2 * i + 1, avg_bias ? avg_bias[C + c] : 0.0f, lab, inner, any_general);
+    const float4 xv = *reinterpret_cast<const float4 *>(x + ((long long)b * C + c) * hw + pc);
+    const float4 gs4 = *reinterpret_cast<const float4 *>(sp + (sb + c) * hw + pc);
+    const float4 bs4 = *reinterpret_cast<const float4 *>(sp + (sb + C + c) * hw + pc);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gs4.x, gs4.y, gs4.z, gs4.w}, bs[4] = {bs4.x, bs4.y, bs4.z, bs4.w};
+    const float nv = noise_var ? noise_var[c] : 0.0f, sc = bn_scale[c], sh = bn_shift[c];
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = ag * ga[j] + (1.0f - ag) * gs[j], bt = ab * ba[j] + (1.0f - ab) * bs[j];
+      const float v = ((xs[j] + rr[j] * nv) * sc + sh) * (1.0f + g) + bt;
+      o[j] = v > 0.0f ? v : v * slope;
+    }
+    if (live) *reinterpret_cast<float4 *>(out + ((long long)b * C + c) * hw + pc) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int hf_ace_modulate_table_f32(float *out, const float *x, const float *noise, const float *noise_var,
+                                         const float *bn_scale, const float *bn_shift, const int *labels, const float *table,
+                                         const float *avg_bias, const float *sp, const float *blend, int batch, int channels,
+                                         int h, int w, int table_cols, int n_labels, int group, float slope, int interior,
+                                         void *stream) {
+  if (!out || !x || !bn_scale || !bn_shift || !labels || !table || !sp || !blend || batch <= 0 || channels <= 0 || h <= 0 ||
+      w <= 0 || (w & 3) || group <= 0 || batch > 65535 || n_labels <= 0 || n_labels > kLabelMax ||
+      (long long)batch * n_labels > table_cols)
+    return HF_E_INVALID;
+  const int hw = h * w;
+  int cchunk = min(channels, 32);
+  while (cchunk > 4 && (long long)hf_cdiv(hw, 1024) * hf_cdiv(channels, cchunk) * batch < 1024) cchunk = (cchunk + 1) / 2;
+  const size_t lds = (size_t)10 * 2 * cchunk * n_labels * sizeof(float);
+  hipLaunchKernelGGL(ace_modulate_table, dim3(hf_cdiv(hw, 1024), hf_cdiv(channels, cchunk), batch), dim3(256), lds,
+                     (hipStream_t)stream, out, x, noise, noise_var, bn_scale, bn_shift, labels, table, avg_bias, sp, blend, channels,
+                     h, w, table_cols, n_labels, group, slope, cchunk, interior ? 1 : 0);
   return hf_launch_status();
 }
 

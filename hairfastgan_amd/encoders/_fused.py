@@ -49,6 +49,13 @@ class PreparedConv:
         self.wt, self.k = wt, k
         self.cin, self.cout = wt.shape[-2], wt.shape[-1]
         self._f16 = None
+        self._small = None
+
+    def small(self):
+        """(hi, lo) of a 3x3 weight in the tap-GEMM layout of hf_modconv3x3_small_f16_f32 (the nine taps as rows of one GEMM)."""
+        if self._small is None:
+            self._small = M.split_weights_small(lib(), stream(), self.wt)
+        return self._small
 
     def f16(self):
         if self._f16 is None:
@@ -70,6 +77,19 @@ PRESPLIT = os.environ.get("HAIRFAST_ENC_PRESPLIT", "all")
 USE_GEMM_H = os.environ.get("HAIRFAST_GEMM_H", "1") != "0"
 
 
+def _small_plane_conv(x, w, mode, kw):
+    """A dense 3x3 stride-1 conv on planes too small for the tiled fp16-core kernel (under 16 columns: the CtrlHair shape
+    adaptor's 4^2 / 8^2 layers with 1024-2048 channels, 75-150 MB of weights each) as the tap GEMM of csrc/gemm_h.hip -
+    weight streaming with (tap, channel tile, K split) spread over the chip; the fp32-MFMA kernel took 420-680 us per layer
+    at batch 16.  None when the call has an epilogue the combine pass does not have."""
+    act = kw.get("act", M.ACT_NONE)
+    if (set(kw) - {"bias", "act", "alpha"}) or act not in (M.ACT_NONE, M.ACT_LRELU) or (act == M.ACT_LRELU and kw.get("bias") is None):
+        return None
+    alpha = float(kw.get("alpha", 0.0)) if act == M.ACT_LRELU else 1.0
+    return M.modconv3x3_small(lib(), stream(), x, w.small(), 3 if mode == "f16x3" else 1, None, None, None, None, kw.get("bias"),
+                              w.cout, alpha=alpha, scale=1.0)
+
+
 def conv(x, w, k, stride=1, presplit=False, **kw):
     """Conv2d + folded BN / activation / residual.  3x3 convs whose shape the fp16 matrix-core kernel
     takes run there in the process-wide operand mode (_runtime.conv_precision: f16x3 = fp32-class
@@ -86,6 +106,11 @@ def conv(x, w, k, stride=1, presplit=False, **kw):
                 and x.shape[0] * h * wd >= 512 and w.cin % 8 == 0):
             x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None), want_lo=nterms == 3)
         return M.conv1x1_f16(lib(), stream(), x, hi, lo, nterms, w.cout, stride, **kw)
+    if (mode != "f32" and k == 3 and stride == 1 and x.dim() == 4 and not M.conv2d_f16_supported(w.cin, w.cout, h, wd, k, stride)
+            and M.conv3x3_small_supported(w.cin, w.cout, h, wd, x.shape[0])):
+        y = _small_plane_conv(x, w, mode, kw)
+        if y is not None:
+            return y
     if mode != "f32" and M.conv2d_f16_supported(w.cin, w.cout, h, wd, k, stride):
         hi, lo = w.f16()
         nterms = 3 if mode == "f16x3" else 1

@@ -124,6 +124,9 @@ class ACE(nn.Module):  # normalization.py:70-208
         avg = None
         if self.use_rgb:
             table = conv(mu, p["w_table"], 1, 1)                                                      # [1, 9*2C, D, 19]
+            if M.ace_modulate_table_supported(h, w):  # the avg planes are looked up inside the tail kernel, never stored
+                return M.ace_modulate_table(L, st, x, noise, p["noise_var"], p["bn"][0], p["bn"][1], labels,
+                                            table.reshape(9 * 2 * c, d * N_LABELS), p["b_avg"], sp, p["blend"], group=group, slope=slope)
             avg = M.label_conv3x3(L, st, labels, table.reshape(9 * 2 * c, d * N_LABELS), p["b_avg"], 2 * c, batch=d,
                                   cols_per_sample=N_LABELS, group=group)
         return M.ace_modulate(L, st, x, noise, p["noise_var"], p["bn"][0], p["bn"][1], avg, sp, p["blend"] if avg is not None else None,

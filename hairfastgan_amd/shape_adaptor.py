@@ -115,7 +115,7 @@ class Conv2dBlock(nn.Module):  # my_torchlib/module.py:64-131 (pad_type 'zero', 
             cols = F.unfold(x, kernel_size=4, stride=2, padding=1)                     # [B, cin*16, L]
             if b * cols.shape[2] > 32 and "gemm" not in p:  # the MFMA-GEMM form's weights: only when that branch runs
                 w2 = self.conv.weight.detach().reshape(cout, -1, 1, 1)
-                p["gemm"] = M.conv_prepare(L, st, w2.contiguous())
+                p["gemm"] = PreparedConv(M.conv_prepare(L, st, w2.contiguous()), 1)
             if b * cols.shape[2] <= 32:
                 # a single swap: up to 32 patch rows - the weight-streaming GEMV kernel reads the 34 / 134 MB of weights
                 # once per 8 rows at HBM speed (the MFMA GEMM form below needs more rows to pay: 209 -> ~60 us)
@@ -124,7 +124,9 @@ class Conv2dBlock(nn.Module):  # my_torchlib/module.py:64-131 (pad_type 'zero', 
                 y = y.reshape(b, -1, cout).permute(0, 2, 1).reshape(b, cout, h // 2, w_ // 2).contiguous()
             else:
                 cols = cols.permute(1, 0, 2).contiguous().unsqueeze(0)                     # [1, cin*16, B, L]
-                y = M.conv2d(L, st, cols, p["gemm"], 1, 1, bias=self.conv.bias.detach())   # [1, cout, B, L]
+                # split-K GEMM on the fp16 matrix cores (csrc/gemm_h.hip): K = 8192 / 16384 over 64-256 patch columns is
+                # weight streaming - 420-450 us on the fp32-MFMA 1x1 path
+                y = conv(cols, p["gemm"], 1, 1, bias=self.conv.bias.detach())              # [1, cout, B, L]
                 y = y[0].permute(1, 0, 2).reshape(b, cout, h // 2, w_ // 2).contiguous()
         else:
             if p["w"] is None:

@@ -516,9 +516,11 @@ int hf_add_bcast_f32(float *out, const float *a, const float *b, long long n, lo
  *     cols_per_sample = 19.
  * labels: int32 [batch/group, h, w] (group consecutive samples share a label map - the two decodes of a pair,
  * models/Alignment.py:130-131); relu != 0 applies ReLU; bias may be NULL.
- * tap_sum_scratch: NULL, or channels*table_cols floats of scratch: the sum of the nine taps is computed first and pixels
- * whose whole 3x3 neighbourhood carries one label (the interior of a region) take ONE lookup instead of nine - worth it
- * from ~32x32 planes upward. */
+ * tap_sum_scratch: NULL, or channels*table_cols floats of scratch: non-NULL turns on the interior path - the sum of the
+ * nine taps is formed first (0 + tap 0 + ... + tap 8) and pixels whose whole 3x3 neighbourhood carries one label (the
+ * interior of a region) take ONE lookup instead of nine; worth it from ~32x32 planes upward.  Planes of >= 1024 pixels
+ * with w % 4 == 0 and <= 32 labels per sample keep their tables in LDS, four pixels per thread, and choose interior /
+ * general per PIXEL (the scratch is then not written); smaller ones choose per wave of 64 pixels. */
 int hf_label_conv3x3_f32(float *out, const int *labels, const float *table, const float *bias, int batch, int channels,
                          int h, int w, int table_cols, int cols_per_sample, int group, int relu, float *tap_sum_scratch,
                          void *stream);
@@ -534,6 +536,17 @@ int hf_label_conv3x3_f32(float *out, const int *labels, const float *table, cons
 int hf_ace_modulate_f32(float *out, const float *x, const float *noise, const float *noise_var, const float *bn_scale,
                         const float *bn_shift, const float *avg, const float *sp, const float *blend, int batch,
                         int channels, int hw, int group, float slope, void *stream);
+/* hf_label_conv3x3_f32 (cols_per_sample = n_labels, bias = avg_bias, channels = 2*channels, no ReLU) FOLLOWED BY
+ * hf_ace_modulate_f32 with its result as `avg`, in one pass and bit-identical to the pair: the avg planes - ACE's
+ * conv_gamma / conv_beta of `middle_avg` (normalization.py:117-162) - are looked up from LDS copies of the table rows
+ * instead of being written to and re-read from HBM.  table [9 * 2*channels][table_cols] (rows (tap, gamma|beta
+ * channel)), columns b*n_labels + label; labels int32 [batch/group, h, w]; sp [batch/group, 2*channels, h, w]; x / out
+ * [batch, channels, h, w]; noise [batch, h*w] or NULL; avg_bias [2*channels] or NULL; blend as above (required);
+ * interior != 0: regions' interior pixels take the tap-sum path; w % 4 == 0, n_labels <= 32. */
+int hf_ace_modulate_table_f32(float *out, const float *x, const float *noise, const float *noise_var, const float *bn_scale,
+                              const float *bn_shift, const int *labels, const float *table, const float *avg_bias,
+                              const float *sp, const float *blend, int batch, int channels, int h, int w, int table_cols,
+                              int n_labels, int group, float slope, int interior, void *stream);
 /* Zencoder's per-region average pooling (architecture.py:187-205): out[b,l,c] = mean over {p : labels[b,p] == l} of
  * act(x[b,c,p]), 0 for labels that do not occur; act 1 = tanh (the encoder's last layer, :177), 0 = none.
  * x is a strided view: sample stride batch_stride, plane stride plane_stride, row pitch `pitch` (floats).

@@ -58,6 +58,9 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 struct alignas(16) float4 {
   float x, y, z, w;
 };
+struct alignas(16) int4 {
+  int x, y, z, w;
+};
 struct alignas(8) float2 {
   float x, y;
 };

@@ -98,6 +98,12 @@ def test_conv1x1_presplit_input_and_small_plane_modconv(simlib):
         y = M.modconv3x3_small(simlib, None, xx, w9, 3, s, d, nz, nw, bias, cout)
         ref = M.modconv3x3(simlib, None, xx, wt, s, d, nz, nw, bias)
         assert float((y - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+        # the unmodulated form encoders/_fused.py routes dense small-plane convs to: no s / d, alpha 1 = no activation
+        plain = M.modconv3x3_small(simlib, None, xx, w9, 3, None, None, None, None, bias, cout, alpha=1.0, scale=1.0)
+        ref = F.conv2d(xx, wt.reshape(3, 3, cin, cout).permute(3, 2, 0, 1), bias, padding=1)  # wt = prepared (scaled) weights
+        assert float((plain - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+        act = M.modconv3x3_small(simlib, None, xx, w9, 3, None, None, None, None, bias, cout, alpha=0.01, scale=1.0)
+        assert float((act - F.leaky_relu(ref, 0.01)).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
         t = M.modconv3x3_small(simlib, None, xx, w9, 3, s, d, None, None, None, cout, upsample=True)
         pitch = simlib.hf_modconv_up_pitch(ww)
         tr = torch.zeros(B, cout, 2 * h + 1, pitch)

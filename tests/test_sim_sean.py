@@ -74,6 +74,19 @@ def test_label_conv_and_ace_tail(simlib):
     got = M.ace_modulate(simlib, None, x, None, None, sc, sh, None, sp, None, group=2, slope=1.0)
     want = (x * sc[None, :, None, None] + sh[None, :, None, None]) * (1 + spx[:, :4]) + spx[:, 4:]
     assert float((got - want).abs().max()) < 1e-5
+    # the avg planes looked up INSIDE the tail kernel (hf_ace_modulate_table_f32) = label conv then tail, bit for bit;
+    # plane with interiors, borders and a ragged last block (32 x 40 = 1280 pixels: the four-pixel LDS-table kernels)
+    lab2 = torch.stack([big[0], torch.randint(0, 19, (32, 40), dtype=torch.int32)])
+    lab2[1, 8:24, 8:32] = 2
+    xb, rb = torch.randn(4, 4, 32, 40), torch.randn(4, 32, 40)
+    spb = torch.randn(2, 8, 32, 40)
+    avg_b = M.label_conv3x3(simlib, None, lab2, tab, bg, 8, batch=4, cols_per_sample=19, group=2)
+    for s_ in range(4):
+        mid = vec[s_][lab2[s_ // 2].long()].permute(2, 0, 1)[None]
+        assert float((avg_b[s_:s_ + 1] - F.conv2d(mid, wg, bg, padding=1)).abs().max()) < 1e-4
+    two = M.ace_modulate(simlib, None, xb, rb, nv, sc, sh, avg_b, spb, blend, group=2, slope=0.2)
+    one = M.ace_modulate_table(simlib, None, xb, rb, nv, sc, sh, lab2, tab, bg, spb, blend, group=2, slope=0.2)
+    assert torch.equal(one, two)
     # region pooling with tanh, on the interior of a padded plane
     xp = torch.randn(2, 3, 11, 14)
     lab = labels.clone()
