@@ -9,6 +9,7 @@ these with the HIP library and the current HIP stream after checking that all
 tensors live on the GPU.
 """
 import torch
+import torch.nn.functional as F
 
 from ._lib import check
 
@@ -857,6 +858,46 @@ def dilate_erode(lib, st, mask, radius):
     dil, ero = torch.empty_like(mask), torch.empty_like(mask)
     check(lib, lib.hf_dilate_erode_f32(_p(dil), _p(ero), _p(mask), mask.numel() // (h * w), h, w, radius, st), "hf_dilate_erode_f32")
     return dil, ero
+
+
+def stem_prepare(w):
+    """[cout,3,7,7] conv weight -> (w_hi, w_lo, w_unscale) of hf_stem7x7s2_f16_f32: fp16 (hi, lo) parts of W * 2^k in
+    [cout/64][22 K groups][64][8] - group (ci, ky), eight halves = kx 0..6 + a zero; the 22nd group zero - with 2^k placing
+    max|W| in [2^13, 2^14) (the lo parts of small weights would otherwise be fp16 subnormals, csrc/convh.hip split_weights)."""
+    cout = w.shape[0]
+    if tuple(w.shape[1:]) != (3, 7, 7) or cout % 64:
+        raise ValueError(f"stem weight must be [64n,3,7,7]; got {tuple(w.shape)}")
+    w = w.detach().float()
+    amax = w.abs().max().clamp_min(1e-30)
+    k = torch.floor(13.0 - torch.log2(amax))
+    scale = torch.exp2(k)
+    ws = F.pad(w * scale, (0, 1)).reshape(cout, 21, 8)                           # kx padded to 8
+    ws = torch.cat([ws, ws.new_zeros(cout, 1, 8)], 1)                            # the zero group
+    ws = ws.reshape(cout // 64, 64, 22, 8).permute(0, 2, 1, 3).contiguous()      # [tiles][22][64][8]
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    return hi.contiguous(), lo.contiguous(), torch.exp2(-k).reshape(1).float().contiguous()
+
+
+def stem7x7s2(lib, st, x, w3, out_scale=None, bias=None, alpha=0.0, pool=True):
+    """hf_stem7x7s2_f16_f32: 7x7 stride-2 conv of a 3-channel image + per-channel affine + leaky ReLU (+ 3x3/2 max pool)."""
+    x = _c(x)
+    b, cin, h, w = x.shape
+    hi, lo, unscale = w3
+    cout = hi.shape[0] * 64
+    if cin != 3:
+        raise ValueError("stem input must have 3 channels")
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if pool:
+        oh, ow = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
+    out = x.new_empty((b, cout, oh, ow))
+    code = _launch_profiled(
+        lib, 2.0 * 3 * 49 * cout * ((h - 1) // 2 + 1) * ((w - 1) // 2 + 1) * b,
+        lambda: lib.hf_stem7x7s2_f16_f32(_p(out), _p(x), _p(hi), _p(lo), _p(unscale), _p(_c(out_scale)), _p(_c(bias)), float(alpha),
+                                         b, h, w, cout, 1 if pool else 0, st),
+        label="stem 7x7/2 (+pool)")
+    check(lib, code, "hf_stem7x7s2_f16_f32")
+    return out
 
 
 def maxpool3x3s2(lib, st, x):

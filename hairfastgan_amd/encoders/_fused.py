@@ -4,6 +4,7 @@ with inference-mode BatchNorm folded into per-channel affines once per checkpoin
 import os
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import _marshal as M
@@ -50,12 +51,22 @@ class PreparedConv:
         self.cin, self.cout = wt.shape[-2], wt.shape[-1]
         self._f16 = None
         self._small = None
+        self._patch = None
 
     def small(self):
         """(hi, lo) of a 3x3 weight in the tap-GEMM layout of hf_modconv3x3_small_f16_f32 (the nine taps as rows of one GEMM)."""
         if self._small is None:
             self._small = M.split_weights_small(lib(), stream(), self.wt)
         return self._small
+
+    def patch(self):
+        """(hi, lo) of a 3x3 weight as ONE GEMM over unfolded patches: K = cin*9 ordered (ci, tap) like F.unfold's rows."""
+        if self._patch is None:
+            w4 = self.wt if self.wt.ndim == 4 else self.wt.unsqueeze(0)                       # [G, 9, cin, cout]
+            g, taps, cin, cout = w4.shape
+            w1 = w4.permute(0, 2, 1, 3).reshape(g, 1, cin * taps, cout).contiguous()
+            self._patch = M.conv_split_weights_f16(lib(), stream(), w1 if self.wt.ndim == 4 else w1[0])
+        return self._patch
 
     def f16(self):
         if self._f16 is None:
@@ -90,6 +101,22 @@ def _small_plane_conv(x, w, mode, kw):
                               w.cout, alpha=alpha, scale=1.0)
 
 
+def _patch_gemm_conv(x, w, mode, stride, kw):
+    """A 3x3 conv whose OUTPUT planes are at most 8x8 (the e4e style heads' stride-2 chains 16^2 -> 8^2 -> ... -> 1, eleven
+    heads per grouped launch, 9.4 MB of weights per head and level) as a GEMM over unfolded patches on the fp16 matrix
+    cores: K = cin*9 with exactly the needed flops, (group, channel tile, image pair) blocks over the chip.  The patches
+    are a few MB (F.unfold, glue).  The fp32-MFMA kernel ran these levels at 0.3-1.3 ms per launch of a batched swap."""
+    groups, shared = kw.get("groups", 1), kw.get("x_shared", True)
+    b, cin, h, wd = x.shape[-4:]
+    oh, ow = (h - 1) // stride + 1, (wd - 1) // stride + 1
+    cols = F.unfold(x.reshape(-1, cin, h, wd), 3, padding=1, stride=stride)                   # [(G)B, cin*9, L]
+    cols = cols.reshape(*x.shape[:-3], cin * 9, 1, oh * ow)
+    hi, lo = w.patch()
+    rest = {k_: v for k_, v in kw.items() if k_ not in ("groups", "x_shared")}
+    y = M.conv1x1_f16(lib(), stream(), cols, hi, lo, 3 if mode == "f16x3" else 1, w.cout, 1, groups=groups, x_shared=shared, **rest)
+    return y.reshape(*y.shape[:-2], oh, ow)
+
+
 def conv(x, w, k, stride=1, presplit=False, **kw):
     """Conv2d + folded BN / activation / residual.  3x3 convs whose shape the fp16 matrix-core kernel
     takes run there in the process-wide operand mode (_runtime.conv_precision: f16x3 = fp32-class
@@ -106,6 +133,10 @@ def conv(x, w, k, stride=1, presplit=False, **kw):
                 and x.shape[0] * h * wd >= 512 and w.cin % 8 == 0):
             x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None), want_lo=nterms == 3)
         return M.conv1x1_f16(lib(), stream(), x, hi, lo, nterms, w.cout, stride, **kw)
+    if (mode != "f32" and k == 3 and USE_GEMM_H and h <= 16 and wd <= 16 and (h - 1) // stride < 8 and (wd - 1) // stride < 8
+            and w.cin % 32 == 0 and w.cout % 64 == 0 and w.cin * w.cout >= 256 * 256 and stride == 2
+            and not ({"in_scale", "in_shift", "residual"} & set(kw))):
+        return _patch_gemm_conv(x, w, mode, stride, kw)
     if (mode != "f32" and k == 3 and stride == 1 and x.dim() == 4 and not M.conv2d_f16_supported(w.cin, w.cout, h, wd, k, stride)
             and M.conv3x3_small_supported(w.cin, w.cout, h, wd, x.shape[0])):
         y = _small_plane_conv(x, w, mode, kw)

@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import _marshal as M
-from ._runtime import lib, require_gpu, stream
+from ._runtime import conv_precision, lib, require_gpu, stream
 from .encoders._fused import FrozenPlanMixin, conv, fold_bn, prep_conv
 
 # FaceParsing_tensor.label_list order -> index in PARSING_LABEL_LIST (global_value_utils.py:49-51); 13 = hair
@@ -142,7 +142,9 @@ class BiSeNet(FrozenPlanMixin, nn.Module):  # model.py:230-253
     def _prepared(self):
         if self._plan is None:
             r, cp = self.cp.resnet, self.cp
-            p = {"stem": (prep_conv(r.conv1), fold_bn(r.bn1))}
+            p = {"stem": (prep_conv(r.conv1), fold_bn(r.bn1)), "stem_f16": None}
+            if r.conv1.out_channels % 64 == 0 and tuple(r.conv1.weight.shape[1:]) == (3, 7, 7):
+                p["stem_f16"] = M.stem_prepare(r.conv1.weight)
             for li in (1, 2, 3, 4):
                 for j in (0, 1):
                     p[f"l{li}.{j}"] = getattr(r, f"layer{li}")[j].plan()
@@ -164,8 +166,12 @@ class BiSeNet(FrozenPlanMixin, nn.Module):  # model.py:230-253
         p = self._prepared()
         r = self.cp.resnet
         w, (s, t) = p["stem"]
-        x = conv(x, w, 7, 2, out_scale=s, bias=t, **RELU)
-        x = M.maxpool3x3s2(L, st, x)
+        if p["stem_f16"] is not None and conv_precision() != "f32":
+            # conv1 + bn1 + ReLU + the 3x3/2 max pool in one pass on the fp16 matrix cores (csrc/stem.hip)
+            x = M.stem7x7s2(L, st, x, p["stem_f16"], out_scale=s, bias=t, alpha=0.0, pool=True)
+        else:
+            x = conv(x, w, 7, 2, out_scale=s, bias=t, **RELU)
+            x = M.maxpool3x3s2(L, st, x)
         feats = []
         for li in (1, 2, 3, 4):
             for j in (0, 1):

@@ -556,6 +556,19 @@ int hf_region_mean_f32(float *out, const float *x, const int *labels, int batch,
 /* out = tanh(x), n elements (SPADEGenerator.forward's last line, generator.py:109). */
 int hf_tanh_f32(float *out, const float *x, long long n, void *stream);
 
+/* The ResNet-18 stem of BiSeNet's context path (models/CtrlHair/external_code/face_parsing/resnet.py:57-62, 81-84) on the
+ * fp16 matrix cores (csrc/stem.hip):  y = LeakyReLU_alpha( conv7x7_stride2_pad3(x) * out_scale[co] + bias[co] )  - conv1,
+ * the folded bn1 and ReLU (alpha 0) - and, pool != 0, MaxPool2d(3, 2, 1) of y in the same pass (y is never written).
+ * x [batch,3,h,w] fp32; out [batch,cout,oh,ow] with oh = (h-1)/2+1 (pool == 0) or [batch,cout,(oh-1)/2+1,(ow-1)/2+1];
+ * cout % 64 == 0; 0 <= alpha <= 1; out_scale / bias [cout] or NULL.
+ * Weights: w_hi / w_lo = fp16 (hi, lo) parts of W * 2^k laid out [cout/64][22][64][8 halves] - K group g < 21 = (ci, ky) =
+ * (g / 7, g % 7), the eight halves = kx 0..6 and a zero, group 21 all zero - and w_unscale -> 2^-k on the device
+ * (hairfastgan_amd/_marshal.py stem_prepare builds them from the [cout,3,7,7] tensor).  Operands are split f16x3
+ * (fp32-class, see hf_conv2d_f16_f32). */
+int hf_stem7x7s2_f16_f32(float *out, const float *x, const void *w_hi, const void *w_lo, const float *w_unscale,
+                         const float *out_scale, const float *bias, float alpha, int batch, int h, int w, int cout, int pool,
+                         void *stream);
+
 /* ===========================================================================
  * CLIP ViT-B/32 image tower: `self.clip_model.encode_image(...)` of ClipBlendingModel
  * (models/Encoders.py:75-90; the un-vendored dependency `clip @ git+https://github.com/openai/CLIP@a1d0717`,

@@ -145,3 +145,26 @@ def test_shape_adaptor_vs_reference_golden(golden):
             flips = lab != ref_lab
             assert float(flips.float().mean()) < 1e-3
             assert int(flips.sum()) == 0 or float(margin[flips].max()) < 2e-3 * max(1.0, abs(scale)), (int(flips.sum()), float(margin[flips].max()))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 256, 256), (1, 203, 317)])
+def test_stem_conv_pool_fp16_cores(B, H, W):
+    """hf_stem7x7s2_f16_f32 (csrc/stem.hip) through the C ABI: conv1 + bn1 + ReLU + max pool of BiSeNet's ResNet stem in one
+    pass, against torch's fp32 CPU convolution (tolerance 2e-5 of the largest value: f16x3 operands are fp32-class) and
+    against the unfused result pooled by torch (bit-equal)."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = _dev()
+    torch.manual_seed(W)
+    x = torch.randn(B, 3, H, W)
+    w = torch.randn(64, 3, 7, 7) * 0.05
+    sc, sh = torch.rand(64) + 0.5, torch.randn(64) * 0.3
+    ref = F.relu(F.conv2d(x.double(), w.double(), stride=2, padding=3) * sc[None, :, None, None] + sh[None, :, None, None]).float()
+    w3 = M.stem_prepare(w.to(dev))
+    y = M.stem7x7s2(lib(), stream(), x.to(dev), w3, out_scale=sc.to(dev), bias=sh.to(dev), alpha=0.0, pool=False)
+    yp = M.stem7x7s2(lib(), stream(), x.to(dev), w3, out_scale=sc.to(dev), bias=sh.to(dev), alpha=0.0, pool=True)
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((y.cpu() - ref).abs().max()) < tol
+    assert float((yp.cpu() - F.max_pool2d(ref, 3, 2, 1)).abs().max()) < tol
+    assert torch.equal(yp.cpu(), F.max_pool2d(y.cpu(), 3, 2, 1))

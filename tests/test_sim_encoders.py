@@ -371,3 +371,39 @@ def test_latent_models_oracle_and_layout(golden):
         assert {k: tuple(v.shape) for k, v in sd.items()} == shapes and list(sd) == list(shapes)
     with pytest.raises(NotImplementedError, match="CLIP"):
         ClipBlendingModel().get_image_embed(img_face)
+
+
+def test_fused_conv_small_plane_routes(sim_backend, simlib):
+    """encoders/_fused.conv on planes the tiled fp16 kernel does not take: stride-2 3x3 with outputs up to 8x8 as a GEMM over
+    unfolded patches (grouped like the e4e style heads: shared input first, per-group inputs after), dense stride-1 3x3 as
+    the tap GEMM; both on csrc/gemm_h.hip (hf_debug_last_path family 7) and equal to torch's convolution."""
+    from hairfastgan_amd.encoders._fused import PreparedConv, conv
+
+    torch.manual_seed(5)
+    G, B, cin, cout = 3, 2, 256, 256
+    w = torch.randn(G, cout, cin, 3, 3) / (cin * 9) ** 0.5
+    bias = torch.randn(G, cout)
+    wt = torch.stack([M.conv_prepare(simlib, None, w[g]) for g in range(G)]).contiguous()
+    pc = PreparedConv(wt, 3)
+    x = torch.randn(B, cin, 6, 6)
+    y = conv(x, pc, 3, 2, bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=G, x_shared=True)            # [G,B,cout,3,3]
+    assert simlib.hf_debug_last_path() // 100 == 7 and tuple(y.shape) == (G, B, cout, 3, 3)
+    for g in range(G):
+        ref = F.leaky_relu(F.conv2d(x, w[g], bias[g], stride=2, padding=1), 0.01)
+        assert maxdiff(y[g], ref) < TOL * max(1.0, float(ref.abs().max()))
+    y2 = conv(y, pc, 3, 2, bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=G, x_shared=False)          # 3x3 -> 2x2, own inputs
+    y3 = conv(y2, pc, 3, 2, bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=G, x_shared=False)         # 2x2 -> 1x1
+    for g in range(G):
+        r2 = F.leaky_relu(F.conv2d(y[g], w[g], bias[g], stride=2, padding=1), 0.01)
+        assert maxdiff(y2[g], r2) < TOL * max(1.0, float(r2.abs().max()))
+        r3 = F.leaky_relu(F.conv2d(y2[g], w[g], bias[g], stride=2, padding=1), 0.01)
+        assert tuple(y3[g].shape) == (B, cout, 1, 1) and maxdiff(y3[g], r3) < TOL * max(1.0, float(r3.abs().max()))
+    # dense stride-1 conv on a 4x4 plane with 512 x 512 weights: the tap GEMM
+    w1 = torch.randn(512, 512, 3, 3) / (512 * 9) ** 0.5
+    b1 = torch.randn(512)
+    p1 = PreparedConv(M.conv_prepare(simlib, None, w1), 3)
+    x1 = torch.randn(2, 512, 4, 4)
+    z = conv(x1, p1, 3, 1, bias=b1)
+    assert simlib.hf_debug_last_path() // 100 == 7
+    ref = F.conv2d(x1, w1, b1, padding=1)
+    assert maxdiff(z, ref) < TOL * max(1.0, float(ref.abs().max()))

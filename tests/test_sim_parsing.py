@@ -189,3 +189,25 @@ def test_shape_adaptor_blocks_and_layout(simlib, monkeypatch, golden):
     with torch.inference_mode():
         y3 = blk3(x3)
     assert float((y3 - F.conv2d(x3, blk3.conv.weight, blk3.conv.bias, padding=1)).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 37, 51)])
+def test_stem_conv_pool_on_fp16_cores(simlib, B, H, W):
+    """hf_stem7x7s2_f16_f32 (csrc/stem.hip): conv 7x7/2 + affine + ReLU, alone and with the 3x3/2 max pool fused, against
+    torch on planes with ragged tiles (odd sizes: the last tile row / column, the pooling pad at every border)."""
+    torch.manual_seed(H)
+    x = torch.randn(B, 3, H, W)
+    w = torch.randn(64, 3, 7, 7) * 0.05
+    sc, sh = torch.rand(64) + 0.5, torch.randn(64) * 0.3
+    w3 = M.stem_prepare(w)
+    ref = F.relu(F.conv2d(x, w, stride=2, padding=3) * sc[None, :, None, None] + sh[None, :, None, None])
+    y = M.stem7x7s2(simlib, None, x, w3, out_scale=sc, bias=sh, alpha=0.0, pool=False)
+    assert tuple(y.shape) == tuple(ref.shape) and float((y - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    yp = M.stem7x7s2(simlib, None, x, w3, out_scale=sc, bias=sh, alpha=0.0, pool=True)
+    refp = F.max_pool2d(ref, 3, 2, 1)
+    assert tuple(yp.shape) == tuple(refp.shape) and float((yp - refp).abs().max()) < 2e-5 * max(1.0, float(refp.abs().max()))
+    assert torch.equal(yp, F.max_pool2d(y, 3, 2, 1))  # the fused pool = pooling the unfused result, bit for bit
+    # leaky slope: negative values survive, the pooling pad must still behave like -inf
+    yl = M.stem7x7s2(simlib, None, x, w3, out_scale=sc, bias=sh - 3.0, alpha=0.2, pool=True)
+    refl = F.max_pool2d(F.leaky_relu(F.conv2d(x, w, stride=2, padding=3) * sc[None, :, None, None] + (sh - 3.0)[None, :, None, None], 0.2), 3, 2, 1)
+    assert float((yl - refl).abs().max()) < 2e-5 * max(1.0, float(refl.abs().max()))
