@@ -149,14 +149,20 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2(float *__restrict__ out, con
     }
 
     // ---- epilogue: v = lrelu_alpha(acc * unscale * out_scale[co] + bias[co]); D layout: co = (q&3) + 8*(q>>2) + 4*lh, pixel = li
-    const int cx = cx0 + li;
+    // opaque per tile: otherwise the epilogue's per-lane offsets are computed before the K loop and live - spilled - through it
+    int li_o = li, lh_o = lh, wave_o = wave;
+    HF_OPAQUE_I32(li_o);
+    HF_OPAQUE_I32(lh_o);
+    HF_OPAQUE_I32(wave_o);
+    const int row_e = wave_o * Gm::ROW_STEP;
+    const int cx = cx0 + li_o;
     const bool col_ok = cx >= 0 && cx < OW;
     float *ob = out + ((long long)T.b * cout + co0) * OUT_H * OUT_W;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const int c4 = ct * 32 + 8 * q4 + 4 * lh;
+        const int c4 = ct * 32 + 8 * q4 + 4 * lh_o;
         const float4 sc4 = *reinterpret_cast<const float4 *>(ep + c4), bs4 = *reinterpret_cast<const float4 *>(ep + 64 + c4);
         const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
         const float bsv[4] = {bs4.x, bs4.y, bs4.z, bs4.w};
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2(float *__restrict__ out, con
           if (!POOL) {
 #pragma unroll
             for (int g = 0; g < PG; ++g) {
-              const int cy = cy0 + row_w + g;
+              const int cy = cy0 + row_e + g;
               if (col_ok && cy < OH) oc[(long long)cy * OW + cx] = v[g];
             }
           } else {
@@ -181,13 +187,13 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2(float *__restrict__ out, con
             float hm[PG];
 #pragma unroll
             for (int g = 0; g < PG; ++g) {
-              const int cy = cy0 + row_w + g;
+              const int cy = cy0 + row_e + g;
               const float m = (col_ok && cy >= 0 && cy < OH) ? v[g] : -3.402823466e38f;
               hm[g] = fmaxf(m, fmaxf(hf_lane_up(m), hf_lane_down(m)));
             }
-            const int j = (li - 1) >> 1, px = T.ox0 + j;
-            if ((li & 1) && li <= 29 && px < PW) {
-              const int py = T.oy0 + 2 * wave;
+            const int j = (li_o - 1) >> 1, px = T.ox0 + j;
+            if ((li_o & 1) && li_o <= 29 && px < PW) {
+              const int py = T.oy0 + 2 * wave_o;
               if (py < PH) oc[(long long)py * PW + px] = fmaxf(hm[0], fmaxf(hm[1], hm[2]));
               if (py + 1 < PH) oc[(long long)(py + 1) * PW + px] = fmaxf(hm[2], fmaxf(hm[3], hm[4]));
             }
