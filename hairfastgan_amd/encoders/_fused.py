@@ -60,11 +60,12 @@ class PreparedConv:
         return self._small
 
     def patch(self):
-        """(hi, lo) of a 3x3 weight as ONE GEMM over unfolded patches: K = cin*9 ordered (ci, tap) like F.unfold's rows."""
+        """(hi, lo) of a 3x3 weight as ONE GEMM over patches (`patches`, tap-major): K = 9*cin ordered (tap, ci) - the
+        prepared layout itself."""
         if self._patch is None:
             w4 = self.wt if self.wt.ndim == 4 else self.wt.unsqueeze(0)                       # [G, 9, cin, cout]
             g, taps, cin, cout = w4.shape
-            w1 = w4.permute(0, 2, 1, 3).reshape(g, 1, cin * taps, cout).contiguous()
+            w1 = w4.reshape(g, 1, taps * cin, cout).contiguous()
             self._patch = M.conv_split_weights_f16(lib(), stream(), w1 if self.wt.ndim == 4 else w1[0])
         return self._patch
 
@@ -101,16 +102,28 @@ def _small_plane_conv(x, w, mode, kw):
                               w.cout, alpha=alpha, scale=1.0)
 
 
+def patches(x, k, stride, pad, tap_major=True):
+    """im2col of x [..., cin, h, w] as k*k strided slices of the zero-padded tensor, concatenated along the channel axis:
+    [..., k*k*cin, oh, ow] with K ordered (tap, ci) (tap_major) or (ci, tap) like F.unfold.  One pad and one cat kernel for
+    the whole batch - F.unfold launches an im2col kernel PER SAMPLE (264 launches for one level of the e4e style heads)."""
+    h, wd = x.shape[-2:]
+    oh, ow = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+    xp = F.pad(x, (pad, pad, pad, pad))
+    taps = [xp[..., ky:ky + stride * (oh - 1) + 1:stride, kx:kx + stride * (ow - 1) + 1:stride] for ky in range(k) for kx in range(k)]
+    if tap_major:
+        return torch.cat(taps, dim=-3)
+    return torch.stack(taps, dim=-3).reshape(*x.shape[:-3], x.shape[-3] * k * k, oh, ow)
+
+
 def _patch_gemm_conv(x, w, mode, stride, kw):
     """A 3x3 conv whose OUTPUT planes are at most 8x8 (the e4e style heads' stride-2 chains 16^2 -> 8^2 -> ... -> 1, eleven
     heads per grouped launch, 9.4 MB of weights per head and level) as a GEMM over unfolded patches on the fp16 matrix
     cores: K = cin*9 with exactly the needed flops, (group, channel tile, image pair) blocks over the chip.  The patches
-    are a few MB (F.unfold, glue).  The fp32-MFMA kernel ran these levels at 0.3-1.3 ms per launch of a batched swap."""
+    are a few MB (strided slices of the padded map, glue).  The fp32-MFMA kernel ran these levels at 0.3-1.3 ms per launch of a batched swap."""
     groups, shared = kw.get("groups", 1), kw.get("x_shared", True)
     b, cin, h, wd = x.shape[-4:]
     oh, ow = (h - 1) // stride + 1, (wd - 1) // stride + 1
-    cols = F.unfold(x.reshape(-1, cin, h, wd), 3, padding=1, stride=stride)                   # [(G)B, cin*9, L]
-    cols = cols.reshape(*x.shape[:-3], cin * 9, 1, oh * ow)
+    cols = patches(x, 3, stride, 1).reshape(*x.shape[:-3], 9 * cin, 1, oh * ow)              # K = (tap, ci)
     hi, lo = w.patch()
     rest = {k_: v for k_, v in kw.items() if k_ not in ("groups", "x_shared")}
     y = M.conv1x1_f16(lib(), stream(), cols, hi, lo, 3 if mode == "f16x3" else 1, w.cout, 1, groups=groups, x_shared=shared, **rest)

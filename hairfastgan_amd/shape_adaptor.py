@@ -28,7 +28,7 @@ from torch import nn
 
 from . import _marshal as M
 from ._runtime import lib, require_gpu, stream
-from .encoders._fused import FrozenPlanMixin, PreparedConv, conv
+from .encoders._fused import FrozenPlanMixin, PreparedConv, conv, patches
 
 HAIR_IDX = 13  # models/CtrlHair/global_value_utils.py:49-52 (PARSING_LABEL_LIST.index('hair'))
 
@@ -109,10 +109,10 @@ class Conv2dBlock(nn.Module):  # my_torchlib/module.py:64-131 (pad_type 'zero', 
         if k == 4 and const_planes is None and x.shape[-1] <= 8 and x.shape[-2] <= 8:
             # Deep encoder layers (8x8 and 4x4 inputs, 512 / 1024 channels): a handful of output pixels, each a dot
             # product over cin*16 values - a GEMM [B*L, cin*16] x [cin*16, cout] whose cost is streaming the weights
-            # once.  Patches by F.unfold (glue, a few KB), the product on the 1x1 conv kernel; the space-to-depth form
+            # once.  Patches by strided slices (glue, a few KB), the product on the 1x1 conv kernel; the space-to-depth form
             # would stream 2.25x the weights (its zero taps) through the general 3x3 path: 0.95 ms per layer at batch 16.
             b, _, h, w_ = x.shape
-            cols = F.unfold(x, kernel_size=4, stride=2, padding=1)                     # [B, cin*16, L]
+            cols = patches(x, 4, 2, 1, tap_major=False).flatten(2)                     # [B, cin*16, L], rows ordered like F.unfold's
             if b * cols.shape[2] > 32 and "gemm" not in p:  # the MFMA-GEMM form's weights: only when that branch runs
                 w2 = self.conv.weight.detach().reshape(cout, -1, 1, 1)
                 p["gemm"] = PreparedConv(M.conv_prepare(L, st, w2.contiguous()), 1)
