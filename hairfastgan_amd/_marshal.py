@@ -749,6 +749,44 @@ def conv2d_f16(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None, 
     return out
 
 
+def conv2d_f16_split_supported(lib, b, cin, cout, h, w, stride):
+    """hf_conv2d_f16_split_f32 takes the launch: groups 1 and no split-K plan (the split output is written by the conv kernel's
+    own epilogue)."""
+    return cout % 8 == 0 and lib.hf_conv2d_f16_workspace_floats(b, cin, cout, h, w, stride, 1) == 0
+
+
+def conv2d_f16_split(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None, in_shift=None, out_scale=None, bias=None,
+                     act=ACT_NONE, slope=None, alpha=0.0, residual=None, next_scale=None, next_shift=None, want_f32=False):
+    """hf_conv2d_f16_split_f32: conv2d_f16 whose result leaves as a SplitActivation (next_scale * y + next_shift, fp16 hi / lo,
+    K-blocked) for the next fp16-core conv; want_f32: also the fp32 tensor -> (SplitActivation, out | None)."""
+    pre = isinstance(x, SplitActivation)
+    if pre:
+        if in_scale is not None or in_shift is not None:
+            raise ValueError("a pre-split input carries its affine already")
+        b, cin, h, w = x.shape
+        dev = x.hi.device
+    else:
+        x = _c(x)
+        dev = x.device
+        b, cin, h, w = x.shape
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    out = torch.empty((b, cout, oh, ow), dtype=torch.float32, device=dev) if want_f32 else None
+    hi = torch.empty((b, cout // 8, oh, ow, 8), dtype=torch.float16, device=dev)
+    lo = torch.empty_like(hi) if nterms == 3 else None
+    if residual is not None:
+        residual = _c(residual)
+        if tuple(residual.shape) != (b, cout, oh, ow):
+            raise ValueError(f"residual {tuple(residual.shape)} != output {(b, cout, oh, ow)}")
+    code = _launch_profiled(
+        lib, 2.0 * cin * cout * 9 * oh * ow * b,
+        lambda: lib.hf_conv2d_f16_split_f32(_p(out), _p(hi), _p(lo), _p(_c(next_scale)), _p(_c(next_shift)), None if pre else _p(x),
+                                            _p(x.hi) if pre else None, _p(x.lo) if pre else None, _p(wt_hi), _p(wt_lo), nterms,
+                                            _p(in_scale), _p(in_shift), _p(_c(out_scale)), _p(_c(bias)), act, _p(_c(slope)),
+                                            float(alpha), _p(residual), b, cin, cout, h, w, stride, st))
+    check(lib, code, "hf_conv2d_f16_split_f32")
+    return SplitActivation(hi, lo, None), out
+
+
 def plane_mean(lib, st, x):
     x = _c(x)
     b, c, h, w = x.shape

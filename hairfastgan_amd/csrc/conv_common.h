@@ -72,6 +72,9 @@ struct ConvParams {
   // (hi, lo), K-blocked [batch][cout/8][h][w][8], for a consumer that takes pre-split input
   void *oh, *ol;
   const float *s_next;
+  // convh_enc.hip / gemm_h.hip split output (store_tile_rows): a_next[co] * out + t_next[co] (the consumer's input
+  // affine, NULL = identity) as fp16 (hi, lo) in the K-blocked layout; P.out may then be NULL
+  const float *a_next, *t_next;
   float blur_kx[4], blur_ky[4];  // convh.hip FUSE: flipped 1-D factors of the (rank-1) 4x4 blur kernel applied in the epilogue
   int rgb_slabs;               // convh.hip fused ToRGB: slabs of the raw tensor the caller allocated ([B][slabs*3][H][W])
   int dma_early;               // convh.hip PRE: issue a stage's DMAs in its first tap-step (short K loops) instead of spread
@@ -203,7 +206,7 @@ __device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const 
   const bool prelu = !partial && P.act == ACT_PRELU, lrelu = !partial && P.act == ACT_LRELU, qgelu = !partial && P.act == ACT_QGELU;
   const float neg_u = lrelu ? P.alpha : 1.0f, sc = lrelu ? P.scale : 1.0f;
   const bool res_pre = RES && P.residual_pre;
-  long long pofs[PG];
+  long long pofs[PG], uofs[PG];  // fp32 element / split 16-byte unit of (image, channel 0, Y, X)
   bool pvs[PG];
 #pragma unroll
   for (int g = 0; g < PG; ++g) {
@@ -212,8 +215,13 @@ __device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const 
     const int Y = ty0 + py, X = tx0 + px, b = b0 + im;
     pvs[g] = (Y < G.y0 + G.dh) && (X < G.x0 + G.dw) && (b < P.batch);
     pofs[g] = (long long)b * P.cout * oplane + (long long)Y * P.out_w + X;
+    uofs[g] = (long long)b * (P.cout >> 3) * oplane + (long long)Y * P.out_w + X;
   }
   float *obase = (partial ? P.partial + (long long)blockIdx.z * P.zslab : P.out) + go.o;
+  // split output (launcher: groups == 1, no split-K): unit (b, channel block, Y, X) of 16 bytes, the lane's 4 channels = its half lh
+  const bool split = !partial && P.oh != nullptr, store32 = partial || P.out != nullptr;
+  bool ovf_tile = false;
+  (void)ovf_tile;
   // one 32-channel tile at a time (register budget: some callers run two blocks per CU): its per-channel vectors
   // and residual values are loaded, then its PG * 16 values stored
 #pragma unroll
@@ -245,6 +253,7 @@ __device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const 
         const float bsv[4] = {bs[q].x, bs[q].y, bs[q].z, bs[q].w};
         const float slv[4] = {sl[q].x, sl[q].y, sl[q].z, sl[q].w};
         float *ob = obase + pofs[g] + (long long)(co_wave + ct * 32 + 8 * q + 4 * lh) * oplane;
+        float vq[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int r = 4 * q + k;
@@ -253,11 +262,40 @@ __device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const 
           v = (v > 0.0f ? v : v * slv[k]) * sc;
           if (qgelu) v = v / (1.0f + expf(-1.702f * v));  // uniform branch (per launch)
           if (RES && !res_pre) v += rv[RES ? g : 0][r];
-          HF_STORE_OUT(ob + k * oplane, v);
+          if (store32) HF_STORE_OUT(ob + k * oplane, v);
+          vq[k] = v;
         }
+#ifdef HF_WANT_F16_SPLIT
+        if (split) {
+          const int c4 = go.c + co_wave + ct * 32 + 8 * q + 4 * lh;
+          float vs[4] = {vq[0], vq[1], vq[2], vq[3]};
+          if (P.a_next || P.t_next) {  // one fma like hf_split_activation_f16's (bit-equal to the two-pass form)
+            const float4 an = P.a_next ? *reinterpret_cast<const float4 *>(P.a_next + c4) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            const float4 tn = P.t_next ? *reinterpret_cast<const float4 *>(P.t_next + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            vs[0] = fmaf(vs[0], an.x, tn.x);
+            vs[1] = fmaf(vs[1], an.y, tn.y);
+            vs[2] = fmaf(vs[2], an.z, tn.z);
+            vs[3] = fmaf(vs[3], an.w, tn.w);
+          }
+          hf_half4 h4, l4;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            _Float16 hv, lv;
+            hf_split_f16(vs[k], hv, lv, ovf_tile);
+            h4[k] = hv;
+            l4[k] = lv;
+          }
+          const long long unit = uofs[g] + (long long)(c4 >> 3) * oplane;
+          *reinterpret_cast<hf_half4 *>(static_cast<char *>(P.oh) + unit * 16 + (c4 & 4) * 2) = h4;
+          if (P.ol) *reinterpret_cast<hf_half4 *>(static_cast<char *>(P.ol) + unit * 16 + (c4 & 4) * 2) = l4;
+        }
+#endif
       }
     }
   }
+#ifdef HF_WANT_F16_SPLIT
+  if (split) hf_note_overflow(ovf_tile);
+#endif
 }
 
 template <int CT_TILES, int PG>

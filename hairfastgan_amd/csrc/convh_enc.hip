@@ -367,6 +367,7 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
   const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float);
   if (lds > 160 * 1024) return HF_E_INVALID;
   if (plan_only) return HF_OK;
+  if (P.oh && (P.splits > 1 || groups > 1)) return HF_E_INVALID;  // split output: written by this kernel's own epilogue only
   if (P.splits > 1) {
     if (!workspace || workspace_floats < P.splits * P.zslab) return HF_E_WORKSPACE;
     P.partial = workspace;
@@ -504,6 +505,27 @@ extern "C" int hf_conv2d_f16_f32(float *out, const float *x, const void *x_hi, c
   const _Float16 *hi = static_cast<const _Float16 *>(wt_hi), *lo = static_cast<const _Float16 *>(wt_lo);
   return (nterms == 3) ? run_enc<3>(P, hi, lo, workspace, workspace_floats, st, false)
                        : run_enc<1>(P, hi, lo, workspace, workspace_floats, st, false);
+}
+
+// hf_conv2d_f16_f32 whose result ALSO (or only: out NULL) leaves as the pre-split input of the next fp16-core conv:
+// next_scale[co] * y + next_shift[co] as fp16 (hi, lo), K-blocked - what hf_split_activation_f16 would make of y in a
+// pass of its own.  Launches that would run split-K (hf_conv2d_f16_workspace_floats != 0) or groups are refused.
+extern "C" int hf_conv2d_f16_split_f32(float *out, void *out_hi, void *out_lo, const float *next_scale, const float *next_shift,
+                                       const float *x, const void *x_hi, const void *x_lo, const void *wt_hi, const void *wt_lo,
+                                       int nterms, const float *in_scale, const float *in_shift, const float *out_scale,
+                                       const float *bias, int act, const float *slope, float alpha, const float *residual,
+                                       int batch, int cin, int cout, int h, int w, int stride, void *stream) {
+  if (!out_hi || (!x && !x_hi) || !wt_hi || (nterms != 1 && nterms != 3) || (nterms == 3 && (!wt_lo || !out_lo)) || (cout & 7))
+    return HF_E_INVALID;
+  ConvParams P{};
+  int rc = enc_fill(P, out, x, x_hi, x_lo, in_scale, in_shift, out_scale, bias, act, slope, alpha, residual, batch, cin, cout, h,
+                    w, stride, 1, 0);
+  if (rc != HF_OK) return rc;
+  P.oh = out_hi; P.ol = out_lo; P.a_next = next_scale; P.t_next = next_shift;
+  if ((long long)batch * (cout >> 3) * P.out_h * P.out_w >= (1LL << 40)) return HF_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const _Float16 *hi = static_cast<const _Float16 *>(wt_hi), *lo = static_cast<const _Float16 *>(wt_lo);
+  return (nterms == 3) ? run_enc<3>(P, hi, lo, nullptr, 0, st, false) : run_enc<1>(P, hi, lo, nullptr, 0, st, false);
 }
 
 extern "C" int hf_split_activation_f16(void *out_hi, void *out_lo, const float *x, const float *in_scale, const float *in_shift,

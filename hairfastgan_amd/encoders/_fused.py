@@ -130,13 +130,47 @@ def _patch_gemm_conv(x, w, mode, stride, kw):
     return y.reshape(*y.shape[:-2], oh, ow)
 
 
-def conv(x, w, k, stride=1, presplit=False, **kw):
+def takes_f16_conv(w, h, wd, k, stride, **kw):
+    """Does conv() run this call on the tiled fp16-core 3x3 kernel (hf_conv2d_f16_f32) - the one that accepts a pre-split input
+    and can emit a split output?  (The same tests as conv()'s dispatch, in its order.)"""
+    mode = conv_precision()
+    if mode == "f32" or k != 3:
+        return False
+    if (USE_GEMM_H and h <= 16 and wd <= 16 and (h - 1) // stride < 8 and (wd - 1) // stride < 8 and w.cin % 32 == 0
+            and w.cout % 64 == 0 and w.cin * w.cout >= 256 * 256 and stride == 2 and not ({"in_scale", "in_shift", "residual"} & set(kw))):
+        return False  # patch GEMM
+    return M.conv2d_f16_supported(w.cin, w.cout, h, wd, k, stride)
+
+
+def conv(x, w, k, stride=1, presplit=False, split_out=None, **kw):
     """Conv2d + folded BN / activation / residual.  3x3 convs whose shape the fp16 matrix-core kernel
     takes run there in the process-wide operand mode (_runtime.conv_precision: f16x3 = fp32-class
     split operands, f16 = rounded operands); everything else, and mode f32, on the fp32 MFMA.
-    presplit: this conv's input is shared by many block columns - convert it once (see PRESPLIT)."""
+    presplit: this conv's input is shared by many block columns - convert it once (see PRESPLIT).
+    x may be a SplitActivation when takes_f16_conv(...) holds for the call.
+    split_out = {"next_scale", "next_shift", "want_f32"} (any subset): the result is wanted as the pre-split input of the
+    next fp16-core conv; returns (SplitActivation | None, fp32 out | None) - the split form whenever the launch can emit it
+    from its epilogue (hf_conv2d_f16_split_f32), else (None, out)."""
     mode = conv_precision()
     h, wd = x.shape[-2], x.shape[-1]
+    if split_out is not None:
+        b = x.shape[0]
+        if (kw.get("groups", 1) == 1 and takes_f16_conv(w, h, wd, k, stride, **kw)
+                and M.conv2d_f16_split_supported(lib(), b, w.cin, w.cout, h, wd, stride)):
+            hi, lo = w.f16()
+            nterms = 3 if mode == "f16x3" else 1
+            if not isinstance(x, M.SplitActivation):
+                out_px = b * ((h - 1) // stride + 1) * ((wd - 1) // stride + 1)
+                if PRESPLIT == "all" and (w.cout // 64 >= 8 or (w.cin >= 128 and out_px >= 12288)):
+                    x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None), want_lo=nterms == 3)
+            return M.conv2d_f16_split(lib(), stream(), x, hi, lo, nterms, w.cout, stride, next_scale=split_out.get("next_scale"),
+                                      next_shift=split_out.get("next_shift"), want_f32=split_out.get("want_f32", False), **kw)
+        return None, conv(x, w, k, stride, presplit, **kw)
+    if isinstance(x, M.SplitActivation):  # a hand-off from the producing conv: only the tiled fp16-core kernel reads it
+        if k != 3 or mode == "f32":
+            raise ValueError("a pre-split input goes to a 3x3 conv on the fp16 matrix cores (takes_f16_conv)")
+        hi, lo = w.f16()
+        return M.conv2d_f16(lib(), stream(), x, hi, lo, 3 if mode == "f16x3" else 1, w.cout, stride, **kw)
     if mode != "f32" and k == 1 and USE_GEMM_H and M.conv1x1_f16_supported(w.cin, w.cout):
         hi, lo = w.f16()
         nterms = 3 if mode == "f16x3" else 1
@@ -164,8 +198,20 @@ def conv(x, w, k, stride=1, presplit=False, **kw):
         # (tools/bench_enc_layers.py, ENC_BATCH_MULT=8: 256->256 @32^2 128 -> 111 us, 512->512 stride 2 340 -> 160 us)
         out_px = x.shape[0] * ((h - 1) // stride + 1) * ((wd - 1) // stride + 1)
         many = groups * (w.cout // 64) >= 8 or (w.cin >= 128 and out_px >= 12288)
-        if (PRESPLIT == "all" and many) or (presplit and PRESPLIT in ("all", "heads")):
+        if not isinstance(x, M.SplitActivation) and ((PRESPLIT == "all" and many) or (presplit and PRESPLIT in ("all", "heads"))):
             x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None),
                                        want_lo=nterms == 3)
         return M.conv2d_f16(lib(), stream(), x, hi, lo, nterms, w.cout, stride, **kw)
     return M.conv2d(lib(), stream(), x, w.wt, k, stride, **kw)
+
+
+def conv_pair(x, w1, kw1, w2, stride2, kw2):
+    """conv3x3(x, w1, stride 1, **kw1) -> conv3x3(., w2, stride2, **kw2): the two convolutions of an IR-SE / IBasicBlock unit
+    (helpers.py:99-115, iresnet.py:44-56).  When both run on the tiled fp16-core kernel the first one's epilogue writes its
+    result straight in the second one's pre-split input layout (hf_conv2d_f16_split_f32): no fp32 tensor in between, no
+    split pass, and the second conv stages by LDS-DMA."""
+    h, wd = x.shape[-2], x.shape[-1]
+    if takes_f16_conv(w2, h, wd, 3, stride2, **kw2):
+        mid, mid32 = conv(x, w1, 3, 1, split_out={}, **kw1)
+        return conv(mid if mid is not None else mid32, w2, 3, stride2, **kw2)
+    return conv(conv(x, w1, 3, 1, **kw1), w2, 3, stride2, **kw2)

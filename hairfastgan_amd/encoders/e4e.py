@@ -17,7 +17,7 @@ from torch import nn
 
 from .. import _marshal as M
 from .._runtime import lib, require_gpu, stream
-from ._fused import FrozenPlanMixin, PreparedConv, conv, fold_bn, prep_conv
+from ._fused import FrozenPlanMixin, PreparedConv, conv, conv_pair, fold_bn, prep_conv
 
 # get_blocks(50): (in_channel, depth, stride) per unit (helpers.py:30-37)
 _IR50 = ([(64, 64, 2)] + [(64, 64, 1)] * 2 + [(64, 128, 2)] + [(128, 128, 1)] * 3 +
@@ -66,8 +66,8 @@ class bottleneck_IR_SE(FrozenPlanMixin, nn.Module):  # helpers.py:93-120
             shortcut, sc_stride = conv(x, p["wsc"], 1, self.stride, out_scale=p["sc"][0], bias=p["sc"][1]), 1
         else:
             shortcut, sc_stride = x, self.stride  # MaxPool2d(1, stride) == strided identity
-        r = conv(x, p["w1"], 3, 1, in_scale=p["in"][0], in_shift=p["in"][1], act=M.ACT_PRELU, slope=p["slope"])
-        r = conv(r, p["w2"], 3, self.stride, out_scale=p["out"][0], bias=p["out"][1])
+        r = conv_pair(x, p["w1"], dict(in_scale=p["in"][0], in_shift=p["in"][1], act=M.ACT_PRELU, slope=p["slope"]),
+                      p["w2"], self.stride, dict(out_scale=p["out"][0], bias=p["out"][1]))
         gate = M.se_gate(lib(), stream(), M.plane_mean(lib(), stream(), r), p["fc1"], p["fc2"])
         return M.scale_shortcut_add(lib(), stream(), r, gate, shortcut, sc_stride)
 

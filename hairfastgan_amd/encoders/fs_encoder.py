@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import _marshal as M
 from .._runtime import lib, require_gpu, stream
-from ._fused import FrozenPlanMixin, conv, fold_bn, prep_conv
+from ._fused import FrozenPlanMixin, conv, conv_pair, fold_bn, prep_conv
 
 _IRESNET50 = [(64, 3), (128, 4), (256, 14), (512, 3)]  # (planes, blocks) per layer, arcface/iresnet.py iresnet50
 
@@ -50,9 +50,9 @@ class IBasicBlock(FrozenPlanMixin, nn.Module):  # iresnet.py:28-57
         identity = x
         if "wd" in p:
             identity = conv(x, p["wd"], 1, self.stride, out_scale=p["bnd"][0], bias=p["bnd"][1])
-        out = conv(x, p["w1"], 3, 1, in_scale=p["bn1"][0], in_shift=p["bn1"][1], out_scale=p["bn2"][0],
-                   bias=p["bn2"][1], act=M.ACT_PRELU, slope=p["slope"])
-        return conv(out, p["w2"], 3, self.stride, out_scale=p["bn3"][0], bias=p["bn3"][1], residual=identity)
+        return conv_pair(x, p["w1"], dict(in_scale=p["bn1"][0], in_shift=p["bn1"][1], out_scale=p["bn2"][0], bias=p["bn2"][1],
+                                          act=M.ACT_PRELU, slope=p["slope"]),
+                         p["w2"], self.stride, dict(out_scale=p["bn3"][0], bias=p["bn3"][1], residual=identity))
 
 
 def _make_layer(inplanes, planes, blocks):
@@ -105,9 +105,9 @@ class fs_encoder_v2(FrozenPlanMixin, nn.Module):  # feature_style_encoder.py:12-
         for li in range(4):
             x = getattr(self, f"block_{li + 1}")(x)
             if li == 2:
-                c = conv(x, p["c_w1"], 3, 1, in_scale=p["c_bn0"][0], in_shift=p["c_bn0"][1], out_scale=p["c_bn2"][0],
-                         bias=p["c_bn2"][1], act=M.ACT_PRELU, slope=p["c_slope"])
-                content = conv(c, p["c_w4"], 3, self.content_stride, out_scale=p["c_bn5"][0], bias=p["c_bn5"][1])
+                content = conv_pair(x, p["c_w1"], dict(in_scale=p["c_bn0"][0], in_shift=p["c_bn0"][1], out_scale=p["c_bn2"][0],
+                                                       bias=p["c_bn2"][1], act=M.ACT_PRELU, slope=p["c_slope"]),
+                                    p["c_w4"], self.content_stride, dict(out_scale=p["c_bn5"][0], bias=p["c_bn5"][1]))
             M.adaptive_avgpool_into(L, st, pooled, x, c_off)
             c_off += x.shape[1]
         out = M.linear(L, st, pooled.reshape(b, -1), p["head_w"], p["head_b"], 1.0)

@@ -25,7 +25,7 @@ from torch import nn
 
 from .. import _marshal as M
 from .._runtime import lib, require_gpu, stream
-from ._fused import FrozenPlanMixin, conv, fold_bn, prep_conv
+from ._fused import FrozenPlanMixin, conv, conv_pair, fold_bn, prep_conv
 from .fs_encoder import _IRESNET50, IBasicBlock, _make_layer
 
 
@@ -68,9 +68,9 @@ class FeatureEncoderMult(FrozenPlanMixin, nn.Module):  # models/Net.py:396-477 w
         for li in range(4):
             x = getattr(self, f"block_{li + 1}")(x)
             if li == 1:
-                c = conv(x, p["c_w1"], 3, 1, in_scale=p["c_bn0"][0], in_shift=p["c_bn0"][1], out_scale=p["c_bn2"][0],
-                         bias=p["c_bn2"][1], act=M.ACT_PRELU, slope=p["c_slope"])
-                content = conv(c, p["c_w4"], 3, 1, out_scale=p["c_bn5"][0], bias=p["c_bn5"][1])
+                content = conv_pair(x, p["c_w1"], dict(in_scale=p["c_bn0"][0], in_shift=p["c_bn0"][1], out_scale=p["c_bn2"][0],
+                                                       bias=p["c_bn2"][1], act=M.ACT_PRELU, slope=p["c_slope"]),
+                                    p["c_w4"], 1, dict(out_scale=p["c_bn5"][0], bias=p["c_bn5"][1]))
             M.adaptive_avgpool_into(L, st, pooled, x, c_off)
             c_off += x.shape[1]
         out = M.linear(L, st, pooled.reshape(b, -1), p["head_w"], p["head_b"], 1.0)

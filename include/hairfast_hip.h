@@ -355,6 +355,17 @@ int hf_conv2d_f16_f32(float *out, const float *x, const void *x_hi, const void *
                       const float *residual, int batch, int cin, int cout, int h, int w, int stride, int groups,
                       long long x_group_stride, float *workspace, long long workspace_floats, void *stream);
 long long hf_conv2d_f16_workspace_floats(int batch, int cin, int cout, int h, int w, int stride, int groups);
+/* hf_conv2d_f16_f32 (groups = 1) whose result y also - or, out == NULL, only - leaves as the PRE-SPLIT input of the next
+ * fp16-core convolution: next_scale[co] * y + next_shift[co] (the consumer's input affine, e.g. its folded BatchNorm;
+ * NULL = identity) as fp16 (hi, lo) parts in the K-blocked layout of hf_split_activation_f16, written by the conv's own
+ * epilogue - the conv1 -> PReLU -> conv2 hand-off inside an IR-SE / IBasicBlock unit (helpers.py:99-115, iresnet.py:44-56)
+ * then costs no fp32 round trip and no split pass.  out_lo may be NULL for nterms 1.  Refused (HF_E_INVALID) when the
+ * shape would run split-K (hf_conv2d_f16_workspace_floats(...) != 0): the caller then uses the two-call form. */
+int hf_conv2d_f16_split_f32(float *out, void *out_hi, void *out_lo, const float *next_scale, const float *next_shift,
+                            const float *x, const void *x_hi, const void *x_lo, const void *wt_hi, const void *wt_lo,
+                            int nterms, const float *in_scale, const float *in_shift, const float *out_scale,
+                            const float *bias, int act, const float *slope, float alpha, const float *residual, int batch,
+                            int cin, int cout, int h, int w, int stride, void *stream);
 /* hf_conv2d_f32 for k = 1 on the fp16 matrix cores (csrc/gemm_h.hip): a GEMM over the pixels,
  *   y = act( out_scale[co] * sum_ci W[co,ci] * (in_scale[ci]*x + in_shift[ci]) + bias[co] ) + residual,
  * stride in {1, 2} (the source pixel of output (oy, ox) is (oy*stride, ox*stride)), operand modes as hf_conv2d_f16_f32.

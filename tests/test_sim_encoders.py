@@ -407,3 +407,33 @@ def test_fused_conv_small_plane_routes(sim_backend, simlib):
     assert simlib.hf_debug_last_path() // 100 == 7
     ref = F.conv2d(x1, w1, b1, padding=1)
     assert maxdiff(z, ref) < TOL * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("stride,nterms", [(1, 3), (2, 3), (1, 1)])
+def test_conv2d_f16_split_output(simlib, stride, nterms):
+    """hf_conv2d_f16_split_f32: the conv's epilogue writes next_scale*y + next_shift in the pre-split K-blocked layout - bit
+    for bit what hf_split_activation_f16 makes of the fp32 result, which is also still written when asked for."""
+    torch.manual_seed(7 + stride)
+    B, cin, cout, H, W = 2, 32, 64, 16, 32
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    hi, lo = M.conv_split_weights_f16(simlib, None, M.conv_prepare(simlib, None, w))
+    a, t = torch.rand(cin) + 0.5, torch.randn(cin) * 0.2
+    g, bsh, slope = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2, torch.rand(cout) * 0.5
+    na, nt = torch.rand(cout) + 0.5, torch.randn(cout) * 0.3
+    kw = dict(in_scale=a, in_shift=t, out_scale=g, bias=bsh, act=M.ACT_PRELU, slope=slope)
+    assert M.conv2d_f16_split_supported(simlib, B, cin, cout, H, W, stride)
+    ref = M.conv2d_f16(simlib, None, x, hi, lo, nterms, cout, stride, **kw)
+    sp, y = M.conv2d_f16_split(simlib, None, x, hi, lo, nterms, cout, stride, next_scale=na, next_shift=nt, want_f32=True, **kw)
+    assert torch.equal(y, ref)
+    want = M.split_activation_f16(simlib, None, ref, na, nt, want_lo=nterms == 3)
+    assert torch.equal(sp.hi, want.hi) and (nterms == 1 or torch.equal(sp.lo, want.lo))
+    sp2, none = M.conv2d_f16_split(simlib, None, x, hi, lo, nterms, cout, stride, **kw)   # split only, identity hand-off
+    want2 = M.split_activation_f16(simlib, None, ref, want_lo=nterms == 3)
+    assert none is None and torch.equal(sp2.hi, want2.hi) and (nterms == 1 or torch.equal(sp2.lo, want2.lo))
+    # and it feeds the next conv exactly like the two-call form
+    w2 = torch.randn(64, cout, 3, 3) / (cout * 9) ** 0.5
+    hi2, lo2 = M.conv_split_weights_f16(simlib, None, M.conv_prepare(simlib, None, w2))
+    z1 = M.conv2d_f16(simlib, None, sp2, hi2, lo2, nterms, 64, 1)
+    z2 = M.conv2d_f16(simlib, None, want2, hi2, lo2, nterms, 64, 1)
+    assert torch.equal(z1, z2)
