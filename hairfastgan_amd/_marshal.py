@@ -30,6 +30,7 @@ KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modc
     # csrc/convh.hip (fp16 matrix cores; <CT_TILES,PG,WAVES_CO,WAVES_PX>)
     581: "conv_mfma_h<1,2,2,4,up,pre>", 583: "conv_mfma_h<1,2,1,8,up,pre>",
     571: "conv_mfma_h<1,2,2,4,pre>", 572: "conv_mfma_h<2,2,1,8,pre>", 573: "conv_mfma_h<1,2,1,8,pre>", 575: "conv_mfma_h<1,2,1,8,tw128,pre>",
+    579: "conv_rows_h<32->32,strip64,pre>",
     551: "conv_mfma_h<1,2,2,4>", 552: "conv_mfma_h<2,2,1,8>", 553: "conv_mfma_h<1,2,1,8>", 555: "conv_mfma_h<1,2,1,8,tw128>",
     561: "conv_mfma_h<1,2,2,4,up>", 563: "conv_mfma_h<1,2,1,8,up>",
     573: "conv_mfma_h<1,2,1,8,up,fuse>", 593: "conv_mfma_h<1,2,1,8,up,pre,fuse>",

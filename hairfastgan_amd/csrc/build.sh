@@ -8,7 +8,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC $*"
 OBJS=""
 PIDS=""
-for f in api elementwise upfirdn2d style torgb modconv convh convh_enc encoder_ops sean vit gemm_h stem; do
+for f in api elementwise upfirdn2d style torgb modconv convh convh_enc encoder_ops sean vit gemm_h stem convrow; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hf_common.h -nt $f.o ] || [ conv_common.h -nt $f.o ] || [ ../../include/hairfast_hip.h -nt $f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o $f.o &
     PIDS="$PIDS $!"

@@ -1083,6 +1083,14 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
   }
   if (P.rgb_out && cfg == 51) cfg = 52;  // fused ToRGB needs all cout channels in one wave
   if (P.xh) {  // pre-split activations (ids 7x = the 5x tile shapes with DMA-staged activations)
+    // 32 -> 32 channels (the 1024^2 layer): the row pipeline of convrow.hip (id 79); hf_debug_set_tuning bit 4 = the tiled form
+    if (nterms == 3 && !g_force_h && !(g_h_tune & 16) && P.cin == 32 && P.cout == 32) {
+      rc = launch_conv_rows(P, wth, wtl, st);
+      if (rc == HF_OK) {
+        note_path(5, 79);
+        return rc;
+      }
+    }
     if (cfg == 55) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 128, true>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 128, true>(P, h, l, st);
     else if (cfg == 53) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 32, true>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 32, true>(P, h, l, st);
     else if (cfg == 52) rc = (nterms == 3) ? launch_h<3, 2, 2, 1, 8, false, 32, true>(P, h, l, st) : launch_h<1, 2, 2, 1, 8, false, 32, true>(P, h, l, st);

@@ -7,7 +7,7 @@ CXX=${HIPSIM_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 SRC=../../hairfastgan_amd/csrc
 OBJS=""
 PIDS=""
-for f in api elementwise upfirdn2d style torgb modconv convh convh_enc encoder_ops sean vit gemm_h stem; do
+for f in api elementwise upfirdn2d style torgb modconv convh convh_enc encoder_ops sean vit gemm_h stem convrow; do
   $CXX -x c++ -std=c++17 -O2 -fPIC -Wno-psabi -Wno-pass-failed -I. -c $SRC/$f.hip -o /tmp/hipsim_$f.o &
   PIDS="$PIDS $!"
   OBJS="$OBJS /tmp/hipsim_$f.o"

@@ -554,3 +554,36 @@ def test_modconv_up_fused_blur_persistent_walk(simlib, blocks):
     assert torch.equal(y, ref) and torch.equal(y2, ref)
     full = O.fused_leaky_relu(O.modulated_conv2d(x, sty, wgt, mw, mb, True, True) + nw * nz, bias)
     assert maxdiff(y, full) < TOL * max(1.0, float(full.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 16, 64), (2, 40, 128), (1, 64, 192)])
+def test_conv_rows_pipeline_equals_tiled_kernel(simlib, B, H, W):
+    """csrc/convrow.hip (32 -> 32 channels, pre-split input: the generator's 1024^2 conv as a row pipeline with the weights in
+    registers and an 18-row LDS ring) against the tiled kernel it replaces (hf_debug_set_tuning bit 4), bit for bit: fp32
+    output, fused ToRGB partial sums, noise; strips at both image borders, several super-steps, ring wrap-around."""
+    torch.manual_seed(H + W)
+    cin = cout = 32
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    s, dm = torch.rand(B, cin) + 0.5, torch.rand(B, cout) + 0.5
+    nz, nw, bias = torch.randn(B, 1, H, W), torch.tensor([0.3]), torch.randn(cout)
+    rgb_w, rgb_s = torch.randn(cout, 3) * 0.2, torch.rand(B, cout) + 0.5
+    wt, _ = M.prepare_weights(simlib, None, wgt)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    xh, xl = M.split_activation_reference(x, s)
+    act = M.SplitActivation(xh, xl, None)
+    try:
+        simlib.hf_debug_set_tuning(16)
+        ref_out, ref_raw = M.modconv3x3_f16_pre(simlib, None, act, hi, lo, 3, dm, nz, nw, bias, rgb=(rgb_w, rgb_s))
+        assert simlib.hf_debug_last_path() in (573, 575)
+    finally:
+        simlib.hf_debug_set_tuning(0)
+    out, raw = M.modconv3x3_f16_pre(simlib, None, act, hi, lo, 3, dm, nz, nw, bias, rgb=(rgb_w, rgb_s))
+    assert simlib.hf_debug_last_path() == 579
+    assert torch.equal(out, ref_out) and torch.equal(raw, ref_raw)
+    only_raw = M.modconv3x3_f16_pre(simlib, None, act, hi, lo, 3, dm, nz, nw, bias, rgb=(rgb_w, rgb_s), want_out=False)[1]
+    assert torch.equal(only_raw, ref_raw)
+    plain = M.modconv3x3_f16_pre(simlib, None, act, hi, lo, 3, dm, None, None, bias)
+    assert simlib.hf_debug_last_path() == 579
+    want = M.modconv3x3_f16(simlib, None, x, hi, lo, 3, s, dm, None, None, bias)
+    assert torch.equal(plain, want)
