@@ -18,6 +18,15 @@ def label(name):
                 f"{',pre' if pre else ''}{',fuse' if fuse else ''}>")
     if "blur4x4_split8" in name:
         return "blur4x4_split8"
+    if "conv_rows_h" in name:
+        return "conv_rows_h<32->32,strip64,pre>"  # bench.py's label (csrc/convrow.hip)
+    mg = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if mg and "conv_mfma_h" not in name and "conv_enc_h" not in name:  # other anonymous-namespace kernels: the bare identifier
+        n = int(mg.group(1))
+        ident = name[len(mg.group(0)):len(mg.group(0)) + n]
+        targs = re.findall(r"(?:Li(\d+)E|Lb(\d)E)", name[len(mg.group(0)) + n:].split("Ev")[0])
+        vals = [a or ("true" if b == "1" else "false") for a, b in targs]
+        return ident + (f"<{','.join(vals)}>" if vals else "")
     me = re.search(r"conv_enc_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)E(?:Li(\d)ELi(\d)E)?", name)
     if me:
         nt, pg, wpx, stride, pre = (int(v) for v in me.groups()[:5])
@@ -63,7 +72,7 @@ def main():
         # MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B / lane)
         # coalesced streaming read, `global_load` and `buffer_load ... lds` alike: the kernels whose reads are 16-byte
         # LDS-DMA units (pre-split activations + weights) or 16-byte vector loads get their FETCH doubled
-        wide = (",pre" in k and (k.startswith("conv_mfma_h") or k.startswith("conv_enc_h"))) or k in ("blur4x4_split8", "torgb_kernel", "blur4x4_noise_bias_act")
+        wide = (",pre" in k and (k.startswith("conv_mfma_h") or k.startswith("conv_enc_h"))) or k in ("blur4x4_split8", "torgb_kernel", "blur4x4_noise_bias_act") or k.startswith("conv_rows_h")
         raw_fetch = f[k][0] / n * 1024
         e = {"fetch_bytes_per_launch": raw_fetch * (2.0 if wide else 1.0), "fetch_size_counter_bytes": raw_fetch,
              "fetch_doubled": bool(wide), "write_bytes_per_launch": w[k][0] / max(1, len(w[k][1])) * 1024, "launches": n}

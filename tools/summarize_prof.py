@@ -16,6 +16,13 @@ def short(name):
                 f"{',pre' if pre else ''}{',fuse' if fuse else ''}>")
     if "blur4x4_split8" in name:
         return "blur4x4_split8"
+    mg = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if mg and "conv_mfma_h" not in name and "conv_enc_h" not in name:  # other anonymous-namespace kernels: the bare identifier
+        n = int(mg.group(1))
+        ident = name[len(mg.group(0)):len(mg.group(0)) + n]
+        targs = re.findall(r"(?:Li(\d+)E|Lb(\d)E)", name[len(mg.group(0)) + n:].split("Ev")[0])
+        vals = [a or ("true" if b == "1" else "false") for a, b in targs]
+        return ident + (f"<{','.join(vals)}>" if vals else "")
     me = re.search(r"conv_enc_hILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)E(?:Li(\d)ELi(\d)E)?", name)
     if me:
         nt, pg, wpx, stride, pre = (int(v) for v in me.groups()[:5])
