@@ -303,3 +303,32 @@ def test_split_k_without_empty_splits():
     y = M.conv2d(lib(), stream(), x, M.conv_prepare(lib(), stream(), wgt), 3, 1, act=M.ACT_LRELU, alpha=0.0)
     torch.cuda.synchronize()
     close(y, F.relu(F.conv2d(x.cpu(), wgt.cpu(), padding=1)))
+
+
+@pytest.mark.parametrize("stride,B,cin,cout,H,W", [(1, 24, 256, 256, 32, 32), (2, 8, 64, 64, 128, 128), (1, 3, 64, 64, 256, 256)])
+def test_conv2d_f16_split_output_equals_split_pass(stride, B, cin, cout, H, W):
+    """hf_conv2d_f16_split_f32 at encoder layer sizes: the fp32 result equals hf_conv2d_f16_f32's and the split written by the
+    epilogue equals hf_split_activation_f16 of it (consumer affine included), bit for bit; the next conv reads either."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(stride + H)
+    L, st = lib(), stream()
+    x = torch.randn(B, cin, H, W, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+    hi, lo = M.conv_split_weights_f16(L, st, M.conv_prepare(L, st, w))
+    a, t = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.2
+    g, bsh, slope = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.2, torch.rand(cout, device=dev) * 0.5
+    na, nt = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.3
+    kw = dict(in_scale=a, in_shift=t, out_scale=g, bias=bsh, act=M.ACT_PRELU, slope=slope)
+    if not M.conv2d_f16_split_supported(L, B, cin, cout, H, W, stride):
+        pytest.skip("this shape plans split-K: the two-call form is used")
+    ref = M.conv2d_f16(L, st, x, hi, lo, 3, cout, stride, **kw)
+    sp, y = M.conv2d_f16_split(L, st, x, hi, lo, 3, cout, stride, next_scale=na, next_shift=nt, want_f32=True, **kw)
+    want = M.split_activation_f16(L, st, ref, na, nt)
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref) and torch.equal(sp.hi, want.hi) and torch.equal(sp.lo, want.lo)
+    w2 = torch.randn(64, cout, 3, 3, device=dev) / (cout * 9) ** 0.5
+    hi2, lo2 = M.conv_split_weights_f16(L, st, M.conv_prepare(L, st, w2))
+    assert torch.equal(M.conv2d_f16(L, st, sp, hi2, lo2, 3, 64, 1), M.conv2d_f16(L, st, want, hi2, lo2, 3, 64, 1))

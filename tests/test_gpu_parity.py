@@ -889,3 +889,43 @@ def test_auto_precision_reruns_clamped_forward_in_f32():
     assert torch.equal(ya, y32)
     assert not torch.equal(y16, y32)
     assert _runtime.configured_conv_precision() != "auto" and _runtime.conv_precision() in ("f16x3", "f32", "f16")
+
+
+@pytest.mark.parametrize("B,H,W", [(8, 1024, 1024), (1, 1024, 1024), (3, 256, 192)])
+def test_conv_rows_pipeline_equals_tiled_kernel_on_hardware(B, H, W):
+    """csrc/convrow.hip at BASELINE.json's full size: the row pipeline (weights in registers, 18-slot LDS ring refilled
+    by LDS-DMA while the previous rows are read) against the tiled kernel (hf_debug_set_tuning bit 4), bit for bit, three
+    launches each - a ring slot overwritten too early or read too early shows up as a mismatch - and against the fp32-MFMA
+    kernel within the f16x3 tolerance."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib as _lib_fn, stream
+
+    dev = _dev()
+    lib, st = _lib_fn(), stream()
+    torch.manual_seed(B + W)
+    r = lambda *sz: torch.randn(*sz, device=dev)  # noqa: E731
+    cin = cout = 32
+    x, wgt = r(B, cin, H, W), r(1, cout, cin, 3, 3)
+    s, dm = torch.rand(B, cin, device=dev) + 0.5, torch.rand(B, cout, device=dev) + 0.5
+    nz, nw, bias = r(B, 1, H, W), torch.tensor([0.3], device=dev), r(cout)
+    rgb_w, rgb_s = r(cout, 3) * 0.2, torch.rand(B, cout, device=dev) + 0.5
+    wt, _ = M.prepare_weights(lib, st, wgt)
+    hi, lo = M.split_weights_f16(lib, st, wt)
+    xh, xl = M.split_activation_reference(x, s)
+    act = M.SplitActivation(xh, xl, None)
+    try:
+        lib.hf_debug_set_tuning(16)
+        ref_out, ref_raw = M.modconv3x3_f16_pre(lib, st, act, hi, lo, 3, dm, nz, nw, bias, rgb=(rgb_w, rgb_s))
+        assert lib.hf_debug_last_path() in (573, 575)
+    finally:
+        lib.hf_debug_set_tuning(0)
+    for _ in range(3):
+        out, raw = M.modconv3x3_f16_pre(lib, st, act, hi, lo, 3, dm, nz, nw, bias, rgb=(rgb_w, rgb_s))
+        assert lib.hf_debug_last_path() == 579
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref_out) and torch.equal(raw, ref_raw)
+    only_raw = M.modconv3x3_f16_pre(lib, st, act, hi, lo, 3, dm, nz, nw, bias, rgb=(rgb_w, rgb_s), want_out=False)[1]
+    assert torch.equal(only_raw, ref_raw)
+    if B * H * W <= 1 << 20:
+        exact = M.modconv3x3(lib, st, x, wt, s, dm, nz, nw, bias)
+        assert float((out - exact).abs().max()) <= 2e-5 * max(1.0, float(exact.abs().max()))

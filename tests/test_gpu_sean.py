@@ -78,3 +78,37 @@ def test_sean_vs_reference_golden(golden, mode):
     finally:
         _runtime.set_conv_precision(prev)
     print(f"sean {mode}: codes max-abs {e_codes:.2e}")
+
+
+def test_ace_tail_with_table_lookup_equals_two_kernel_form():
+    """hf_ace_modulate_table_f32 (avg planes looked up in-kernel) = hf_label_conv3x3_f32 + hf_ace_modulate_f32 bit for bit
+    at a decode's own size (8 samples, 256 channels, 128^2, two samples per label map), and the LDS-table label conv against
+    torch's convolution of the broadcast region vectors."""
+    import torch.nn.functional as F
+
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    B, Cc, H, W, group = 8, 256, 128, 128, 2
+    labels = torch.randint(0, 19, (B // group, H // 8, W // 8), device=dev).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    labels = labels.to(torch.int32).contiguous()                       # 8 x 8 blocks: interiors and borders
+    table = torch.randn(9 * 2 * Cc, B * 19, device=dev)
+    b_avg = torch.randn(2 * Cc, device=dev)
+    x, noise = torch.randn(B, Cc, H, W, device=dev), torch.randn(B, H, W, device=dev)
+    sp = torch.randn(B // group, 2 * Cc, H, W, device=dev)
+    nv, sc, sh = torch.randn(Cc, device=dev) * 0.1, torch.rand(Cc, device=dev) + 0.5, torch.randn(Cc, device=dev)
+    blend = torch.tensor([0.3, -0.7], device=dev)
+    L, st = lib(), stream()
+    avg = M.label_conv3x3(L, st, labels, table, b_avg, 2 * Cc, batch=B, cols_per_sample=19, group=group)
+    two = M.ace_modulate(L, st, x, noise, nv, sc, sh, avg, sp, blend, group=group, slope=0.2)
+    one = M.ace_modulate_table(L, st, x, noise, nv, sc, sh, labels, table, b_avg, sp, blend, group=group, slope=0.2)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two)
+    # the lookup conv itself: sample 5's table columns as a dense conv of its one-hot map
+    s_ = 5
+    onehot = F.one_hot(labels[s_ // group].long(), 19).permute(2, 0, 1).float()[None]
+    wdense = table[:, s_ * 19:(s_ + 1) * 19].reshape(3, 3, 2 * Cc, 19).permute(2, 3, 0, 1).contiguous()
+    ref = F.conv2d(onehot.cpu().double(), wdense.cpu().double(), b_avg.cpu().double(), padding=1).float()
+    assert float((avg[s_:s_ + 1].cpu() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
