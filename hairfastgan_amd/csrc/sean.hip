@@ -224,6 +224,15 @@ extern "C" int hf_label_conv3x3_f32(float *out, const int *labels, const float *
 //   bt  = a_b * avg[b, C + c] + (1 - a_b) * sp[b / group, C + c], a_b = sigmoid(blend[1])
 //   out = lrelu_slope( n * (1 + g) + bt )                                           (slope 1: no activation)
 // avg / sp: [*, 2C, H, W] (gamma planes first, then beta planes).
+// one element of the tail, every product-sum an explicit fma: ace_modulate and ace_modulate_table must agree bit for bit
+// (left to the compiler, the two kernels contracted a * b + c * d differently)
+__device__ __forceinline__ float ace_tail(float x, float r, float nv, float sc, float sh, float g, float bt, float slope) {
+  const float n = fmaf(fmaf(r, nv, x), sc, sh);
+  const float v = fmaf(n, 1.0f + g, bt);
+  return v > 0.0f ? v : v * slope;
+}
+__device__ __forceinline__ float ace_blend(float a, float avg, float spv) { return fmaf(a, avg, (1.0f - a) * spv); }
+
 __global__ __launch_bounds__(256) void ace_modulate(float *__restrict__ out, const float *__restrict__ x,
                                                     const float *__restrict__ r, const float *__restrict__ noise_var,
                                                     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
@@ -246,20 +255,14 @@ __global__ __launch_bounds__(256) void ace_modulate(float *__restrict__ out, con
     const float ag = 1.0f / (1.0f + expf(-blend[0])), ab = 1.0f / (1.0f + expf(-blend[1]));
     const float4 ga = reinterpret_cast<const float4 *>(avg)[((long long)b * 2 * C + c) * plane + i];
     const float4 ba = reinterpret_cast<const float4 *>(avg)[((long long)b * 2 * C + C + c) * plane + i];
-    g = make_float4(ag * ga.x + (1.0f - ag) * gs.x, ag * ga.y + (1.0f - ag) * gs.y, ag * ga.z + (1.0f - ag) * gs.z,
-                    ag * ga.w + (1.0f - ag) * gs.w);
-    bt = make_float4(ab * ba.x + (1.0f - ab) * bs.x, ab * ba.y + (1.0f - ab) * bs.y, ab * ba.z + (1.0f - ab) * bs.z,
-                     ab * ba.w + (1.0f - ab) * bs.w);
+    g = make_float4(ace_blend(ag, ga.x, gs.x), ace_blend(ag, ga.y, gs.y), ace_blend(ag, ga.z, gs.z), ace_blend(ag, ga.w, gs.w));
+    bt = make_float4(ace_blend(ab, ba.x, bs.x), ace_blend(ab, ba.y, bs.y), ace_blend(ab, ba.z, bs.z), ace_blend(ab, ba.w, bs.w));
   }
   float4 o;
-  o.x = ((xv.x + rv.x * nv) * sc + sh) * (1.0f + g.x) + bt.x;
-  o.y = ((xv.y + rv.y * nv) * sc + sh) * (1.0f + g.y) + bt.y;
-  o.z = ((xv.z + rv.z * nv) * sc + sh) * (1.0f + g.z) + bt.z;
-  o.w = ((xv.w + rv.w * nv) * sc + sh) * (1.0f + g.w) + bt.w;
-  o.x = o.x > 0.0f ? o.x : o.x * slope;
-  o.y = o.y > 0.0f ? o.y : o.y * slope;
-  o.z = o.z > 0.0f ? o.z : o.z * slope;
-  o.w = o.w > 0.0f ? o.w : o.w * slope;
+  o.x = ace_tail(xv.x, rv.x, nv, sc, sh, g.x, bt.x, slope);
+  o.y = ace_tail(xv.y, rv.y, nv, sc, sh, g.y, bt.y, slope);
+  o.z = ace_tail(xv.z, rv.z, nv, sc, sh, g.z, bt.z, slope);
+  o.w = ace_tail(xv.w, rv.w, nv, sc, sh, g.w, bt.w, slope);
   reinterpret_cast<float4 *>(out)[((long long)b * C + c) * plane + i] = o;
 }
 
@@ -321,9 +324,7 @@ __global__ __launch_bounds__(256) void ace_modulate_table(float *__restrict__ ou
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float g = ag * ga[j] + (1.0f - ag) * gs[j], bt = ab * ba[j] + (1.0f - ab) * bs[j];
-      const float v = ((xs[j] + rr[j] * nv) * sc + sh) * (1.0f + g) + bt;
-      o[j] = v > 0.0f ? v : v * slope;
+      o[j] = ace_tail(xs[j], rr[j], nv, sc, sh, ace_blend(ag, ga[j], gs[j]), ace_blend(ab, ba[j], bs[j]), slope);
     }
     if (live) *reinterpret_cast<float4 *>(out + ((long long)b * C + c) * hw + pc) = make_float4(o[0], o[1], o[2], o[3]);
   }
