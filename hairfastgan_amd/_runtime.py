@@ -100,3 +100,13 @@ def set_conv_precision(mode):
         raise ValueError(f"conv precision must be one of {CONV_PRECISIONS}, got {mode!r}")
     prev, _conv_precision = _conv_precision, mode
     return prev
+
+
+def reference_rng_walk():
+    """HAIRFAST_RNG_WALK=reference: consume torch's device RNG in the reference's ORDER - one normal_() per NoiseInjection
+    layer (models/stylegan2/model.py:289-291) instead of one per forward, and the FS encoder's discarded generator forward
+    (trainer.py:295) run for its 17 draws.  Costs ~16 launches and 148.5 GFLOP per embedded image; the draws still come from
+    hipRAND's Philox, so a CUDA run is matched in distribution and call order, not bit for bit.  Read per call."""
+    import os
+
+    return os.environ.get("HAIRFAST_RNG_WALK", "") == "reference"

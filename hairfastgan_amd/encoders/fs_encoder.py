@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from .. import _marshal as M
-from .._runtime import lib, require_gpu, stream
+from .._runtime import lib, reference_rng_walk, require_gpu, stream
 from ._fused import FrozenPlanMixin, conv, conv_pair, fold_bn, prep_conv
 
 _IRESNET50 = [(64, 3), (128, 4), (256, 14), (512, 3)]  # (planes, blocks) per layer, arcface/iresnet.py iresnet50
@@ -143,7 +143,7 @@ class FSEncoder(nn.Module):
         w_recon, fea = self.enc(x)
         w_recon = M.add_bcast(L, st, w_recon, self.dlatent_avg)  # trainer.py:289
         x_recon = None
-        if self.run_discarded_generator and self.generator is not None:
+        if (self.run_discarded_generator or reference_rng_walk()) and self.generator is not None:
             x_recon, _ = self.generator([w_recon], input_is_latent=True)  # trainer.py:295 (discarded by the caller)
         output = [img[:, :3], x_recon]
         if return_latent:

@@ -657,7 +657,9 @@ class HairFast:
         reproduce a seeded run of the reference sample for sample: the per-layer noise of a generator forward is one draw
         here (17 in the reference), the FS encoder's discarded generator forward (trainer.py:295, which only advances the
         RNG) is not run, SEAN's 18 ACE noise maps per decode are one draw, and hipRAND's Philox walk differs from cuRAND's
-        in any case.  Bit-level comparisons with the reference therefore inject the noise explicitly
+        in any case.  `HAIRFAST_RNG_WALK=reference` restores the reference's ORDER of consumption (one draw per noise layer,
+        the discarded forward run; _runtime.reference_rng_walk) at the cost of those launches.  Bit-level comparisons with
+        the reference inject the noise explicitly
         (Generator.forward(noise= / randomize_noise=False), SPADEGenerator.noise_source; tests/test_gpu_pipeline.py)."""
         cache = {}
         images = [self._as_tensor(img, cache) for img in (face_img, shape_img, color_img)]

@@ -25,7 +25,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from .. import _marshal as M
-from .._runtime import conv_precision, lib, require_gpu, run_guarded, stream
+from .._runtime import conv_precision, lib, reference_rng_walk, require_gpu, run_guarded, stream
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 
 
@@ -510,8 +510,8 @@ class Generator(nn.Module):  # :368-565
         device RNG (the reference draws one tensor per layer inside NoiseInjection, :289-291 - 17 launches per forward;
         same distribution, same seed -> same images, but a different walk through the Philox stream: bit-level
         noise parity with a CUDA run does not exist either way).  Stand-alone layers still draw their own."""
-        if any(n is not None for n in noise) or not latent.is_cuda:
-            return noise
+        if any(n is not None for n in noise) or not latent.is_cuda or reference_rng_walk():
+            return noise  # HAIRFAST_RNG_WALK=reference: every NoiseInjection draws its own map, in the reference's order
         b = latent.shape[0]
         run = [i for i in range(self.num_layers)
                if (i == 0 and start_layer == 0) or (i > 0 and max(start_layer, 1) <= (i + 1) // 2 and

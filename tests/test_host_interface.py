@@ -188,3 +188,19 @@ def test_torch_custom_ops_are_registered():
     assert ops.conv2d(x, wt, 3, 2, None, None, None, None, 0, None, 0.0, None).shape == (2, 8, 5, 5)
     with pytest.raises((NotImplementedError, RuntimeError)):  # no CPU kernel registered: the dispatcher refuses
         ops.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(4, 4), 1, 1, 1, 1, 1, 1, 1, 1)
+
+
+def test_reference_rng_walk_switch(monkeypatch):
+    """HAIRFAST_RNG_WALK=reference (advisor, round 2): the generator hands the per-layer draws back to the NoiseInjection
+    layers (the reference's order of consumption) and the FS encoder wrapper runs its discarded forward."""
+    from hairfastgan_amd import _runtime
+    from hairfastgan_amd.stylegan2.model import Generator
+
+    g = Generator(16, 32, 2).eval()
+    lat = torch.zeros(1, g.n_latent, 32)
+    noise = [None] * g.num_layers
+    monkeypatch.delenv("HAIRFAST_RNG_WALK", raising=False)
+    assert not _runtime.reference_rng_walk()
+    monkeypatch.setenv("HAIRFAST_RNG_WALK", "reference")
+    assert _runtime.reference_rng_walk()
+    assert g._draw_noise(noise, lat, 0, 8) is noise  # untouched: each layer draws its own
