@@ -87,6 +87,8 @@ def prep_conv(conv):
 PRESPLIT = os.environ.get("HAIRFAST_ENC_PRESPLIT", "all")
 # 1x1 convolutions / Linear layers on the fp16 matrix cores (csrc/gemm_h.hip) instead of the fp32-MFMA general kernel
 USE_GEMM_H = os.environ.get("HAIRFAST_GEMM_H", "1") != "0"
+# conv -> conv hand-off through the first conv's epilogue (conv_pair): tuning knob, "0" = fp32 tensor + split pass
+USE_PAIR = os.environ.get("HAIRFAST_CONV_PAIR", "1") != "0"
 
 
 def _small_plane_conv(x, w, mode, kw):
@@ -205,13 +207,15 @@ def conv(x, w, k, stride=1, presplit=False, split_out=None, **kw):
     return M.conv2d(lib(), stream(), x, w.wt, k, stride, **kw)
 
 
-def conv_pair(x, w1, kw1, w2, stride2, kw2):
-    """conv3x3(x, w1, stride 1, **kw1) -> conv3x3(., w2, stride2, **kw2): the two convolutions of an IR-SE / IBasicBlock unit
-    (helpers.py:99-115, iresnet.py:44-56).  When both run on the tiled fp16-core kernel the first one's epilogue writes its
-    result straight in the second one's pre-split input layout (hf_conv2d_f16_split_f32): no fp32 tensor in between, no
-    split pass, and the second conv stages by LDS-DMA."""
+def conv_pair(x, w1, kw1, w2, stride2, kw2, stride1=1):
+    """conv3x3(x, w1, stride1, **kw1) -> conv3x3(., w2, stride2, **kw2): the two convolutions of an IR-SE / IBasicBlock unit
+    (helpers.py:99-115, iresnet.py:44-56; stride on the second) or of a ResNet BasicBlock (resnet.py:36-45; stride on the
+    first).  When both run on the tiled fp16-core kernel the first one's epilogue writes its result straight in the second
+    one's pre-split input layout (hf_conv2d_f16_split_f32): no fp32 tensor in between, no split pass, and the second conv
+    stages by LDS-DMA."""
     h, wd = x.shape[-2], x.shape[-1]
-    if takes_f16_conv(w2, h, wd, 3, stride2, **kw2):
-        mid, mid32 = conv(x, w1, 3, 1, split_out={}, **kw1)
+    h1, w1d = (h - 1) // stride1 + 1, (wd - 1) // stride1 + 1
+    if USE_PAIR and takes_f16_conv(w2, h1, w1d, 3, stride2, **kw2):
+        mid, mid32 = conv(x, w1, 3, stride1, split_out={}, **kw1)
         return conv(mid if mid is not None else mid32, w2, 3, stride2, **kw2)
-    return conv(conv(x, w1, 3, 1, **kw1), w2, 3, stride2, **kw2)
+    return conv(conv(x, w1, 3, stride1, **kw1), w2, 3, stride2, **kw2)

@@ -22,7 +22,7 @@ from torch import nn
 
 from . import _marshal as M
 from ._runtime import conv_precision, lib, require_gpu, stream
-from .encoders._fused import FrozenPlanMixin, conv, fold_bn, prep_conv
+from .encoders._fused import FrozenPlanMixin, conv, conv_pair, fold_bn, prep_conv
 
 # FaceParsing_tensor.label_list order -> index in PARSING_LABEL_LIST (global_value_utils.py:49-51); 13 = hair
 _BISENET_LABELS = ["background", "skin_other", "l_brow", "r_brow", "l_eye", "r_eye", "eye_g", "l_ear", "r_ear", "ear_r",
@@ -86,11 +86,12 @@ class BasicBlock(nn.Module):  # resnet.py:19-46
         return p
 
     def run(self, p, x):
-        r = conv(x, p["w1"], 3, self.stride, out_scale=p["bn1"][0], bias=p["bn1"][1], **RELU)
         sc = x if "wd" not in p else conv(x, p["wd"], 1, self.stride, out_scale=p["bnd"][0], bias=p["bnd"][1])
-        # relu(shortcut + bn2(conv2(r))): the residual joins BEFORE the activation (resnet.py:41-45)
-        return conv(r, p["w2"], 3, 1, out_scale=p["bn2"][0], bias=p["bn2"][1], act=M.ACT_LRELU | M.ACT_RESIDUAL_FIRST,
-                    alpha=0.0, residual=sc)
+        # relu(shortcut + bn2(conv2(r))): the residual joins BEFORE the activation (resnet.py:41-45); conv1's result goes to
+        # conv2 in its pre-split input layout when both run on the fp16 matrix cores (conv_pair)
+        return conv_pair(x, p["w1"], dict(out_scale=p["bn1"][0], bias=p["bn1"][1], **RELU),
+                         p["w2"], 1, dict(out_scale=p["bn2"][0], bias=p["bn2"][1], act=M.ACT_LRELU | M.ACT_RESIDUAL_FIRST,
+                                          alpha=0.0, residual=sc), stride1=self.stride)
 
 
 def _layer(in_chan, out_chan, stride):
