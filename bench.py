@@ -50,6 +50,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+F16_CORE_KERNELS = ("conv_mfma_h", "conv_enc_h", "gemm_h", "conv_rows_h", "stem 7x7")  # label prefixes of the fp16-MFMA kernels
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_f16: 32768 FLOP / 32 cycles / SIMD, 1024 SIMDs x 2.4 GHz
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (~6.3 TB/s achievable)
@@ -242,7 +243,7 @@ def kernel_report(prof, elapsed, precision, sampled=1.0):
         dom = max(mfma, key=lambda k: mfma[k][1])
         d = mfma[dom]
         ach = d[0] / d[1] / 1e12
-        if dom.startswith("conv_mfma_h"):
+        if dom.startswith(F16_CORE_KERNELS):
             terms = 3 if precision == "f16x3" else 1
             peak = PEAK_F16_MFMA_TFLOPS / terms
             peak_note = (f"fp16 dense MFMA peak {PEAK_F16_MFMA_TFLOPS} TFLOP/s / {terms} MFMA per product; "
@@ -264,7 +265,7 @@ def kernel_report(prof, elapsed, precision, sampled=1.0):
     # upsampling StyledConv, the 1024^2 layer, the 4^2-32^2 tower - shows here)
     fam_roof = {}
     for k, v in sorted(mfma.items(), key=lambda kv: -kv[1][1]):
-        if k.startswith("conv_mfma_h") or k.startswith("conv_enc_h") or k.startswith("gemm_h"):
+        if k.startswith(F16_CORE_KERNELS):
             terms = 3 if precision == "f16x3" else 1
             pk = PEAK_F16_MFMA_TFLOPS / terms
         else:
