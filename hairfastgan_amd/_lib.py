@@ -73,10 +73,10 @@ SIGNATURES = {
     "hf_axpby_bcast_f32": [_f, _f, _fl, _f, _fl, _ll, _ll, _st],
     "hf_add_bcast_f32": [_f, _f, _f, _ll, _ll, _st],
     "hf_label_conv3x3_f32": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _st],
-    "hf_ace_modulate_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _st],
+    "hf_ace_modulate_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _i, _st],
     "hf_conv2d_f16_split_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _st],
     "hf_stem7x7s2_f16_f32": [_f, _f, _f, _f, _f, _f, _f, _fl, _i, _i, _i, _i, _i, _st],
-    "hf_ace_modulate_table_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _i, _st],
+    "hf_ace_modulate_table_f32": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _i, _i, _st],
     "hf_region_mean_f32": [_f, _f, _f, _i, _i, _i, _i, _i, _ll, _ll, _i, _i, _st],
     "hf_tanh_f32": [_f, _f, _ll, _st],
     "hf_channel_layernorm_f32": [_f, _f, _f, _f, _i, _ll, _fl, _st],

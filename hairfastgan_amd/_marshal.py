@@ -1058,37 +1058,45 @@ def label_conv3x3(lib, st, labels, table, bias, channels, batch=None, cols_per_s
     return out
 
 
-def ace_modulate(lib, st, x, noise, noise_var, bn_scale, bn_shift, avg, sp, blend, group=1, slope=1.0):
+def ace_modulate(lib, st, x, noise, noise_var, bn_scale, bn_shift, avg, sp, blend, group=1, slope=1.0, x_up=False):
     """hf_ace_modulate_f32: the tail of ACE.forward; x [B,C,H,W], noise [B,H,W] | None, avg [B,2C,H,W] | None,
-    sp [B/group,2C,H,W], blend = device tensor (blending_gamma, blending_beta)."""
+    sp [B/group,2C,H,W], blend = device tensor (blending_gamma, blending_beta).  x_up: x is [B,C,H/2,W/2] and its nearest
+    x2 up-sampling is read in place."""
     x, sp = _c(x), _c(sp)
-    b, c, h, w = x.shape
+    b, c = x.shape[:2]
+    h, w = sp.shape[-2:]
+    if tuple(x.shape[-2:]) != ((h // 2, w // 2) if x_up else (h, w)):
+        raise ValueError(f"x {tuple(x.shape)} does not match the {h} x {w} planes of sp (x_up={x_up})")
     if tuple(sp.shape) != (b // group, 2 * c, h, w) or (avg is not None and tuple(avg.shape) != (b, 2 * c, h, w)):
         raise ValueError("sp / avg must be [B/group | B, 2C, H, W]")
     if noise is not None and noise.numel() != b * h * w:
         raise ValueError("noise must be [B, H, W]")
-    out = torch.empty_like(x)
+    out = x.new_empty((b, c, h, w))
     check(lib, lib.hf_ace_modulate_f32(_p(out), _p(x), _p(_c(noise)), _p(_c(noise_var)), _p(_c(bn_scale)), _p(_c(bn_shift)),
-                                       _p(_c(avg)), _p(sp), _p(_c(blend)), b, c, h * w, group, float(slope), st),
+                                       _p(_c(avg)), _p(sp), _p(_c(blend)), b, c, h * w, group, float(slope), w if x_up else 0, st),
           "hf_ace_modulate_f32")
     return out
 
 
-def ace_modulate_table(lib, st, x, noise, noise_var, bn_scale, bn_shift, labels, table, avg_bias, sp, blend, group=1, slope=1.0):
+def ace_modulate_table(lib, st, x, noise, noise_var, bn_scale, bn_shift, labels, table, avg_bias, sp, blend, group=1, slope=1.0,
+                       x_up=False):
     """hf_ace_modulate_table_f32: label_conv3x3(labels, table, avg_bias, 2C, batch=B, cols_per_sample=19, group) fused into
     ace_modulate (the [B,2C,H,W] avg planes never exist).  table [9*2C, >= B*19]; labels int32 [B/group,H,W]."""
     x, sp, table = _c(x), _c(sp), _c(table)
-    b, c, h, w = x.shape
+    b, c = x.shape[:2]
+    h, w = sp.shape[-2:]
+    if tuple(x.shape[-2:]) != ((h // 2, w // 2) if x_up else (h, w)):
+        raise ValueError(f"x {tuple(x.shape)} does not match the {h} x {w} planes of sp (x_up={x_up})")
     if labels.dtype != torch.int32 or not labels.is_contiguous() or tuple(labels.shape) != (b // group, h, w):
         raise TypeError("labels must be contiguous int32 [B/group, H, W]")
     if tuple(sp.shape) != (b // group, 2 * c, h, w) or table.shape[0] != 9 * 2 * c or table.shape[1] < b * 19:
         raise ValueError("sp must be [B/group, 2C, H, W] and table [9*2C, >= 19*B]")
     if noise is not None and noise.numel() != b * h * w:
         raise ValueError("noise must be [B, H, W]")
-    out = torch.empty_like(x)
+    out = x.new_empty((b, c, h, w))
     check(lib, lib.hf_ace_modulate_table_f32(_p(out), _p(x), _p(_c(noise)), _p(_c(noise_var)), _p(_c(bn_scale)), _p(_c(bn_shift)),
                                              _p(labels), _p(table), _p(_c(avg_bias)), _p(sp), _p(_c(blend)), b, c, h, w,
-                                             table.shape[1], 19, group, float(slope), 1 if h * w >= 1024 else 0, st),
+                                             table.shape[1], 19, group, float(slope), 1 if h * w >= 1024 else 0, 1 if x_up else 0, st),
           "hf_ace_modulate_table_f32")
     return out
 

@@ -237,12 +237,20 @@ __global__ __launch_bounds__(256) void ace_modulate(float *__restrict__ out, con
                                                     const float *__restrict__ r, const float *__restrict__ noise_var,
                                                     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
                                                     const float *__restrict__ avg, const float *__restrict__ sp,
-                                                    const float *__restrict__ blend, int C, int hw4, int group, float slope) {
+                                                    const float *__restrict__ blend, int C, int hw4, int group, float slope,
+                                                    int w, int x_up) {
   const int c = blockIdx.y, b = blockIdx.z;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= hw4) return;
   const long long plane = (long long)hw4;  // in float4 units
-  const float4 xv = reinterpret_cast<const float4 *>(x)[((long long)b * C + c) * plane + i];
+  float4 xv;
+  if (x_up) {  // x is the HALF-resolution plane [h/2, w/2]: nearest-neighbour x2 (generator.py:80-103 `self.up`) read in place
+    const int p = i * 4, y = p / w, xx = p - y * w;
+    const float2 lo = *reinterpret_cast<const float2 *>(x + ((long long)b * C + c) * plane + (long long)(y >> 1) * (w >> 1) + (xx >> 1));  // low-res plane = hw/4 = `plane` floats
+    xv = make_float4(lo.x, lo.x, lo.y, lo.y);
+  } else {
+    xv = reinterpret_cast<const float4 *>(x)[((long long)b * C + c) * plane + i];
+  }
   float4 rv = make_float4(0, 0, 0, 0);
   const float nv = noise_var ? noise_var[c] : 0.0f;
   if (r) rv = reinterpret_cast<const float4 *>(r)[(long long)b * plane + i];
@@ -268,12 +276,14 @@ __global__ __launch_bounds__(256) void ace_modulate(float *__restrict__ out, con
 
 extern "C" int hf_ace_modulate_f32(float *out, const float *x, const float *noise, const float *noise_var,
                                    const float *bn_scale, const float *bn_shift, const float *avg, const float *sp,
-                                   const float *blend, int batch, int channels, int hw, int group, float slope, void *stream) {
+                                   const float *blend, int batch, int channels, int hw, int group, float slope, int x_upsample_w,
+                                   void *stream) {
   if (!out || !x || !bn_scale || !bn_shift || !sp || batch <= 0 || channels <= 0 || hw <= 0 || (hw & 3) || group <= 0 ||
-      (avg && !blend) || batch > 65535 || channels > 65535)
+      (avg && !blend) || batch > 65535 || channels > 65535 || x_upsample_w < 0 ||
+      (x_upsample_w && ((x_upsample_w & 3) || hw % x_upsample_w || ((hw / x_upsample_w) & 1))))
     return HF_E_INVALID;
   hipLaunchKernelGGL(ace_modulate, dim3(hf_cdiv(hw / 4, 256), channels, batch), dim3(256), 0, (hipStream_t)stream, out, x, noise,
-                     noise_var, bn_scale, bn_shift, avg, sp, blend, channels, hw / 4, group, slope);
+                     noise_var, bn_scale, bn_shift, avg, sp, blend, channels, hw / 4, group, slope, x_upsample_w, x_upsample_w ? 1 : 0);
   return hf_launch_status();
 }
 
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(256) void ace_modulate_table(float *__restrict__ ou
                                                           const int *__restrict__ labels, const float *__restrict__ table,
                                                           const float *__restrict__ avg_bias, const float *__restrict__ sp,
                                                           const float *__restrict__ blend, int C, int H, int W, int tcols, int nl,
-                                                          int group, float slope, int cchunk, int interior) {
+                                                          int group, float slope, int cchunk, int interior, int x_up) {
   HF_DYN_LDS;
   float *tl = reinterpret_cast<float *>(hf_dyn_lds);  // [9][2*nc][nl]: local row 2*i = gamma of channel c0+i, 2*i+1 = beta
   const int b = blockIdx.z, c0 = blockIdx.y * cchunk, nc = min(cchunk, C - c0);
@@ -316,7 +326,13 @@ __global__ __launch_bounds__(256) void ace_modulate_table(float *__restrict__ ou
     float ga[4], ba[4];
     label_lookup4(ga, tl, ts, 2 * nc, nl, 2 * i, avg_bias ? avg_bias[c] : 0.0f, lab, inner, any_general);
     label_lookup4(ba, tl, ts, 2 * nc, nl, 2 * i + 1, avg_bias ? avg_bias[C + c] : 0.0f, lab, inner, any_general);
-    const float4 xv = *reinterpret_cast<const float4 *>(x + ((long long)b * C + c) * hw + pc);
+    float4 xv;
+    if (x_up) {  // x [B, C, H/2, W/2]: the nearest-neighbour x2 up-sampling read in place
+      const float2 lo = *reinterpret_cast<const float2 *>(x + ((long long)b * C + c) * (hw >> 2) + (long long)(y >> 1) * (W >> 1) + (xx >> 1));
+      xv = make_float4(lo.x, lo.x, lo.y, lo.y);
+    } else {
+      xv = *reinterpret_cast<const float4 *>(x + ((long long)b * C + c) * hw + pc);
+    }
     const float4 gs4 = *reinterpret_cast<const float4 *>(sp + (sb + c) * hw + pc);
     const float4 bs4 = *reinterpret_cast<const float4 *>(sp + (sb + C + c) * hw + pc);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gs4.x, gs4.y, gs4.z, gs4.w}, bs[4] = {bs4.x, bs4.y, bs4.z, bs4.w};
@@ -334,10 +350,10 @@ extern "C" int hf_ace_modulate_table_f32(float *out, const float *x, const float
                                          const float *bn_scale, const float *bn_shift, const int *labels, const float *table,
                                          const float *avg_bias, const float *sp, const float *blend, int batch, int channels,
                                          int h, int w, int table_cols, int n_labels, int group, float slope, int interior,
-                                         void *stream) {
+                                         int x_upsample, void *stream) {
   if (!out || !x || !bn_scale || !bn_shift || !labels || !table || !sp || !blend || batch <= 0 || channels <= 0 || h <= 0 ||
       w <= 0 || (w & 3) || group <= 0 || batch > 65535 || n_labels <= 0 || n_labels > kLabelMax ||
-      (long long)batch * n_labels > table_cols)
+      (long long)batch * n_labels > table_cols || (x_upsample && (h & 1)))
     return HF_E_INVALID;
   const int hw = h * w;
   int cchunk = min(channels, 32);
@@ -345,7 +361,7 @@ extern "C" int hf_ace_modulate_table_f32(float *out, const float *x, const float
   const size_t lds = (size_t)10 * 2 * cchunk * n_labels * sizeof(float);
   hipLaunchKernelGGL(ace_modulate_table, dim3(hf_cdiv(hw, 1024), hf_cdiv(channels, cchunk), batch), dim3(256), lds,
                      (hipStream_t)stream, out, x, noise, noise_var, bn_scale, bn_shift, labels, table, avg_bias, sp, blend, channels,
-                     h, w, table_cols, n_labels, group, slope, cchunk, interior ? 1 : 0);
+                     h, w, table_cols, n_labels, group, slope, cchunk, interior ? 1 : 0, x_upsample ? 1 : 0);
   return hf_launch_status();
 }
 

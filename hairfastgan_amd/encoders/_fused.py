@@ -178,8 +178,11 @@ def conv(x, w, k, stride=1, presplit=False, split_out=None, **kw):
         nterms = 3 if mode == "f16x3" else 1
         # one input feeding >= 8 output-channel tiles over enough pixels: convert it once (hf_split_activation_f16), the
         # GEMM then stages it by LDS-DMA instead of converting it in every block column
-        if (PRESPLIT == "all" and stride == 1 and kw.get("groups", 1) == 1 and w.cout // 64 >= 8
-                and x.shape[0] * h * wd >= 512 and w.cin % 8 == 0):
+        # (from 32 tiles already at 128 pixels: SEAN's table GEMM - 288 channel tiles over 304 label columns - spent 3/4 of its
+        # 160 us converting the same 512 x 304 input in every block column)
+        px = x.shape[0] * h * wd
+        if (PRESPLIT == "all" and stride == 1 and kw.get("groups", 1) == 1 and w.cin % 8 == 0
+                and ((w.cout // 64 >= 8 and px >= 512) or (w.cout // 64 >= 32 and px >= 128))):
             x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None), want_lo=nterms == 3)
         return M.conv1x1_f16(lib(), stream(), x, hi, lo, nterms, w.cout, stride, **kw)
     if (mode != "f32" and k == 3 and USE_GEMM_H and h <= 16 and wd <= 16 and (h - 1) // stride < 8 and (wd - 1) // stride < 8

@@ -112,12 +112,15 @@ class ACE(nn.Module):  # normalization.py:70-208
         bs = torch.stack([getattr(self, f"fc_mu{j}").bias.detach() for j in range(N_LABELS)])
         return ws, bs
 
-    def forward(self, x, labels, mu, noise, group, slope):
+    def forward(self, x, labels, mu, noise, group, slope, x_up=False):
         """x [D,C,H,W]; labels int32 [D/group,H,W]; mu [1,512,D,19] (relu(fc_mu_j(code_j)) of every sample, GEMM layout) or
-        None; noise [D,H,W] | None.  Returns LeakyReLU_slope(ACE(x)) (slope 1: the shortcut branch, no activation)."""
+        None; noise [D,H,W] | None.  Returns LeakyReLU_slope(ACE(x)) (slope 1: the shortcut branch, no activation).
+        x_up: x is the HALF-resolution tensor [D,C,H/2,W/2]; the generator's nearest x2 up-sampling is read in place by the
+        tail kernel (both tail kernels take it)."""
         L, st = lib(), stream()
         p = self.plan()
-        d, c, h, w = x.shape
+        d, c = x.shape[:2]
+        h, w = labels.shape[-2:]
         N_HIDDEN = self.hidden
         actv = M.label_conv3x3(L, st, labels, p["t_shared"], p["b_shared"], N_HIDDEN, relu=True)      # [D/group,128,H,W]
         sp = conv(actv, p["w_gb"], 3, 1, bias=p["b_gb"])                                              # [D/group,2C,H,W]
@@ -126,11 +129,12 @@ class ACE(nn.Module):  # normalization.py:70-208
             table = conv(mu, p["w_table"], 1, 1)                                                      # [1, 9*2C, D, 19]
             if M.ace_modulate_table_supported(h, w):  # the avg planes are looked up inside the tail kernel, never stored
                 return M.ace_modulate_table(L, st, x, noise, p["noise_var"], p["bn"][0], p["bn"][1], labels,
-                                            table.reshape(9 * 2 * c, d * N_LABELS), p["b_avg"], sp, p["blend"], group=group, slope=slope)
+                                            table.reshape(9 * 2 * c, d * N_LABELS), p["b_avg"], sp, p["blend"], group=group, slope=slope,
+                                            x_up=x_up)
             avg = M.label_conv3x3(L, st, labels, table.reshape(9 * 2 * c, d * N_LABELS), p["b_avg"], 2 * c, batch=d,
                                   cols_per_sample=N_LABELS, group=group)
         return M.ace_modulate(L, st, x, noise, p["noise_var"], p["bn"][0], p["bn"][1], avg, sp, p["blend"] if avg is not None else None,
-                              group=group, slope=slope)
+                              group=group, slope=slope, x_up=x_up)
 
 
 class SPADEResnetBlock(nn.Module):  # architecture.py:21-97
@@ -152,9 +156,13 @@ class SPADEResnetBlock(nn.Module):  # architecture.py:21-97
     def aces(self):  # in call order (:67-93)
         return ([self.ace_s] if self.learned_shortcut else []) + [self.ace_0, self.ace_1]
 
-    def forward(self, x, labels, mus, noises, group, final_lrelu=False):
+    def forward(self, x, labels, mus, noises, group, final_lrelu=False, x_up=False):
         """mus / noises: per ACE of `aces()`.  final_lrelu: the LeakyReLU(0.2) SPADEGenerator applies to the LAST block's
-        output before conv_img (generator.py:108) rides in conv_1's epilogue."""
+        output before conv_img (generator.py:108) rides in conv_1's epilogue.  x_up (learned-shortcut blocks only: x is read
+        by ace_s and ace_0 and by nothing else): x arrives at HALF resolution and the generator's `self.up` happens inside the
+        two ACE tails - the up-sampled tensor (4x the bytes) is neither written nor re-read."""
+        if x_up and not self.learned_shortcut:
+            raise ValueError("x_up needs a learned shortcut (the identity shortcut adds x itself)")
         L, st = lib(), stream()
         if self._plan is None:
             prep = lambda m: PreparedConv(M.conv_prepare(L, st, m.normalized_weight().contiguous()), m.k)  # noqa: E731
@@ -163,9 +171,9 @@ class SPADEResnetBlock(nn.Module):  # architecture.py:21-97
         k = 0
         x_s = x
         if self.learned_shortcut:
-            x_s = conv(self.ace_s(x, labels, mus[0], noises[0], group, 1.0), p["ws"], 1, 1)
+            x_s = conv(self.ace_s(x, labels, mus[0], noises[0], group, 1.0, x_up=x_up), p["ws"], 1, 1)
             k = 1
-        dx = self.ace_0(x, labels, mus[k], noises[k], group, 0.2)
+        dx = self.ace_0(x, labels, mus[k], noises[k], group, 0.2, x_up=x_up)
         dx = conv(dx, p["w0"], 3, 1, bias=self.conv_0.bias.detach())
         dx = self.ace_1(dx, labels, mus[k + 1], noises[k + 1], group, 0.2)
         if final_lrelu:
@@ -297,15 +305,18 @@ class SPADEGenerator(FrozenPlanMixin, nn.Module):  # generator.py:14-110, num_up
             x = x.repeat_interleave(group, 0)
         res, ai, si = S // 32, 0, 0
         for i, blk in enumerate(self.blocks()):
+            x_up = False
             if i in self.UP_BEFORE:
                 res *= 2
-                x = M.upsample_nearest(L, st, x, res, res)
+                x_up = blk.learned_shortcut and res % 4 == 0   # the block's ACE tails read the low-resolution x in place
+                if not x_up:
+                    x = M.upsample_nearest(L, st, x, res, res)
             n_a = len(blk.aces())
             mus = []
             for a in blk.aces():
                 mus.append(mu[si:si + 1] if a.use_rgb else None)
                 si += 1 if a.use_rgb else 0
-            x = blk(x, labels[res], mus, noise[ai:ai + n_a], group, final_lrelu=(i == len(self.BLOCKS) - 1))
+            x = blk(x, labels[res], mus, noise[ai:ai + n_a], group, final_lrelu=(i == len(self.BLOCKS) - 1), x_up=x_up)
             ai += n_a
             if taps is not None:
                 taps[self.BLOCKS[i][0]] = x

@@ -543,21 +543,25 @@ int hf_label_conv3x3_f32(float *out, const int *labels, const float *table, cons
  *   out = LeakyReLU_slope( n * (1 + g) + bt )                                (slope 1 = none; SPADEResnetBlock.actvn)
  * x, out [batch,channels,hw]; noise [batch,hw] or NULL (ACE draws randn(B,W,H,1) and transposes: the caller's layout
  * choice); avg [batch,2*channels,hw], sp [batch/group,2*channels,hw]: gamma planes then beta planes; blend: DEVICE
- * pointer to (blending_gamma, blending_beta); hw % 4 == 0. */
+ * pointer to (blending_gamma, blending_beta); hw % 4 == 0.
+ * x_upsample_w != 0 (ABI 9): x is the HALF-resolution tensor [batch,channels,h/2,w/2] with w = x_upsample_w and the
+ * generator's nearest-neighbour x2 up-sampling (`self.up`, generator.py:80-103) is read in place - x[.., y/2, x/2] - instead
+ * of being materialised; w % 4 == 0, h = hw / w even. */
 int hf_ace_modulate_f32(float *out, const float *x, const float *noise, const float *noise_var, const float *bn_scale,
                         const float *bn_shift, const float *avg, const float *sp, const float *blend, int batch,
-                        int channels, int hw, int group, float slope, void *stream);
+                        int channels, int hw, int group, float slope, int x_upsample_w, void *stream);
 /* hf_label_conv3x3_f32 (cols_per_sample = n_labels, bias = avg_bias, channels = 2*channels, no ReLU) FOLLOWED BY
  * hf_ace_modulate_f32 with its result as `avg`, in one pass and bit-identical to the pair: the avg planes - ACE's
  * conv_gamma / conv_beta of `middle_avg` (normalization.py:117-162) - are looked up from LDS copies of the table rows
  * instead of being written to and re-read from HBM.  table [9 * 2*channels][table_cols] (rows (tap, gamma|beta
  * channel)), columns b*n_labels + label; labels int32 [batch/group, h, w]; sp [batch/group, 2*channels, h, w]; x / out
  * [batch, channels, h, w]; noise [batch, h*w] or NULL; avg_bias [2*channels] or NULL; blend as above (required);
- * interior != 0: regions' interior pixels take the tap-sum path; w % 4 == 0, n_labels <= 32. */
+ * interior != 0: regions' interior pixels take the tap-sum path; w % 4 == 0, n_labels <= 32.  x_upsample != 0: x is
+ * [batch, channels, h/2, w/2], up-sampled x2 (nearest) in place as in hf_ace_modulate_f32. */
 int hf_ace_modulate_table_f32(float *out, const float *x, const float *noise, const float *noise_var, const float *bn_scale,
                               const float *bn_shift, const int *labels, const float *table, const float *avg_bias,
                               const float *sp, const float *blend, int batch, int channels, int h, int w, int table_cols,
-                              int n_labels, int group, float slope, int interior, void *stream);
+                              int n_labels, int group, float slope, int interior, int x_upsample, void *stream);
 /* Zencoder's per-region average pooling (architecture.py:187-205): out[b,l,c] = mean over {p : labels[b,p] == l} of
  * act(x[b,c,p]), 0 for labels that do not occur; act 1 = tanh (the encoder's last layer, :177), 0 = none.
  * x is a strided view: sample stride batch_stride, plane stride plane_stride, row pitch `pitch` (floats).

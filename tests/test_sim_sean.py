@@ -87,6 +87,13 @@ def test_label_conv_and_ace_tail(simlib):
     two = M.ace_modulate(simlib, None, xb, rb, nv, sc, sh, avg_b, spb, blend, group=2, slope=0.2)
     one = M.ace_modulate_table(simlib, None, xb, rb, nv, sc, sh, lab2, tab, bg, spb, blend, group=2, slope=0.2)
     assert torch.equal(one, two)
+    # x_up: the tails read a half-resolution x in place = the materialised nearest x2 up-sampling, bit for bit (both kernels)
+    x_lo = torch.randn(4, 4, 16, 20)
+    x_hi = x_lo.repeat_interleave(2, 2).repeat_interleave(2, 3).contiguous()
+    assert torch.equal(M.ace_modulate_table(simlib, None, x_lo, rb, nv, sc, sh, lab2, tab, bg, spb, blend, group=2, slope=0.2, x_up=True),
+                       M.ace_modulate_table(simlib, None, x_hi, rb, nv, sc, sh, lab2, tab, bg, spb, blend, group=2, slope=0.2))
+    assert torch.equal(M.ace_modulate(simlib, None, x_lo, rb, nv, sc, sh, None, spb, None, group=2, slope=1.0, x_up=True),
+                       M.ace_modulate(simlib, None, x_hi, rb, nv, sc, sh, None, spb, None, group=2, slope=1.0))
     # region pooling with tanh, on the interior of a padded plane
     xp = torch.randn(2, 3, 11, 14)
     lab = labels.clone()
