@@ -40,7 +40,7 @@ for B in (8, 1, 3):
             line += f" | f16x3 {t16:7.1f} us ({fl / t16 * 1e-6:6.1f} TF/s, rel err {err:.1e}, path {L.hf_debug_last_path()})"
         except Exception as e:
             line += f" | f16x3 n/a"
-        if M.modconv3x3_small_supported(c, c, h, h) or h <= 32:
+        if h <= 32:
             w9 = M.split_weights_small(L, st, wt)
             ys = M.modconv3x3_small(L, st, x, w9, 3, s, d, nz, nw, bias, c)
             ref = M.modconv3x3(L, st, x, wt, s, d, nz, nw, bias)
@@ -48,7 +48,7 @@ for B in (8, 1, 3):
             ts = timeit(lambda: M.modconv3x3_small(L, st, x, w9, 3, s, d, nz, nw, bias, c))
             line += f" | tap-GEMM {ts:7.1f} us (rel err {err:.1e})"
         print(line, flush=True)
-        if h < 32:
+        if h <= 16:
             tu = timeit(lambda: M.modconv3x3_up(L, st, x, wt, s, d, k4, nz2, nw, bias))
             line = f"up   {h:3d}->{2*h:3d}: fp32 {tu:7.1f} us"
             if M.modconv3x3_up_f16_supported(c, c, h, h):
