@@ -52,6 +52,17 @@ class PreparedConv:
         self._f16 = None
         self._small = None
         self._patch = None
+        self.cout_true, self.cin_true = self.cout, self.cin   # prep_conv(pad=True): the module's own channel counts
+        self._padded = {}
+
+    def pad_vec(self, v):
+        """A per-output-channel epilogue vector (bias, BN scale, PReLU slope) extended with zeros to the padded cout; cached."""
+        if v is None or self.cout_true == self.cout:
+            return v
+        key = (v.data_ptr(), v._version)
+        if key not in self._padded:
+            self._padded[key] = torch.cat([v.detach().reshape(-1), v.new_zeros(self.cout - self.cout_true)]).contiguous()
+        return self._padded[key]
 
     def small(self):
         """(hi, lo) of a 3x3 weight in the tap-GEMM layout of hf_modconv3x3_small_f16_f32 (the nine taps as rows of one GEMM)."""
@@ -75,9 +86,23 @@ class PreparedConv:
         return self._f16
 
 
-def prep_conv(conv):
+def prep_conv(conv, pad=False):
+    """pad: zero input planes / zero filters up to the multiples the fp16 matrix-core kernels take (cin % 16, cout % 64):
+    a 3-channel input layer or a 3- / 19-channel output head then runs there instead of on the fp32 MFMA (2.6x the flops
+    of a 19-filter 1x1 head, at 10x the rate).  conv() pads the input's channels and slices the output back; the
+    per-channel epilogue vectors are padded by `PreparedConv.pad_vec`."""
     require_gpu(conv.weight)
-    return PreparedConv(M.conv_prepare(lib(), stream(), conv.weight.detach()), conv.kernel_size[0])
+    w = conv.weight.detach()
+    cout, cin = w.shape[:2]
+    if pad and conv_precision() != "f32":
+        ci_pad, co_pad = -(-cin // 16) * 16, -(-cout // 64) * 64
+        if ci_pad != cin:
+            w = torch.cat([w, w.new_zeros(cout, ci_pad - cin, *w.shape[2:])], 1)
+        if co_pad != cout:
+            w = torch.cat([w, w.new_zeros(co_pad - cout, *w.shape[1:])], 0)
+    pc = PreparedConv(M.conv_prepare(lib(), stream(), w.contiguous()), conv.kernel_size[0])
+    pc.cout_true, pc.cin_true = cout, cin
+    return pc
 
 
 # Which convs hand the fp16-core kernel a PRE-SPLIT input (one hf_split_activation_f16 pass, then LDS-DMA
@@ -153,6 +178,21 @@ def conv(x, w, k, stride=1, presplit=False, split_out=None, **kw):
     split_out = {"next_scale", "next_shift", "want_f32"} (any subset): the result is wanted as the pre-split input of the
     next fp16-core conv; returns (SplitActivation | None, fp32 out | None) - the split form whenever the launch can emit it
     from its epilogue (hf_conv2d_f16_split_f32), else (None, out)."""
+    if w.cout_true != w.cout or w.cin_true != w.cin:  # prep_conv(pad=True): zero planes in, zero filters sliced off
+        if split_out is not None or kw.get("groups", 1) != 1 or kw.get("residual") is not None:
+            raise ValueError("padded convs are plain single-group layers")
+        if w.cin_true != w.cin:
+            x = F.pad(x, (0, 0, 0, 0, 0, w.cin - w.cin_true))
+            for k_ in ("in_scale", "in_shift"):
+                if kw.get(k_) is not None:
+                    raise ValueError("padded input channels carry no affine")
+        kw = {k_: (w.pad_vec(v) if k_ in ("out_scale", "bias", "slope") else v) for k_, v in kw.items()}
+        y = _conv_unpadded(x, w, k, stride, presplit, **kw)
+        return y if w.cout_true == w.cout else y[:, :w.cout_true].contiguous()
+    return _conv_unpadded(x, w, k, stride, presplit, split_out, **kw)
+
+
+def _conv_unpadded(x, w, k, stride=1, presplit=False, split_out=None, **kw):
     mode = conv_precision()
     h, wd = x.shape[-2], x.shape[-1]
     if split_out is not None:
@@ -167,7 +207,7 @@ def conv(x, w, k, stride=1, presplit=False, split_out=None, **kw):
                     x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None), want_lo=nterms == 3)
             return M.conv2d_f16_split(lib(), stream(), x, hi, lo, nterms, w.cout, stride, next_scale=split_out.get("next_scale"),
                                       next_shift=split_out.get("next_shift"), want_f32=split_out.get("want_f32", False), **kw)
-        return None, conv(x, w, k, stride, presplit, **kw)
+        return None, _conv_unpadded(x, w, k, stride, presplit, **kw)
     if isinstance(x, M.SplitActivation):  # a hand-off from the producing conv: only the tiled fp16-core kernel reads it
         if k != 3 or mode == "f32":
             raise ValueError("a pre-split input goes to a 3x3 conv on the fp16 matrix cores (takes_f16_conv)")

@@ -131,7 +131,7 @@ class Encoder4Editing(FrozenPlanMixin, nn.Module):  # psp_encoders.py:124-200
         require_gpu(x)
         if self._plan is None:
             il = self.input_layer
-            self._plan = {"w_in": prep_conv(il[0]), "bn_in": fold_bn(il[1]), "slope_in": il[2].weight.detach(),
+            self._plan = {"w_in": prep_conv(il[0], pad=True), "bn_in": fold_bn(il[1]), "slope_in": il[2].weight.detach(),
                           "lat1": prep_conv(self.latlayer1), "lat2": prep_conv(self.latlayer2)}
         p = self._plan
         x = conv(x, p["w_in"], 3, 1, out_scale=p["bn_in"][0], bias=p["bn_in"][1], act=M.ACT_PRELU, slope=p["slope_in"])

@@ -91,7 +91,7 @@ class fs_encoder_v2(FrozenPlanMixin, nn.Module):  # feature_style_encoder.py:12-
         if self._plan is None:
             c, cl = self.conv, self.content_layer
             self._plan = {
-                "w_in": prep_conv(c[0]), "bn_in": fold_bn(c[1]), "slope_in": c[2].weight.detach(),
+                "w_in": prep_conv(c[0], pad=True), "bn_in": fold_bn(c[1]), "slope_in": c[2].weight.detach(),
                 "c_bn0": fold_bn(cl[0]), "c_w1": prep_conv(cl[1]), "c_bn2": fold_bn(cl[2]),
                 "c_slope": cl[3].weight.detach(), "c_w4": prep_conv(cl[4]), "c_bn5": fold_bn(cl[5]),
                 # the 18 heads share their input: one [18*512, 8640] GEMV batch

@@ -55,7 +55,7 @@ class FeatureEncoderMult(FrozenPlanMixin, nn.Module):  # models/Net.py:396-477 w
         if self._plan is None:
             c, cl = self.conv, self.content_layer[0]
             self._plan = {
-                "w_in": prep_conv(c[0]), "bn_in": fold_bn(c[1]), "slope_in": c[2].weight.detach(),
+                "w_in": prep_conv(c[0], pad=True), "bn_in": fold_bn(c[1]), "slope_in": c[2].weight.detach(),
                 "c_bn0": fold_bn(cl[0]), "c_w1": prep_conv(cl[1]), "c_bn2": fold_bn(cl[2]),
                 "c_slope": cl[3].weight.detach(), "c_w4": prep_conv(cl[4]), "c_bn5": fold_bn(cl[5]),
                 "head_w": torch.cat([m.weight.detach() for m in self.styles], 0).contiguous(),

@@ -155,7 +155,7 @@ class BiSeNet(FrozenPlanMixin, nn.Module):  # model.py:230-253
             for name in ("conv_head32", "conv_head16", "conv_avg"):
                 p[name] = getattr(cp, name).plan()
             p["ffm"] = (self.ffm.convblk.plan(), prep_conv(self.ffm.conv1), prep_conv(self.ffm.conv2))
-            p["out"] = (self.conv_out.conv.plan(), prep_conv(self.conv_out.conv_out))
+            p["out"] = (self.conv_out.conv.plan(), prep_conv(self.conv_out.conv_out, pad=True))  # 19 class filters padded to 64
             p["remap"] = torch.tensor(LABEL_REMAP, dtype=torch.int32, device=self.conv_out.conv_out.weight.device)
             self._plan = p
         return self._plan

@@ -30,7 +30,7 @@ from torch import nn
 
 from . import _marshal as M
 from ._runtime import lib, require_gpu, stream
-from .encoders._fused import FrozenPlanMixin, PreparedConv, conv
+from .encoders._fused import FrozenPlanMixin, PreparedConv, conv, prep_conv
 
 N_LABELS = 19  # SEAN_OPT.semantic_nc / label_nc
 
@@ -257,7 +257,7 @@ class SPADEGenerator(FrozenPlanMixin, nn.Module):  # generator.py:14-110, num_up
                 "mu_w": PreparedConv(torch.cat(ws, 0).unsqueeze(1).contiguous(), 1),  # [15*19, 1, 512, 512] grouped 1x1 conv weights
                 "mu_b": torch.cat(bs, 0).contiguous(),                # [15*19, 512]
                 "n_styled": len(styled),
-                "w_img": PreparedConv(M.conv_prepare(L, st, self.conv_img.weight.detach()), 3)}
+                "w_img": prep_conv(self.conv_img, pad=True)}  # 64 -> 3: zero filters up to 64, sliced off again
         return self._plan
 
     def decode(self, codes, target_labels, group=1, noise=None, taps=None):
