@@ -21,7 +21,7 @@ wt, _ = M.prepare_weights(L, st, wgt)
 hi, lo = M.split_weights_f16(L, st, wt)
 act = M.split_activation_f16(L, st, x) if not hasattr(M, "split_activation_mod") else None
 act = M.split_activation_f16(L, st, x)
-for tune, name in [(16, "tiled"), (0, "rows"), (32, "rows, no DMA"), (64, "rows, no epilogue"), (96, "rows, no DMA no epilogue"), (128, "rows, no MFMA loop"), (224, "rows, nothing")]:
+for tune, name in [(16, "tiled"), (0, "rows"),  (32, "rows, no DMA"), (64, "rows, no epilogue"), (96, "rows, no DMA no epilogue"), (128, "rows, no MFMA loop"), (224, "rows, nothing")]:
     L.hf_debug_set_tuning(tune)
     t = timeit(lambda: M.modconv3x3_f16_pre(L, st, act, hi, lo, 3, dm, nz, nw, bias, rgb=(rgb_w, rgb_s), want_out=False))
     print(f"{name:28s} {t:8.1f} us", flush=True)
