@@ -18,8 +18,9 @@ extern "C" unsigned long long hf_f16_overflow_count_convh(int reset);
 extern "C" unsigned long long hf_f16_overflow_count_blur(int reset);
 extern "C" unsigned long long hf_f16_overflow_count_enc(int reset);
 extern "C" unsigned long long hf_f16_overflow_count_gemm(int reset);
+extern "C" unsigned long long hf_f16_overflow_count_stem(int reset);
 
 extern "C" long long hf_f16_overflow_count(int reset) {
   return (long long)(hf_f16_overflow_count_convh(reset) + hf_f16_overflow_count_blur(reset) + hf_f16_overflow_count_enc(reset) +
-                     hf_f16_overflow_count_gemm(reset));
+                     hf_f16_overflow_count_gemm(reset) + hf_f16_overflow_count_stem(reset));
 }

@@ -205,6 +205,8 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2(float *__restrict__ out, con
 
 }  // namespace
 
+extern "C" unsigned long long hf_f16_overflow_count_stem(int reset) { return hf_f16_overflow_read_tu(reset); }
+
 // LDS bytes of a launch
 template <bool POOL>
 static size_t stem_lds() {
