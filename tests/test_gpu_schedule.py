@@ -251,6 +251,33 @@ def test_swap_graphed_equals_eager_swap():
     assert torch.equal(same, hf.swap(a, b, b.clone(), seed=5)) and len(hf._swap_graphs) == 1
 
 
+def test_swap_survives_a_precision_switch_after_planning():
+    """HAIRFAST_CONV_PRECISION=auto re-runs a swap on the fp32 kernels with every plan already built for f16x3 (padded
+    channel counts, fused stem weights, pre-split hand-offs, GEMM routes): each mode must run on those plans - single and
+    batched - and stay within its own accuracy class of the default result (noise strengths zero: one RNG walk)."""
+    from hairfastgan_amd import _runtime
+
+    dev = torch.device("cuda:0")
+    hf = _hairfast(dev)
+    with torch.no_grad():
+        for name, p in hf.net.generator.named_parameters():
+            if name.endswith("noise.weight"):
+                p.zero_()
+    hf.stages.sean_model.netG.noise_source = lambda d, sizes: [torch.zeros(d, r, r, device=dev) for r in sizes]
+    a, b, c = (im.to(dev) for im in C.pipeline_images())
+    ref = hf.swap(a, b, c, seed=5).float()
+    for mode, bar in (("f32", 2e-3), ("f16", 5e-2), ("f16x3", 0.0)):
+        prev = _runtime.set_conv_precision(mode)
+        try:
+            out = hf.swap(a, b, c, seed=5).float()
+            both = hf.swap_batch([(a, b, c), (c, a, b)], seed=5)
+        finally:
+            _runtime.set_conv_precision(prev)
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((out - ref).abs().mean()) <= bar * scale, mode
+        assert len(both) == 2 and both[0].shape == ref.shape
+
+
 def test_swap_many_forced_rccl_single_rank():
     """BASELINE configs[3] code path with RCCL actually initialised on the hardware (world size 1,
     HF_FORCE_DIST=1): sharding, H2D prefetch stream, uint8 conversion and the chunked all-gather."""
