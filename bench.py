@@ -356,8 +356,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (generator workload)")
     ap.add_argument("--workload", choices=("generator", "swap256", "launch-check"), default="generator")
     ap.add_argument("--triples", type=int, default=256, help="swap256: triples of the whole job")
-    ap.add_argument("--swap-batch", type=int, default=8,
-                    help="swap256: triples per batched pass over the hot path (HairFast.swap_batch); 1 = one HairFast.swap per triple")
+    ap.add_argument("--swap-batch", type=int, default=16,
+                    help="swap256: triples per batched pass over the hot path (HairFast.swap_batch); 1 = one HairFast.swap per triple. "
+                         "Measured (tools/probes/swap_batch_sizes.py): 1: 29 triples/s, 4: 54, 8: 64, 16: 70, 32: 73 (32 GiB)")
     ap.add_argument("--precision", choices=("f16x3", "f32", "f16"), default=None,
                     help="matrix-core mode of the 3x3 convs (default: HAIRFAST_CONV_PRECISION or f16x3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -564,7 +565,7 @@ def main():
                 if args.swap_batch > 1:
                     hf.swap_batch([tuple(t.to(dev) for t in load(i)) for i in range(args.swap_batch)])
             barrier()
-            n_pipe = 2 * args.swap_triples * world
+            n_pipe = 2 * args.swap_batch * world  # two full batched passes per rank
             t0 = time.perf_counter()
             parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), n_pipe, load, device=dev, batch=args.swap_batch,
                                swap_batch_fn=hf.swap_batch if args.swap_batch > 1 else None)

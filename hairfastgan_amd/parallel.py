@@ -116,7 +116,8 @@ def swap_many(swap_fn, n_total, load_triple, device=None, chunk=8, group=None, b
 
     if batch > 1 and swap_batch_fn is None:
         raise ValueError("batch > 1 needs swap_batch_fn")
-    batch = max(1, min(batch, chunk))
+    batch = max(1, batch)
+    chunk = max(chunk, batch)  # a batched pass is never split across gather rounds: one all-gather per `chunk` >= batch triples
 
     def fetch_group(j0, j1):  # local triples j0..j1-1
         return [fetch(lo + j) for j in range(j0, j1)]
