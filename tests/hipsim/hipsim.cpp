@@ -1,4 +1,5 @@
 // TEST INFRASTRUCTURE - scheduler of the hipsim CPU interpreter (see hip/hip_runtime.h).
+#include <setjmp.h>
 #include <ucontext.h>
 
 #include <cstdio>
@@ -19,7 +20,9 @@ enum State { READY, WAIT_BLOCK, WAIT_WAVE, DONE };
 enum WaveOp { OP_NONE, OP_SHFL_XOR, OP_SHFL_REL, OP_MFMA, OP_MFMA_H, OP_GLDS, OP_GLDS4, OP_GLDS_MASKED };
 
 struct Fiber {
-  ucontext_t ctx;
+  ucontext_t ctx;   // first entry only (makecontext: a fresh stack)
+  jmp_buf jb;       // every later switch: _setjmp / _longjmp (swapcontext costs a sigprocmask system call per switch -
+  bool started = false;  // a third of the interpreter's run time)
   std::vector<unsigned char> stack;
   State state = READY;
   Dim3 tid;
@@ -36,16 +39,29 @@ struct Fiber {
 
 std::vector<Fiber> g_f;
 ucontext_t g_sched;
+jmp_buf g_sched_jb;
 int g_cur = -1;
 const std::function<void()> *g_body = nullptr;
 
 void trampoline() {
   (*g_body)();
   g_f[g_cur].state = DONE;
-  swapcontext(&g_f[g_cur].ctx, &g_sched);
+  _longjmp(g_sched_jb, 1);
 }
 
-void yield_to_sched() { swapcontext(&g_f[g_cur].ctx, &g_sched); }
+void yield_to_sched() {
+  if (_setjmp(g_f[g_cur].jb) == 0) _longjmp(g_sched_jb, 1);
+}
+
+// run fiber i until it yields or finishes (in a function of its own: the frame the fibers jump back into holds no
+// scheduler loop state)
+__attribute__((noinline)) void switch_to(int i) {
+  if (_setjmp(g_sched_jb) == 0) {
+    if (g_f[i].started) _longjmp(g_f[i].jb, 1);
+    g_f[i].started = true;
+    setcontext(&g_f[i].ctx);  // onto the fiber's fresh stack; control returns through g_sched_jb
+  }
+}
 
 void resolve_wave(int w0, int w1) {
   // all live lanes of the wave [w0, w1) are waiting: perform the op
@@ -131,6 +147,7 @@ void run_block(int nthreads) {
     Fiber &f = g_f[i];
     f.state = READY;
     f.op = OP_NONE;
+    f.started = false;
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = f.stack.data();
     f.ctx.uc_stack.ss_size = f.stack.size();
@@ -146,7 +163,7 @@ void run_block(int nthreads) {
       if (g_f[i].state != READY) continue;
       g_cur = i;
       threadIdx_ = g_f[i].tid;
-      swapcontext(&g_sched, &g_f[i].ctx);
+      switch_to(i);
       progressed = true;
     }
     if (done == nthreads) return;
