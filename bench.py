@@ -102,6 +102,7 @@ def build_hairfast(sd, dev):
     # ViT-B/32 image tower, the CtrlHair shape adaptor, SEAN
     return HairFast(args, generator_state={"g_ema": sd, "latent_avg": torch.zeros(512)},
                     e4e_state=synth_state("e4e", E.e4e_param_shapes()), fs_state=synth_state("fs", E.fs_param_shapes()),
+                    e4e_latent_avg=torch.zeros(18, 512), fs_dlatent_avg=torch.zeros(18, 512), pp_latent_avg=torch.zeros(18, 512),
                     pp_state=synth_state("pp", pp_shapes), bisenet_state=C.bisenet_params(),
                     rotate_state=synth_state("rotate", PP.rotate_param_shapes()),
                     blend_state=synth_state("clipblend", PP.clip_blending_param_shapes()), clip_state=C.clip_params(),
@@ -182,7 +183,7 @@ def swap_schedule_bench(g, sd, dev, n_triples):
     args = get_parser().parse_args([])
     args.device = dev
     hp = HairFastHotPath(args, {"g_ema": sd, "latent_avg": torch.zeros(512)}, synth_state("e4e", E.e4e_param_shapes()),
-                         synth_state("fs", E.fs_param_shapes()))
+                         synth_state("fs", E.fs_param_shapes()), torch.zeros(18, 512), torch.zeros(18, 512))
     torch.manual_seed(3407)
     z = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
     inputs = (z(3, 3, 1024, 1024) * 0.5, z(3, 3, 256, 256) * 0.5, z(2, 3, 256, 256) * 0.5, z(1, 512, 32, 32),

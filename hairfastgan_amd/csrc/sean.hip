@@ -36,13 +36,15 @@ __global__ __launch_bounds__(256) void label_conv3x3(float *__restrict__ out, co
   const int pc = live ? p : hw - 1;
   const int y = pc / W, x = pc - y * W;
   const int *lb = labels + (long long)(b / group) * hw;
+  const int nl = cols_per_sample > 0 ? cols_per_sample : tcols;  // labels per sample
   int col[9];
   bool uniform = tsum != nullptr;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
     const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-    col[t] = in ? b * cols_per_sample + lb[yy * W + xx] : -1;
+    // labels outside [0, nl) (an 'ignore' value) are clamped as in label_window: both kernels agree, no read outside the sample's columns
+    col[t] = in ? b * cols_per_sample + min(max(lb[yy * W + xx], 0), nl - 1) : -1;
   }
 #pragma unroll
   for (int t = 0; t < 9; ++t) uniform = uniform && col[t] == col[4];

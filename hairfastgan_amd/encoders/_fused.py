@@ -59,7 +59,7 @@ class PreparedConv:
         """A per-output-channel epilogue vector (bias, BN scale, PReLU slope) extended with zeros to the padded cout; cached."""
         if v is None or self.cout_true == self.cout:
             return v
-        key = (v.data_ptr(), v._version)
+        key = (v.data_ptr(), None if v.is_inference() else v._version)  # inference tensors carry no version counter
         if key not in self._padded:
             self._padded[key] = torch.cat([v.detach().reshape(-1), v.new_zeros(self.cout - self.cout_true)]).contiguous()
         return self._padded[key]

@@ -12,14 +12,13 @@ What runs where:
   reference issues (Embedding.py:51-53,71-90, Alignment.py:63, Blending.py:62,66,68) - runs on the HIP
   library (hairfastgan_amd.encoders, hairfastgan_amd.stylegan2);
 * BiSeNet face parsing + get_segmentation (row f2) likewise (hairfastgan_amd.face_parsing);
-* the networks BETWEEN those calls are `Stages`: named callables injected at construction.
-  Three of the four have native implementations that take over when their state dicts are passed to `HairFast`
-  (`NativeLatentStages`): the Rotate encoder (encoders.RotateModel), the CLIP blending encoder
-  (encoders.ClipBlendingModel - everything but the CLIP ViT-B/32 image tower, which stays a callable) and the
-  CtrlHair shape adaptor (shape_adaptor.MaskGenerator); SEAN inpainting is always a stage.  With the reference
-  installed the stages are its own modules (INTEGRATION.md shows the binding); `SyntheticStages` provides shape- and
-  dtype-faithful stand-ins so that the complete call schedule can be executed and timed on a box that has neither
-  the reference nor checkpoints;
+* the networks BETWEEN those calls - RotateModel, ClipBlendingModel incl. its CLIP ViT-B/32
+  image tower, the CtrlHair shape adaptor, SEAN encode / decode - run natively too (`NativeLatentStages`).  `Stages`
+  remains as the injection point for a caller who wants one of the reference's own modules instead
+  (INTEGRATION.md shows the binding);
+* CHECKPOINTS: like the reference, `HairFast(args)` reads every network from the file its parser carries or the
+  reference hard-codes (hairfastgan_amd.checkpoints: the key handling of each file); a missing file raises
+  FileNotFoundError naming it.  State dicts passed to the constructor take precedence (tests, benchmarks);
 * the stencils on either side of the path (BicubicDownSample, DilateErosion: row f2) are HIP kernels too;
   the remaining glue (normalisation, mask arithmetic, two small F.interpolate calls) is torch elementwise
   code, as in the reference.
@@ -46,7 +45,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _marshal as M
-from ._runtime import lib, require_gpu, run_guarded, stream
+from . import checkpoints as ckpt_files
+from ._runtime import configured_conv_precision, lib, reference_rng_walk, require_gpu, run_guarded, stream
 from .encoders import ClipBlendingModel, Encoder4Editing, FSEncoder, PostProcessModel, RotateModel, get_latents
 from .face_parsing import BiSeNet, get_segmentation
 from .net import Net
@@ -166,7 +166,7 @@ class Stages:
     def _missing(self, what):
         raise NotImplementedError(
             f"stage '{what}' is outside this backend's scope (SURVEY.md section 8); construct HairFast with "
-            f"stages=<object providing {what}()> - the reference's own module (INTEGRATION.md) or SyntheticStages")
+            f"stages=<object providing {what}()> - the reference's own module (INTEGRATION.md)")
 
     def rotate(self, w_source_0_6, w_target_0_6):
         """models/Encoders.py:60-72 RotateModel: ([P,6,512], [P,6,512]) -> [P,6,512] (P pairs: 1 or 2 per triple)."""
@@ -194,9 +194,10 @@ class Stages:
 
 
 class NativeLatentStages(Stages):
-    """`rotate`, `blend` and `shape_adaptor` on this backend's own RotateModel / ClipBlendingModel / CtrlHair mask generator
-     where their state dicts are given, everything else (SEAN) delegated to `base`.  The CLIP ViT-B/32 image tower inside the blending
-    model remains the caller's (`clip_image_embed`, the reference's `clip_model.encode_image`)."""
+    """`rotate`, `blend` (incl. the CLIP ViT-B/32 image tower when `clip_state` is given; `clip_image_embed` injects the
+    reference's `clip_model.encode_image` instead), `shape_adaptor` and SEAN (`sean_inpaint`) on this backend's own
+    RotateModel / ClipBlendingModel / CtrlHair mask generator / SeanModel where their state
+    dicts are given; a stage whose state dict is absent is delegated to `base`."""
 
     def __init__(self, base, device, rotate_state=None, blend_state=None, clip_image_embed=None, shape_state=None,
                  sean_state=None, sean_mean_codes=None, clip_state=None):
@@ -213,6 +214,11 @@ class NativeLatentStages(Stages):
         if sean_state is not None:    # pretrained_models/sean_checkpoints/CelebA-HQ_pretrained/latest_net_G.pth (Alignment.py:29-30)
             from .sean import SeanModel
 
+            if sean_mean_codes is None:
+                raise ValueError("sean_state needs sean_mean_codes [19,512] (the median ACE.npy codes decode_sean starts "
+                                 "from, pix2pix_model.py:268-293,311): without them a label of the target mask that the "
+                                 "source image lacks would silently be rendered from an all-zero style code")
+
             self.sean_model = SeanModel(sean_mean_codes).eval()
             own = {(k if k.startswith("netG.") else "netG." + k): v for k, v in sean_state.items()}  # util.load_network loads netG's dict
             self.sean_model.load_state_dict(own)
@@ -228,6 +234,9 @@ class NativeLatentStages(Stages):
             self.rotate_model.load_state_dict(rotate_state)
             self.rotate_model.to(device)
         if blend_state is not None:   # pretrained_models/Blending/checkpoint.pth ['model_state_dict'] (Blending.py:22-26)
+            if clip_image_embed is None:
+                raise ValueError("blend_state needs the CLIP ViT-B/32 image tower: clip_state (the OpenAI model's state "
+                                 "dict, run natively) or clip_image_embed (a callable, models/Encoders.py:91-94)")
             self.blend_model = ClipBlendingModel(image_embed=clip_image_embed).eval()
             own = {k: v for k, v in blend_state.items() if not k.startswith("clip_model.")}  # the frozen tower's entries
             self.blend_model.load_state_dict(own)
@@ -263,57 +272,80 @@ class NativeLatentStages(Stages):
         return self.base.blend(s_face_6_18, s_color_6_18, image_face_masked, image_color_masked)
 
 
-class SyntheticStages(Stages):
-    """Deterministic stand-ins with the right shapes, dtypes and value ranges (cheap torch ops), so
-    that the whole call schedule of a swap runs where neither the reference nor any checkpoint
-    exists (the GPU box).  They are NOT models: the images they lead to are meaningless; the
-    hot-path work they trigger (which kernels, which batch sizes, which layer ranges) is exact."""
-
-    def rotate(self, w_source_0_6, w_target_0_6):
-        return w_source_0_6 + 0.25 * (w_target_0_6 - w_source_0_6)
-
-    def shape_adaptor(self, mask_target_pose, mask_hair_source):
-        out = mask_target_pose.clone()
-        out[mask_target_pose == 13] = 0
-        out[mask_hair_source == 13] = 13
-        return out
-
-    def sean_inpaint(self, images_256, labels, target_mask):
-        keep = (target_mask != 13).float()
-        return [(images_256[i] * 2 - 1) * keep[0] for i in range(2)]
-
-    def blend(self, s_face_6_18, s_color_6_18, image_face_masked, image_color_masked):
-        return 0.5 * (s_face_6_18 + s_color_6_18)
-
+def native_stages(opts, which=("sean", "shape", "rotate", "blend"), base=None, root=None, rotate_state=None, blend_state=None,
+                  clip_image_embed=None, shape_state=None, sean_state=None, sean_mean_codes=None, clip_state=None):
+    """NativeLatentStages with every network of `which` whose state dict is not given read from the reference's
+    checkpoint files (hairfastgan_amd.checkpoints; models/Alignment.py:29-38, models/Blending.py:24-27).  A missing file
+    raises FileNotFoundError: no stage is ever left randomly initialised."""
+    if "sean" in which and sean_state is None:
+        sean_state, file_codes = ckpt_files.sean(root)
+        sean_mean_codes = sean_mean_codes if sean_mean_codes is not None else file_codes
+    if "shape" in which and shape_state is None:
+        shape_state = ckpt_files.shape_adaptor(root)
+    if "rotate" in which and rotate_state is None:
+        rotate_state = ckpt_files.rotate(opts.rotate_checkpoint, root)
+    if "blend" in which and blend_state is None:
+        need_tower = clip_state is None and clip_image_embed is None
+        blend_state, file_clip = ckpt_files.blending(opts.blending_checkpoint, root, need_tower=need_tower)
+        if need_tower:
+            clip_state = file_clip
+    elif "blend" in which and clip_state is None and clip_image_embed is None:
+        clip_state = ckpt_files.clip_tower("ViT-B/32", root)
+    return NativeLatentStages(base or Stages(), opts.device, rotate_state, blend_state, clip_image_embed, shape_state,
+                              sean_state, sean_mean_codes, clip_state)
 
 
 # ---------------------------------------------------------------------------------------------
 # the three stage objects of the reference
 # ---------------------------------------------------------------------------------------------
+def build_parsing(opts, state=None, root=None):
+    """The BiSeNet singleton of my_parsing_util.py:72-81 (pretrained_models/BiSeNet/face_parsing_79999_iter.pth)."""
+    net = BiSeNet(19).eval()
+    net.load_state_dict(state if state is not None else ckpt_files.bisenet(root))
+    return net.to(opts.device)
+
+
+def build_e4e(opts, state=None, latent_avg=None, root=None):
+    """models/encoder4editing/utils/model_utils.py:17-28 setup_model: `pSp(opts).encoder` + `latent_avg` as the
+    namespace get_latents reads (the decoder half of pSp is never called by HairFast)."""
+    if state is None:
+        state, file_avg = ckpt_files.e4e(root)
+        latent_avg = latent_avg if latent_avg is not None else file_avg
+    if latent_avg is None:
+        raise ValueError("e4e_state needs e4e_latent_avg (ckpt['latent_avg'] of e4e_ffhq_encode.pt, psp.py:93-95)")
+    enc = Encoder4Editing(50, "ir_se", argparse.Namespace(stylegan_size=opts.size)).eval()
+    enc.load_state_dict(state)
+    return argparse.Namespace(encoder=enc.to(opts.device), opts=argparse.Namespace(start_from_latent_avg=True),
+                              latent_avg=torch.as_tensor(latent_avg).float().to(opts.device))
+
+
+def build_fs_encoder(opts, generator, state=None, dlatent_avg=None, root=None):
+    """models/FeatureStyleEncoder/FSencoder.py:31-41 get_trainer: `trainer.enc` <- 143_enc.pth, `dlatent_avg` <- the pSp
+    checkpoint's latent_avg (trainer.py:192)."""
+    if state is None:
+        state, file_avg = ckpt_files.fs_encoder(root)
+        dlatent_avg = dlatent_avg if dlatent_avg is not None else file_avg
+    if dlatent_avg is None:
+        raise ValueError("fs_state needs fs_dlatent_avg (psp_ffhq_encode.pt['latent_avg'], trainer.py:192)")
+    enc = FSEncoder(generator=generator)
+    enc.enc.load_state_dict(state)
+    enc.to(opts.device)
+    enc.dlatent_avg.copy_(torch.as_tensor(dlatent_avg).float().to(opts.device).expand_as(enc.dlatent_avg))
+    return enc
+
+
 class Embedding(nn.Module):  # models/Embedding.py:17-117
     def __init__(self, opts, net=None, stages=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
-                 fs_dlatent_avg=None, parsing=None):
+                 fs_dlatent_avg=None, parsing=None, pretrained_root=None):
+        """Like the reference's constructor (:22-39) every network is read from its checkpoint file; a state dict passed
+        here replaces the file (`e4e_state` with `e4e_latent_avg`, `fs_state` with `fs_dlatent_avg`)."""
         super().__init__()
         self.opts = opts
         self.net = net if net is not None else Net(opts)
         self.stages = stages or Stages()
-        self.parsing = parsing if parsing is not None else BiSeNet(19).eval().to(opts.device)  # models/Net.py:29 singleton
-        dev = opts.device
-        # models/encoder4editing/utils/model_utils.py setup_model: pSp(opts).encoder + latent_avg
-        self.e4e = argparse.Namespace(
-            encoder=Encoder4Editing(50, "ir_se", argparse.Namespace(stylegan_size=opts.size)).eval(),
-            opts=argparse.Namespace(start_from_latent_avg=True), latent_avg=None)
-        if e4e_state is not None:
-            self.e4e.encoder.load_state_dict(e4e_state)
-        self.e4e.encoder.to(dev)
-        self.e4e.latent_avg = (e4e_latent_avg if e4e_latent_avg is not None else torch.zeros(18, 512)).to(dev)
-        # models/FeatureStyleEncoder/FSencoder.py get_trainer
-        self.encoder = FSEncoder(generator=self.net.generator)
-        if fs_state is not None:
-            self.encoder.enc.load_state_dict(fs_state)
-        self.encoder.to(dev)
-        if fs_dlatent_avg is not None:
-            self.encoder.dlatent_avg.copy_(fs_dlatent_avg.to(dev))
+        self.parsing = parsing if parsing is not None else build_parsing(opts, root=pretrained_root)  # models/Net.py:29 singleton
+        self.e4e = build_e4e(opts, e4e_state, e4e_latent_avg, pretrained_root)
+        self.encoder = build_fs_encoder(opts, self.net.generator, fs_state, fs_dlatent_avg, pretrained_root)
         self.downsample_512 = BicubicDownSample(factor=2)
         self.downsample_256 = BicubicDownSample(factor=4)
         self._overlap = os.environ.get("HAIRFAST_EMBED_OVERLAP", "1") != "0"
@@ -398,13 +430,14 @@ class Embedding(nn.Module):  # models/Embedding.py:17-117
 
 
 class Alignment(nn.Module):  # models/Alignment.py:15-175
-    def __init__(self, opts, latent_encoder=None, net=None, stages=None, parsing=None):
+    def __init__(self, opts, latent_encoder=None, net=None, stages=None, parsing=None, pretrained_root=None):
+        """`stages` None: SEAN, the shape adaptor and RotateModel are read from their checkpoint files (:29-38)."""
         super().__init__()
         self.opts = opts
         self.latent_encoder = latent_encoder
         self.net = net if net is not None else Net(opts)
-        self.stages = stages or Stages()
-        self.parsing = parsing if parsing is not None else BiSeNet(19).eval().to(opts.device)
+        self.stages = stages if stages is not None else native_stages(opts, ("sean", "shape", "rotate"), root=pretrained_root)
+        self.parsing = parsing if parsing is not None else build_parsing(opts, root=pretrained_root)
         self.dilate_erosion = DilateErosion(dilate_erosion=opts.smooth, device=opts.device)
 
     @torch.inference_mode()
@@ -491,15 +524,21 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
 
 
 class Blending(nn.Module):  # models/Blending.py:11-82
-    def __init__(self, opts, net=None, stages=None, pp_state=None, pp_latent_avg=None):
+    def __init__(self, opts, net=None, stages=None, pp_state=None, pp_latent_avg=None, pretrained_root=None):
+        """`stages` None: ClipBlendingModel and its CLIP tower are read from args.blending_checkpoint (:24-27);
+        `pp_state` None: PostProcessModel from args.pp_checkpoint + PostProcess/latent_avg.pt (:29-30, Encoders.py:112)."""
         super().__init__()
         self.opts = opts
         self.net = net if net is not None else Net(opts)
-        self.stages = stages or Stages()
-        # :28-29 PostProcessModel().load_state_dict(torch.load(pp_checkpoint)['model_state_dict']); latent_avg.pt
-        self.post_process = PostProcessModel(latent_avg=pp_latent_avg).eval()
-        if pp_state is not None:
-            self.post_process.load_state_dict(pp_state)
+        self.stages = stages if stages is not None else native_stages(opts, ("blend",), root=pretrained_root)
+        if pp_state is None:
+            pp_state, file_avg = ckpt_files.post_process(opts.pp_checkpoint, pretrained_root)
+            pp_latent_avg = pp_latent_avg if pp_latent_avg is not None else file_avg
+        if pp_latent_avg is None:
+            raise ValueError("pp_state needs pp_latent_avg (pretrained_models/PostProcess/latent_avg.pt, models/Encoders.py:112)")
+        avg = torch.as_tensor(pp_latent_avg).float().reshape(-1, 512)  # [18,512], [1,18,512] or one [512] row for all 18
+        self.post_process = PostProcessModel(latent_avg=avg.expand(18, 512) if avg.shape[0] == 1 else avg).eval()
+        self.post_process.load_state_dict(pp_state)
         self.post_process.to(opts.device)
         self.dilate_erosion = DilateErosion(dilate_erosion=opts.smooth, device=opts.device)
         self.downsample_256 = BicubicDownSample(factor=4)
@@ -553,24 +592,25 @@ class Blending(nn.Module):  # models/Blending.py:11-82
 class HairFast:
     """HairFast with the reference's hairstyle-transfer interface (hair_swap.py:27-103).
 
-    Extra keyword-only constructor arguments (the reference reads everything from files):
-      stages          the out-of-scope networks (Stages; SyntheticStages() for schedule runs)
+    `HairFast(args)` reads every network from the reference's checkpoint files - args.ckpt, args.rotate_checkpoint,
+    args.blending_checkpoint, args.pp_checkpoint and the paths the reference hard-codes (hairfastgan_amd.checkpoints lists
+    them with their key handling) - relative to the working directory or `pretrained_root`; a missing file raises
+    FileNotFoundError naming it.  Keyword-only arguments replace files by in-memory state dicts (tests, benchmarks):
+      pretrained_root directory the checkpoint paths are relative to (default: cwd / HAIRFAST_PRETRAINED_ROOT)
+      stages          a `Stages` object supplying rotate / shape_adaptor / sean_inpaint / blend (e.g. the reference's own
+                      modules); networks whose state dicts are passed below still run natively, the
+                      files of the others are then NOT read
       generator_state {'g_ema': ..., 'latent_avg': ...} instead of args.ckpt
-      e4e_state / fs_state (+ e4e_latent_avg / fs_dlatent_avg)  encoder state dicts
-      pp_state (+ pp_latent_avg)  PostProcessModel state dict ('model_state_dict' of args.pp_checkpoint)
+      e4e_state + e4e_latent_avg / fs_state + fs_dlatent_avg   encoder state dicts with their average latents
+      pp_state + pp_latent_avg    PostProcessModel ('model_state_dict' of args.pp_checkpoint; PostProcess/latent_avg.pt)
       bisenet_state   BiSeNet state dict (pretrained_models/BiSeNet/face_parsing_79999_iter.pth)
-      rotate_state    RotateModel state dict ('model_state_dict' of args.rotate_checkpoint): the Rotate stage runs natively
-      blend_state (+ clip_image_embed)  ClipBlendingModel state dict ('model_state_dict' of args.blending_checkpoint) and
-                      the CLIP ViT-B/32 image encoder callable: the blending stage runs natively around that callable
-      shape_state     CtrlHair mask-generator state dict (pretrained_models/ShapeAdaptor/mask_generator.pth): the shape
-                      adaptor runs natively (hairfastgan_amd.shape_adaptor)
-      clip_state      state dict of the OpenAI CLIP ViT-B/32 model (its `visual.*` entries; what clip.load("ViT-B/32") holds,
-                      models/Encoders.py:79): the image tower inside the blending model runs natively (hairfastgan_amd.clip_vit)
-                      instead of through `clip_image_embed`
-      sean_state (+ sean_mean_codes)  SEAN generator state dict (pretrained_models/sean_checkpoints/CelebA-HQ_pretrained/
-                      latest_net_G.pth) and the [19,512] per-label median style codes
-                      (models/sean_codes/styles_test/mean_style_code/median/<label>/ACE.npy): SEAN inpainting runs natively
-                      (hairfastgan_amd.sean)
+      rotate_state    RotateModel ('model_state_dict' of args.rotate_checkpoint)
+      blend_state     ClipBlendingModel ('model_state_dict' of args.blending_checkpoint, `clip_model.*` dropped) with
+      clip_state      the OpenAI CLIP ViT-B/32 state dict (its `visual.*` entries; what clip.load("ViT-B/32") holds,
+                      models/Encoders.py:79; run natively by hairfastgan_amd.clip_vit) or `clip_image_embed`, a callable
+      shape_state     CtrlHair mask generator (pretrained_models/ShapeAdaptor/mask_generator.pth)
+      sean_state + sean_mean_codes   SEAN generator (…/CelebA-HQ_pretrained/latest_net_G.pth) and the [19,512] per-label
+                      median style codes (models/sean_codes/styles_test/mean_style_code/median/<label>/ACE.npy)
     """
 
     @staticmethod
@@ -592,25 +632,29 @@ class HairFast:
     def __init__(self, args, *, stages=None, generator_state=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
                  fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None, bisenet_state=None, rotate_state=None,
                  blend_state=None, clip_image_embed=None, shape_state=None, sean_state=None, sean_mean_codes=None,
-                 clip_state=None):
+                 clip_state=None, pretrained_root=None):
         self.args = args
         if getattr(args, "save_all", False):
             raise NotImplementedError(
                 "--save_all (intermediate images / latents written by the reference's utils/save_utils.py, Embedding.py:94-108, "
                 "Alignment.py:84-93, 159-179, Blending.py:70-78) is not implemented by this backend: nothing would be written")
-        self.stages = stages or Stages()
-        if any(s_ is not None for s_ in (rotate_state, blend_state, shape_state, sean_state)):
-            self.stages = NativeLatentStages(self.stages, args.device, rotate_state, blend_state, clip_image_embed, shape_state,
-                                             sean_state, sean_mean_codes, clip_state)
-        self.net = Net(args, state=generator_state)
-        self.parsing = BiSeNet(19).eval()  # pretrained_models/BiSeNet/face_parsing_79999_iter.pth (my_parsing_util.py:77-79)
-        if bisenet_state is not None:
-            self.parsing.load_state_dict(bisenet_state)
-        self.parsing.to(args.device)
+        root = pretrained_root
+        given = dict(rotate_state=rotate_state, blend_state=blend_state, clip_image_embed=clip_image_embed,
+                     shape_state=shape_state, sean_state=sean_state, sean_mean_codes=sean_mean_codes, clip_state=clip_state)
+        if stages is None:  # the reference's constructor: everything from files unless handed over in memory
+            self.stages = native_stages(args, root=root, **given)
+        elif any(given[k] is not None for k in ("rotate_state", "blend_state", "shape_state", "sean_state")):
+            self.stages = native_stages(args, which=(), base=stages, root=root, **given)
+        else:
+            self.stages = stages
+        self.net = Net(args, state=generator_state, root=root)
+        self.parsing = build_parsing(args, bisenet_state, root)  # my_parsing_util.py:77-79
         self.embed = Embedding(args, net=self.net, stages=self.stages, e4e_state=e4e_state, fs_state=fs_state,
-                               e4e_latent_avg=e4e_latent_avg, fs_dlatent_avg=fs_dlatent_avg, parsing=self.parsing)
+                               e4e_latent_avg=e4e_latent_avg, fs_dlatent_avg=fs_dlatent_avg, parsing=self.parsing,
+                               pretrained_root=root)
         self.align = Alignment(args, self.embed.get_e4e_embed, net=self.net, stages=self.stages, parsing=self.parsing)
-        self.blend = Blending(args, net=self.net, stages=self.stages, pp_state=pp_state, pp_latent_avg=pp_latent_avg)
+        self.blend = Blending(args, net=self.net, stages=self.stages, pp_state=pp_state, pp_latent_avg=pp_latent_avg,
+                              pretrained_root=root)
         self._times = []
 
     def _swap_from_tensors(self, face, shape, color, **kwargs):  # hair_swap.py:38-61
@@ -700,7 +744,8 @@ class HairFast:
         if len({id(im) for im in images}) != 3 or getattr(self.args, "save_all", False):
             return self.swap(*images, seed=seed)
         images = [im.float().contiguous() for im in images]
-        key = tuple(tuple(im.shape) for im in images)
+        # a graph replays the kernels of the mode it was captured in: the conv precision and the RNG walk are part of the key
+        key = (tuple(tuple(im.shape) for im in images), configured_conv_precision(), reference_rng_walk())
         graphs = self.__dict__.setdefault("_swap_graphs", {})
         if key not in graphs:
             set_seed(3407 if seed is None else seed)
@@ -747,9 +792,8 @@ class HairFastHotPath(torch.nn.Module):
         super().__init__()
         self.args = args
         self.net = Net(args, state=generator_state)
-        emb = Embedding(args, net=self.net, e4e_state=e4e_state, fs_state=fs_state, e4e_latent_avg=e4e_latent_avg,
-                        fs_dlatent_avg=fs_dlatent_avg)
-        self.e4e, self.encoder = emb.e4e, emb.encoder
+        self.e4e = build_e4e(args, e4e_state, e4e_latent_avg)
+        self.encoder = build_fs_encoder(args, self.net.generator, fs_state, fs_dlatent_avg)
         self._graphs = {}
 
     def _call(self, key, fn, *tensors, use_graphs=False):

@@ -7,29 +7,27 @@ freezing the parameters and `cal_layer_num` (:78-88).  Out of scope (SURVEY.md s
 the PCA model used only by training losses (:48-76), the BiSeNet singleton trigger (:29)
 and the gdown auto-download (:32-34) - a missing checkpoint raises instead.
 """
-import os
-
 import torch
 from torch import nn
 
+from .checkpoints import load_file
 from .stylegan2.model import Generator
 
 
 class Net(nn.Module):
-    def __init__(self, opts, state=None):
+    def __init__(self, opts, state=None, root=None):
         """`state`: optional in-memory checkpoint dict {'g_ema': ..., 'latent_avg': ...}
-        (used by tests / benchmarks with synthetic weights); otherwise `opts.ckpt` is loaded."""
+        (used by tests / benchmarks with synthetic weights); otherwise `opts.ckpt` is loaded
+        (relative to `root` / HAIRFAST_PRETRAINED_ROOT / the working directory)."""
         super().__init__()
         self.opts = opts
         self.generator = Generator(opts.size, opts.latent, opts.n_mlp, channel_multiplier=opts.channel_multiplier)
         self.cal_layer_num()
-        self.load_weights(state)
+        self.load_weights(state, root)
 
-    def load_weights(self, state=None):
+    def load_weights(self, state=None, root=None):
         if state is None:
-            if not os.path.exists(self.opts.ckpt):
-                raise FileNotFoundError(f"StyleGAN2 checkpoint {self.opts.ckpt} not found (no network download here)")
-            state = torch.load(self.opts.ckpt, map_location="cpu")
+            state = load_file(self.opts.ckpt, "StyleGAN2 generator (--ckpt, models/Net.py:31-40)", root)
         device = self.opts.device
         self.generator.load_state_dict(state["g_ema"])
         self.latent_avg = state["latent_avg"].to(device)

@@ -330,10 +330,18 @@ class SeanModel(nn.Module):
     models/sean_codes/styles_test/mean_style_code/median/<label>/ACE.npy files as one [19,512] tensor `mean_codes`)."""
 
     def __init__(self, mean_codes=None, **generator_sizes):
+        """mean_codes None builds the module without them (state-dict layout checks, encode-only use): `decode` then
+        raises - the reference ALWAYS starts from load_average_feature() and a label of the target mask that the source
+        image lacks is common, so an implicit all-zero default would render it from fc_mu(0) without any error."""
         super().__init__()
         self.netG = SPADEGenerator(**generator_sizes)
-        self.register_buffer("mean_codes", torch.zeros(N_LABELS, self.netG.style) if mean_codes is None else mean_codes.clone().float(),
-                             persistent=False)
+        if mean_codes is not None:
+            mean_codes = torch.as_tensor(mean_codes).float()
+            if tuple(mean_codes.shape) != (N_LABELS, self.netG.style):
+                raise ValueError(f"sean_mean_codes: expected [{N_LABELS}, {self.netG.style}] (one median ACE.npy code per label, "
+                                 f"pix2pix_model.py:268-293), got {tuple(mean_codes.shape)}")
+            mean_codes = mean_codes.clone()
+        self.register_buffer("mean_codes", mean_codes, persistent=False)
 
     @torch.inference_mode()
     def encode(self, images, labels):
@@ -346,6 +354,9 @@ class SeanModel(nn.Module):
     def decode(self, image_code, target_mask, group=1, noise=None, taps=None):
         """decode_sean (:310-325) for D codes at once: a label's code is the image's where it is not all zero (the label
         occurs in the image), the median code otherwise."""
+        if self.mean_codes is None:
+            raise ValueError("SeanModel.decode needs the per-label median style codes (sean_mean_codes [19,512]: "
+                             "models/sean_codes/styles_test/mean_style_code/median/<label>/ACE.npy, pix2pix_model.py:268-293)")
         absent = (image_code == 0).all(dim=-1, keepdim=True)
         codes = torch.where(absent, self.mean_codes.to(image_code.device).unsqueeze(0).expand_as(image_code), image_code)
         return self.netG.decode(codes.contiguous(), target_mask, group=group, noise=noise, taps=taps)

@@ -196,9 +196,11 @@ class ModulatedConv2d(nn.Module):  # :183-279
     def fuses_torgb(self, input):
         """True when the layer's ToRGB can be computed in this conv's epilogue (fp16-core modes; a wave sums the
         64 / 32 output channels it holds, ToRGB.finish adds the slabs)."""
-        _, cin, h, w = input.shape
+        b_, cin, h, w = input.shape
+        # the same predicates conv_same_res dispatches on: the fp16-core kernel must be the one that runs (batch-dependent)
         return (conv_precision() != "f32" and not self.upsample and self.kernel_size == 3
-                and M.torgb_fusable(cin, self.out_channel, h, w))
+                and M.torgb_fusable(cin, self.out_channel, h, w)
+                and M.modconv3x3_f16_supported(cin, self.out_channel, h, w, batch=b_))
 
     def blur_factors(self):
         """1-D factors of the module's blur kernel when it is separable (it is: make_kernel of a 1-D list,

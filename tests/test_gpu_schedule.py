@@ -68,7 +68,7 @@ def test_graph_runner_matches_eager():
 
 
 def _hairfast(dev):
-    from hairfastgan_amd.hair_swap import HairFast, SyntheticStages, get_parser
+    from hairfastgan_amd.hair_swap import HairFast, get_parser
 
     args = get_parser().parse_args([])
     args.device = dev
@@ -78,10 +78,11 @@ def _hairfast(dev):
 
     pp_shapes = PP.post_process_param_shapes()
     pp_shapes.pop("latent_avg")
-    return HairFast(args, stages=SyntheticStages(), generator_state=state,
-                    e4e_state=C.params_from_shapes("e4e", E.e4e_param_shapes()),
-                    fs_state=C.params_from_shapes("fs", E.fs_param_shapes()),
-                    pp_state=C.params_from_shapes("pp", pp_shapes), bisenet_state=C.bisenet_params(),
+    zeros = torch.zeros(18, 512)
+    return HairFast(args, generator_state=state,
+                    e4e_state=C.params_from_shapes("e4e", E.e4e_param_shapes()), e4e_latent_avg=zeros,
+                    fs_state=C.params_from_shapes("fs", E.fs_param_shapes()), fs_dlatent_avg=zeros,
+                    pp_state=C.params_from_shapes("pp", pp_shapes), pp_latent_avg=zeros, bisenet_state=C.bisenet_params(),
                     rotate_state=C.params_from_shapes("rotate", PP.rotate_param_shapes()),
                     blend_state=C.params_from_shapes("clipblend", PP.clip_blending_param_shapes()),
                     clip_state=C.clip_params(), shape_state=C.shape_adaptor_params(),
@@ -90,8 +91,7 @@ def _hairfast(dev):
 
 def test_hairfast_swap_call_surface():
     """`HairFast(args).swap(face, shape, color, benchmark=False, align=False, seed=None, exp_name=None)`
-    (hair_swap.py:27-103): runs the whole stage sequence on the HIP hot path with SyntheticStages in
-    between; seeded runs reproduce; equal images collapse like the reference's equal_replacer."""
+    (hair_swap.py:27-103): runs the whole stage sequence, every network native; seeded runs reproduce; equal images collapse like the reference's equal_replacer."""
     import inspect
 
     from hairfastgan_amd.hair_swap import HairFast, Stages

@@ -61,6 +61,13 @@ def test_label_conv_and_ace_tail(simlib):
     yb = M.label_conv3x3(simlib, None, big, table, b, 6, relu=False)
     ohb = F.one_hot(big.long(), 19).permute(0, 3, 1, 2).float()
     assert float((yb - F.conv2d(ohb, w, b, padding=1)).abs().max()) < 2e-5
+    # labels outside 0..18 (a 255 'ignore' value, a negative one): both kernels clamp into the sample's own columns -
+    # the per-pixel kernel (small plane) and the LDS-table kernel (>= 1024 pixels, W % 4 == 0) give the clamped map's result
+    for shape in ((1, 9, 12), (1, 32, 40)):
+        odd = torch.randint(0, 19, shape, dtype=torch.int32)
+        odd[0, 2, 3], odd[0, 4, 4], odd[0, 0, 0] = 255, -3, 19
+        want = M.label_conv3x3(simlib, None, odd.clamp(0, 18), table, b, 6)
+        assert torch.equal(M.label_conv3x3(simlib, None, odd, table, b, 6), want)
     # ACE tail
     x, r = torch.randn(4, 4, 9, 12), torch.randn(4, 9, 12)
     nv, sc, sh = torch.randn(4) * 0.1, torch.rand(4) + 0.5, torch.randn(4)
