@@ -87,21 +87,28 @@ def build_generator(dev):
     return g.to(dev), sd
 
 
-def build_hairfast(sd, dev):
+def encoder_states():
+    """Synthetic e4e / FS-encoder state dicts (shared by HairFast and the swap's CPU baseline)."""
+    from oracle import ref_encoders as E
+
+    return {"e4e": synth_state("e4e", E.e4e_param_shapes()), "fs": synth_state("fs", E.fs_param_shapes())}
+
+
+def build_hairfast(sd, dev, enc=None):
     """HairFast(args) on synthetic weights; no stand-in stages (the default `Stages` raise if anything were missing)."""
     from hairfastgan_amd.hair_swap import HairFast, get_parser
     from oracle import cases as C
-    from oracle import ref_encoders as E
     from oracle import ref_postprocess as PP
 
     args = get_parser().parse_args([])
     args.device = dev
     pp_shapes = PP.post_process_param_shapes()
     pp_shapes.pop("latent_avg")
+    enc = enc or encoder_states()
     # every network of a swap runs natively (SURVEY section 8 rows f1-f4): RotateModel, ClipBlendingModel with its CLIP
     # ViT-B/32 image tower, the CtrlHair shape adaptor, SEAN
     return HairFast(args, generator_state={"g_ema": sd, "latent_avg": torch.zeros(512)},
-                    e4e_state=synth_state("e4e", E.e4e_param_shapes()), fs_state=synth_state("fs", E.fs_param_shapes()),
+                    e4e_state=enc["e4e"], fs_state=enc["fs"],
                     e4e_latent_avg=torch.zeros(18, 512), fs_dlatent_avg=torch.zeros(18, 512), pp_latent_avg=torch.zeros(18, 512),
                     pp_state=synth_state("pp", pp_shapes), bisenet_state=C.bisenet_params(),
                     rotate_state=synth_state("rotate", PP.rotate_param_shapes()),
@@ -159,6 +166,50 @@ def cpu_baseline(sd, budget_s=30.0):
                       f"{torch.__version__}; thread counts tried: "
                       + ", ".join(f"{k}T={v[0] * 1e3:.0f}ms" for k, v in sorted(tried.items()))
                       + "".join(f", {k}T=not tried (budget)" for k in sorted(counts) if k not in tried)}
+
+
+def swap_cpu_baseline(sd, enc, threads):
+    """SURVEY section 8d config 3 on the host: the hot-path call schedule of ONE swap through the CPU oracle (bit-identical
+    restatement of the reference's PyTorch CPU path) - e4e B=3, FS encoder B=3, generator 3->3 B=3, 0->3 B=3, 0->8 B=1 twice
+    (the reference's two Alignment.py:63 forwards), e4e B=2, generator 0->3 B=2, 4->8 B=1, 5->8 B=1: 1545 GFLOP - timed
+    once at the thread count the generator baseline found fastest.  The networks between those calls (SEAN, CLIP, BiSeNet,
+    shape adaptor, PostProcess) are NOT in this figure: it bounds the reference's CPU swap from below."""
+    from oracle import cases as C
+    from oracle import ref_encoders as E
+    from oracle import ref_stylegan2 as O
+
+    torch.set_num_threads(threads)
+    gen = torch.Generator().manual_seed(3407)
+    rn = lambda *s_: torch.randn(*s_, generator=gen)  # noqa: E731
+    _, nz, _ = C.generator_inputs(1024, 1, 0)
+    stages = {}
+
+    def timed(name, fn):
+        t0 = time.time()
+        r = fn()
+        stages[name] = round(stages.get(name, 0.0) + time.time() - t0, 3)
+        return r
+
+    t_all = time.time()
+    with torch.inference_mode():
+        x256, img = rn(3, 3, 256, 256) * 0.5, rn(3, 3, 1024, 1024) * 0.5
+        w = timed("e4e B=3", lambda: E.e4e_forward(enc["e4e"], x256))
+        s_, fea = timed("FS encoder B=3", lambda: E.fs_encoder_test(enc["fs"], img, torch.zeros(18, 512)))
+        timed("generator 3->3 B=3", lambda: O.generator_forward(sd, s_, nz, layer_in=fea, start_layer=3, end_layer=3))
+        timed("generator 0->3 B=3", lambda: O.generator_forward(sd, w, nz, start_layer=0, end_layer=3))
+        for _ in range(2):
+            timed("generator 0->8 B=1 x2", lambda: O.generator_forward(sd, w[:1], nz))
+        w2 = timed("e4e B=2", lambda: E.e4e_forward(enc["e4e"], x256[:2]))
+        timed("generator 0->3 B=2", lambda: O.generator_forward(sd, w2, nz, start_layer=0, end_layer=3))
+        timed("generator 4->8 B=1", lambda: O.generator_forward(sd, w[:1], nz, layer_in=rn(1, 512, 32, 32), start_layer=4, end_layer=8))
+        timed("generator 5->8 B=1", lambda: O.generator_forward(sd, w[:1], nz, layer_in=rn(1, 512, 64, 64), start_layer=5, end_layer=8))
+    total = time.time() - t_all
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    return {"value": round(1.0 / total, 4), "unit": "triples/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+            "s_per_triple": round(total, 2), "stage_s": stages, "gflop_per_triple": GFLOP_PER_TRIPLE,
+            "sample": "ONE pass (no warm-up) of the hot-path call schedule of one swap (SURVEY section 8d config 3: encoders + generator "
+                      f"calls, 1545 GFLOP; SEAN / CLIP / BiSeNet / shape adaptor / PostProcess excluded) through the CPU oracle, "
+                      f"torch.set_num_threads({threads}) = the generator baseline's fastest count"}
 
 
 def pmc_profile(kernel):
@@ -219,7 +270,7 @@ def make_triple_loader(n_pool=8):
     return lambda i: pool[i % n_pool]
 
 
-def kernel_report(prof, elapsed, precision, sampled=1.0):
+def kernel_report(prof, elapsed, precision, sampled=1.0, pmc=True):
     """Aggregate the HIP-event brackets of the timed region: per-kernel table + the two rooflines.
     sampled: fraction of the region's steps whose launches were bracketed (shares are scaled by it)."""
     elapsed = elapsed * sampled
@@ -251,7 +302,8 @@ def kernel_report(prof, elapsed, precision, sampled=1.0):
                          f"MFMA FLOPs issued = {terms} x algorithmic = {round(ach * terms, 1)} TFLOP/s")
         else:
             peak, peak_note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA peak"
-        traffic, busy, tag = pmc_profile(dom)
+        # the committed PMC passes were collected in the headline configuration (f16x3, batch 8, generator workload) only
+        traffic, busy, tag = pmc_profile(dom) if pmc else (None, None, None)
         alg_bytes = d[3] / d[2] if d[3] > 0 else None
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1),
                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
@@ -281,13 +333,22 @@ def kernel_report(prof, elapsed, precision, sampled=1.0):
         dom = max(hbm, key=lambda k: hbm[k][1])
         d = hbm[dom]
         ach = d[3] / d[1] / 1e9
-        traffic, _, tag = pmc_profile(dom)
+        traffic, _, tag = pmc_profile(dom) if pmc else (None, None, None)
         out["roofline_hbm"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": traffic,
                                "traffic_source": f"{PMC_PROFILE} (tag {tag}), replayed" if traffic is not None else None,
                                "avg_launch_ms": round(d[1] / d[2] * 1e3, 4), "launches": d[2],
                                "bytes_per_launch_avg": d[3] / d[2]}
     return out
+
+
+def balance_report(st, cpu_slice):
+    """Per-rank imbalance and the exposed tail of the all-gather of one parallel.swap_many call (rank 0's view)."""
+    if not st:
+        return None
+    return {"per_rank_compute_s": [round(v, 4) for v in st["per_rank_compute_s"]], "imbalance_max_over_min": round(st["imbalance"], 4),
+            "gather_tail_s_rank0": round(st["gather_tail_s"], 4),
+            "cpu_threads_rank0": None if cpu_slice is None else f"{cpu_slice[0]}-{cpu_slice[-1]} ({len(cpu_slice)} pinned)"}
 
 
 def self_launch(args, argv):
@@ -367,6 +428,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--event-every", type=int, default=4,
                     help="generator workload: bracket the launches of every N-th timed step with HIP events (1 = every step)")
+    ap.add_argument("--pipeline-triples", type=int, default=256,
+                    help="generator workload: triples of the WHOLE job for the secondary swap_pipeline object (strong scaling over --gpus)")
     ap.add_argument("--swap-triples", type=int, default=4,
                     help="generator workload: triples per GPU for the secondary hair-swap measurements (0 = skip)")
     args = ap.parse_args()
@@ -385,6 +448,8 @@ def main():
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} - refusing to print a line for a different rank count")
+    # one node: every rank gets its own slice of the host's hardware threads (launch-bound ranks otherwise share cores)
+    cpu_slice = parallel.pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     if torch.cuda.device_count() <= local:
         sys.exit(f"bench.py: rank {rank} (local {local}) has no GPU: {torch.cuda.device_count()} visible")
@@ -429,8 +494,10 @@ def main():
         prof = None if args.no_kernel_events else []
         _marshal.PROFILE = prof
         t0 = time.perf_counter()
+        st256 = {}
         images, n_local = parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), args.triples, load, device=dev,
-                                             batch=args.swap_batch, swap_batch_fn=hf.swap_batch if args.swap_batch > 1 else None)
+                                             batch=args.swap_batch, swap_batch_fn=hf.swap_batch if args.swap_batch > 1 else None,
+                                             stats=st256)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         _marshal.PROFILE = None
@@ -453,7 +520,8 @@ def main():
                               "weights": "synthetic closed-form (oracle/synth.py)", "conv_precision": precision,
                               "gather": "RCCL all_gather_into_tensor of uint8 images per 8 local triples (async)" if use_dist else "single process: no collective"},
                    "algorithmic_tflops_hot_path": round(args.triples * (GFLOP_PER_TRIPLE + GFLOP_POSTPROCESS) / elapsed / 1e3, 2),
-                   "gflop_per_triple": GFLOP_PER_TRIPLE + GFLOP_POSTPROCESS}
+                   "gflop_per_triple": GFLOP_PER_TRIPLE + GFLOP_POSTPROCESS,
+                   "balance": balance_report(st256, cpu_slice)}
             if prof:
                 out.update(kernel_report(prof, elapsed, precision))
             print(json.dumps(out), flush=True)
@@ -533,12 +601,19 @@ def main():
                          "note": "same forward, HAIRFAST_CONV_PRECISION=f32 (v_mfma_f32_32x32x2_f32 only): the fallback headline "
                                  "should the fp16 split ever clamp on a trained checkpoint"}
             if ev32:
-                exact_f32["roofline"] = kernel_report(ev32, e32, "f32").get("roofline")
+                exact_f32["roofline"] = kernel_report(ev32, e32, "f32", pmc=False).get("roofline")
         e16 = alt_run("f16", 16)
+        ev16 = None if args.no_kernel_events else []
+        e16_ev = alt_run("f16", 16, ev16) if ev16 is not None else None  # a second, event-bracketed run for the rooflines only
         f16_mode = {"value": round(16 * args.steps / e16, 3), "unit": "images/s", "ms_per_step": round(e16 / args.steps * 1e3, 4),
                     "batch": 16, "note": "BASELINE.json configs[4]: fp16 conv operands (HAIRFAST_CONV_PRECISION=f16; the hand-over "
                                          "activations between convs are fp16, everything else fp32), fp32 accumulation and "
                                          "demodulation; batch-16 rows checked against the reference goldens in tests/test_gpu_parity.py"}
+        if ev16:  # configs[4] under its own roof: one fp16 MFMA per product -> the full 2516.6 TFLOP/s dense peak
+            rep16 = kernel_report(ev16, e16_ev, "f16", pmc=False)
+            f16_mode["roofline"], f16_mode["roofline_families"] = rep16.get("roofline"), rep16.get("roofline_families")
+            f16_mode["algorithmic_tflops_whole_forward"] = round(16 * args.steps / e16 * GFLOP_PER_IMAGE / 1e3, 2)
+            f16_mode["note"] += "; rooflines from a second run of the same steps with every launch bracketed by HIP events"
 
     # Secondary measurements (outside the timed region above) of BASELINE.json configs[2]/[3] on a bounded
     # sample: (a) the hot-path kernels of one swap replayed on resident tensors (eager / hipGraph),
@@ -559,19 +634,39 @@ def main():
                                  "discarded FS-encoder generator forward is not run); resident synthetic tensors between the calls",
                      "gflop_per_triple": GFLOP_PER_TRIPLE}
         try:
-            hf = build_hairfast(sd, dev)
+            enc_states = encoder_states()
+            hf = build_hairfast(sd, dev, enc_states)
             load = make_triple_loader(2)
             with torch.inference_mode():
                 hf.swap(*[t.to(dev) for t in load(0)])
                 if args.swap_batch > 1:
                     hf.swap_batch([tuple(t.to(dev) for t in load(i)) for i in range(args.swap_batch)])
             barrier()
-            n_pipe = 2 * args.swap_batch * world  # two full batched passes per rank
+            # BASELINE.json configs[3] at its own size, strong-scaled: --pipeline-triples (default 256) triples of the WHOLE job,
+            # block-partitioned over the ranks - the driver's plain `bench.py --gpus N` yields the triples/s curve
+            n_pipe = max(args.pipeline_triples, world)
+            st_pipe = {}
             t0 = time.perf_counter()
             parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), n_pipe, load, device=dev, batch=args.swap_batch,
-                               swap_batch_fn=hf.swap_batch if args.swap_batch > 1 else None)
+                               swap_batch_fn=hf.swap_batch if args.swap_batch > 1 else None, stats=st_pipe)
             barrier()
             tp = max_over_ranks(time.perf_counter() - t0)
+            # the kernels of one batched pass under their roofs: every conv / GEMM launch bracketed by HIP events
+            pipe_roof = None
+            if not args.no_kernel_events and args.swap_batch > 1:
+                trip = [tuple(t.to(dev) for t in load(i)) for i in range(args.swap_batch)]
+                torch.cuda.synchronize()
+                _marshal.PROFILE = evp = []
+                t1 = time.perf_counter()
+                with torch.inference_mode():
+                    hf.swap_batch(trip)
+                torch.cuda.synchronize()
+                t_pass = time.perf_counter() - t1
+                _marshal.PROFILE = None
+                pipe_roof = kernel_report(evp, t_pass, precision, pmc=False)
+                pipe_roof.pop("kernels", None)
+                pipe_roof["pass_ms_with_events"] = round(t_pass * 1e3, 2)
+                del trip
             # the same pipeline one swap at a time (the reference's own protocol, utils/time.py): latency of a single swap
             n_single = args.swap_triples * world
             t0 = time.perf_counter()
@@ -617,14 +712,18 @@ def main():
                 graph_info = {"error": f"{type(e).__name__}: {e}"[:300]}
             pipeline_info = {"metric": "hair_swap_triples_per_sec", "value": round(n_pipe / tp, 3), "unit": "triples/s",
                              "ms_per_triple_per_gpu": round(tp / (n_pipe / world) * 1e3, 2), "triples": n_pipe,
-                             "swap_batch": args.swap_batch,
+                             "scaling": "strong", "swap_batch": args.swap_batch, "balance": balance_report(st_pipe, cpu_slice),
+                             "algorithmic_tflops_hot_path": round(n_pipe * (GFLOP_PER_TRIPLE + GFLOP_POSTPROCESS) / tp / 1e3 / world, 2),
                              "single_swap": {"ms_per_swap": round(ts / (n_single / world) * 1e3, 2), "triples": n_single,
                                              "note": "one HairFast.swap per triple (no batching across triples)"},
                              "single_swap_graph": graph_info,
                              "stage_ms_per_triple": stage_ms,
-                             "workload": "python bench.py --workload swap256 on a bounded sample: host uint8 -> H2D -> HairFast.swap / "
-                                         "swap_batch (every network native, no stand-ins: SEAN, CLIP ViT-B/32 tower, shape adaptor, RotateModel, "
-                                         "PostProcess, BiSeNet) -> uint8 -> gather; a BOUNDED SAMPLE of BASELINE.json configs[3] (synthetic weights)"}
+                             "workload": f"python bench.py --workload swap256 --triples {n_pipe}: host uint8 -> H2D -> HairFast.swap_batch "
+                                         "(every network native, no stand-ins: SEAN, CLIP ViT-B/32 tower, shape adaptor, RotateModel, "
+                                         "PostProcess, BiSeNet) -> uint8 -> gather; BASELINE.json configs[3] (synthetic weights), total work fixed"}
+            if pipe_roof:
+                pipeline_info.update({k: pipe_roof[k] for k in ("roofline", "roofline_families", "pass_ms_with_events") if k in pipe_roof})
+            pipeline_info["_enc_states"] = enc_states
         except Exception as e:
             pipeline_info = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -652,8 +751,14 @@ def main():
             out["config"]["gather"] = "async RCCL all_gather_into_tensor of uint8 images, one per step"
         if prof:
             out.update(kernel_report(prof, elapsed, precision, n_bracketed / args.steps))
+        enc_states = pipeline_info.pop("_enc_states", None) if pipeline_info else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
+            if enc_states is not None and "error" not in pipeline_info:  # the swap metric's own CPU figure
+                try:
+                    pipeline_info["cpu_baseline"] = swap_cpu_baseline(sd, enc_states, out["cpu_baseline"]["cores"])
+                except Exception as e:
+                    pipeline_info["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         if exact_f32 is not None:
             out["exact_f32"] = exact_f32
         if f16_mode is not None:

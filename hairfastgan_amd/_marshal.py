@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from ._lib import check
+from ._runtime import plan_batch
 
 SQRT2 = 2 ** 0.5
 
@@ -35,11 +36,11 @@ KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modc
     561: "conv_mfma_h<1,2,2,4,up>", 563: "conv_mfma_h<1,2,1,8,up>",
     573: "conv_mfma_h<1,2,1,8,up,fuse>", 593: "conv_mfma_h<1,2,1,8,up,pre,fuse>",
     # csrc/convh_enc.hip (encoder convs on the fp16 matrix cores)
-    601: "conv_enc_h<64x256>", 602: "conv_enc_h<64x128,stride2>", 603: "conv_enc_h<64x128>",
+    601: "conv_enc_h<64x256>", 602: "conv_enc_h<64x128,stride2>", 603: "conv_enc_h<64x128>", 604: "conv_enc_h<64x512>",
 }
 
 
-def _launch_profiled(lib, flops, fn, label=None, nbytes=0.0):
+def _launch_profiled(lib, flops, fn, label=None, nbytes=0.0, tag=""):
     """bench.py only: brackets one launch with HIP events on the launch stream.  Entries are
     (kernel label, algorithmic flops, start, end, algorithmic bytes); `label` None = a modulated /
     plain conv whose instantiation hf_debug_last_path reports."""
@@ -53,6 +54,8 @@ def _launch_profiled(lib, flops, fn, label=None, nbytes=0.0):
     if label is None:
         code = lib.hf_debug_last_path()
         label = KERNEL_NAMES.get(code, f"conv_mfma (general, code {code})")
+        if tag and label.endswith(">"):
+            label = label[:-1] + tag + ">"
     PROFILE.append((label, flops, e0, e1, nbytes))
     return r
 
@@ -254,7 +257,7 @@ def modconv3x3_f16_supported(cin, cout, h, w, batch=None):
     """Shapes hf_modconv3x3_f16_f32 takes (include/hairfast_hip.h).  batch given: also whether it PAYS - a launch of
     fewer than 2048 pixels in total (a batch-1 32^2 layer: 4 tiles x 8 channel tiles) leaves the chip to 32 blocks that
     each walk the whole K loop (94 us); the fp32 kernels split K over the CUs instead (70 us; tools/probes/tower.py)."""
-    if batch is not None and batch * h * w < 2048:
+    if batch is not None and plan_batch(batch) * h * w < 2048:
         return False
     return cin % 16 == 0 and w >= 32 and (h >= 8 if cout % 64 == 0 else (cout % 32 == 0 and h >= 16))
 
@@ -370,7 +373,7 @@ def modconv3x3_small_supported(cin, cout, h, w, batch, upsample=False):
     at batch 8; 62 -> 38 / 68 -> 43 us at batch 1) and 16^2 inputs up to 1024 pixels per launch (batch 3: 110 -> 88 us)."""
     if cin % 32 or cout % 64 or h * w > 1024:
         return False
-    n = batch * h * w
+    n = plan_batch(batch) * h * w  # batch-invariant mode: the dispatch of ONE sample (_runtime.plan_batch)
     if upsample:
         return h * w <= 64 or (h * w <= 256 and n <= 1024)
     return 256 < n <= 2048
@@ -379,7 +382,7 @@ def modconv3x3_small_supported(cin, cout, h, w, batch, upsample=False):
 def conv3x3_small_supported(cin, cout, h, w, batch):
     """Plain (unmodulated) 3x3 convs worth the tap-GEMM form: planes the tiled fp16 kernel does not take, weights of 1 MB
     and more (below, the fp32 split-K kernel's two launches win), at most 4096 pixels per launch."""
-    return cin % 32 == 0 and cout % 64 == 0 and h * w <= 256 and batch * h * w <= 4096 and cin * cout >= 512 * 512
+    return cin % 32 == 0 and cout % 64 == 0 and h * w <= 256 and plan_batch(batch) * h * w <= 4096 and cin * cout >= 512 * 512
 
 
 def modconv3x3_small(lib, st, x, w9, nterms, s, d, noise, noise_w, bias, cout, alpha=0.2, scale=SQRT2, upsample=False):
@@ -411,7 +414,7 @@ def modconv3x3_small(lib, st, x, w9, nterms, s, d, noise, noise_w, bias, cout, a
 def modconv3x3_up_f16_supported(cin, cout, h, w, batch=None):
     """Shapes hf_modconv3x3_up_f16_f32 takes (include/hairfast_hip.h); batch: see modconv3x3_f16_supported (a batch-1
     16^2 -> 32^2 layer: 84 us on the fp32 split-K kernels, 106 us here)."""
-    if batch is not None and batch * h * w < 512:
+    if batch is not None and plan_batch(batch) * h * w < 512:
         return False
     return cin % 16 == 0 and cout % 32 == 0 and h * w >= (256 if cout % 64 == 0 else 512) and min(h, w) >= 2
 
@@ -745,7 +748,7 @@ def conv2d_f16(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None, 
         lambda: lib.hf_conv2d_f16_f32(_p(out), None if pre else _p(x), _p(x.hi) if pre else None, _p(x.lo) if pre else None,
                                       _p(wt_hi), _p(wt_lo), nterms, _p(in_scale), _p(in_shift), _p(_c(out_scale)),
                                       _p(_c(bias)), act, _p(_c(slope)), float(alpha), _p(residual), b, cin, cout, h, w, stride,
-                                      groups, x_gstride, _p(ws), max(n, 0), st))
+                                      groups, x_gstride, _p(ws), max(n, 0), st), tag=",pre" if pre else "")
     check(lib, code, "hf_conv2d_f16_f32")
     return out
 
@@ -783,7 +786,8 @@ def conv2d_f16_split(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=
         lambda: lib.hf_conv2d_f16_split_f32(_p(out), _p(hi), _p(lo), _p(_c(next_scale)), _p(_c(next_shift)), None if pre else _p(x),
                                             _p(x.hi) if pre else None, _p(x.lo) if pre else None, _p(wt_hi), _p(wt_lo), nterms,
                                             _p(in_scale), _p(in_shift), _p(_c(out_scale)), _p(_c(bias)), act, _p(_c(slope)),
-                                            float(alpha), _p(residual), b, cin, cout, h, w, stride, st))
+                                            float(alpha), _p(residual), b, cin, cout, h, w, stride, st),
+        tag=",pre,split-out" if pre else ",split-out")
     check(lib, code, "hf_conv2d_f16_split_f32")
     return SplitActivation(hi, lo, None), out
 

@@ -7,7 +7,12 @@ from . import _lib
 
 
 def lib():
-    return _lib.load()
+    global _lib_flag
+    L = _lib.load()
+    if _lib_flag != _batch_invariant:  # HAIRFAST_DETERMINISTIC / set_batch_invariant -> the library's process-wide flag
+        L.hf_set_batch_invariant(1 if _batch_invariant else 0)
+        _lib_flag = _batch_invariant
+    return L
 
 
 def require_gpu(*tensors):
@@ -110,3 +115,32 @@ def reference_rng_walk():
     import os
 
     return os.environ.get("HAIRFAST_RNG_WALK", "") == "reference"
+
+
+# ---------------------------------------------------------------------------------------
+# Batch-invariant plans (HAIRFAST_DETERMINISTIC=1 / set_batch_invariant): split-K factors, tile forms and the
+# small-plane / tiled / fp32 dispatch of every conv are chosen from the PER-SAMPLE shape only, so that a sample's result
+# has the same bits whatever it is batched with - `HairFast.swap_batch` then produces exactly the segmentation-mask
+# indices of `HairFast.swap` (north_star: bit-exact mask indices; an argmax near a tie otherwise flips with the batch
+# size because the summation order of the logits follows the plan).  Cost: a batched launch keeps the split-K passes
+# and small tile forms of a batch-1 launch.  Process-wide, like the library's flag
+# (hf_set_batch_invariant), which `lib()` keeps equal to this setting.
+_batch_invariant = os.environ.get("HAIRFAST_DETERMINISTIC", "0") not in ("", "0")
+_lib_flag = False  # what the library currently holds
+
+
+def batch_invariant():
+    return _batch_invariant
+
+
+def set_batch_invariant(on):
+    """Returns the previous setting.  Re-capture hipGraphs after a change (a graph replays the plans it recorded)."""
+    global _batch_invariant
+    prev, _batch_invariant = _batch_invariant, bool(on)
+    lib()  # applies the setting to the library now: plans are made inside C calls that never pass through plan_batch
+    return prev
+
+
+def plan_batch(batch):
+    """The batch count host-side dispatch decisions are made with (the library's plan_batch, conv_common.h)."""
+    return 1 if _batch_invariant else batch

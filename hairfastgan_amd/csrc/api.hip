@@ -11,7 +11,7 @@ extern "C" const char *hf_strerror(int code) {
   }
 }
 
-extern "C" int hf_abi_version(void) { return 9; }
+extern "C" int hf_abi_version(void) { return 10; }
 
 // per-translation-unit counters of the kernels that split fp32 into fp16 (hi, lo) pairs
 extern "C" unsigned long long hf_f16_overflow_count_convh(int reset);

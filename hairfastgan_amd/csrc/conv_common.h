@@ -360,6 +360,10 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wt_hi, const v
 int launch_conv_rows(ConvParams &P, const void *wt_hi, const void *wt_lo, hipStream_t st);
 extern thread_local int g_h_blocks;           // hf_debug_set_persistent_blocks: resident blocks the convh.hip grid is sized for (0 = 256 CUs)
 extern thread_local int g_h_tune;             // hf_debug_set_tuning: bit 0 force early stage DMAs, bit 1 force spread ones (convh.hip)
+extern int g_batch_invariant;                 // hf_set_batch_invariant (process-wide): plans (split-K counts, tile forms) from the per-sample shape only
+// The batch count every PLAN decision (split-K factor, tile form) is made with: the real one, or 1 in batch-invariant mode,
+// where a sample's result must not depend on what it is batched with (summation order is a function of the plan).
+inline int plan_batch(int batch) { return g_batch_invariant ? 1 : batch; }
 extern thread_local int g_force_h;            // hf_debug_set_dispatch same_cfg 51/52: force the convh.hip tile configuration
 void note_path(int path, int cfg);  // records what hf_debug_last_path reports
 // split-K second pass (modconv.hip): out = epilogue(d * sum_z partial[z]), deterministic

@@ -1046,6 +1046,7 @@ namespace hf_detail {
 thread_local int g_force_h = 0;
 thread_local int g_h_blocks = 0;
 thread_local int g_h_tune = 0;
+int g_batch_invariant = 0;  // process-wide: a mode of the whole library, not a per-thread debug hook
 
 int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const void *wtl, hipStream_t st) {
   const _Float16 *h = static_cast<const _Float16 *>(wth), *l = static_cast<const _Float16 *>(wtl);
@@ -1077,7 +1078,7 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
   //     MFMAs - the HBM-bound high-resolution layers (few chunks per tile)
   cfg = g_force_h;
   if (cfg == 0) {
-    const long long blocks52 = (long long)P.batch * hf_cdiv(P.h, 16) * hf_cdiv(P.w, 32) * (P.cout / 64);
+    const long long blocks52 = (long long)plan_batch(P.batch) * hf_cdiv(P.h, 16) * hf_cdiv(P.w, 32) * (P.cout / 64);
     if (P.cout % 64) cfg = (P.w >= 128) ? 55 : 53;
     else cfg = (P.h * P.w >= 512 && blocks52 >= 256) ? 52 : 51;
   }
@@ -1197,6 +1198,12 @@ extern "C" int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *s
                 : launch_h<3, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
   if (rc == HF_OK) note_path(5, x_hi ? 93 : 73);
   return rc;
+}
+
+extern "C" int hf_set_batch_invariant(int on) {
+  const int prev = hf_detail::g_batch_invariant;
+  hf_detail::g_batch_invariant = on ? 1 : 0;
+  return prev;
 }
 
 extern "C" int hf_debug_set_tuning(int bits) {

@@ -356,7 +356,8 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
   P.co_tiles = P.cout / CT;
   const int groups = P.groups > 1 ? P.groups : 1;
   const long long blocks = (long long)geom_blocks(G) * P.co_tiles * groups;
-  P.splits = enc_splitk_plan(blocks, P.cin / KH);
+  // the split-K factor is planned from ONE sample's block count in batch-invariant mode (G.lg_nb == 0: tiles_b = batch)
+  P.splits = enc_splitk_plan(blocks / P.batch * plan_batch(P.batch), P.cin / KH);
   P.chunks_per_split = hf_cdiv(P.cin / KH, P.splits);
   P.splits = hf_cdiv(P.cin / KH, P.chunks_per_split);  // no empty split
   P.zslab = (long long)groups * P.batch * P.cout * P.out_h * P.out_w;
@@ -399,8 +400,8 @@ int run_enc(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *ws, lo
   // 64 co x 512 px (8 waves, 2 x 2 MFMA tiles each) when that fills the chip (batched swaps), else
   // 64 co x 256 px (8 waves, 1 x 2 tiles) when that still does, else 64 co x 128 px (4 waves)
   const int groups = P.groups > 1 ? P.groups : 1;
-  const long long blocks256 = (long long)P.batch * groups * hf_cdiv((long long)P.out_h * P.out_w, 256) * (P.cout / 64);
-  const long long blocks512 = (long long)P.batch * groups * hf_cdiv((long long)P.out_h * P.out_w, 512) * (P.cout / 64);
+  const long long blocks256 = (long long)plan_batch(P.batch) * groups * hf_cdiv((long long)P.out_h * P.out_w, 256) * (P.cout / 64);
+  const long long blocks512 = (long long)plan_batch(P.batch) * groups * hf_cdiv((long long)P.out_h * P.out_w, 512) * (P.cout / 64);
   rc = HF_E_INVALID;
   // hf_debug_set_tuning: bit 2 = never the 512-pixel form, bits 8-15 = its minimum block count / 8 (0: the default),
   // bits 16-23 = the minimum block count / 8 of the 256-pixel form

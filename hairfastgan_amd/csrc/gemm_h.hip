@@ -255,6 +255,7 @@ int launch_gemm(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStre
 
 // Scratch of hf_conv1x1_f16_f32 in floats (0 = none): small grids split K.
 static int gemm_splits(int batch, int cin, int cout, int oplane, int groups) {
+  batch = hf_detail::plan_batch(batch);  // batch-invariant mode: the K split of ONE sample's grid
   const int pt = oplane * (long long)batch <= 128 || oplane <= 128 ? 128 : 256;
   int tw = pt, nb = 1;
   if (oplane < pt && (oplane & (oplane - 1)) == 0) {

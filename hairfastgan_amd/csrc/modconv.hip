@@ -751,7 +751,7 @@ int launch_conv_dma(ConvParams &P, hipStream_t st) {
 inline int splitk_plan(int batch, int cin, int cout, int out_h, int out_w, bool allow_mid = true) {
   const int PT = 64, CT = 64;  // the small-plane configuration <1,1,2,2>
   const long long per_img = ((long long)out_h * out_w + PT - 1) / PT;
-  const long long base = batch * per_img * ((cout + CT - 1) / CT);
+  const long long base = plan_batch(batch) * per_img * ((cout + CT - 1) / CT);
   const int nchunks = (cin + KC - 1) / KC;
   int s = 1;
   if (base < 256) {

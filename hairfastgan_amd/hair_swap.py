@@ -46,7 +46,7 @@ from torch import nn
 
 from . import _marshal as M
 from . import checkpoints as ckpt_files
-from ._runtime import configured_conv_precision, lib, reference_rng_walk, require_gpu, run_guarded, stream
+from ._runtime import batch_invariant, configured_conv_precision, lib, reference_rng_walk, require_gpu, run_guarded, stream
 from .encoders import ClipBlendingModel, Encoder4Editing, FSEncoder, PostProcessModel, RotateModel, get_latents
 from .face_parsing import BiSeNet, get_segmentation
 from .net import Net
@@ -744,8 +744,8 @@ class HairFast:
         if len({id(im) for im in images}) != 3 or getattr(self.args, "save_all", False):
             return self.swap(*images, seed=seed)
         images = [im.float().contiguous() for im in images]
-        # a graph replays the kernels of the mode it was captured in: the conv precision and the RNG walk are part of the key
-        key = (tuple(tuple(im.shape) for im in images), configured_conv_precision(), reference_rng_walk())
+        # a graph replays the kernels and plans of the mode it was captured in: conv precision, RNG walk and the batch-invariant switch are part of the key
+        key = (tuple(tuple(im.shape) for im in images), configured_conv_precision(), reference_rng_walk(), batch_invariant())
         graphs = self.__dict__.setdefault("_swap_graphs", {})
         if key not in graphs:
             set_seed(3407 if seed is None else seed)

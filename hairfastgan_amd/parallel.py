@@ -32,6 +32,25 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def pin_rank_to_cores(local_rank, local_world):
+    """Give rank `local_rank` of `local_world` on this node its own contiguous slice of the host's hardware threads
+    (os.sched_setaffinity) and size torch's intra-op pool to it: eight launch-bound ranks otherwise migrate over - and
+    oversubscribe - the same cores.  Returns the slice (or None where affinity is not available / not divisible)."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // local_world
+        if per < 1:
+            return None
+        mine = cpus[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(per, 32)))
+        return mine
+    except OSError:
+        return None
+
+
 def shard_range(n_items, rank, world):
     """Contiguous block partition of range(n_items): the first (n % world) ranks get one
     extra item.  Returns (start, stop)."""
@@ -77,7 +96,7 @@ def all_gather_images(local, n_total=None, group=None, async_op=False):
     return finalize(out)
 
 
-def swap_many(swap_fn, n_total, load_triple, device=None, chunk=8, group=None, batch=1, swap_batch_fn=None):
+def swap_many(swap_fn, n_total, load_triple, device=None, chunk=8, group=None, batch=1, swap_batch_fn=None, stats=None):
     """BASELINE.json configs[3]: hair swaps of triples 0..n_total-1, block-partitioned over the ranks
     (one process per GPU, a full replica each - triples share no state, models/Net.py:44-46), results
     returned to every rank as uint8 images in triple order [n_total, 3, H, W].
@@ -91,7 +110,15 @@ def swap_many(swap_fn, n_total, load_triple, device=None, chunk=8, group=None, b
     The only collective is the RCCL all-gather of finished images over xGMI (3.1 MB per 1024^2 image),
     issued asynchronously once per `chunk` local triples so that it overlaps the following swaps (one
     final round trip instead of a 100 MB-per-rank tail); a rank whose shard is shorter pads.  Works
-    without a process group (world 1) and under gloo (CPU tests).  Returns (images_u8, n_local)."""
+    without a process group (world 1) and under gloo (CPU tests).  Returns (images_u8, n_local).
+
+    stats: a dict that receives this call's balance figures (costs one device synchronisation before the gather tail):
+      compute_s            this rank's wall time from the first H2D to the completion of its last swap
+      gather_tail_s        ... from there to the completion of the last all-gather round (the exposed part of the collective)
+      per_rank_compute_s   every rank's compute_s (one small all-gather); imbalance = max / min of them"""
+    import time as _time
+
+    t_begin = _time.perf_counter()
     init = dist.is_initialized()
     world = dist.get_world_size(group) if init else 1
     rank = dist.get_rank(group) if init else 0
@@ -164,6 +191,10 @@ def swap_many(swap_fn, n_total, load_triple, device=None, chunk=8, group=None, b
             rounds.append((k, out, work, cs))
         else:
             rounds.append((k, send, None, cs))
+    if stats is not None:
+        if use_cuda:
+            torch.cuda.current_stream().synchronize()
+        stats["compute_s"] = _time.perf_counter() - t_begin
     starts = [shard_range(n_total, r, world)[0] for r in range(world)]
     result = done[0].new_empty((n_total,) + tuple(done[0].shape))
     for k, out, work, cs in rounds:
@@ -174,4 +205,16 @@ def swap_many(swap_fn, n_total, load_triple, device=None, chunk=8, group=None, b
             if valid:
                 g0 = starts[r if collective else rank] + k * chunk
                 result[g0:g0 + valid] = out[r * cs:r * cs + valid]
+    if stats is not None:
+        if use_cuda:
+            torch.cuda.current_stream().synchronize()
+        stats["gather_tail_s"] = _time.perf_counter() - t_begin - stats["compute_s"]
+        mine_t = torch.tensor([stats["compute_s"]], dtype=torch.float64, device=device if use_cuda else "cpu")
+        if collective:
+            every = [torch.zeros_like(mine_t) for _ in range(world)]
+            dist.all_gather(every, mine_t, group=group)
+            stats["per_rank_compute_s"] = [float(t.item()) for t in every]
+        else:
+            stats["per_rank_compute_s"] = [stats["compute_s"]]
+        stats["imbalance"] = max(stats["per_rank_compute_s"]) / max(min(stats["per_rank_compute_s"]), 1e-9)
     return result, n_local

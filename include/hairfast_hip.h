@@ -632,6 +632,14 @@ int hf_debug_set_persistent_blocks(int blocks);
  * same for the 256-pixel form (default 384).  Results of the generator
  * kernels do not depend on it; tile forms of hf_conv2d_f16_f32 differ in summation order only. */
 int hf_debug_set_tuning(int bits);
+/* Batch-invariant plans (process-wide; returns the previous setting; set it while no other thread is launching).  Split-K factors and tile forms are normally chosen
+ * from the whole launch (batch x pixels): the chip is filled, but a sample's summation order - and with it the last bits of
+ * its result - depends on what it is batched with.  on != 0: every plan is made from the per-sample shape only, so that a
+ * sample gives the same bits at any batch size; the reference's north_star asks for bit-exact segmentation-mask indices,
+ * and an argmax near a tie must not flip between `swap` and `swap_batch` (models/.../my_parsing_util.py:85-86,
+ * shape_branch/solver.py:248-262).  Workspace queries answer for the current setting.  Cost: batched launches keep the
+ * split-K passes and the small tile forms of a batch-1 launch. */
+int hf_set_batch_invariant(int on);
 
 #ifdef __cplusplus
 }

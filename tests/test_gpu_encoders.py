@@ -7,6 +7,7 @@ import argparse
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from oracle import cases as C
@@ -332,3 +333,95 @@ def test_conv2d_f16_split_output_equals_split_pass(stride, B, cin, cout, H, W):
     w2 = torch.randn(64, cout, 3, 3, device=dev) / (cout * 9) ** 0.5
     hi2, lo2 = M.conv_split_weights_f16(L, st, M.conv_prepare(L, st, w2))
     assert torch.equal(M.conv2d_f16(L, st, sp, hi2, lo2, 3, 64, 1), M.conv2d_f16(L, st, want, hi2, lo2, 3, 64, 1))
+
+
+def _fp64_conv_rows(x, w, rows, stride, in_scale, in_shift, out_scale, bias, slope, residual, groups=1):
+    """The ORACLE for one conv call on the images `rows` of a batch: F.conv2d on the CPU in fp64 (ATen's direct path,
+    models/encoders/helpers.py / iresnet.py compositions: BN affine on real pixels -> zero padding -> conv -> affine ->
+    PReLU / LeakyReLU -> + residual)."""
+    xs = x[rows].double().cpu()
+    if in_scale is not None:
+        xs = xs * in_scale.double().cpu().view(1, -1, 1, 1) + in_shift.double().cpu().view(1, -1, 1, 1)
+    y = F.conv2d(xs, w.double().cpu(), stride=stride, padding=1, groups=groups)
+    if out_scale is not None:
+        y = y * out_scale.double().cpu().view(1, -1, 1, 1)
+    if bias is not None:
+        y = y + bias.double().cpu().reshape(1, -1, 1, 1)
+    if slope is not None:
+        sl = slope.double().cpu().view(1, -1, 1, 1) if torch.is_tensor(slope) else slope
+        y = torch.where(y >= 0, y, y * sl)
+    if residual is not None:
+        y = y + residual[rows].double().cpu()
+    return y
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,stride,want_path", [
+    (48, 64, 64, 256, 256, 1, 604),      # e4e / FS input stages of a 16-triple pass: 64 x 512 tile form, register-staged input
+    (48, 128, 128, 64, 64, 1, 604),      # ... pre-split input (cin >= 128 in a batched pass): conv_enc_h<64x512, pre>
+    (48, 256, 256, 32, 32, 1, 601),      # 256-channel 32^2 units, pre-split: 384 blocks of 512 px do not fill the chip -> the 64 x 256 form
+    (32, 1024, 1024, 64, 64, 1, 604),    # PostProcess trunk at 16 triples (source + target)
+    (48, 64, 64, 256, 256, 2, 602),      # stride 2, eight-wave form, parity-split halo tile
+    (48, 128, 128, 128, 128, 2, 602),
+    (48, 512, 512, 32, 32, 2, 602),
+])
+def test_batched_kernel_forms_vs_fp64_oracle(B, cin, cout, H, W, stride, want_path):
+    """Round-3 verdict weak #4: the kernel FORMS a batched swap runs (B = 32-48 images per call) meet the oracle
+    directly - not another HIP kernel - through the encoders' own dispatch (`_fused.conv` on a prepared nn.Conv2d):
+    sampled images of the batch against F.conv2d in fp64 on the CPU, BN affine on real pixels, PReLU, residual."""
+    from torch import nn
+
+    from hairfastgan_amd._runtime import lib
+    from hairfastgan_amd.encoders._fused import conv, prep_conv
+
+    dev = _dev()
+    torch.manual_seed(B + cin + H + stride)
+    m = nn.Conv2d(cin, cout, 3, stride, 1, bias=False).to(dev)
+    with torch.no_grad():
+        m.weight.normal_(0, 1.0 / (cin * 9) ** 0.5)
+    x = torch.randn(B, cin, H, W, device=dev)
+    a, t = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.2
+    g, bsh, slope = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.2, torch.rand(cout, device=dev) * 0.5
+    oh, ow = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = torch.randn(B, cout, oh, ow, device=dev)
+    from hairfastgan_amd import _marshal as M
+
+    with torch.inference_mode():
+        y = conv(x, prep_conv(m), 3, stride, in_scale=a, in_shift=t, out_scale=g, bias=bsh, act=M.ACT_PRELU, slope=slope, residual=res)
+    torch.cuda.synchronize()
+    assert lib().hf_debug_last_path() == want_path, lib().hf_debug_last_path()
+    rows = [0, B // 2 - 1, B - 1]
+    want = _fp64_conv_rows(x, m.weight.detach(), rows, stride, a, t, g, bsh, slope, res)
+    err = float((y[rows].double().cpu() - want).abs().max())
+    scale = max(1.0, float(want.abs().max()))
+    assert err <= 5e-6 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("B,groups,cin,cout,H", [(48, 11, 512, 512, 16), (48, 4, 512, 512, 8), (48, 3, 512, 512, 4)])
+def test_batched_patch_gemm_heads_vs_fp64_oracle(B, groups, cin, cout, H):
+    """The e4e style heads' stride-2 chains below 16^2 as ONE grouped GEMM over patches (`gemm1x1_h`, `_patch_gemm_conv`):
+    eleven / four / three heads per launch at the 48 images of a 16-triple pass, against F.conv2d (fp64, CPU) per head on
+    sampled images: conv + bias + LeakyReLU(0.01) (GradualStyleBlock, psp_encoders.py:34-55)."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+    from hairfastgan_amd.encoders._fused import PreparedConv, conv
+
+    dev = _dev()
+    torch.manual_seed(B + groups + H)
+    L, st = lib(), stream()
+    ws = torch.randn(groups, cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+    bias = torch.randn(groups, cout, device=dev) * 0.3
+    shared = H == 16   # the first patch-GEMM level reads the map all heads share, the deeper ones each head's own [G,B,...]
+    x = torch.randn(B, cin, H, H, device=dev) if shared else torch.randn(groups, B, cin, H, H, device=dev)
+    wt = torch.stack([M.conv_prepare(L, st, ws[g_]) for g_ in range(groups)]).contiguous()
+    with torch.inference_mode():
+        y = conv(x, PreparedConv(wt, 3), 3, 2, bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=groups, x_shared=shared)
+    torch.cuda.synchronize()
+    assert lib().hf_debug_last_path() // 100 == 7, lib().hf_debug_last_path()  # the GEMM kernel, not the tiled conv
+    oh = (H - 1) // 2 + 1
+    assert tuple(y.shape) == (groups, B, cout, oh, oh)
+    rows = [0, B // 2, B - 1]
+    for g_ in (0, groups - 1):
+        want = _fp64_conv_rows(x if shared else x[g_], ws[g_], rows, 2, None, None, None, bias[g_], 0.01, None)
+        err = float((y[g_][rows].double().cpu() - want).abs().max())
+        scale = max(1.0, float(want.abs().max()))
+        assert err <= 5e-6 * scale, (g_, err, scale)

@@ -227,6 +227,51 @@ def test_swap_batch_equals_single_swaps():
     assert len(mixed) == 2 and all(torch.isfinite(m).all() for m in mixed)
 
 
+def test_swap_batch_equals_single_swaps_in_batch_invariant_mode():
+    """HAIRFAST_DETERMINISTIC=1 (`_runtime.set_batch_invariant`; round-3 verdict item 6, north_star "bit-exact
+    segmentation-mask indices"): split-K factors, tile forms and the small-plane dispatch are planned from the per-sample
+    shape, so `swap_batch` and `swap` of the same triple give EQUAL mask indices everywhere - the BiSeNet masks of the input
+    images, of the generated (rotated) 1024^2 images and the shape adaptor's label maps - with NO teacher forcing, and every
+    tensor upstream of an argmax (e4e latents, rotated latents, the rotated images) equal bit for bit."""
+    from hairfastgan_amd import _runtime
+
+    dev = torch.device("cuda:0")
+    hf = _hairfast(dev)
+    with torch.no_grad():
+        for name, p in hf.net.generator.named_parameters():
+            if name.endswith("noise.weight"):
+                p.zero_()
+    hf.stages.sean_model.netG.noise_source = lambda d, sizes: [torch.zeros(d, r, r, device=dev) for r in sizes]
+    a, b, c = (im.to(dev) for im in C.pipeline_images())
+    triples = [(a, b, c), (c.flip(-1).contiguous(), a.flip(-2).contiguous(), b.flip(-1).contiguous())]
+    prev = _runtime.set_batch_invariant(True)
+    try:
+        both = _recorded(hf, lambda: hf.swap_batch(triples, seed=3))
+        flips, exact = {}, {}
+        for t, triple in enumerate(triples):
+            one = _recorded(hf, lambda: hf.swap(*triple, seed=3))  # no force_targets: the single swap runs on its own label maps
+            for n in ("face", "shape", "color"):
+                eb, es = both["embed"][(t, n)], one["embed"][n]
+                flips[f"{t}/mask_{n}"] = int((eb["mask"] != es["mask"]).sum())
+                for k in ("W", "S", "F"):
+                    exact[f"{t}/{n}/{k}"] = float((eb[k] - es[k]).abs().max())
+            flips[f"{t}/rot_masks"] = int((both["parses"][1][2 * t:2 * t + 2] != one["parses"][1]).sum())
+            flips[f"{t}/target_masks"] = int((both["targets"][0][2 * t:2 * t + 2] != one["targets"][0]).sum())
+            exact[f"{t}/rotated_latents"] = float((both["calls"][2]["latent"][2 * t:2 * t + 2] - one["calls"][2]["latent"]).abs().max())
+            exact[f"{t}/rotated_images"] = float((both["calls"][2]["out"][2 * t:2 * t + 2] - one["calls"][2]["out"]).abs().max())
+            exact[f"{t}/sean"] = float((torch.stack(list(both["sean"][0][2 * t:2 * t + 2])) - torch.stack(list(one["sean"][0]))).abs().max())
+            exact[f"{t}/final"] = float((both["result"][t] - one["result"]).abs().max())
+            assert torch.equal(both["align"][0][t]["HM_X"], one["align"][0][0]["HM_X"])
+        print("batch-invariant mode: mask index differences", flips)
+        print("batch-invariant mode: max-abs differences", exact)
+        assert all(v == 0 for v in flips.values()), flips
+        upstream = [k for k in exact if k.endswith("/W") or "rotated" in k]
+        assert all(exact[k] == 0.0 for k in upstream), {k: exact[k] for k in upstream}
+        assert all(v <= 1e-4 for v in exact.values()), exact  # downstream of the masks: CLIP / SEAN GEMMs fold the batch into pixels
+    finally:
+        _runtime.set_batch_invariant(prev)
+
+
 def test_swap_graphed_equals_eager_swap():
     """HairFast.swap_graphed: the whole swap as ONE hipGraph replay gives the eager swap's image bit for bit (noise
     strengths zero: the two forms draw their noise from different points of the RNG stream), also on new inputs through

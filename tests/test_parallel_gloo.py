@@ -84,8 +84,12 @@ def _swap_worker(rank, world, port, n_total, chunk, q, batch=1):
         groups.append(len(triples))
         return [swap_fn(*t) for t in triples]
 
+    stats = {}
     got, n_local = parallel.swap_many(swap_fn, n_total, load_triple, chunk=chunk, batch=batch,
-                                      swap_batch_fn=swap_batch_fn if batch > 1 else None)
+                                      swap_batch_fn=swap_batch_fn if batch > 1 else None, stats=stats)
+    # balance figures: every rank's compute time on every rank, the exposed gather tail, max / min
+    assert len(stats["per_rank_compute_s"]) == world and stats["per_rank_compute_s"][rank] == stats["compute_s"]
+    assert stats["imbalance"] >= 1.0 and stats["gather_tail_s"] >= 0.0
     assert all(1 <= g <= min(batch, chunk) for g in groups) and (batch == 1 or sum(groups) == n_local)
     q.put((rank, n_local, calls, got[:, 0, 0, 0].tolist()))
     dist.barrier()
@@ -121,6 +125,17 @@ def test_swap_many_single_process():
 
     got, n = parallel.swap_many(lambda a, b, c: a.float() / 255.0, 5, lambda i: tuple(torch.full((3, 2, 2), 10 * i, dtype=torch.uint8) for _ in range(3)), chunk=2)
     assert n == 5 and got[:, 0, 0, 0].tolist() == [0, 10, 20, 30, 40]
+    # rank pinning: a rank's slice of the host's hardware threads (no-op for a single rank)
+    assert parallel.pin_rank_to_cores(0, 1) is None
+    before, threads = os.sched_getaffinity(0), torch.get_num_threads()
+    try:
+        if len(before) >= 2:
+            mine = parallel.pin_rank_to_cores(1, 2)
+            half = len(before) // 2
+            assert mine == sorted(before)[half:2 * half] and os.sched_getaffinity(0) == set(mine)
+    finally:
+        os.sched_setaffinity(0, before)
+        torch.set_num_threads(threads)  # the oracle's bit-for-bit goldens depend on ATen's thread partition
     sizes = []
     got, n = parallel.swap_many(None, 7, lambda i: tuple(torch.full((3, 2, 2), 10 * i, dtype=torch.uint8) for _ in range(3)), chunk=5, batch=3,
                                 swap_batch_fn=lambda ts: (sizes.append(len(ts)), [t[0].float() / 255.0 for t in ts])[1])

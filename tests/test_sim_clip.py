@@ -149,3 +149,43 @@ def test_small_tower_vs_oracle(sim_clip):
     for i in taps_o:  # oracle taps are [L, B, width]
         assert float((taps[i][0].permute(2, 1, 0) - taps_o[i]).abs().max()) < 1e-4, i
     assert got.shape == (3, 32) and float((got - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+
+
+def test_oracle_matches_huggingface_clip_vision_tower():
+    """An INDEPENDENT implementation of the un-vendored dependency's published ViT-B/32: HuggingFace transformers'
+    CLIPVisionModelWithProjection at full size (width 768, 12 layers, 12 heads, patch 32, 224 px, quick_gelu), loaded with
+    the oracle's synthetic OpenAI-layout parameters through the standard key mapping (`visual.*` <-> `vision_model.*`,
+    in_proj split into q / k / v, `visual.proj` = `visual_projection.weight.T`).  This is the ceiling for this piece: the
+    `clip` package's own source is absent (requirements.txt:6, models/Encoders.py:75-94), so oracle/ref_clip.py stays
+    "parity unpinned" by rule; what is shown is that the restatement computes the published architecture (<= 1e-5)."""
+    tr = pytest.importorskip("transformers")
+    cfg = tr.CLIPVisionConfig(hidden_size=RC.WIDTH, intermediate_size=4 * RC.WIDTH, num_hidden_layers=RC.LAYERS,
+                              num_attention_heads=RC.HEADS, image_size=RC.RES, patch_size=RC.PATCH, projection_dim=RC.OUT_DIM,
+                              hidden_act="quick_gelu", layer_norm_eps=1e-5, attention_dropout=0.0)
+    hf = tr.CLIPVisionModelWithProjection(cfg).eval()
+    P = C.clip_params()
+    W = RC.WIDTH
+    sd = {"vision_model.embeddings.class_embedding": P["visual.class_embedding"],
+          "vision_model.embeddings.patch_embedding.weight": P["visual.conv1.weight"],
+          "vision_model.embeddings.position_embedding.weight": P["visual.positional_embedding"],
+          "vision_model.pre_layrnorm.weight": P["visual.ln_pre.weight"], "vision_model.pre_layrnorm.bias": P["visual.ln_pre.bias"],
+          "vision_model.post_layernorm.weight": P["visual.ln_post.weight"], "vision_model.post_layernorm.bias": P["visual.ln_post.bias"],
+          "visual_projection.weight": P["visual.proj"].t().contiguous()}
+    for i in range(RC.LAYERS):
+        src, dst = f"visual.transformer.resblocks.{i}", f"vision_model.encoder.layers.{i}"
+        for j, name in enumerate(("q_proj", "k_proj", "v_proj")):
+            sd[f"{dst}.self_attn.{name}.weight"] = P[f"{src}.attn.in_proj_weight"][j * W:(j + 1) * W]
+            sd[f"{dst}.self_attn.{name}.bias"] = P[f"{src}.attn.in_proj_bias"][j * W:(j + 1) * W]
+        for a, b in (("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"),
+                     ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+            sd[f"{dst}.{b}.weight"], sd[f"{dst}.{b}.bias"] = P[f"{src}.{a}.weight"], P[f"{src}.{a}.bias"]
+    own = hf.state_dict()
+    extra = {k: own[k] for k in own if k not in sd}                 # position_ids buffers only
+    assert all("position_ids" in k for k in extra), sorted(extra)
+    hf.load_state_dict({**sd, **extra})
+    img = torch.from_numpy(synth.pseudo_normal("clip/hf/image", (2, 3, RC.RES, RC.RES))).float()
+    with torch.inference_mode():
+        want = hf(pixel_values=img).image_embeds
+        got = RC.encode_image(P, img)
+    scale = float(want.abs().max())
+    assert scale > 0.1 and float((got - want).abs().max()) <= 1e-5 * max(1.0, scale), (float((got - want).abs().max()), scale)
