@@ -87,6 +87,7 @@ SIGNATURES = {
     "hf_debug_set_persistent_blocks": [_i],
     "hf_debug_set_tuning": [_i],
     "hf_set_batch_invariant": [_i],
+    "hf_set_splitk_counters": [_f, _i],
     "hf_modconv3x3_f16_rgb_slabs": [_i],
 }
 

@@ -34,10 +34,47 @@ def require_gpu(*tensors):
                 "wrap the call in torch.inference_mode() / torch.no_grad() or detach the input")
 
 
+# In-kernel split-K reduction (csrc/conv_common.h splitk_arrive_last): the kernels count the arrivals of a tile's K-split
+# blocks in a caller-owned zero-initialised buffer that every launch leaves zero again.  One buffer per (device, stream) -
+# launches of one stream are ordered, launches of different streams (the Embedding stage's side streams) may overlap -
+# registered with the library whenever the current stream changes.
+# OFF by default (HAIRFAST_SPLITK_INKERNEL=1 / set_splitk_inkernel turn it on): measured on the MI355X it LOSES - a single
+# swap 34.4 -> 57.6 ms (328 splitk_reduce launches saved, but the split-K kernels themselves 3-5x slower): the release /
+# acquire fences that make one block's slab visible to a block on another XCD are L2 write-backs / invalidations
+# (buffer_wbl2 / buffer_inv sc1), paid by every block of every split-K launch, and the last block's z-ordered re-read of
+# all slabs is serial.  Results are bit-identical to the two-launch form (tests/test_gpu_encoders.py).
+SPLITK_COUNTER_INTS = 1 << 16
+_splitk_inkernel = os.environ.get("HAIRFAST_SPLITK_INKERNEL", "0") not in ("", "0")
+_counter_bufs = {}
+_counter_key = None
+
+
+def set_splitk_inkernel(on):
+    """Process-wide switch of the in-kernel split-K reduction (returns the previous setting); off = every split-K launch is
+    followed by the splitk_reduce kernel.  Results are bit-identical either way."""
+    global _splitk_inkernel, _counter_key
+    prev, _splitk_inkernel = _splitk_inkernel, bool(on)
+    _counter_key = None
+    if not on:
+        lib().hf_set_splitk_counters(None, 0)
+    return prev
+
+
 def stream():
     """Raw hipStream_t of torch's current stream (kernels are enqueued asynchronously on it,
     like the reference's at::cuda::getCurrentCUDAStream(), upfirdn2d_kernel.cu:213-215)."""
-    return torch.cuda.current_stream().cuda_stream
+    global _counter_key
+    s = torch.cuda.current_stream()
+    raw = s.cuda_stream
+    if _splitk_inkernel:
+        key = (s.device_index, raw)
+        if key != _counter_key:
+            buf = _counter_bufs.get(key)
+            if buf is None:
+                buf = _counter_bufs[key] = torch.zeros(SPLITK_COUNTER_INTS, dtype=torch.int32, device=s.device)
+            lib().hf_set_splitk_counters(buf.data_ptr(), SPLITK_COUNTER_INTS)
+            _counter_key = key
+    return raw
 
 
 # ---------------------------------------------------------------------------------------

@@ -61,6 +61,8 @@ struct ConvParams {
   int splits;                  // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps); 1 = off
   int chunks_per_split;
   float *partial;              // splits > 1: raw accumulators go to partial[z][b][co][oh][ow]
+  unsigned int *counters;      // splits > 1, non-null: one arrival counter per (blockIdx.x, blockIdx.y) output tile, zero on entry - the
+                               // LAST block of a tile to arrive adds the z slabs in z order and runs the epilogue (no second launch)
   // convh.hip, fused ToRGB: raw 1x1 modulated conv of the epilogue's output values,
   // rgb_out[b][c][Y][X] = sum_co rgb_w[co*3+c] * rgb_s[b*cout+co] * y[b][co][Y][X]  (null = off)
   const float *rgb_w, *rgb_s;
@@ -112,16 +114,80 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha, float 
   return v;
 }
 
+// ---- split-K: the second half ---------------------------------------------------------------------------------
+// out[i] = epilogue( d * sum_z partial[z][i] ): the z slabs are added in z order from 0.0f, then the per-element tail in
+// this operation order - shared by the splitk_reduce kernel (modconv.hip) and by the in-kernel form below, so that the
+// two give identical bits.  i = element index in out / a slab, b = image, gc = group*cout + channel, pix = Y*out_w + X.
+__device__ __forceinline__ float splitk_finish(const ConvParams &P, long long i, long long b, long long gc, long long pix,
+                                               float nw, bool with_epilogue) {
+  float v = 0.0f;
+  for (int z = 0; z < P.splits; ++z) v += P.partial[(long long)z * P.zslab + i];
+  if (P.d) v *= P.d[b * P.d_bstride + gc];
+  if (with_epilogue) {
+    if (P.noise) v = fmaf(nw, P.noise[b * P.noise_bstride + pix], v);
+    if (P.bias) v += P.bias[gc];
+    if (P.residual && P.residual_pre) v += P.residual[i];
+    v = apply_act(v, P.act, P.alpha, P.scale, P.act == ACT_PRELU ? P.slope[gc] : 0.0f);
+    if (P.residual && !P.residual_pre) v += P.residual[i];
+  }
+  return v;
+}
+
+// In-kernel second half (P.counters != NULL): every block of a split-K launch stores its raw sums into its z slab, then
+// announces itself on its output tile's counter; the block that arrives LAST (all other slabs of the tile are complete and,
+// after the fences, visible - agent scope: the blocks of a tile may sit on different XCDs) reads the tile's elements back
+// from ALL slabs in z order and writes the finished values.  Deterministic: the order of the additions does not depend on
+// which block is last.  The counter is left at zero for the next launch.  `flag`: one LDS word no wave still reads.
+// Returns true in every thread of the last block.
+__device__ __forceinline__ bool splitk_arrive_last(const ConvParams &P, int *flag) {
+  __threadfence();   // release: this thread's slab stores before the arrival
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tile = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    const unsigned int old = atomicAdd(P.counters + tile, 1u);
+    const int last = old == (unsigned int)(P.splits - 1);
+    if (last) P.counters[tile] = 0u;
+    *flag = last;
+  }
+  __syncthreads();
+  const bool last = *flag != 0;
+  if (last) __threadfence();  // acquire: the other blocks' slabs
+  return last;
+}
+
 // Epilogue.  MFMA D layout: row (= co) = (r&3) + 8*(r>>2) + 4*(lane>>5), col (= pixel) = lane&31.
 // Per pixel group the 16*CT_TILES output-scale / bias / slope values of the lane's output
 // channels are fetched with independent loads up front (no load->wait->store chains).
 //   v = acc*d + noise_w*noise + bias ; v = act(v) ; v += residual
-template <int CT_TILES, int PG, bool UP, int NPH = (UP ? 4 : 1)>
+// REDUCE: the last block of a split-K tile (splitk_arrive_last) - the same element walk, values = splitk_finish of the slabs
+template <int CT_TILES, int PG, bool UP, int NPH = (UP ? 4 : 1), bool REDUCE = false>
 __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &G, const GroupOfs &go,
                                            f32x16 (&acc)[NPH][CT_TILES][PG], int co_wave, int wave_pg, int li,
                                            int lh, int ty0, int tx0, int b0) {
+  static_assert(!(REDUCE && UP), "in-kernel split-K reduction: same-resolution / strided forms only");
   const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
   const long long oplane = (long long)P.out_h * P.out_w;
+  if constexpr (REDUCE) {
+    const float nw_r = P.noise ? P.noise_w[0] : 0.0f;
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+      const int p = (wave_pg + g) * 32 + li;
+      const int px = p & (tw - 1), py = (p >> G.lg_tw) & (th - 1), im = p >> (G.lg_tw + G.lg_th);
+      const int Y = ty0 + py, X = tx0 + px, b = b0 + im;
+      if (!((Y < G.y0 + G.dh) && (X < G.x0 + G.dw) && (b < P.batch))) continue;
+      const long long pix = (long long)Y * P.out_w + X;
+#pragma unroll
+      for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co >= P.cout) continue;
+          const long long i = go.o + ((long long)b * P.cout + co) * oplane + pix;
+          P.out[i] = splitk_finish(P, i, b, go.c + co, pix, nw_r, true);
+        }
+    }
+    return;
+  }
   const bool partial = P.splits > 1;  // split-K: raw sums, epilogue runs in splitk_reduce
   const bool full = !UP && !partial;
   const float nw = (full && P.noise) ? P.noise_w[0] : 0.0f;
@@ -298,6 +364,30 @@ __device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const 
 #endif
 }
 
+// the last block of a split-K tile, for the kernels whose blocks store through store_tile_rows (whole channel tiles)
+template <int CT_TILES, int PG>
+__device__ __forceinline__ void reduce_tile_rows(const ConvParams &P, const TileGeom &G, const GroupOfs &go, int co_wave,
+                                                 int wave_pg, int li, int lh, int ty0, int tx0, int b0) {
+  const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
+  const long long oplane = (long long)P.out_h * P.out_w;
+#pragma unroll
+  for (int g = 0; g < PG; ++g) {
+    const int p = (wave_pg + g) * 32 + li;
+    const int px = p & (tw - 1), py = (p >> G.lg_tw) & (th - 1), im = p >> (G.lg_tw + G.lg_th);
+    const int Y = ty0 + py, X = tx0 + px, b = b0 + im;
+    if (!((Y < G.y0 + G.dh) && (X < G.x0 + G.dw) && (b < P.batch))) continue;
+    const long long pix = (long long)Y * P.out_w + X;
+#pragma unroll
+    for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_wave + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const long long i = go.o + ((long long)b * P.cout + co) * oplane + pix;
+        P.out[i] = splitk_finish(P, i, b, go.c + co, pix, 0.0f, true);
+      }
+  }
+}
+
 template <int CT_TILES, int PG>
 __device__ __forceinline__ void store_tile_rows(const ConvParams &P, const TileGeom &G, const GroupOfs &go,
                                                 f32x16 (&acc)[1][CT_TILES][PG], int co_wave, int wave_pg, int li, int lh,
@@ -368,5 +458,8 @@ extern thread_local int g_force_h;            // hf_debug_set_dispatch same_cfg 
 void note_path(int path, int cfg);  // records what hf_debug_last_path reports
 // split-K second pass (modconv.hip): out = epilogue(d * sum_z partial[z]), deterministic
 int launch_splitk_reduce(ConvParams &P, bool with_epilogue, hipStream_t st);
+// the registered arrival-counter buffer (hf_set_splitk_counters) when it can hold one counter per output tile
+// (grid.x * grid.y) of this launch, else NULL (= the splitk_reduce launch)
+unsigned int *splitk_counters_for(long long tiles);
 
 }  // namespace hf_detail

@@ -37,6 +37,9 @@
 using namespace hf_detail;
 
 #define HF_H_BARRIER() hf_barrier_keep_young<0>()
+#ifndef HF_H_SPLIT_STORE16
+#define HF_H_SPLIT_STORE16 0  // fused upsampling epilogue: 1 = split output as ONE 16-byte store per lane (v_permlane32_swap of the half-waves) instead of two 8-byte stores; measured equal (587 vs 595 us on the 1024^2 layer): the epilogue is not store-bound
+#endif
 #ifndef HF_H_ABLATE
 #define HF_H_ABLATE 0  // timing experiments only: 1 no activation loads, 2 no epilogue stores, 4 no weight DMA, 8 no activation DMA
 #endif
@@ -611,6 +614,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       // values; the accumulators are only READ (writing elements back into the 16-wide accumulator vectors makes
       // the compiler copy whole register tuples).  Lanes 0 / 31 of a half-wave hold tile-edge positions whose
       // results are never used (their neighbours belong to the other half).
+      // (Round 4, measured and rejected again: the same arithmetic on channel pairs as ext_vector float2 - every multiply-add
+      // a v_pk_fma_f32 / v_pk_mul_f32: 7413 -> 6322 VALU instructions in the kernel, but the eight broadcast tap pairs and
+      // the paired temporaries cost 76 B more scratch with reloads INSIDE the K loop: 595 -> 670 us on the 1024^2 layer.)
       float H[4][PG][4];  // [pr*2+pc][g][k]
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr)
@@ -689,6 +695,22 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
               hf_half4 h4, l4;
               bool ovf = false;
               hf_split4_f16(vs, h4, l4, ovf);
+#if HF_H_SPLIT_STORE16
+              // one 16-byte store per lane: the half-waves trade halves, lanes 0-31 write the hi unit of the pixel,
+              // lanes 32-63 its lo unit (both halves of a wave share li, i.e. the pixel and its validity)
+              typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+              u32x2 hu = __builtin_bit_cast(u32x2, h4), lu = __builtin_bit_cast(u32x2, l4);
+              unsigned a0 = hu.x, b0 = lu.x, a1 = hu.y, b1 = lu.y;
+              hf_half_swap(a0, b0);
+              hf_half_swap(a1, b1);
+              if (pv) {
+                ovf_tile = ovf_tile || ovf;
+                u32x4 unit;
+                unit.x = a0; unit.y = a1; unit.z = b0; unit.w = b1;
+                *reinterpret_cast<u32x4 *>((lh_o ? ol_b : oh_b) + (long long)q * oplane * 16 + (long long)pix * 16) = unit;
+              }
+#else
               if (pv) {
                 ovf_tile = ovf_tile || ovf;
                 *reinterpret_cast<hf_half4 *>(oh_b + cb_ofs + (long long)pix * 16) = h4;
@@ -698,6 +720,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
             __builtin_amdgcn_sched_barrier(0);
           }
       }
+#endif
       hf_barrier_lds();  // everyone has read: the region may be overwritten (next quad / next tile's DMA)
     }
     hf_note_overflow(ovf_tile);

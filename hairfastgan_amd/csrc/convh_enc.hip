@@ -323,6 +323,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
     store_tile_rows<CT_TILES, PG>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
   else
     store_tile<CT_TILES, PG, false>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+  // split-K without a second launch: the tile's last block adds the slabs and runs the epilogue (conv_common.h)
+  if (P.splits > 1 && P.counters && splitk_arrive_last(P, reinterpret_cast<int *>(hf_dyn_lds)))
+    store_tile<CT_TILES, PG, false, 1, true>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
 // split-K plan: fill the chip (>= ~1.5 blocks per CU) when the output grid alone cannot, keeping at
@@ -372,6 +375,7 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
   if (P.splits > 1) {
     if (!workspace || workspace_floats < P.splits * P.zslab) return HF_E_WORKSPACE;
     P.partial = workspace;
+    P.counters = splitk_counters_for((long long)grid.x * grid.y);
   }
   if (P.xh) {
     if ((long long)2 * P.h * P.w * 16 >= (1LL << 31) || (NTERMS == 3 && !P.xl)) return HF_E_INVALID;
@@ -380,7 +384,7 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
     hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, false, CT_TILES, WAVES_CO>), grid, dim3(NT), lds, st, P, wth, wtl);
   }
   int rc = hf_launch_status();
-  if (rc == HF_OK && P.splits > 1) rc = launch_splitk_reduce(P, true, st);  // deterministic second pass + epilogue
+  if (rc == HF_OK && P.splits > 1 && !P.counters) rc = launch_splitk_reduce(P, true, st);  // deterministic second pass + epilogue
   return rc;
 }
 

@@ -19,6 +19,13 @@
 
 #include "hf_common.h"
 
+// Floating-point contraction: "on" = a multiply and an add are fused only where they are written in ONE expression (or as
+// fmaf), never across statements.  hipcc's default ("fast") lets the backend fuse opportunistically per basic block: the
+// unrolled body of a grid-stride loop and its remainder iterations then round differently, i.e. a sample's bits depend on
+// how many elements the launch has - on what it is batched with (found by tools/probes/batch_variance.py in
+// upsample_bilinear_add: the third of three images differed from the third of six by one ulp).
+#pragma clang fp contract(on)
+
 namespace {
 
 __global__ __launch_bounds__(256) void conv_prepare(float *__restrict__ wt, const float *__restrict__ weight,

@@ -216,6 +216,9 @@ __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Floa
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][g][r] *= w_unscale;
   store_tile_rows<1, PG>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, 0, tx0, b0);
+  // split-K without a second launch: the tile's last block adds the slabs and runs the epilogue (conv_common.h)
+  if (P.splits > 1 && P.counters && splitk_arrive_last(P, reinterpret_cast<int *>(hf_dyn_lds)))
+    reduce_tile_rows<1, PG>(P, G, go, co0 + wave_co, wave_pg, li, lh, 0, tx0, b0);
 }
 
 template <int NTERMS, int PG>
@@ -240,6 +243,9 @@ int launch_gemm(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStre
   const size_t lds = (size_t)2 * NPART * ((KS / 8) * 64 + (KS / 8) * PT) * 16;
   dim3 grid(nblocks, P.co_tiles * max(1, P.groups), P.splits);
   if (grid.y > 65535 || grid.z > 65535) return HF_E_INVALID;
+  // split-K of hf_conv1x1_f16_f32 (P.out = the result tensor): the in-kernel second half when a counter buffer is registered;
+  // the tap-GEMM of the small-plane convs (P.out = its own slab workspace, combined by small_combine) keeps raw slabs
+  P.counters = (P.splits > 1 && P.out != P.partial) ? splitk_counters_for((long long)grid.x * grid.y) : nullptr;
   if (P.xh) {
     if (P.stride != 1 || P.s || P.t || (NTERMS == 3 && !P.xl) || P.groups > 1 ||
         (long long)P.batch * P.cin * P.h * P.w * 2 >= (1LL << 32))
@@ -324,7 +330,7 @@ extern "C" int hf_conv1x1_f16_f32(float *out, const float *x, const void *x_hi, 
   else rc = (nterms == 3) ? launch_gemm<3, 4>(P, hi, lo, (hipStream_t)stream) : launch_gemm<1, 4>(P, hi, lo, (hipStream_t)stream);
   if (rc != HF_OK) return rc;
   note_path(7, small ? 1 : 2);
-  if (P.splits > 1) {
+  if (P.splits > 1 && !P.counters) {
     P.out_h = 1; P.out_w = oplane;
     return launch_splitk_reduce(P, true, (hipStream_t)stream);
   }
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(256) void small_combine(float *__restrict__ out, co
                                                      long long noise_bstride, const float *__restrict__ bias, int batch,
                                                      int cout, int h, int w, int up, int out_h, int out_pitch, int out_wv,
                                                      float alpha, float scale) {
+#pragma clang fp contract(on)  // see encoder_ops.hip: no cross-statement fusion in grid-stride loops
   const long long oplane = (long long)out_h * out_pitch, iplane = (long long)h * w;
   const long long total = (long long)batch * cout * oplane;
   const long long stride = (long long)gridDim.x * 256;

@@ -187,6 +187,19 @@ __device__ __forceinline__ float hf_lane_down(float v) {  // from lane+1: DPP wa
 }
 #endif
 
+// The two half-waves exchange one dword each (v_permlane32_swap_b32, gfx950): afterwards lanes 0-31 hold (a of lane i,
+// a of lane i+32) and lanes 32-63 hold (b of lane i-32, b of lane i) in (a, b).  Used to turn two 8-byte stores of a
+// split activation (a lane owns HALF of a 16-byte hi unit and half of a lo unit) into one 16-byte store per lane: the low
+// half-wave writes whole hi units, the high half-wave whole lo units.
+#ifndef HF_HALF_SWAP_DEFINED
+#define HF_HALF_SWAP_DEFINED
+__device__ __forceinline__ void hf_half_swap(unsigned &a, unsigned &b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+#endif
+
 static inline int hf_launch_status() {
   return hipGetLastError() == hipSuccess ? HF_OK : HF_E_LAUNCH;
 }

@@ -254,10 +254,14 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const ConvParams P) {
   if constexpr (!UP) {
     // whole channel tiles of an encoder-type launch (per-channel scale / bias, no noise): the epilogue without
     // per-element switches (conv_common.h)
-    if (!P.noise && P.d_bstride == 0 && co0 + CT <= P.cout) {
+    if (!P.noise && P.d_bstride == 0 && co0 + CT <= P.cout)
       store_tile_rows<CT_TILES, PG>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
-      return;
-    }
+    else
+      store_tile<CT_TILES, PG, UP>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+    // split-K without a second launch: the tile's last block adds the slabs and runs the epilogue (conv_common.h)
+    if (P.splits > 1 && P.counters && splitk_arrive_last(P, reinterpret_cast<int *>(hf_dyn_lds)))
+      store_tile<CT_TILES, PG, false, 1, true>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+    return;
   }
   store_tile<CT_TILES, PG, UP>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
@@ -439,10 +443,14 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_pipe(const
   if constexpr (!UP) {
     // whole channel tiles of an encoder-type launch (per-channel scale / bias, no noise): the epilogue without
     // per-element switches (conv_common.h)
-    if (!P.noise && P.d_bstride == 0 && co0 + CT <= P.cout) {
+    if (!P.noise && P.d_bstride == 0 && co0 + CT <= P.cout)
       store_tile_rows<CT_TILES, PG>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
-      return;
-    }
+    else
+      store_tile<CT_TILES, PG, UP>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+    // split-K without a second launch: the tile's last block adds the slabs and runs the epilogue (conv_common.h)
+    if (P.splits > 1 && P.counters && splitk_arrive_last(P, reinterpret_cast<int *>(hf_dyn_lds)))
+      store_tile<CT_TILES, PG, false, 1, true>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+    return;
   }
   store_tile<CT_TILES, PG, UP>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
@@ -605,27 +613,18 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_mfma_dma(const 
 
 // Split-K second pass: out = epilogue(d * sum_z partial[z]) - deterministic (fixed z order).
 __global__ __launch_bounds__(256) void splitk_reduce(const ConvParams P, long long slab, int with_epilogue) {
+#pragma clang fp contract(on)  // no cross-statement fusion: remainder iterations of the grid-stride loop must round like the unrolled ones (see encoder_ops.hip)
   const long long oplane = (long long)P.out_h * P.out_w;
   const long long ovol = (long long)P.batch * P.cout * oplane;  // one group
   const float nw = (with_epilogue && P.noise) ? P.noise_w[0] : 0.0f;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slab; i += stride) {
-    float v = 0.0f;
-    for (int z = 0; z < P.splits; ++z) v += P.partial[(long long)z * slab + i];
     const long long g = i / ovol;
     const long long pl = (i - g * ovol) / oplane;
     const int co = (int)(pl % P.cout);
     const long long b = pl / P.cout;
-    const long long gc = g * P.cout + co;  // per-channel vectors of group g follow those of g-1
-    if (P.d) v *= P.d[b * P.d_bstride + gc];
-    if (with_epilogue) {
-      if (P.noise) v = fmaf(nw, P.noise[b * P.noise_bstride + (i % oplane)], v);
-      if (P.bias) v += P.bias[gc];
-      if (P.residual && P.residual_pre) v += P.residual[i];
-      v = apply_act(v, P.act, P.alpha, P.scale, P.act == ACT_PRELU ? P.slope[gc] : 0.0f);
-      if (P.residual && !P.residual_pre) v += P.residual[i];
-    }
-    P.out[i] = v;
+    // per-channel vectors of group g follow those of g-1
+    P.out[i] = splitk_finish(P, i, b, g * P.cout + co, i % oplane, nw, with_epilogue != 0);
   }
 }
 
@@ -667,6 +666,7 @@ int launch_conv(ConvParams &P, hipStream_t st) {
   P.zslab = (long long)max(1, P.groups) * P.batch * P.cout * P.out_h * P.out_w;
   dim3 grid(nblocks, P.co_tiles * max(1, P.groups), P.splits);
   if (grid.y > 65535) return HF_E_INVALID;
+  P.counters = (!UP && P.splits > 1) ? splitk_counters_for((long long)grid.x * grid.y) : nullptr;
   hipLaunchKernelGGL((conv_mfma<CT_TILES, PG, WAVES_CO, WAVES_PX, UP, TAPS>), grid, dim3(kThreads), lds, st, P);
   return hf_launch_status();
 }
@@ -708,6 +708,7 @@ int launch_conv_pipe(ConvParams &P, hipStream_t st) {
   P.zslab = (long long)max(1, P.groups) * P.batch * P.cout * P.out_h * P.out_w;
   dim3 grid(nblocks, P.co_tiles * max(1, P.groups), P.splits);
   if (grid.y > 65535) return HF_E_INVALID;
+  P.counters = (!UP && P.splits > 1) ? splitk_counters_for((long long)grid.x * grid.y) : nullptr;
   hipLaunchKernelGGL((conv_mfma_pipe<CT_TILES, PG, WAVES_CO, WAVES_PX, UP, ABLATE, STRIDE>), grid, dim3(NT), lds, st,
                      P);
   return hf_launch_status();
@@ -767,6 +768,21 @@ inline int splitk_plan(int batch, int cin, int cout, int out_h, int out_w, bool 
 }
 
 }  // namespace
+// Arrival counters of the in-kernel split-K reduction: a caller-owned, zero-initialised device buffer registered per
+// thread (hf_set_splitk_counters); every launch leaves it zero again.  NULL / too small: the two-launch form.
+namespace hf_detail {
+thread_local unsigned int *g_splitk_counters = nullptr;
+thread_local int g_splitk_counter_ints = 0;
+unsigned int *splitk_counters_for(long long tiles) {
+  return (g_splitk_counters && tiles > 0 && tiles <= g_splitk_counter_ints) ? g_splitk_counters : nullptr;
+}
+}  // namespace hf_detail
+extern "C" int hf_set_splitk_counters(void *zeroed_ints, int n_ints) {
+  hf_detail::g_splitk_counters = static_cast<unsigned int *>(zeroed_ints);
+  hf_detail::g_splitk_counter_ints = zeroed_ints ? n_ints : 0;
+  return HF_OK;
+}
+
 int hf_detail::launch_splitk_reduce(ConvParams &P, bool with_epilogue, hipStream_t st) {
   const long long slab = (long long)max(1, P.groups) * P.batch * P.cout * P.out_h * P.out_w;
   long long g = (slab + 255) / 256;
@@ -793,6 +809,7 @@ int run_splitk(ConvParams &P, int sk, float *workspace, long long workspace_floa
   sk = (nchunks + P.chunks_per_split - 1) / P.chunks_per_split;
   P.splits = sk;
   P.partial = workspace;
+  P.counters = nullptr;  // set by the launcher once the grid is known
   int rc = HF_E_INVALID;
   if (!UP && TAPS == 9) {  // double-buffered 64 co x 64 px kernel when the shape qualifies
     rc = (P.stride == 2) ? launch_conv_pipe<1, 1, 2, 2, false, 0, 2>(P, st) : launch_conv_pipe<1, 1, 2, 2, false, 0, 1>(P, st);
@@ -801,6 +818,7 @@ int run_splitk(ConvParams &P, int sk, float *workspace, long long workspace_floa
   if (rc == HF_E_INVALID) rc = launch_conv<1, 1, 2, 2, UP, TAPS>(P, st);
   if (rc != HF_OK) return rc;
   g_last_path = 3;
+  if (P.counters) return HF_OK;  // the tiles' last blocks finished the sum and the epilogue in the kernel
   return launch_splitk_reduce(P, !UP, st);
 }
 

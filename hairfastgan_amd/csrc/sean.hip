@@ -12,6 +12,13 @@
 //  * The style encoder's per-region average pooling (architecture.py:187-205) with the final tanh folded in.
 #include "hf_common.h"
 
+// Floating-point contraction: "on" = a multiply and an add are fused only where they are written in ONE expression (or as
+// fmaf), never across statements.  hipcc's default ("fast") lets the backend fuse opportunistically per basic block: the
+// unrolled body of a grid-stride loop and its remainder iterations then round differently, i.e. a sample's bits depend on
+// how many elements the launch has - on what it is batched with (found by tools/probes/batch_variance.py in
+// upsample_bilinear_add: the third of three images differed from the third of six by one ulp).
+#pragma clang fp contract(on)
+
 constexpr int kSeanLabels = 19;
 
 #ifndef HF_WAVE_ANY_DEFINED

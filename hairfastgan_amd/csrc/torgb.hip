@@ -9,6 +9,13 @@
 // channel loop is unrolled 8x to keep 8 independent 16 B loads in flight.
 #include "hf_common.h"
 
+// Floating-point contraction: "on" = a multiply and an add are fused only where they are written in ONE expression (or as
+// fmaf), never across statements.  hipcc's default ("fast") lets the backend fuse opportunistically per basic block: the
+// unrolled body of a grid-stride loop and its remainder iterations then round differently, i.e. a sample's bits depend on
+// how many elements the launch has - on what it is batched with (found by tools/probes/batch_variance.py in
+// upsample_bilinear_add: the third of three images differed from the third of six by one ulp).
+#pragma clang fp contract(on)
+
 namespace {
 
 template <int VEC>

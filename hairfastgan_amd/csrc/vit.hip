@@ -4,6 +4,13 @@
 // tokens); these kernels work on the same layout so that nothing is transposed between layers.
 #include "hf_common.h"
 
+// Floating-point contraction: "on" = a multiply and an add are fused only where they are written in ONE expression (or as
+// fmaf), never across statements.  hipcc's default ("fast") lets the backend fuse opportunistically per basic block: the
+// unrolled body of a grid-stride loop and its remainder iterations then round differently, i.e. a sample's bits depend on
+// how many elements the launch has - on what it is batched with (found by tools/probes/batch_variance.py in
+// upsample_bilinear_add: the third of three images differed from the third of six by one ulp).
+#pragma clang fp contract(on)
+
 // LayerNorm over the FEATURE axis of x [C][T] (per token t: mean / biased variance over c, eps inside the sqrt),
 // affine gamma / beta [C].  One block per 64 consecutive tokens, 16 waves: lane = token (coalesced rows), wave w owns the
 // features w, w+16, ... and keeps them IN REGISTERS (one pass over x; all loads of a thread are independent and in

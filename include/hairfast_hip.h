@@ -640,6 +640,14 @@ int hf_debug_set_tuning(int bits);
  * shape_branch/solver.py:248-262).  Workspace queries answer for the current setting.  Cost: batched launches keep the
  * split-K passes and the small tile forms of a batch-1 launch. */
 int hf_set_batch_invariant(int on);
+/* In-kernel second half of split-K launches (per thread).  Small launches split their K loop over blockIdx.z
+ * (hf_conv2d_f32 / hf_modconv3x3_f32 on small planes, hf_conv2d_f16_f32, hf_conv1x1_f16_f32); by default a second
+ * kernel (splitk_reduce) adds the z slabs and runs the epilogue.  With a registered buffer of `n_ints` ZEROED 32-bit
+ * counters in device memory - caller-owned like every other buffer, one per stream that launches concurrently - the
+ * blocks of an output tile count their arrivals instead and the LAST one adds the slabs (in z order: the same bits as
+ * the second kernel, whichever block is last) and finishes the tile; every launch leaves the buffer zero.  Launches with
+ * more output tiles than counters, and the transposed forms, keep the two-kernel form.  NULL unregisters. */
+int hf_set_splitk_counters(void *zeroed_ints, int n_ints);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,7 @@ inline float __shfl_down(float v, int d, int /*width*/ = 64) { return ::hipsim::
 inline float rsqrtf(float v) { return 1.0f / sqrtf(v); }
 // single OS thread, fibers only switch at rendezvous points: plain read-modify-write is atomic
 inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
+inline void __threadfence() {}
 inline unsigned int atomicMax(unsigned int *p, unsigned int v) { unsigned int o = *p; if (v > o) *p = v; return o; }
 inline unsigned int __float_as_uint(float f) { unsigned int u; __builtin_memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned int u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
@@ -93,6 +94,12 @@ inline bool hf_wave_any(bool p) {  // wave vote through the shuffle rendezvous
   float v = p ? 1.0f : 0.0f;
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, ::hipsim::shfl_xor(v, m));
   return v > 0.0f;
+}
+#define HF_HALF_SWAP_DEFINED
+inline void hf_half_swap(unsigned &a, unsigned &b) {  // v_permlane32_swap_b32: a[32:63] <-> b[0:31]
+  const float pa = ::hipsim::shfl_xor(__builtin_bit_cast(float, a), 32), pb = ::hipsim::shfl_xor(__builtin_bit_cast(float, b), 32);
+  if ((threadIdx.x & 63) < 32) b = __builtin_bit_cast(unsigned, pa);
+  else a = __builtin_bit_cast(unsigned, pb);
 }
 #define HF_LANE_SHIFT_DEFINED
 inline float hf_lane_up(float v) { return ::hipsim::shfl_rel0(v, -1); }

@@ -425,3 +425,64 @@ def test_batched_patch_gemm_heads_vs_fp64_oracle(B, groups, cin, cout, H):
         err = float((y[g_][rows].double().cpu() - want).abs().max())
         scale = max(1.0, float(want.abs().max()))
         assert err <= 5e-6 * scale, (g_, err, scale)
+
+
+def test_split_k_in_kernel_reduction_on_hardware():
+    """The in-kernel second half of split-K launches (last-arriving block, agent-scope fences: the blocks of a tile sit on
+    different XCDs) against the two-launch form, on hardware and repeatedly (a missed fence would show as a stale slab):
+    bit-equal results, the counter buffer zero after every launch - batch-3 encoder layers, a CLIP-sized GEMM, a
+    small-plane fp32 modulated conv."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd import _runtime
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = _dev()
+    torch.manual_seed(9)
+    L = lib()
+
+    def both(fn, reps=25):
+        prev = _runtime.set_splitk_inkernel(False)
+        try:
+            stream()
+            two_pass = fn().clone()
+            _runtime.set_splitk_inkernel(True)
+            stream()  # registers this stream's counter buffer
+            outs = [fn().clone() for _ in range(reps)]
+            torch.cuda.synchronize()
+            buf = _runtime._counter_bufs[_runtime._counter_key]
+            assert int(buf.abs().sum()) == 0
+        finally:
+            _runtime.set_splitk_inkernel(prev)
+        for o in outs:
+            assert torch.equal(o, two_pass)
+        return two_pass
+
+    for B, cin, cout, H, W, stride in ((3, 256, 256, 32, 32, 1), (3, 512, 512, 16, 16, 1), (2, 512, 512, 32, 32, 2), (1, 1024, 1024, 16, 16, 1)):
+        st = stream()
+        assert L.hf_conv2d_f16_workspace_floats(B, cin, cout, H, W, stride, 1) > 0, "shape must plan split-K"
+        x = torch.randn(B, cin, H, W, device=dev)
+        w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+        g, bsh, slope = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.2, torch.rand(cout, device=dev) * 0.5
+        oh, ow = (H - 1) // stride + 1, (W - 1) // stride + 1
+        res = torch.randn(B, cout, oh, ow, device=dev)
+        hi, lo = M.conv_split_weights_f16(L, st, M.conv_prepare(L, st, w))
+        y = both(lambda: M.conv2d_f16(L, stream(), x, hi, lo, 3, cout, stride, out_scale=g, bias=bsh, act=M.ACT_PRELU, slope=slope, residual=res))
+        want = _fp64_conv_rows(x, w, [0, B - 1], stride, None, None, g, bsh, slope, res)
+        assert float((y[[0, B - 1]].double().cpu() - want).abs().max()) <= 5e-6 * max(1.0, float(want.abs().max()))
+    # CLIP-sized feature-major GEMM: 100 tokens, 768 -> 3072
+    st = stream()
+    xg = torch.randn(1, 768, 2, 50, device=dev)
+    wg, bg = torch.randn(3072, 768, 1, 1, device=dev) * 0.03, torch.randn(3072, device=dev)
+    assert L.hf_conv1x1_f16_workspace_floats(1, 768, 3072, 2, 50, 1, 1) > 0
+    hg, lg = M.conv_split_weights_f16(L, st, M.conv_prepare(L, st, wg))
+    y = both(lambda: M.conv1x1_f16(L, stream(), xg, hg, lg, 3, 3072, bias=bg, act=M.ACT_QGELU))
+    ref = F.conv2d(xg.double().cpu(), wg.double().cpu(), bg.double().cpu())
+    ref = ref * torch.sigmoid(1.702 * ref)
+    assert float((y.double().cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    # small-plane fp32 modulated conv (generator tower in f32 mode)
+    xm = torch.randn(2, 512, 8, 8, device=dev)
+    wt, _ = M.prepare_weights(L, st, torch.randn(1, 512, 512, 3, 3, device=dev))
+    s, d = torch.rand(2, 512, device=dev) + 0.5, torch.rand(2, 512, device=dev) + 0.5
+    nz, nw, bias = torch.randn(1, 1, 8, 8, device=dev), torch.tensor([0.3], device=dev), torch.randn(512, device=dev)
+    assert L.hf_modconv_workspace_floats(2, 512, 512, 8, 8, 0) > 0
+    both(lambda: M.modconv3x3(L, stream(), xm, wt, s, d, nz, nw, bias, 0.2, 2 ** 0.5))

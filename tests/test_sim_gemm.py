@@ -112,3 +112,50 @@ def test_conv1x1_presplit_input_and_small_plane_modconv(simlib):
         assert simlib.hf_modconv3x3_up_f32(tr.data_ptr(), xx.data_ptr(), wt.data_ptr(), s.data_ptr(), d.data_ptr(), B, cin, cout, h, ww,
                                            pitch, ws.data_ptr() if n > 0 else None, n, None) == 0
         assert float((t[..., :2 * ww + 1] - tr[..., :2 * ww + 1]).abs().max()) < 2e-5 * max(1.0, float(tr.abs().max()))
+
+
+def test_split_k_in_kernel_reduction_equals_the_second_pass(simlib):
+    """hf_set_splitk_counters: with a registered zeroed counter buffer the LAST block of every output tile adds the z slabs
+    and runs the epilogue inside the split-K launch (csrc/conv_common.h splitk_arrive_last) - the same bits as the
+    splitk_reduce pass (z order, one shared per-element tail), counters zero again after every launch, on the three kernel
+    families that split K: the tiled fp16-core conv, the 1x1 GEMM, the fp32-MFMA conv (incl. noise / per-image d)."""
+    torch.manual_seed(5)
+    counters = torch.zeros(4096, dtype=torch.int32)
+
+    def both(fn):
+        simlib.hf_set_splitk_counters(None, 0)
+        two_pass = fn()
+        simlib.hf_set_splitk_counters(counters.data_ptr(), counters.numel())
+        try:
+            in_kernel = fn()
+        finally:
+            simlib.hf_set_splitk_counters(None, 0)
+        assert int(counters.abs().sum()) == 0
+        assert torch.equal(two_pass, in_kernel)
+        return in_kernel
+
+    # tiled fp16-core conv (hf_conv2d_f16_f32): 2 tiles x 16 stages -> split; BN affine, PReLU, residual in the tail
+    B, cin, cout, H, W = 2, 256, 64, 16, 16
+    assert simlib.hf_conv2d_f16_workspace_floats(B, cin, cout, H, W, 1, 1) > 0
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    g, bsh, slope, res = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2, torch.rand(cout) * 0.5, torch.randn(B, cout, H, W)
+    hi, lo = M.conv_split_weights_f16(simlib, None, M.conv_prepare(simlib, None, w))
+    y = both(lambda: M.conv2d_f16(simlib, None, x, hi, lo, 3, cout, 1, out_scale=g, bias=bsh, act=M.ACT_PRELU, slope=slope, residual=res))
+    want = F.prelu(F.conv2d(x, w, padding=1) * g.view(1, -1, 1, 1) + bsh.view(1, -1, 1, 1), slope) + res
+    assert float((y - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    # 1x1 GEMM (hf_conv1x1_f16_f32), ragged pixel count
+    xg = torch.randn(1, 256, 2, 17)
+    wg, bg, rg = torch.randn(64, 256, 1, 1) * 0.05, torch.randn(64), torch.randn(1, 64, 2, 17)
+    assert simlib.hf_conv1x1_f16_workspace_floats(1, 256, 64, 2, 17, 1, 1) > 0
+    hg, lg = _prep(simlib, wg)
+    y = both(lambda: M.conv1x1_f16(simlib, None, xg, hg, lg, 3, 64, bias=bg, residual=rg))
+    assert float((y - (F.conv2d(xg, wg, bg) + rg)).abs().max()) < 2e-5 * 4
+    # fp32-MFMA modulated conv on a small plane (split-K of modconv.hip): per-image s / d, noise, bias, leaky ReLU
+    xm = torch.randn(2, 64, 8, 8)
+    wm = torch.randn(1, 64, 64, 3, 3)
+    wt, wsq = M.prepare_weights(simlib, None, wm)
+    s, d = torch.rand(2, 64) + 0.5, torch.rand(2, 64) + 0.5
+    nz, nw, bias = torch.randn(1, 1, 8, 8), torch.tensor([0.3]), torch.randn(64)
+    assert simlib.hf_modconv_workspace_floats(2, 64, 64, 8, 8, 0) > 0
+    both(lambda: M.modconv3x3(simlib, None, xm, wt, s, d, nz, nw, bias, 0.2, 2 ** 0.5))
