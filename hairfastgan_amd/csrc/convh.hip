@@ -69,14 +69,16 @@ constexpr int KH = 16;  // input channels per stage = K of one MFMA
 // (UP) the 2-row / 2-column rim tiles of make_geom(one_image).  Wide tiles (TWMAX 128) turn the
 // 128-byte row segments of a 32-pixel-wide tile into 512-byte ones: the high-resolution layers
 // are HBM-bound and DRAM row locality decides their bandwidth.
-template <int PT, bool UP, int TWMAX>
+// FUSE: overlapping th x 32 tiles only, no rim families (see below) - the four-wave form's two stage buffers then fit
+// twice into a CU's 160 KB (2 x 37.4 KB per block instead of 2 x 43.2 KB).
+template <int PT, bool UP, int TWMAX, bool FUSE = false>
 constexpr int halo_pixels_max() {
   constexpr int h = UP ? 1 : 2;
   constexpr int narrow = (PT / 32 + h) * (32 + h), wide = (PT / TWMAX + h) * (TWMAX + h);
   constexpr int main_tile = wide > narrow ? wide : narrow;
   constexpr int rim = PT >= 512 ? 4 : 2;  // rows (columns) of a rim tile: keeps its halo below the main tile's
   constexpr int rim_tile = (rim + 1) * (PT / rim + 1);
-  return (UP && rim_tile > main_tile) ? rim_tile : main_tile;
+  return (UP && !FUSE && rim_tile > main_tile) ? rim_tile : main_tile;
 }
 
 // UP: the transposed (stride 2) conv of the upsampling StyledConv, as in modconv.hip: 4 output
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   constexpr int PT = 32 * PG * WAVES_PX;  // pixels (UP: phase-domain positions) per tile
   constexpr int NPH = UP ? 4 : 1;
   constexpr int HALO = UP ? 1 : 2;
-  constexpr int NPIX = halo_pixels_max<PT, UP, TWMAX>();
+  constexpr int NPIX = halo_pixels_max<PT, UP, TWMAX, FUSE>();
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;          // hi (+ lo)
   constexpr int W_UNITS = 9 * 2 * CT;                   // 16-byte units of one weight part per stage
   constexpr int X_UNITS = 2 * NPIX;                     // 16-byte units of one activation part per stage
@@ -985,7 +987,7 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
   constexpr int NT = 64 * WAVES_CO * WAVES_PX;
   constexpr int CT = 32 * CT_TILES * WAVES_CO;
   constexpr int PT = 32 * PG * WAVES_PX;
-  constexpr int NPIX = halo_pixels_max<PT, UP, TWMAX>();
+  constexpr int NPIX = halo_pixels_max<PT, UP, TWMAX, FUSE>();
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;
   if (P.cin % KH || P.cout % CT || P.stride != 1 || P.t || P.groups > 1 || P.residual || P.act == ACT_PRELU)
     return HF_E_INVALID;
@@ -1215,11 +1217,26 @@ extern "C" int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *s
     P.blur_ky[j] = blur_k1d_y[3 - j];
   }
   const _Float16 *hi = static_cast<const _Float16 *>(wt_hi), *lo = static_cast<const _Float16 *>(wt_lo);
-  // 32 co x 512 positions (16 rows x 32), 8 waves x 2 rows - the tile shape of the unfused <1,2,1,8,up> kernel.
-  // (An 8-row / 4-wave form with two blocks per CU measured 2x slower: 43 % halo recompute and half the rows per barrier.)
-  int rc = x_hi ? launch_h<3, 1, 2, 1, 8, true, 32, true, true>(P, hi, lo, (hipStream_t)stream)
-                : launch_h<3, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
-  if (rc == HF_OK) note_path(5, x_hi ? 93 : 73);
+  // <1,2,1,8>: 32 co x 512 positions (16 rows x 32), 8 waves x 2 rows, one block per CU - all eight waves in lock-step, so
+  // the VALU-bound epilogue (29 k of a tile's 70 k cycles) and the MFMA loop never overlap.
+  // hf_debug_set_tuning bit 3 selects <1,2,1,4> instead: 8 rows x 32, FOUR waves, TWO independent blocks per CU (2 x 37.4 KB
+  // of stage buffers each; the FUSE-aware halo size makes them fit), so that a SIMD issues one block's epilogue under the
+  // other block's MFMAs.  Measured in round 4 with both blocks resident (round 2's "2x slower" was one block per CU: the
+  // rim-tile halo size made its LDS 86 KB): 752 vs 602 us on the 1024^2 layer, 546 vs 432, 449 vs 424 - the overlap is there,
+  // but every block stages the full weight stage (twice the LDS-DMA issues per wave) and recomputes 43 % instead of 22 %
+  // halo.  Bit-identical results (tests/test_sim_kernels.py); the eight-wave form stays the default.
+  int rc = HF_E_INVALID;
+  int form = 0;
+  if ((hf_detail::g_h_tune & 8) && x_hi) {
+    rc = launch_h<3, 1, 2, 1, 4, true, 32, true, true>(P, hi, lo, (hipStream_t)stream);
+    form = 94;
+  }
+  if (rc == HF_E_INVALID) {
+    rc = x_hi ? launch_h<3, 1, 2, 1, 8, true, 32, true, true>(P, hi, lo, (hipStream_t)stream)
+              : launch_h<3, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
+    form = x_hi ? 93 : 73;
+  }
+  if (rc == HF_OK) note_path(5, form);
   return rc;
 }
 
