@@ -34,7 +34,7 @@ KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modc
     579: "conv_rows_h<32->32,strip64,pre>",
     551: "conv_mfma_h<1,2,2,4>", 552: "conv_mfma_h<2,2,1,8>", 553: "conv_mfma_h<1,2,1,8>", 555: "conv_mfma_h<1,2,1,8,tw128>",
     561: "conv_mfma_h<1,2,2,4,up>", 563: "conv_mfma_h<1,2,1,8,up>",
-    573: "conv_mfma_h<1,2,1,8,up,fuse>", 593: "conv_mfma_h<1,2,1,8,up,pre,fuse>", 594: "conv_mfma_h<1,2,1,4,up,pre,fuse>",
+    573: "conv_mfma_h<1,2,1,8,up,fuse>", 593: "conv_mfma_h<1,2,1,8,up,pre,fuse>",
     # csrc/convh_enc.hip (encoder convs on the fp16 matrix cores)
     601: "conv_enc_h<64x256>", 602: "conv_enc_h<64x128,stride2>", 603: "conv_enc_h<64x128>", 604: "conv_enc_h<64x512>",
 }

@@ -1219,23 +1219,14 @@ extern "C" int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *s
   const _Float16 *hi = static_cast<const _Float16 *>(wt_hi), *lo = static_cast<const _Float16 *>(wt_lo);
   // <1,2,1,8>: 32 co x 512 positions (16 rows x 32), 8 waves x 2 rows, one block per CU - all eight waves in lock-step, so
   // the VALU-bound epilogue (29 k of a tile's 70 k cycles) and the MFMA loop never overlap.
-  // hf_debug_set_tuning bit 3 selects <1,2,1,4> instead: 8 rows x 32, FOUR waves, TWO independent blocks per CU (2 x 37.4 KB
-  // of stage buffers each; the FUSE-aware halo size makes them fit), so that a SIMD issues one block's epilogue under the
-  // other block's MFMAs.  Measured in round 4 with both blocks resident (round 2's "2x slower" was one block per CU: the
-  // rim-tile halo size made its LDS 86 KB): 752 vs 602 us on the 1024^2 layer, 546 vs 432, 449 vs 424 - the overlap is there,
-  // but every block stages the full weight stage (twice the LDS-DMA issues per wave) and recomputes 43 % instead of 22 %
-  // halo.  Bit-identical results (tests/test_sim_kernels.py); the eight-wave form stays the default.
-  int rc = HF_E_INVALID;
-  int form = 0;
-  if ((hf_detail::g_h_tune & 8) && x_hi) {
-    rc = launch_h<3, 1, 2, 1, 4, true, 32, true, true>(P, hi, lo, (hipStream_t)stream);
-    form = 94;
-  }
-  if (rc == HF_E_INVALID) {
-    rc = x_hi ? launch_h<3, 1, 2, 1, 8, true, 32, true, true>(P, hi, lo, (hipStream_t)stream)
-              : launch_h<3, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
-    form = x_hi ? 93 : 73;
-  }
+  // (Round 4 measured <1,2,1,4> - 8 rows x 32, FOUR waves, TWO independent blocks per CU, 2 x 37.4 KB of stage buffers each
+  // with the FUSE-aware halo size, so that a SIMD issues one block's epilogue under the other block's MFMAs - with both
+  // blocks resident (round 2's "2x slower" was one block per CU: the rim-tile halo size made its LDS 86 KB): bit-identical,
+  // 752 vs 602 us on the 1024^2 layer, 546 vs 432, 449 vs 424: every block stages the full weight stage - twice the LDS-DMA
+  // issues per wave - and recomputes 43 % instead of 22 % halo.  Not kept.)
+  int rc = x_hi ? launch_h<3, 1, 2, 1, 8, true, 32, true, true>(P, hi, lo, (hipStream_t)stream)
+                : launch_h<3, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
+  const int form = x_hi ? 93 : 73;
   if (rc == HF_OK) note_path(5, form);
   return rc;
 }

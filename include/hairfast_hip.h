@@ -628,7 +628,6 @@ int hf_debug_set_persistent_blocks(int blocks);
 /* Tuning switches of the fp16 matrix-core kernels (per thread, like the other debug hooks): bit 0 = issue every
  * stage's LDS-DMA copies in the stage's first tap-step instead of spreading them one per tap-step (the default,
  * measured 0-8 % faster on every generator layer); bit 2 = hf_conv2d_f16_f32 never uses its 512-pixel tile form,
- * bit 3 = hf_modconv3x3_up_blur_f16_f32 runs its four-wave form (8 x 32 positions, two blocks per CU; same bits, measured slower),
  * bits 8-15 = the minimum number of 512-pixel blocks / 8 for that form (0 = the default, 512), bits 16-23 = the
  * same for the 256-pixel form (default 384).  Results of the generator
  * kernels do not depend on it; tile forms of hf_conv2d_f16_f32 differ in summation order only. */

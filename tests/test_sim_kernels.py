@@ -523,19 +523,9 @@ def test_modconv_up_fused_blur(simlib, B, cin, cout, H, W):
     eh, el = M.split_activation_reference(y, s2)
     assert torch.equal(sp.hi, eh) and torch.equal(sp.lo, el)
     xh, xl = M.split_activation_reference(x, s)
-    # pre-split input: the eight-wave form (16 x 32 positions) by default, the four-wave form (8 x 32, two blocks per CU)
-    # under hf_debug_set_tuning bit 3 - different tilings of the same per-output arithmetic: equal bits
     y3 = M.modconv3x3_up_fused(simlib, None, M.SplitActivation(xh, xl, None), hi, lo, None, dm, fac, nz, nw, bias, split_for=s2)
     assert simlib.hf_debug_last_path() == 593
     assert torch.equal(y3.hi, eh) and torch.equal(y3.lo, el)
-    try:
-        simlib.hf_debug_set_tuning(8)
-        y4 = M.modconv3x3_up_fused(simlib, None, M.SplitActivation(xh, xl, None), hi, lo, None, dm, fac, nz, nw, bias, split_for=s2)
-        assert simlib.hf_debug_last_path() == 594
-        y5 = M.modconv3x3_up_fused(simlib, None, M.SplitActivation(xh, xl, None), hi, lo, None, dm, fac, nz, nw, bias)
-    finally:
-        simlib.hf_debug_set_tuning(0)
-    assert torch.equal(y4.hi, eh) and torch.equal(y4.lo, el) and torch.equal(y5, y)
     y6 = M.modconv3x3_up_fused(simlib, None, M.SplitActivation(xh, xl, None), hi, lo, None, dm, fac, nz, nw, bias)  # fp32 output
     assert torch.equal(y6, y)
 
