@@ -144,6 +144,28 @@ def set_conv_precision(mode):
     return prev
 
 
+class conv_precision_scope:
+    """`with conv_precision_scope(mode):` - the matrix-core mode for the calls inside (None: no change).  What lets two
+    HairFast objects of one process run in different modes (`HairFast(args, conv_precision=...)`): the switch itself is
+    process-wide, every call of such an object sets it for its own duration and restores it.  Not thread-safe, like the
+    reference's single-threaded callers."""
+
+    def __init__(self, mode):
+        if mode is not None and mode not in CONV_PRECISIONS:
+            raise ValueError(f"conv precision must be one of {CONV_PRECISIONS}, got {mode!r}")
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        if self.mode is not None:
+            self.prev = set_conv_precision(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        if self.mode is not None:
+            set_conv_precision(self.prev)
+        return False
+
+
 def reference_rng_walk():
     """HAIRFAST_RNG_WALK=reference: consume torch's device RNG in the reference's ORDER - one normal_() per NoiseInjection
     layer (models/stylegan2/model.py:289-291) instead of one per forward, and the FS encoder's discarded generator forward

@@ -46,7 +46,7 @@ from torch import nn
 
 from . import _marshal as M
 from . import checkpoints as ckpt_files
-from ._runtime import batch_invariant, configured_conv_precision, lib, reference_rng_walk, require_gpu, run_guarded, stream
+from ._runtime import batch_invariant, configured_conv_precision, conv_precision_scope, lib, reference_rng_walk, require_gpu, run_guarded, stream
 from .encoders import ClipBlendingModel, Encoder4Editing, FSEncoder, PostProcessModel, RotateModel, get_latents
 from .face_parsing import BiSeNet, get_segmentation
 from .net import Net
@@ -609,6 +609,9 @@ class HairFast:
       clip_state      the OpenAI CLIP ViT-B/32 state dict (its `visual.*` entries; what clip.load("ViT-B/32") holds,
                       models/Encoders.py:79; run natively by hairfastgan_amd.clip_vit) or `clip_image_embed`, a callable
       shape_state     CtrlHair mask generator (pretrained_models/ShapeAdaptor/mask_generator.pth)
+      conv_precision  this object's matrix-core mode ("f16x3" | "f32" | "f16" | "auto"; _runtime.CONV_PRECISIONS): set for
+                      the duration of each swap / swap_batch / swap_graphed call and restored, so that two HairFast objects
+                      of one process can differ (default None: the process-wide HAIRFAST_CONV_PRECISION / set_conv_precision)
       sean_state + sean_mean_codes   SEAN generator (…/CelebA-HQ_pretrained/latest_net_G.pth) and the [19,512] per-label
                       median style codes (models/sean_codes/styles_test/mean_style_code/median/<label>/ACE.npy)
     """
@@ -632,8 +635,10 @@ class HairFast:
     def __init__(self, args, *, stages=None, generator_state=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
                  fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None, bisenet_state=None, rotate_state=None,
                  blend_state=None, clip_image_embed=None, shape_state=None, sean_state=None, sean_mean_codes=None,
-                 clip_state=None, pretrained_root=None):
+                 clip_state=None, pretrained_root=None, conv_precision=None):
         self.args = args
+        self.conv_precision = conv_precision  # None: the process-wide mode; else this object's own (set per call)
+        conv_precision_scope(conv_precision)  # validates
         if getattr(args, "save_all", False):
             raise NotImplementedError(
                 "--save_all (intermediate images / latents written by the reference's utils/save_utils.py, Embedding.py:94-108, "
@@ -720,7 +725,8 @@ class HairFast:
             set_seed(seed_)
             return self._swap_from_tensors(*images, exp_name=exp_name, **kwargs)
 
-        final_image = run_guarded(run)
+        with conv_precision_scope(self.conv_precision):
+            final_image = run_guarded(run)
         if benchmark:
             torch.cuda.current_stream().synchronize()
             self._times.append(time.time() - t0)
@@ -737,13 +743,17 @@ class HairFast:
         fixed size on the GPU (anything else falls back to `swap`); the result is a fresh tensor.  Noise is drawn inside the
         graph from torch's graph-safe generator: set by `seed` before every replay, advanced by it.  The first call per
         image size captures (two eager warm-up swaps + the capture)."""
-        from .graphs import GraphRunner
-
         images = [self._as_tensor(img) for img in (face_img, shape_img, color_img)]
         images = equal_replacer([im.to(self.args.device) for im in images])
         if len({id(im) for im in images}) != 3 or getattr(self.args, "save_all", False):
             return self.swap(*images, seed=seed)
         images = [im.float().contiguous() for im in images]
+        with conv_precision_scope(self.conv_precision):
+            return self._swap_graphed(images, seed)
+
+    def _swap_graphed(self, images, seed):
+        from .graphs import GraphRunner
+
         # a graph replays the kernels and plans of the mode it was captured in: conv precision, RNG walk and the batch-invariant switch are part of the key
         key = (tuple(tuple(im.shape) for im in images), configured_conv_precision(), reference_rng_walk(), batch_invariant())
         graphs = self.__dict__.setdefault("_swap_graphs", {})
@@ -751,7 +761,7 @@ class HairFast:
             set_seed(3407 if seed is None else seed)
             graphs[key] = GraphRunner(lambda a, b, c: self._swap_from_tensors(a, b, c), *images)
         set_seed(3407 if seed is None else seed)
-        return graphs[key](*images).clone()
+        return graphs[key](*images).clone()  # (the key carries the mode the graph was captured in)
 
     def swap_batch(self, triples, seed=None, **kwargs):
         """Several swaps as ONE batched pass over the hot path (not in the reference: BASELINE.json configs[3],
@@ -777,7 +787,8 @@ class HairFast:
                     res[t] = self._swap_from_tensors(*tr, **kwargs)
             return res
 
-        return run_guarded(run)
+        with conv_precision_scope(self.conv_precision):
+            return run_guarded(run)
 
 
 # ---------------------------------------------------------------------------------------------

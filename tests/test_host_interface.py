@@ -204,3 +204,23 @@ def test_reference_rng_walk_switch(monkeypatch):
     monkeypatch.setenv("HAIRFAST_RNG_WALK", "reference")
     assert _runtime.reference_rng_walk()
     assert g._draw_noise(noise, lat, 0, 8) is noise  # untouched: each layer draws its own
+
+
+def test_conv_precision_scope_sets_and_restores():
+    from hairfastgan_amd import _runtime
+
+    base = _runtime.configured_conv_precision()
+    other = "f32" if base != "f32" else "f16"
+    with _runtime.conv_precision_scope(other):
+        assert _runtime.configured_conv_precision() == other
+        with _runtime.conv_precision_scope(None):  # no change
+            assert _runtime.configured_conv_precision() == other
+    assert _runtime.configured_conv_precision() == base
+    with pytest.raises(ValueError):
+        _runtime.conv_precision_scope("f8")
+    try:
+        with _runtime.conv_precision_scope(other):
+            raise RuntimeError("x")
+    except RuntimeError:
+        pass
+    assert _runtime.configured_conv_precision() == base  # restored on exceptions too
