@@ -516,8 +516,10 @@ def modconv3x3_up_fused_supported(cin, cout, h, w):
     return cin % 16 == 0 and cout % 32 == 0 and h >= 16 and w >= 32
 
 
-def modconv3x3_up_fused(lib, st, x, wt_hi, wt_lo, s, d, factors, noise, noise_w, bias, alpha=0.2, scale=SQRT2, split_for=None):
-    """hf_modconv3x3_up_blur_f16_f32: transposed conv + blur + noise + bias + lrelu in one kernel (f16x3).
+def modconv3x3_up_fused(lib, st, x, wt_hi, wt_lo, s, d, factors, noise, noise_w, bias, alpha=0.2, scale=SQRT2, split_for=None,
+                        nterms=3):
+    """hf_modconv3x3_up_blur_f16_f32: transposed conv + blur + noise + bias + lrelu in one kernel (nterms 3: f16x3; 1: plain
+    fp16 operands - wt_lo is then not passed, a split output has no lo part).
     x: fp32 tensor (with s) or SplitActivation.  Returns the fp32 activation, or - split_for = s_next [B,cout] -
     the SplitActivation of s_next * activation for a pre-split consumer (one output form per launch)."""
     pre = isinstance(x, SplitActivation)
@@ -531,7 +533,7 @@ def modconv3x3_up_fused(lib, st, x, wt_hi, wt_lo, s, d, factors, noise, noise_w,
     if split_for is not None:
         s_next = _c(split_for)
         sh = torch.empty((b, cout // 8, 2 * h, 2 * w, 8), dtype=torch.float16, device=dev)
-        sl = torch.empty_like(sh)
+        sl = torch.empty_like(sh) if nterms == 3 else None
     else:
         out = torch.empty((b, cout, 2 * h, 2 * w), dtype=torch.float32, device=dev)
     kx, ky = factors
@@ -539,7 +541,8 @@ def modconv3x3_up_fused(lib, st, x, wt_hi, wt_lo, s, d, factors, noise, noise_w,
     code = _launch_profiled(
         lib, 2.0 * cin * cout * 9 * h * w * b,
         lambda: lib.hf_modconv3x3_up_blur_f16_f32(_p(out), _p(sh), _p(sl), None if pre else _p(x), _p(x.hi) if pre else None,
-                                                  _p(x.lo) if pre else None, _p(wt_hi), _p(wt_lo), None if pre else _p(s), _p(d),
+                                                  _p(x.lo) if (pre and nterms == 3) else None, _p(wt_hi),
+                                                  _p(wt_lo) if nterms == 3 else None, None if pre else _p(s), _p(d),
                                                   kx, ky, _p(noise), _p(_c(noise_w)), nbs, _p(_c(bias)), _p(s_next), b, cin, cout,
                                                   h, w, alpha, scale, st), nbytes=nb_alg)
     check(lib, code, "hf_modconv3x3_up_blur_f16_f32")

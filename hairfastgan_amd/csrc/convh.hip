@@ -132,7 +132,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;          // hi (+ lo)
   constexpr int W_UNITS = 9 * 2 * CT;                   // 16-byte units of one weight part per stage
   constexpr int X_UNITS = 2 * NPIX;                     // 16-byte units of one activation part per stage
-  constexpr int BUF_UNITS = NPART * (W_UNITS + X_UNITS);
+  // FUSE: the epilogue's vertical exchange (NW * 6 slots of 64 lanes x 16 B) lives in the free stage buffer - with plain
+  // fp16 operands (one part) a stage is smaller than that, the buffer is sized for the exchange
+  constexpr int BUF_UNITS = (FUSE && NPART * (W_UNITS + X_UNITS) < NW * 6 * 64) ? NW * 6 * 64 : NPART * (W_UNITS + X_UNITS);
   constexpr int N_WPIECE = NPART * W_UNITS / 64;        // 1 KiB DMA pieces per stage
   constexpr int ND = (N_WPIECE + NW - 1) / NW;          // per wave
   // weight DMAs: all in the first three tap-steps when activations are staged through registers
@@ -698,6 +700,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
               bool ovf = false;
               hf_split4_f16(vs, h4, l4, ovf);
 #if HF_H_SPLIT_STORE16
+              static_assert(NTERMS == 3, "HF_H_SPLIT_STORE16 pairs the hi and lo units of a pixel");
               // one 16-byte store per lane: the half-waves trade halves, lanes 0-31 write the hi unit of the pixel,
               // lanes 32-63 its lo unit (both halves of a wave share li, i.e. the pixel and its validity)
               typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -716,13 +719,13 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
               if (pv) {
                 ovf_tile = ovf_tile || ovf;
                 *reinterpret_cast<hf_half4 *>(oh_b + cb_ofs + (long long)pix * 16) = h4;
-                *reinterpret_cast<hf_half4 *>(ol_b + cb_ofs + (long long)pix * 16) = l4;
+                if (NTERMS == 3) *reinterpret_cast<hf_half4 *>(ol_b + cb_ofs + (long long)pix * 16) = l4;  // plain fp16 consumer: no lo part
               }
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
           }
       }
-#endif
       hf_barrier_lds();  // everyone has read: the region may be overwritten (next quad / next tile's DMA)
     }
     hf_note_overflow(ovf_tile);
@@ -1022,7 +1025,9 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
     if (P.g[i].lg_nb != 0 || (1 << (P.g[i].lg_tw + P.g[i].lg_th)) != PT) return HF_E_INVALID;
     if (geom_xs(P.g[i], 1, UP ? 1 : 2) > NPIX) return HF_E_INVALID;
   }
-  const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float) +
+  constexpr int NW_ = WAVES_CO * WAVES_PX;
+  constexpr int BUF_UNITS = (FUSE && NPART * (9 * 2 * CT + 2 * NPIX) < NW_ * 6 * 64) ? NW_ * 6 * 64 : NPART * (9 * 2 * CT + 2 * NPIX);
+  const size_t lds = (size_t)2 * BUF_UNITS * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float) +
                      2 * 3 * CT * sizeof(float) + (P.rgb_out ? 2 * 3 * CT * sizeof(float) : 0);
   // stages + s[2][cin] + epilogue d/bias/s_next [2][3][CT] (+ fused ToRGB weights [2][3][CT])
   // fused ToRGB: the standard StyledConv tail (the kernel's fast epilogue) writes one raw slab per 32*CT_TILES output
@@ -1196,9 +1201,11 @@ extern "C" int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *s
                                              const float *d, const float *blur_k1d_x, const float *blur_k1d_y, const float *noise, const float *noise_w,
                                              long long noise_bstride, const float *bias, const float *s_next, int batch, int cin,
                                              int cout, int h, int w, float alpha, float scale, void *stream) {
-  if ((!out == !split_hi) || (!x && !x_hi) || !wt_hi || !wt_lo || !blur_k1d_x || !blur_k1d_y || batch <= 0 || cin <= 0 || cout <= 0 ||
-      h < 2 || w < 2 || (noise && !noise_w) || (x_hi && !x_lo) || (!x_hi && !s) || (cout % 32) || (cin % 16) ||
-      (split_hi && (!split_lo || (cout & 7))) || !bias || !(alpha >= 0.0f && alpha <= 1.0f) || !(scale > 0.0f))
+  // wt_lo NULL: plain fp16 operands (nterms 1, BASELINE.json configs[4]) - then x_lo / split_lo are not used either
+  const int nterms = wt_lo ? 3 : 1;
+  if ((!out == !split_hi) || (!x && !x_hi) || !wt_hi || !blur_k1d_x || !blur_k1d_y || batch <= 0 || cin <= 0 || cout <= 0 ||
+      h < 2 || w < 2 || (noise && !noise_w) || (nterms == 3 && x_hi && !x_lo) || (!x_hi && !s) || (cout % 32) || (cin % 16) ||
+      (split_hi && ((nterms == 3 && !split_lo) || (cout & 7))) || !bias || !(alpha >= 0.0f && alpha <= 1.0f) || !(scale > 0.0f))
     return HF_E_INVALID;  // exactly one output form; the epilogue assumes bias + leaky ReLU (0 <= alpha <= 1), scale > 0
   ConvParams P{};
   P.out = out; P.x = x; P.xh = x_hi; P.xl = x_lo; P.s = x_hi ? nullptr : s; P.d = d; P.noise = noise; P.noise_w = noise_w;
@@ -1211,7 +1218,7 @@ extern "C" int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *s
   P.stride = 1;
   P.act = bias ? ACT_LRELU : ACT_NONE;
   P.alpha = alpha; P.scale = scale;
-  P.oh = split_hi; P.ol = split_lo; P.s_next = s_next;
+  P.oh = split_hi; P.ol = nterms == 3 ? split_lo : nullptr; P.s_next = s_next;
   for (int j = 0; j < 4; ++j) {  // upfirdn2d is a true convolution: flipped taps (op/upfirdn2d.py:186)
     P.blur_kx[j] = blur_k1d_x[3 - j];
     P.blur_ky[j] = blur_k1d_y[3 - j];
@@ -1224,8 +1231,13 @@ extern "C" int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *s
   // blocks resident (round 2's "2x slower" was one block per CU: the rim-tile halo size made its LDS 86 KB): bit-identical,
   // 752 vs 602 us on the 1024^2 layer, 546 vs 432, 449 vs 424: every block stages the full weight stage - twice the LDS-DMA
   // issues per wave - and recomputes 43 % instead of 22 % halo.  Not kept.)
-  int rc = x_hi ? launch_h<3, 1, 2, 1, 8, true, 32, true, true>(P, hi, lo, (hipStream_t)stream)
-                : launch_h<3, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
+  int rc;
+  if (nterms == 3)
+    rc = x_hi ? launch_h<3, 1, 2, 1, 8, true, 32, true, true>(P, hi, lo, (hipStream_t)stream)
+              : launch_h<3, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
+  else
+    rc = x_hi ? launch_h<1, 1, 2, 1, 8, true, 32, true, true>(P, hi, lo, (hipStream_t)stream)
+              : launch_h<1, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
   const int form = x_hi ? 93 : 73;
   if (rc == HF_OK) note_path(5, form);
   return rc;

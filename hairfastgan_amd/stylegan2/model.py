@@ -217,17 +217,18 @@ class ModulatedConv2d(nn.Module):  # :183-279
     def conv_up(self, input, wt, s, d, noise, noise_w, bias, alpha=0.2, scale=math.sqrt(2), split_for=None):
         """Transposed 3x3 conv + blur (+ fused noise/bias/lrelu), matrix cores per the mode.
         split_for=(key, s_next): the blur pass writes a SplitActivation for the next conv.
-        Large planes in f16x3 mode run the ONE-kernel form (hf_modconv3x3_up_blur_f16_f32: no (2h+1)^2
+        Large planes in the fp16-core modes run the ONE-kernel form (hf_modconv3x3_up_blur_f16_f32: no (2h+1)^2
         intermediate); FUSE_BLUR_MIN_H is the smallest input height that takes it."""
         mode = conv_precision()
         _, cin, h, w = input.shape
-        if (mode == "f16x3" and h >= FUSE_BLUR_MIN_H and noise is not None and bias is not None and 0.0 <= alpha <= 1.0
+        if (mode in ("f16x3", "f16") and h >= FUSE_BLUR_MIN_H and noise is not None and bias is not None and 0.0 <= alpha <= 1.0
                 and M.modconv3x3_up_fused_supported(cin, self.out_channel, h, w)):
             fac = self.blur_factors()
             if fac is not None:
                 hi, lo = self.prepared_f16()
                 return M.modconv3x3_up_fused(lib(), stream(), input, hi, lo, s, d, fac, noise, noise_w, bias, alpha, scale,
-                                             split_for=None if split_for is None else split_for[1])
+                                             split_for=None if split_for is None else split_for[1],
+                                             nterms=3 if mode == "f16x3" else 1)
         f16 = small = None
         if (mode != "f32" and not isinstance(input, M.SplitActivation)
                 and M.modconv3x3_small_supported(cin, self.out_channel, h, w, input.shape[0], upsample=True)):

@@ -231,7 +231,8 @@ int hf_modconv3x3_up_f16_f32(float *tmp, const float *x, const void *wt_hi, cons
  *   blur_k1d_x / blur_k1d_y: HOST pointers to the 4 taps of the two 1-D factors of the blur kernel
  *   (kernel4x4[r][j] = blur_k1d_y[r] * blur_k1d_x[j]; the module's `blur.kernel` is such an outer product,
  *   model.py:24-32): the fused form needs a separable kernel - callers with a general 4x4 kernel use the
- *   two-pass entry points.  cin % 16 == 0, cout % 32 == 0; nterms is 3 (f16x3). */
+ *   two-pass entry points.  cin % 16 == 0, cout % 32 == 0.  Operand mode: wt_lo != NULL = f16x3 (three MFMAs per product);
+ *   wt_lo NULL = plain fp16 operands (BASELINE.json configs[4]) - x_lo and split_lo are then not read / written. */
 int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *split_lo, const float *x, const void *x_hi,
                                   const void *x_lo, const void *wt_hi, const void *wt_lo, const float *s, const float *d,
                                   const float *blur_k1d_x, const float *blur_k1d_y, const float *noise, const float *noise_w,

@@ -530,6 +530,38 @@ def test_modconv_up_fused_blur(simlib, B, cin, cout, H, W):
     assert torch.equal(y6, y)
 
 
+def test_modconv_up_fused_blur_plain_fp16_operands(simlib):
+    """The one-kernel upsampling StyledConv with plain fp16 operands (nterms 1, BASELINE.json configs[4]; wt_lo NULL at the
+    C ABI): same products as the two-pass fp16 path (operands rounded identically; the separable blur reassociates), the
+    split output has a hi part only = fp16(s_next * out), the stage buffer is sized for the epilogue's exchange."""
+    B, cin, cout, H, W = 2, 32, 32, 20, 45
+    torch.manual_seed(3)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    mw, mb, sty = torch.randn(cin, 16), torch.randn(cin), torch.randn(B, 16)
+    nz, nw, bias = torch.randn(B, 1, 2 * H, 2 * W), torch.tensor([0.3]), torch.randn(cout)
+    wt, wsq = M.prepare_weights(simlib, None, wgt)
+    s = M.modulation(simlib, None, sty, mw, mb)
+    dm = M.demod(simlib, None, s, wsq)
+    M.style_normalize(simlib, None, s, dm)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0)
+    fac = M.blur_factors(k4)
+    ref = M.modconv3x3_up(simlib, None, x, wt, s, dm, k4, nz, nw, bias, f16=(hi, lo, 1))
+    y = M.modconv3x3_up_fused(simlib, None, x, hi, None, s, dm, fac, nz, nw, bias, nterms=1)
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxdiff(y, ref) < 2e-6 * scale
+    full = O.fused_leaky_relu(O.modulated_conv2d(x, sty, wgt, mw, mb, True, True) + nw * nz, bias)
+    assert maxdiff(y, full) < 2e-2 * max(1.0, float(full.abs().max()))  # fp16 operands
+    s2 = torch.rand(B, cout) + 0.5
+    xh, _ = M.split_activation_reference(x, s)
+    sp = M.modconv3x3_up_fused(simlib, None, M.SplitActivation(xh, None, None), hi, None, None, dm, fac, nz, nw, bias, split_for=s2, nterms=1)
+    assert sp.lo is None
+    y2 = M.modconv3x3_up_fused(simlib, None, M.SplitActivation(xh, None, None), hi, None, None, dm, fac, nz, nw, bias, nterms=1)
+    eh, _ = M.split_activation_reference(y2, s2)
+    assert torch.equal(sp.hi, eh)
+
+
 @pytest.mark.parametrize("blocks", [1, 3])
 def test_modconv_up_fused_blur_persistent_walk(simlib, blocks):
     """The fused kernel under the resident-block tile walk: the LDS stage buffer that carries the vertical
