@@ -447,7 +447,7 @@ inline int geom_xs(const TileGeom &g, int stride, int ext) {
 int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wt_hi, const void *wt_lo, hipStream_t st);
 // convrow.hip: the row-pipeline form of a 32 -> 32 channel same-resolution layer with pre-split input (the 1024^2 conv);
 // HF_E_INVALID when the layer does not qualify
-int launch_conv_rows(ConvParams &P, const void *wt_hi, const void *wt_lo, hipStream_t st);
+int launch_conv_rows(ConvParams &P, int nterms, const void *wt_hi, const void *wt_lo, hipStream_t st);
 extern thread_local int g_h_blocks;           // hf_debug_set_persistent_blocks: resident blocks the convh.hip grid is sized for (0 = 256 CUs)
 extern thread_local int g_h_tune;             // hf_debug_set_tuning: bit 0 force early stage DMAs, bit 1 force spread ones (convh.hip)
 extern int g_batch_invariant;                 // hf_set_batch_invariant (process-wide): plans (split-K counts, tile forms) from the per-sample shape only

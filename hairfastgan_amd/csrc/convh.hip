@@ -1115,8 +1115,8 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
   if (P.rgb_out && cfg == 51) cfg = 52;  // fused ToRGB needs all cout channels in one wave
   if (P.xh) {  // pre-split activations (ids 7x = the 5x tile shapes with DMA-staged activations)
     // 32 -> 32 channels (the 1024^2 layer): the row pipeline of convrow.hip (id 79); hf_debug_set_tuning bit 4 = the tiled form
-    if (nterms == 3 && !g_force_h && !(g_h_tune & 16) && P.cin == 32 && P.cout == 32) {
-      rc = launch_conv_rows(P, wth, wtl, st);
+    if (!g_force_h && !(g_h_tune & 16) && P.cin == 32 && P.cout == 32) {
+      rc = launch_conv_rows(P, nterms, wth, wtl, st);
       if (rc == HF_OK) {
         note_path(5, 79);
         return rc;

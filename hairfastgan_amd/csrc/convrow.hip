@@ -1,5 +1,5 @@
 // convrow.hip - the generator's last 3x3 convolution (1024^2, 32 -> 32 channels, models/stylegan2/model.py:337-343 with the
-// ToRGB of :356-362 fused) as a ROW PIPELINE on the fp16 matrix cores, f16x3 operands (csrc/convh.hip).
+// ToRGB of :356-362 fused) as a ROW PIPELINE on the fp16 matrix cores, f16x3 or plain fp16 operands (csrc/convh.hip).
 //
 // Why a kernel of its own: with K = 32 input channels a 512-pixel tile of the tiled kernel is two K stages - 6.9k MFMA
 // cycles per SIMD against 136 KB of LDS-DMA per tile (at 100-185 issue cycles per KB), of which 36 KB are the SAME weights
@@ -34,6 +34,9 @@ constexpr int kRing = 18;                    // row slots: 10 in use + 8 arrivin
 constexpr int kStep = 8;                     // output rows per super-step
 constexpr int kDmaPerPart = (kPartUnits + 63) / 64;  // 5 (the fifth carries 8 lanes)
 
+// NTERMS 3: f16x3 operands (hi, lo); 1: plain fp16 operands (BASELINE.json configs[4]) - no lo weights, no lo row parts, one
+// MFMA per (tap, row) instead of three
+template <int NTERMS>
 __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const _Float16 *__restrict__ wth,
                                                       const _Float16 *__restrict__ wtl, int rows_per_block, int segs, int ablate) {
   // ablate (hf_debug_set_tuning bits 5-7, timing experiments only): 1 no row copies, 2 no epilogue, 4 no MFMAs
@@ -52,14 +55,15 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
   const int nsteps = min(rows_per_block, H - r0) / kStep;
 
   // ---- weights: [chunk16][tap][kgroup 2][cout 32][8 halves] -> this lane's A fragments (co = li, kgroup = lh)
-  half8 ah[2][9], al[2][9];
+  constexpr int NPART = NTERMS == 3 ? 2 : 1;
+  half8 ah[2][9], al[NTERMS == 3 ? 2 : 1][NTERMS == 3 ? 9 : 1];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const long long o = ((long long)((c * 9 + t) * 2 + lh) * 32 + li) * 8;
       ah[c][t] = *reinterpret_cast<const half8 *>(wth + o);
-      al[c][t] = *reinterpret_cast<const half8 *>(wtl + o);
+      if constexpr (NTERMS == 3) al[c][t] = *reinterpret_cast<const half8 *>(wtl + o);
     }
   if (tid < 32) {
     const float unscale = *reinterpret_cast<const float *>(wth + 9LL * 32 * 32);  // 2^-k of the weights' pre-scale (split_weights)
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
 
   // ---- LDS-DMA of one input row into a ring slot: per part 5 copies of 64 units; unit u = cb*66 + px of the part
   const char *xh_b = static_cast<const char *>(P.xh) + (long long)b * 4 * plane * 16;
-  const char *xl_b = static_cast<const char *>(P.xl) + (long long)b * 4 * plane * 16;
+  const char *xl_b = NTERMS == 3 ? static_cast<const char *>(P.xl) + (long long)b * 4 * plane * 16 : nullptr;
   int goff[kDmaPerPart];   // byte offset of the lane's unit inside the image at row 0; -1: no unit, -2: column outside the image
 #pragma unroll
   for (int k = 0; k < kDmaPerPart; ++k) {
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
   };
   auto dma_row = [&](int y, int slot) {
 #pragma unroll
-    for (int idx = 0; idx < 2 * kDmaPerPart; ++idx) dma_piece(idx, y, slot);
+    for (int idx = 0; idx < NPART * kDmaPerPart; ++idx) dma_piece(idx, y, slot);
   };
   // prologue: input rows r0-1 .. r0+8 -> slots 0 .. 9
   dma_row(r0 - 1 + wave, wave);
@@ -131,14 +135,14 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
         srow[r][ky] = s * kSlotUnits + 32 * j + li;
       }
     // fragments of tap i+1 are fetched before the MFMAs of tap i (two register slots): the LDS latency runs under them
-    half8 bh[2][2], bl[2][2];  // [slot][row]
+    half8 bh[2][2], bl[NTERMS == 3 ? 2 : 1][2];  // [slot][row]
     auto fetch = [&](int i, int slot) {
       const int c = i / 9, t = i % 9;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int u = srow[r][t / 3] + (2 * c + lh) * kPXW + t % 3;
         bh[slot][r] = ring[u];
-        bl[slot][r] = ring[u + kPartUnits];
+        if constexpr (NTERMS == 3) bl[slot][r] = ring[u + kPartUnits];
       }
     };
     fetch(0, 0);
@@ -147,14 +151,16 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
       const int c = i / 9, t = i % 9, sl = i & 1;
       if (i + 1 < 18) fetch(i + 1, sl ^ 1);
       if (ablate & 4) continue;
-      if (dma && !(ablate & 1) && i < 2 * kDmaPerPart) dma_piece(i, y_next, slot_next);
+      if (dma && !(ablate & 1) && i < NPART * kDmaPerPart) dma_piece(i, y_next, slot_next);
       __builtin_amdgcn_sched_barrier(0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][t], bh[sl][0], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][t], bh[sl][1], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][t], bl[sl][0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][t], bl[sl][1], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c][t], bh[sl][0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c][t], bh[sl][1], acc[1], 0, 0, 0);
+      if constexpr (NTERMS == 3) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][t], bl[sl][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][t], bl[sl][1], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c][t], bh[sl][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c][t], bh[sl][1], acc[1], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -243,9 +249,10 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
 namespace hf_detail {
 
 // The row-pipeline form of a same-resolution 3x3 layer (launch_conv_h's contract): HF_E_INVALID when the layer does not qualify.
-int launch_conv_rows(ConvParams &P, const void *wth, const void *wtl, hipStream_t st) {
-  if (P.cin != 32 || P.cout != 32 || !P.xh || !P.xl || P.s || P.t || P.oh || P.residual || P.groups > 1 || P.stride != 1 ||
-      (P.w % kSW) || (P.h % kStep) || P.out_h != P.h || P.out_w != P.w || !wth || !wtl)
+int launch_conv_rows(ConvParams &P, int nterms, const void *wth, const void *wtl, hipStream_t st) {
+  if (P.cin != 32 || P.cout != 32 || !P.xh || (nterms == 3 && !P.xl) || P.s || P.t || P.oh || P.residual || P.groups > 1 ||
+      P.stride != 1 || (P.w % kSW) || (P.h % kStep) || P.out_h != P.h || P.out_w != P.w || !wth || (nterms == 3 && !wtl) ||
+      (nterms != 1 && nterms != 3))
     return HF_E_INVALID;
   if (!P.bias || P.act != ACT_LRELU || !(P.alpha >= 0.0f && P.alpha <= 1.0f) || !(P.scale > 0.0f)) return HF_E_INVALID;
   if ((!P.out && !P.rgb_out) || (P.rgb_out && (!P.rgb_w || !P.rgb_s || P.rgb_slabs != 1))) return HF_E_INVALID;
@@ -269,8 +276,12 @@ int launch_conv_rows(ConvParams &P, const void *wth, const void *wtl, hipStream_
   const long long blocks = (long long)P.batch * strips * segs;
   if (blocks >= (1LL << 31)) return HF_E_INVALID;
   const size_t lds = (size_t)kRing * kSlotUnits * 16 + 5 * 32 * sizeof(float);
-  hipLaunchKernelGGL(conv_rows_h, dim3((unsigned)blocks), dim3(512), lds, st, P, static_cast<const _Float16 *>(wth),
-                     static_cast<const _Float16 *>(wtl), rows_per_block, segs, (g_h_tune >> 5) & 7);
+  if (nterms == 3)
+    hipLaunchKernelGGL(conv_rows_h<3>, dim3((unsigned)blocks), dim3(512), lds, st, P, static_cast<const _Float16 *>(wth),
+                       static_cast<const _Float16 *>(wtl), rows_per_block, segs, (g_h_tune >> 5) & 7);
+  else
+    hipLaunchKernelGGL(conv_rows_h<1>, dim3((unsigned)blocks), dim3(512), lds, st, P, static_cast<const _Float16 *>(wth),
+                       static_cast<const _Float16 *>(wtl), rows_per_block, segs, (g_h_tune >> 5) & 7);
   return hf_launch_status();
 }
 

@@ -621,3 +621,14 @@ def test_conv_rows_pipeline_equals_tiled_kernel(simlib, B, H, W):
     assert simlib.hf_debug_last_path() == 579
     want = M.modconv3x3_f16(simlib, None, x, hi, lo, 3, s, dm, None, None, bias)
     assert torch.equal(plain, want)
+    # plain fp16 operands (nterms 1, BASELINE.json configs[4]): hi parts only - the same row pipeline, bit-equal to the tiled form
+    act1 = M.SplitActivation(xh, None, None)
+    try:
+        simlib.hf_debug_set_tuning(16)
+        ref1_out, ref1_raw = M.modconv3x3_f16_pre(simlib, None, act1, hi, lo, 1, dm, nz, nw, bias, rgb=(rgb_w, rgb_s))
+        assert simlib.hf_debug_last_path() in (573, 575)
+    finally:
+        simlib.hf_debug_set_tuning(0)
+    out1, raw1 = M.modconv3x3_f16_pre(simlib, None, act1, hi, lo, 1, dm, nz, nw, bias, rgb=(rgb_w, rgb_s))
+    assert simlib.hf_debug_last_path() == 579
+    assert torch.equal(out1, ref1_out) and torch.equal(raw1, ref1_raw) and not torch.equal(out1, out)
