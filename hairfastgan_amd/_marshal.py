@@ -376,7 +376,8 @@ def modconv3x3_small_supported(cin, cout, h, w, batch, upsample=False):
     n = plan_batch(batch) * h * w  # batch-invariant mode: the dispatch of ONE sample (_runtime.plan_batch)
     if upsample:
         return h * w <= 64 or (h * w <= 256 and n <= 1024)
-    return 256 < n <= 2048
+    # n = 256 from tiny planes (4^2 at batch 16, 8^2 at batch 4): the fp32 split-K kernel takes 180 us there, the tap GEMM 60
+    return 256 < n <= 2048 or (n == 256 and h * w <= 64)
 
 
 def conv3x3_small_supported(cin, cout, h, w, batch):
