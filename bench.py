@@ -418,9 +418,11 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (generator workload)")
     ap.add_argument("--workload", choices=("generator", "swap256", "launch-check"), default="generator")
     ap.add_argument("--triples", type=int, default=256, help="swap256: triples of the whole job")
-    ap.add_argument("--swap-batch", type=int, default=16,
+    ap.add_argument("--swap-batch", type=int, default=32,
                     help="swap256: triples per batched pass over the hot path (HairFast.swap_batch); 1 = one HairFast.swap per triple. "
-                         "Measured (tools/probes/swap_batch_sizes.py): 1: 29 triples/s, 4: 54, 8: 64, 16: 70, 32: 73 (32 GiB)")
+                         "Measured on resident inputs (tools/probes/swap_batch_sizes.py, round 4): 1: 29 triples/s, 4: 54, 8: 64, "
+                         "16: 70.6 (22.6 GiB), 32: 72.9 (32.1 GiB), 48: 72.4, 64: 72.8 (50.9 GiB) - a plateau from 32, which is "
+                         "also one pass per rank for 256 triples on 8 GPUs")
     ap.add_argument("--precision", choices=("f16x3", "f32", "f16"), default=None,
                     help="matrix-core mode of the 3x3 convs (default: HAIRFAST_CONV_PRECISION or f16x3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
