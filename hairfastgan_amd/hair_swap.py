@@ -349,6 +349,9 @@ class Embedding(nn.Module):  # models/Embedding.py:17-117
         self.downsample_512 = BicubicDownSample(factor=2)
         self.downsample_256 = BicubicDownSample(factor=4)
         self._overlap = os.environ.get("HAIRFAST_EMBED_OVERLAP", "1") != "0"
+        # inside a hipGraph capture (swap_graphed) the side streams fork from / join the capturing stream: the graph gets
+        # three parallel branches (round 4: swap_graphed 35.0 -> 32.4 ms, bit-equal to the eager swap; "0" = one chain)
+        self._overlap_in_capture = os.environ.get("HAIRFAST_GRAPH_OVERLAP", "1") != "0"
         self._side = None  # two HIP side streams, created on first use
         # Lazily derived weights (prepared / split layouts, folded BatchNorms) are computed on whatever stream first
         # needs them and then shared by all: the first pass after construction or load_state_dict runs sequentially.
@@ -389,7 +392,7 @@ class Embedding(nn.Module):  # models/Embedding.py:17-117
             # the parsing branch are ENQUEUED on two side streams so that the GPU overlaps them with e4e; the host
             # order of the calls - and with it torch's RNG stream - is that of the sequential form: same results.
             overlap = (self._overlap and self._warmed and image.is_cuda and image.shape[0] <= 6
-                       and not torch.cuda.is_current_stream_capturing())
+                       and (self._overlap_in_capture or not torch.cuda.is_current_stream_capturing()))
             main = torch.cuda.current_stream() if overlap else None
             if overlap:
                 if self._side is None:
