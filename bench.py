@@ -65,6 +65,19 @@ GFLOP_POSTPROCESS = 774.0      # PostProcessModel (5
 PMC_PROFILE = os.path.join("profiles", "pmc_traffic.json")
 
 
+def emit(out):
+    """Rank 0's ONE JSON line, as the LAST line of stdout: RCCL prints a version banner through C stdio (buffered until
+    exit, i.e. it would land behind the line) - flush C stdio first."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def synth_state(prefix, shapes):
     import numpy as np
 
@@ -526,7 +539,7 @@ def main():
                    "balance": balance_report(st256, cpu_slice)}
             if prof:
                 out.update(kernel_report(prof, elapsed, precision))
-            print(json.dumps(out), flush=True)
+            emit(out)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -769,7 +782,7 @@ def main():
             out["swap_schedule"] = swap_info
         if pipeline_info is not None:
             out["swap_pipeline"] = pipeline_info
-        print(json.dumps(out), flush=True)
+        emit(out)
 
     if use_dist:
         dist.barrier()
