@@ -138,13 +138,26 @@ class DilateErosion:
         return M.dilate_erode(lib(), stream(), mask.float(), self.dilate_erosion)
 
 
+def _same_content(a, b, fa, fb):
+    """torch.allclose(fa, fb) of utils/image_utils.py:21 without its ten elementwise launches where the answer is exact:
+    the same storage, or two 8-bit images (distinct 8-bit values differ by 1/255 after the division, far above allclose's
+    1e-5 relative + 1e-8 absolute tolerance: allclose <=> equal)."""
+    if a is b or (a.dtype == b.dtype and a.device == b.device and a.data_ptr() == b.data_ptr() and a.stride() == b.stride()):
+        return True
+    if a.dtype is torch.uint8 and b.dtype is torch.uint8 and a.device == b.device:
+        return torch.equal(a, b)
+    return torch.allclose(fa, fb)
+
+
 def equal_replacer(images):
     """utils/image_utils.py:14-24: uint8 -> [0,1]; images with equal content become the same object."""
-    images = [im / 255 if im.dtype is torch.uint8 else im for im in images]
+    raw = list(images)
+    images = [im / 255 if im.dtype is torch.uint8 else im for im in raw]
     for i in range(len(images)):
         for j in range(i + 1, len(images)):
-            if images[i].shape == images[j].shape and torch.allclose(images[i], images[j]):
+            if images[i].shape == images[j].shape and _same_content(raw[i], raw[j], images[i], images[j]):
                 images[j] = images[i]
+                raw[j] = raw[i]
     return images
 
 

@@ -224,3 +224,28 @@ def test_conv_precision_scope_sets_and_restores():
     except RuntimeError:
         pass
     assert _runtime.configured_conv_precision() == base  # restored on exceptions too
+
+
+def test_equal_replacer_matches_the_reference_rule():
+    """utils/image_utils.py:14-24: images with equal content collapse to ONE object (later stages test `is`); the 8-bit fast
+    path (torch.equal instead of allclose's ten launches) gives the reference's answers, floats keep allclose."""
+    from hairfastgan_amd.hair_swap import equal_replacer
+
+    g = torch.Generator().manual_seed(0)
+    a = torch.randint(0, 256, (3, 16, 16), dtype=torch.uint8, generator=g)
+    c = torch.randint(0, 256, (3, 16, 16), dtype=torch.uint8, generator=g)
+    r = equal_replacer([a, a.clone(), c])
+    assert r[0] is r[1] and r[2] is not r[0] and r[0].dtype == torch.float32 and float(r[0].max()) <= 1.0
+    r = equal_replacer([a, c, c.clone()])
+    assert r[1] is r[2] and r[0] is not r[1]
+    r = equal_replacer([a, a, a.float() / 255])            # mixed dtypes: allclose on the converted images
+    assert r[0] is r[1] and r[2] is r[0]
+    f = a.float() / 255
+    r = equal_replacer([f, f + 1e-9, c])                   # floats within allclose's tolerance collapse, as in the reference
+    assert r[1] is r[0]
+    off = a.clone()
+    off[0, 0, 0] = (int(off[0, 0, 0]) + 1) % 256           # one 8-bit step apart: not equal, not allclose
+    r = equal_replacer([a, off, c])
+    assert r[1] is not r[0]
+    r = equal_replacer([a, torch.zeros(3, 8, 8, dtype=torch.uint8), c])  # different shapes never compare
+    assert r[1] is not r[0]
