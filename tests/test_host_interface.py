@@ -249,3 +249,29 @@ def test_equal_replacer_matches_the_reference_rule():
     assert r[1] is not r[0]
     r = equal_replacer([a, torch.zeros(3, 8, 8, dtype=torch.uint8), c])  # different shapes never compare
     assert r[1] is not r[0]
+
+
+def test_batch_invariant_plans_scale_with_the_batch():
+    """hf_set_batch_invariant (HAIRFAST_DETERMINISTIC=1): split-K plans are made from ONE sample's grid, so the workspace of
+    a batch-B launch is exactly B times the batch-1 workspace - whereas the default plan splits a batch-8 launch less (or not
+    at all) than a batch-1 launch.  Host-side planning code of the product library: runs without a GPU."""
+    from hairfastgan_amd import _lib, _runtime
+
+    L = _lib.load()
+    shapes = [(256, 64, 16, 16, 1), (256, 256, 32, 32, 1), (512, 512, 32, 32, 2)]
+    try:
+        assert L.hf_set_batch_invariant(1) in (0, 1)
+        for cin, cout, h, w, stride in shapes:
+            one = L.hf_conv2d_f16_workspace_floats(1, cin, cout, h, w, stride, 1)
+            assert one > 0, "batch 1 must plan split-K for these shapes"
+            for b in (2, 3, 8, 48):
+                assert L.hf_conv2d_f16_workspace_floats(b, cin, cout, h, w, stride, 1) == b * one
+            g1 = L.hf_conv1x1_f16_workspace_floats(1, 768, 3072, 1, 50, 1, 1)
+            assert L.hf_conv1x1_f16_workspace_floats(4, 768, 3072, 1, 50, 1, 1) == 4 * g1 > 0
+        L.hf_set_batch_invariant(0)
+        cin, cout, h, w, stride = shapes[1]
+        one = L.hf_conv2d_f16_workspace_floats(1, cin, cout, h, w, stride, 1)
+        assert L.hf_conv2d_f16_workspace_floats(48, cin, cout, h, w, stride, 1) < 48 * one  # the default plan follows the launch
+    finally:
+        L.hf_set_batch_invariant(1 if _runtime.batch_invariant() else 0)
+    assert _runtime.plan_batch(7) == (1 if _runtime.batch_invariant() else 7)
