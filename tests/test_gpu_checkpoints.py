@@ -57,3 +57,25 @@ def test_swap_from_checkpoint_files_equals_swap_from_state_dicts(tmp_path, monke
     assert out_files.shape == (3, 1024, 1024) and torch.isfinite(out_files).all()
     assert torch.equal(out_files, out_mem)
     assert float(out_files.std()) > 1e-3  # not a constant image
+
+
+def test_check_checkpoint_tool_runs_a_whole_swap_from_files(tmp_path, capsys):
+    """tools/check_checkpoint.py --swap: the real-checkpoint validation a user runs first (f32 / f16x3 / f16 swaps from the
+    reference's files through the per-object precision switch; clamp counter, image and mask agreement) - exercised on the
+    synthetic tree: nothing clamps, the f16x3 image is fp32-class, the tool reports success."""
+    import argparse
+    import importlib.util
+    import os
+
+    from tests import ckpt_tree as T
+
+    T.write_reference_tree(str(tmp_path), _states(), clip_mode="in_checkpoint")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_checkpoint", os.path.join(root, "tools", "check_checkpoint.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    rc = tool.check_swap(argparse.Namespace(pretrained_root=str(tmp_path), images=None, seed=3))
+    text = capsys.readouterr().out
+    assert rc == 0 and "f16x3 is safe on this swap" in text, text
+    line = [ln for ln in text.splitlines() if ln.startswith("f16x3")][0]
+    assert "clamped elements 0" in line
