@@ -67,6 +67,7 @@ SIGNATURES = {
     "hf_upsample_nearest_f32": [_f, _f, _ll, _i, _i, _i, _i, _st],
     "hf_parsing_mask_i64": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _st],
     "hf_layernorm_f32": [_f, _f, _f, _f, _i, _i, _fl, _i, _fl, _st],
+    "hf_layernorm_grouped_f32": [_f, _f, _f, _f, _i, _i, _i, _fl, _i, _fl, _st],
     "hf_modulate_f32": [_f, _f, _f, _f, _ll, _i, _fl, _st],
     "hf_sample_layernorm_f32": [_f, _f, _f, _f, _i, _i, _i, _ll, _fl, _fl, _f, _ll, _st],
     "hf_pixel_norm_dim1_f32": [_f, _f, _i, _i, _i, _st],

@@ -984,12 +984,20 @@ def parsing_mask(lib, st, logits, remap, full_hw, out_hw):
     return out
 
 
-def layernorm(lib, st, x, dim, gamma=None, beta=None, eps=1e-5, lrelu=False, alpha=0.01):
-    """F.layer_norm over the trailing `dim` elements (x viewed as [rows, dim]), optional affine + LeakyReLU."""
+def layernorm(lib, st, x, dim, gamma=None, beta=None, eps=1e-5, lrelu=False, alpha=0.01, groups=1):
+    """F.layer_norm over the trailing `dim` elements (x viewed as [rows, dim]), optional affine + LeakyReLU.
+    groups > 1 (hf_layernorm_grouped_f32): gamma / beta [groups, dim], row r of the [rows, dim] view takes group r % groups."""
     x = _c(x)
     if x.numel() % dim:
         raise ValueError("dim must divide the tensor")
     out = torch.empty_like(x)
+    if groups > 1:
+        rows = x.numel() // dim
+        if rows % groups or gamma is None or tuple(gamma.shape) != (groups, dim) or (beta is not None and tuple(beta.shape) != (groups, dim)):
+            raise ValueError("grouped layernorm: rows % groups == 0 and gamma / beta [groups, dim]")
+        check(lib, lib.hf_layernorm_grouped_f32(_p(out), _p(x), _p(_c(gamma)), _p(_c(beta)), rows, dim, groups, float(eps),
+                                                1 if lrelu else 0, float(alpha), st), "hf_layernorm_grouped_f32")
+        return out
     check(lib, lib.hf_layernorm_f32(_p(out), _p(x), _p(_c(gamma)), _p(_c(beta)), x.numel() // dim, dim, float(eps),
                                     1 if lrelu else 0, float(alpha), st), "hf_layernorm_f32")
     return out

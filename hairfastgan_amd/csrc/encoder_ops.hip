@@ -326,11 +326,16 @@ __global__ __launch_bounds__(256) void pixel_norm_rows(float *__restrict__ out, 
 
 // LayerNorm over the last `dim` elements of each row (F.layer_norm: biased variance, eps inside the
 // sqrt), optional elementwise affine (gamma/beta [dim]) and LeakyReLU(alpha) on top; one block per row.
+// groups > 1: gamma / beta are [groups][dim] and row r takes those of group r % groups (several LayerNorms with different
+// affines over the columns of one stacked Linear output, viewed as [rows * groups, dim])
 __global__ __launch_bounds__(256) void layernorm_rows(float *__restrict__ out, const float *__restrict__ x,
                                                       const float *__restrict__ gamma, const float *__restrict__ beta, int dim,
-                                                      float eps, int act, float alpha) {
+                                                      float eps, int act, float alpha, int groups) {
   HF_DYN_LDS;
   float *red = reinterpret_cast<float *>(hf_dyn_lds);  // [8]
+  const long long gofs = (long long)((int)blockIdx.x % groups) * dim;
+  if (gamma) gamma += gofs;
+  if (beta) beta += gofs;
   const float *xr = x + (long long)blockIdx.x * dim;
   float *orow = out + (long long)blockIdx.x * dim;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -683,7 +688,15 @@ extern "C" int hf_layernorm_f32(float *out, const float *x, const float *gamma, 
                                 int lrelu, float alpha, void *stream) {
   if (!out || !x || rows <= 0 || dim <= 0) return HF_E_INVALID;
   hipLaunchKernelGGL(layernorm_rows, dim3(rows), dim3(256), 32, (hipStream_t)stream, out, x, gamma, beta, dim, eps, lrelu ? 1 : 0,
-                     alpha);
+                     alpha, 1);
+  return hf_launch_status();
+}
+
+extern "C" int hf_layernorm_grouped_f32(float *out, const float *x, const float *gamma, const float *beta, int rows, int dim,
+                                        int groups, float eps, int lrelu, float alpha, void *stream) {
+  if (!out || !x || rows <= 0 || dim <= 0 || groups <= 0 || (rows % groups)) return HF_E_INVALID;
+  hipLaunchKernelGGL(layernorm_rows, dim3(rows), dim3(256), 32, (hipStream_t)stream, out, x, gamma, beta, dim, eps, lrelu ? 1 : 0,
+                     alpha, groups);
   return hf_launch_status();
 }
 

@@ -499,6 +499,12 @@ int hf_dilate_erode_f32(float *dilated, float *eroded, const float *mask, long l
  * applies LeakyReLU(alpha) on top (the LayerNorm -> LeakyReLU of gamma_function / beta_function, :20-21). */
 int hf_layernorm_f32(float *out, const float *x, const float *gamma, const float *beta, int rows, int dim, float eps,
                      int lrelu, float alpha, void *stream);
+/* hf_layernorm_f32 for `groups` LayerNorms at once: x is [rows][dim] with rows % groups == 0, gamma / beta are
+ * [groups][dim] and row r takes group r % groups - the LayerNorm + LeakyReLU of the 2 x 5 gamma / beta branches of a
+ * ModulationModule stack (models/Encoders.py:20-23) over the columns of ONE stacked first Linear, viewed as
+ * [rows * groups, dim].  Same per-row arithmetic as hf_layernorm_f32. */
+int hf_layernorm_grouped_f32(float *out, const float *x, const float *gamma, const float *beta, int rows, int dim, int groups,
+                             float eps, int lrelu, float alpha, void *stream);
 /* out = x * (1 + gamma) + beta (all [n]), lrelu != 0: LeakyReLU(alpha) on top (ModulationModule.forward :29-31). */
 int hf_modulate_f32(float *out, const float *x, const float *gamma, const float *beta, long long n, int lrelu, float alpha,
                     void *stream);
