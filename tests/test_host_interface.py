@@ -275,3 +275,18 @@ def test_batch_invariant_plans_scale_with_the_batch():
     finally:
         L.hf_set_batch_invariant(1 if _runtime.batch_invariant() else 0)
     assert _runtime.plan_batch(7) == (1 if _runtime.batch_invariant() else 7)
+
+
+def test_deterministic_env_switch_reaches_the_library():
+    """HAIRFAST_DETERMINISTIC=1 is read at import and applied to the library by the first `_runtime.lib()` call (plans are
+    made inside C calls: the flag must be there before the first launch, not after the first host-side predicate)."""
+    import subprocess
+    import sys
+
+    code = ("from hairfastgan_amd import _runtime; L = _runtime.lib(); "
+            "print(int(_runtime.batch_invariant()), L.hf_set_batch_invariant(1), _runtime.plan_batch(9))")
+    for env_val, want in (("1", "1 1 1"), ("0", "0 0 9")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                           env=dict(os.environ, HAIRFAST_DETERMINISTIC=env_val), timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert r.stdout.strip().splitlines()[-1] == want, r.stdout
