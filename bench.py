@@ -63,6 +63,7 @@ GFLOP_PER_IMAGE = 148.52       # modulated-conv FLOPs of o
 GFLOP_PER_TRIPLE = 1545.0      # hot-path FLOPs of one swap (encoders + generator calls)
 GFLOP_POSTPROCESS = 774.0      # PostProcessModel (594 + 2 x 90 GFLOP)
 PMC_PROFILE = os.path.join("profiles", "pmc_traffic.json")
+PMC_PROFILE_SWAP = os.path.join("profiles", "pmc_traffic_swap.json")  # the batched swap pass (tools/make_pmc_traffic.py --between)
 
 
 def emit(out):
@@ -203,24 +204,28 @@ def swap_cpu_baseline(sd, enc, threads):
         stages[name] = round(stages.get(name, 0.0) + time.time() - t0, 3)
         return r
 
-    t_all = time.time()
+    totals = []
     with torch.inference_mode():
-        x256, img = rn(3, 3, 256, 256) * 0.5, rn(3, 3, 1024, 1024) * 0.5
-        w = timed("e4e B=3", lambda: E.e4e_forward(enc["e4e"], x256))
-        s_, fea = timed("FS encoder B=3", lambda: E.fs_encoder_test(enc["fs"], img, torch.zeros(18, 512)))
-        timed("generator 3->3 B=3", lambda: O.generator_forward(sd, s_, nz, layer_in=fea, start_layer=3, end_layer=3))
-        timed("generator 0->3 B=3", lambda: O.generator_forward(sd, w, nz, start_layer=0, end_layer=3))
-        for _ in range(2):
-            timed("generator 0->8 B=1 x2", lambda: O.generator_forward(sd, w[:1], nz))
-        w2 = timed("e4e B=2", lambda: E.e4e_forward(enc["e4e"], x256[:2]))
-        timed("generator 0->3 B=2", lambda: O.generator_forward(sd, w2, nz, start_layer=0, end_layer=3))
-        timed("generator 4->8 B=1", lambda: O.generator_forward(sd, w[:1], nz, layer_in=rn(1, 512, 32, 32), start_layer=4, end_layer=8))
-        timed("generator 5->8 B=1", lambda: O.generator_forward(sd, w[:1], nz, layer_in=rn(1, 512, 64, 64), start_layer=5, end_layer=8))
-    total = time.time() - t_all
+        for _pass in ("warm-up", "timed"):  # the first pass pays oneDNN primitive creation and the thread pool's start
+            stages.clear()
+            t_all = time.time()
+            x256, img = rn(3, 3, 256, 256) * 0.5, rn(3, 3, 1024, 1024) * 0.5
+            w = timed("e4e B=3", lambda: E.e4e_forward(enc["e4e"], x256))
+            s_, fea = timed("FS encoder B=3", lambda: E.fs_encoder_test(enc["fs"], img, torch.zeros(18, 512)))
+            timed("generator 3->3 B=3", lambda: O.generator_forward(sd, s_, nz, layer_in=fea, start_layer=3, end_layer=3))
+            timed("generator 0->3 B=3", lambda: O.generator_forward(sd, w, nz, start_layer=0, end_layer=3))
+            for _ in range(2):
+                timed("generator 0->8 B=1 x2", lambda: O.generator_forward(sd, w[:1], nz))
+            w2 = timed("e4e B=2", lambda: E.e4e_forward(enc["e4e"], x256[:2]))
+            timed("generator 0->3 B=2", lambda: O.generator_forward(sd, w2, nz, start_layer=0, end_layer=3))
+            timed("generator 4->8 B=1", lambda: O.generator_forward(sd, w[:1], nz, layer_in=rn(1, 512, 32, 32), start_layer=4, end_layer=8))
+            timed("generator 5->8 B=1", lambda: O.generator_forward(sd, w[:1], nz, layer_in=rn(1, 512, 64, 64), start_layer=5, end_layer=8))
+            totals.append(time.time() - t_all)
+    total = totals[-1]
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     return {"value": round(1.0 / total, 4), "unit": "triples/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
-            "s_per_triple": round(total, 2), "stage_s": stages, "gflop_per_triple": GFLOP_PER_TRIPLE,
-            "sample": "ONE pass (no warm-up) of the hot-path call schedule of one swap (SURVEY section 8d config 3: encoders + generator "
+            "s_per_triple": round(total, 2), "s_warmup_pass": round(totals[0], 2), "stage_s": stages, "gflop_per_triple": GFLOP_PER_TRIPLE,
+            "sample": "ONE timed pass after one untimed warm-up pass of the hot-path call schedule of one swap (SURVEY section 8d config 3: encoders + generator "
                       f"calls, 1545 GFLOP; SEAN / CLIP / BiSeNet / shape adaptor / PostProcess excluded) through the CPU oracle, "
                       f"torch.set_num_threads({threads}) = the generator baseline's fastest count"}
 
@@ -237,6 +242,34 @@ def pmc_profile(kernel):
         return round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]), k.get("mfma_busy"), doc.get("tag", "r01h")
     except (OSError, KeyError, ValueError):
         return None, None, None
+
+
+def attach_swap_pmc(rep, swap_batch, precision):
+    """Fill `traffic` / `mfma_busy_pmc` of a batched swap pass's roofline from the committed rocprofv3 --pmc passes of
+    `bench.py --workload swap256` (profiles/pmc_traffic_swap.json, cut to the timed region by the profile markers) - replayed,
+    not measured in this run, and only when that profile was taken at the same pass size and conv precision."""
+    roof = rep.get("roofline")
+    if not roof:
+        return
+    try:
+        with open(os.path.join(ROOT, PMC_PROFILE_SWAP)) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
+        return
+    if doc.get("swap_batch") != swap_batch or doc.get("conv_precision", "f16x3") != precision:
+        roof["traffic_source"] = (f"{PMC_PROFILE_SWAP} holds a {doc.get('swap_batch')}-per-pass {doc.get('conv_precision', 'f16x3')} "
+                                  f"profile, this run is {swap_batch}-per-pass {precision}: not attached")
+        return
+    k = doc.get("kernels", {}).get(roof["kernel"].replace(",split-out", ""))  # one kernel, with or without the split hand-over output
+    if k is None:
+        return
+    traffic = round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
+    src = f"{PMC_PROFILE_SWAP} (tag {doc.get('tag')}): rocprofv3 --pmc passes of bench.py --workload swap256, timed region only, replayed - NOT measured in this run"
+    roof.update({"traffic": traffic, "traffic_source": src, "mfma_busy_pmc": k.get("mfma_busy"),
+                 "mfma_busy_pmc_source": src if k.get("mfma_busy") is not None else None,
+                 "pmc_launches_averaged": k.get("launches"), "pmc_avg_launch_us_kernel_trace": k.get("avg_us")})
+    if roof.get("algorithmic_bytes_per_launch"):
+        roof["traffic_over_algorithmic"] = round(traffic / roof["algorithmic_bytes_per_launch"], 3)
 
 
 def swap_schedule_bench(g, sd, dev, n_triples):
@@ -281,6 +314,40 @@ def make_triple_loader(n_pool=8):
             imgs.append(im.pin_memory() if torch.cuda.is_available() else im)
         pool.append(tuple(imgs))
     return lambda i: pool[i % n_pool]
+
+
+def verify_gathered(hf, images, load, dev, n_total, rank, world, pass_size, groups=(0, -1)):
+    """Outside the timed region: the uint8 images `parallel.swap_many` returned for this rank's first / last batched pass
+    against a DIRECT `HairFast.swap_batch` call on the same triples (same seed -> same noise draws): equal bit for bit, or
+    the line says by how much not.  The comparison with single `HairFast.swap` calls, stage by stage, at this pass size is
+    tests/test_gpu_schedule.py::test_swap_batch_at_the_timed_pass_size_equals_single_swaps."""
+    from hairfastgan_amd import parallel
+
+    lo, hi = parallel.shard_range(n_total, rank, world)
+    starts = list(range(lo, hi, pass_size))
+    picked = sorted({starts[g] for g in groups if starts})
+    worst, n_cmp, unequal = 0, 0, 0
+    with torch.inference_mode():
+        for g0 in picked:
+            idx = list(range(g0, min(g0 + pass_size, hi)))
+            trip = [tuple(t.to(dev) for t in load(i)) for i in idx]
+            direct = hf.swap_batch(trip) if len(trip) > 1 and pass_size > 1 else [hf.swap(*tr) for tr in trip]
+            for i, img in zip(idx, direct):
+                ref = parallel.to_uint8_image(img * 2.0 - 1.0)
+                d = int((ref.to(torch.int16) - images[i].to(ref.device).to(torch.int16)).abs().max())
+                worst, n_cmp, unequal = max(worst, d), n_cmp + 1, unequal + (d != 0)
+            del trip, direct
+    return {"passes_checked_first_triple": picked, "images_compared": n_cmp, "images_differing": unequal,
+            "max_abs_diff_uint8_levels": worst, "equal": unequal == 0,
+            "what": "gathered uint8 images of the timed swap_many call vs direct HairFast.swap_batch calls on the same triples "
+                    f"({pass_size} per pass), outside the timed region"}
+
+
+def auto_swap_batch(n_total, world, cap=32):
+    """Triples per batched pass when --swap-batch 0: half the rank's shard (so that every rank has at least two passes - the
+    H2D prefetch of pass 2 and the all-gather of pass 1 then overlap compute), capped at the throughput plateau (32)."""
+    per_rank = -(-n_total // world)
+    return max(1, min(cap, -(-per_rank // 2)))
 
 
 def kernel_report(prof, elapsed, precision, sampled=1.0, pmc=True):
@@ -431,8 +498,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (generator workload)")
     ap.add_argument("--workload", choices=("generator", "swap256", "launch-check"), default="generator")
     ap.add_argument("--triples", type=int, default=256, help="swap256: triples of the whole job")
-    ap.add_argument("--swap-batch", type=int, default=32,
-                    help="swap256: triples per batched pass over the hot path (HairFast.swap_batch); 1 = one HairFast.swap per triple. "
+    ap.add_argument("--swap-batch", type=int, default=0,
+                    help="swap256: triples per batched pass over the hot path (HairFast.swap_batch); 1 = one HairFast.swap per triple; "
+                         "0 (default) = auto: min(32, half the rank's shard) - 32 on 1-4 GPUs for 256 triples, 16 on 8 (two passes "
+                         "per rank, so that copy-in and gather overlap compute). "
                          "Measured on resident inputs (tools/probes/swap_batch_sizes.py, round 4): 1: 29 triples/s, 4: 54, 8: 64, "
                          "16: 70.6 (22.6 GiB), 32: 72.9 (32.1 GiB), 48: 72.4, 64: 72.8 (50.9 GiB) - a plateau from 32, which is "
                          "also one pass per rank for 256 triples on 8 GPUs")
@@ -441,6 +510,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the fp32-MFMA comparison run (profiling)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="swap workloads: skip the comparison of gathered images with direct swap_batch calls")
     ap.add_argument("--event-every", type=int, default=4,
                     help="generator workload: bracket the launches of every N-th timed step with HIP events (1 = every step)")
     ap.add_argument("--pipeline-triples", type=int, default=256,
@@ -456,6 +526,7 @@ def main():
 
     from hairfastgan_amd import _marshal, _runtime, parallel
 
+    swap_batch_auto = args.swap_batch <= 0
     if args.precision:
         _runtime.set_conv_precision(args.precision)
     precision = _runtime.conv_precision()
@@ -498,6 +569,8 @@ def main():
 
     # =========================== workload swap256 (BASELINE.json configs[3]) ===========================
     if args.workload == "swap256":
+        if swap_batch_auto:
+            args.swap_batch = auto_swap_batch(args.triples, world)
         hf = build_hairfast(sd, dev)
         load = make_triple_loader()
         with torch.inference_mode():
@@ -508,6 +581,9 @@ def main():
         barrier()
         prof = None if args.no_kernel_events else []
         _marshal.PROFILE = prof
+        # hf_profile_marker_kernel dispatches bracket the timed region: tools/summarize_prof.py / make_pmc_traffic.py cut
+        # rocprofv3's per-dispatch tables to it (warm-up and plan-time kernels - weight splits, conv_prepare - excluded)
+        _runtime.lib().hf_profile_marker(1, _runtime.stream())
         t0 = time.perf_counter()
         st256 = {}
         images, n_local = parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), args.triples, load, device=dev,
@@ -515,8 +591,10 @@ def main():
                                              stats=st256)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        _runtime.lib().hf_profile_marker(2, _runtime.stream())
         _marshal.PROFILE = None
         assert images.shape == (args.triples, 3, 1024, 1024) and images.dtype == torch.uint8
+        verified = None if args.no_verify else verify_gathered(hf, images, load, dev, args.triples, rank, world, args.swap_batch)
         if rank == 0:
             out = {"metric": "hair_swap_triples_per_sec", "value": round(args.triples / elapsed, 3), "unit": "triples/s",
                    "n_gpus": world, "ranks_observed": ranks_observed, "steps": args.triples, "warmup": max(1, args.warmup),
@@ -536,9 +614,11 @@ def main():
                               "gather": "RCCL all_gather_into_tensor of uint8 images per 8 local triples (async)" if use_dist else "single process: no collective"},
                    "algorithmic_tflops_hot_path": round(args.triples * (GFLOP_PER_TRIPLE + GFLOP_POSTPROCESS) / elapsed / 1e3, 2),
                    "gflop_per_triple": GFLOP_PER_TRIPLE + GFLOP_POSTPROCESS,
-                   "balance": balance_report(st256, cpu_slice)}
+                   "balance": balance_report(st256, cpu_slice), "verified": verified}
             if prof:
-                out.update(kernel_report(prof, elapsed, precision))
+                rep = kernel_report(prof, elapsed, precision, pmc=False)
+                attach_swap_pmc(rep, args.swap_batch, precision)
+                out.update(rep)
             emit(out)
         if use_dist:
             dist.barrier()
@@ -652,6 +732,9 @@ def main():
             enc_states = encoder_states()
             hf = build_hairfast(sd, dev, enc_states)
             load = make_triple_loader(2)
+            n_pipe = max(args.pipeline_triples, world)
+            if swap_batch_auto:
+                args.swap_batch = auto_swap_batch(n_pipe, world)
             with torch.inference_mode():
                 hf.swap(*[t.to(dev) for t in load(0)])
                 if args.swap_batch > 1:
@@ -659,13 +742,14 @@ def main():
             barrier()
             # BASELINE.json configs[3] at its own size, strong-scaled: --pipeline-triples (default 256) triples of the WHOLE job,
             # block-partitioned over the ranks - the driver's plain `bench.py --gpus N` yields the triples/s curve
-            n_pipe = max(args.pipeline_triples, world)
             st_pipe = {}
             t0 = time.perf_counter()
-            parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), n_pipe, load, device=dev, batch=args.swap_batch,
-                               swap_batch_fn=hf.swap_batch if args.swap_batch > 1 else None, stats=st_pipe)
+            pipe_images, _ = parallel.swap_many(lambda a, b, c: hf.swap(a, b, c), n_pipe, load, device=dev, batch=args.swap_batch,
+                                                swap_batch_fn=hf.swap_batch if args.swap_batch > 1 else None, stats=st_pipe)
             barrier()
             tp = max_over_ranks(time.perf_counter() - t0)
+            pipe_verified = None if args.no_verify else verify_gathered(hf, pipe_images, load, dev, n_pipe, rank, world, args.swap_batch)
+            del pipe_images
             # the kernels of one batched pass under their roofs: every conv / GEMM launch bracketed by HIP events
             pipe_roof = None
             if not args.no_kernel_events and args.swap_batch > 1:
@@ -679,6 +763,7 @@ def main():
                 t_pass = time.perf_counter() - t1
                 _marshal.PROFILE = None
                 pipe_roof = kernel_report(evp, t_pass, precision, pmc=False)
+                attach_swap_pmc(pipe_roof, args.swap_batch, precision)
                 pipe_roof.pop("kernels", None)
                 pipe_roof["pass_ms_with_events"] = round(t_pass * 1e3, 2)
                 del trip
@@ -728,6 +813,7 @@ def main():
             pipeline_info = {"metric": "hair_swap_triples_per_sec", "value": round(n_pipe / tp, 3), "unit": "triples/s",
                              "ms_per_triple_per_gpu": round(tp / (n_pipe / world) * 1e3, 2), "triples": n_pipe,
                              "scaling": "strong", "swap_batch": args.swap_batch, "balance": balance_report(st_pipe, cpu_slice),
+                             "verified": pipe_verified,
                              "algorithmic_tflops_hot_path": round(n_pipe * (GFLOP_PER_TRIPLE + GFLOP_POSTPROCESS) / tp / 1e3 / world, 2),
                              "single_swap": {"ms_per_swap": round(ts / (n_single / world) * 1e3, 2), "triples": n_single,
                                              "note": "one HairFast.swap per triple (no batching across triples)"},

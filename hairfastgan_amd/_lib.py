@@ -90,6 +90,7 @@ SIGNATURES = {
     "hf_set_batch_invariant": [_i],
     "hf_set_splitk_counters": [_f, _i],
     "hf_modconv3x3_f16_rgb_slabs": [_i],
+    "hf_profile_marker": [_i, _st],
 }
 
 

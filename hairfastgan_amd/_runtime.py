@@ -1,5 +1,6 @@
 """Device / stream plumbing shared by the public ops."""
 import os
+import threading
 
 import torch
 
@@ -46,16 +47,21 @@ def require_gpu(*tensors):
 SPLITK_COUNTER_INTS = 1 << 16
 _splitk_inkernel = os.environ.get("HAIRFAST_SPLITK_INKERNEL", "0") not in ("", "0")
 _counter_bufs = {}
-_counter_key = None
+# which (device, stream) buffer the CALLING THREAD last registered: the library keeps the pointer in thread_local storage
+# (hf_set_splitk_counters), so the Python-side memo is per thread as well - a second thread launching on the same stream
+# registers for itself instead of silently taking the two-launch form
+_counter_tls = threading.local()
+_counter_epoch = [0]  # bumped by set_splitk_inkernel: every thread re-registers (or, switched off, never registers again)
 
 
 def set_splitk_inkernel(on):
     """Process-wide switch of the in-kernel split-K reduction (returns the previous setting); off = every split-K launch is
     followed by the splitk_reduce kernel.  Results are bit-identical either way."""
-    global _splitk_inkernel, _counter_key
+    global _splitk_inkernel
     prev, _splitk_inkernel = _splitk_inkernel, bool(on)
-    _counter_key = None
-    if not on:
+    _counter_epoch[0] += 1
+    _counter_tls.key = None
+    if not on:  # clears the calling thread's pointer; other threads' pointers are dropped the next time they ask for a stream
         lib().hf_set_splitk_counters(None, 0)
     return prev
 
@@ -63,17 +69,19 @@ def set_splitk_inkernel(on):
 def stream():
     """Raw hipStream_t of torch's current stream (kernels are enqueued asynchronously on it,
     like the reference's at::cuda::getCurrentCUDAStream(), upfirdn2d_kernel.cu:213-215)."""
-    global _counter_key
     s = torch.cuda.current_stream()
     raw = s.cuda_stream
     if _splitk_inkernel:
-        key = (s.device_index, raw)
-        if key != _counter_key:
-            buf = _counter_bufs.get(key)
+        key = (s.device_index, raw, _counter_epoch[0])
+        if key != getattr(_counter_tls, "key", None):
+            buf = _counter_bufs.get(key[:2])
             if buf is None:
-                buf = _counter_bufs[key] = torch.zeros(SPLITK_COUNTER_INTS, dtype=torch.int32, device=s.device)
+                buf = _counter_bufs[key[:2]] = torch.zeros(SPLITK_COUNTER_INTS, dtype=torch.int32, device=s.device)
             lib().hf_set_splitk_counters(buf.data_ptr(), SPLITK_COUNTER_INTS)
-            _counter_key = key
+            _counter_tls.key = key
+    elif getattr(_counter_tls, "key", None) is not None:  # switched off by another thread: drop this thread's pointer too
+        lib().hf_set_splitk_counters(None, 0)
+        _counter_tls.key = None
     return raw
 
 

@@ -65,9 +65,15 @@ def load_file(path, what, root=None):
                 return torch.load(str(p), map_location="cpu", weights_only=True, mmap=True)
             except (RuntimeError, ValueError):  # torch < 1.6 legacy (non-zip) files cannot be mapped
                 return torch.load(str(p), map_location="cpu", weights_only=True)
-    except pickle.UnpicklingError:
-        # the reference's plain torch.load (torch 1.13) unpickles arbitrary objects; these are the user's own files
-        warnings.warn(f"{p}: not loadable with weights_only=True, falling back to full unpickling as the reference does")
+    except pickle.UnpicklingError as e:
+        # The reference's plain torch.load (torch 1.13) unpickles arbitrary objects - i.e. runs arbitrary code from the file.
+        # Not by default here: only with an explicit opt-in for files the user trusts.
+        if os.environ.get("HAIRFAST_UNSAFE_LOAD", "0") in ("", "0"):
+            raise pickle.UnpicklingError(
+                f"{what}: '{p}' does not load with torch.load(weights_only=True): {e}  The file pickles objects beyond tensors / "
+                f"containers / argparse.Namespace; loading it would execute code from the file.  If you trust it, set "
+                f"HAIRFAST_UNSAFE_LOAD=1 (full unpickling, what the reference's torch.load does), or re-save its state dicts.") from e
+        warnings.warn(f"{p}: HAIRFAST_UNSAFE_LOAD=1 - full unpickling (weights_only=False) as the reference does")
         return torch.load(str(p), map_location="cpu", weights_only=False)
 
 

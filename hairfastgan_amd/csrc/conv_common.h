@@ -107,7 +107,12 @@ __device__ __forceinline__ GroupOfs group_offsets(const ConvParams &P) {
   return go;
 }
 
+// (`#pragma clang fp contract(on)` at the head of the two bodies below: clang applies FP contraction lexically, so a
+// pragma in the CALLER does not reach these inlined bodies - without it hipcc's default `fast` contraction may fuse
+// `v * d + bias` differently in the unrolled and in the remainder iterations of a grid-stride loop, which is the
+// batch-size-dependent rounding the batch-invariant plans exclude.)
 __device__ __forceinline__ float apply_act(float v, int act, float alpha, float scale, float slope) {
+#pragma clang fp contract(on)
   if (act == ACT_LRELU) return hf_lrelu(v, alpha, scale);
   if (act == ACT_PRELU) return v > 0.0f ? v : v * slope;
   if (act == ACT_QGELU) return v / (1.0f + expf(-1.702f * v));
@@ -120,6 +125,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha, float 
 // two give identical bits.  i = element index in out / a slab, b = image, gc = group*cout + channel, pix = Y*out_w + X.
 __device__ __forceinline__ float splitk_finish(const ConvParams &P, long long i, long long b, long long gc, long long pix,
                                                float nw, bool with_epilogue) {
+#pragma clang fp contract(on)
   float v = 0.0f;
   for (int z = 0; z < P.splits; ++z) v += P.partial[(long long)z * P.zslab + i];
   if (P.d) v *= P.d[b * P.d_bstride + gc];

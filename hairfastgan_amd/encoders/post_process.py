@@ -2,8 +2,9 @@
 models/Encoders.py:106-137 (`PostProcessModel`), :13-32 (`ModulationModule`), :35-57
 (`FeatureiResnet`) and models/Net.py:396-477 (`FeatureEncoderMult(fs_layers=[9])`) - and, built from the same
 ModulationModule, the two latent-space models of row f4: `RotateModel` (:60-72, complete) and
-`ClipBlendingModel` (:75-103: its own parameters; the CLIP ViT-B/32 image tower it embeds the two images with is an
-un-vendored dependency of the reference - `clip @ git+...`, requirements.txt:6 - and stays an injected callable).
+`ClipBlendingModel` (:75-103: its own parameters; the CLIP ViT-B/32 image tower it embeds the two images with - an
+un-vendored dependency of the reference, `clip @ git+...`, requirements.txt:6 - runs natively too since round 3:
+hairfastgan_amd/clip_vit.py, handed in as `clip_image_embed`).
 
 It sits immediately before the last generator call of a swap (models/Blending.py:66-68):
 `S_final, F_final = post_process(I_1, I_blend_256)`, then `generator([S_final], start_layer=5,
@@ -80,12 +81,27 @@ class FeatureEncoderMult(FrozenPlanMixin, nn.Module):  # models/Net.py:396-477 w
 _STACK_GENERATION = [0]  # bumped by every ModulationModule.load_state_dict (see modulation_stack)
 
 
+def _bump_stack_generation(_module, _incompatible_keys):  # a module-level function: a lambda hook would make the module unpicklable
+    _STACK_GENERATION[0] += 1
+
+
+def _param_version(p):
+    """What tells a stacked copy of `p` is stale: the storage, the dtype and the in-place update counter (inference tensors
+    have none: they cannot be updated in place).  Writes through `param.data` bypass autograd's counters by design and
+    stay invisible here as anywhere else in torch: bump `_STACK_GENERATION[0]` after such a write."""
+    try:
+        ver = p._version
+    except RuntimeError:
+        ver = None
+    return (p.data_ptr(), p.dtype, ver)
+
+
 class ModulationModule(nn.Module):  # models/Encoders.py:13-32
     def __init__(self, layernum, last=False, inp=512, middle=512):
         super().__init__()
         # modulation_stack caches stacked copies of the branch weights on the stack's first module: a load into ANY
         # ModulationModule outdates every cached stack (the generation counter below)
-        self.register_load_state_dict_post_hook(lambda mod, _keys: _STACK_GENERATION.__setitem__(0, _STACK_GENERATION[0] + 1))
+        self.register_load_state_dict_post_hook(_bump_stack_generation)
         self.layernum, self.last = layernum, last
         self.fc = nn.Linear(512, 512)
         self.norm = nn.LayerNorm([layernum, 512], elementwise_affine=False)
@@ -124,9 +140,12 @@ def modulation_stack(mods, x, embedding):
     mods = list(mods)
     head = mods[0]
     plan = head.__dict__.get("_stack_plan")
-    key = (tuple(id(m) for m in mods), _STACK_GENERATION[0], mods[0].fc.weight.device)
+    branches = [f for m in mods for f in (m.gamma_function, m.beta_function)]
+    # the stacked copies follow their sources: module identities, load_state_dict, and - per stacked parameter - storage,
+    # dtype and in-place version (param.data.copy_, .half(), an optimizer step, a sub-module's _load_from_state_dict)
+    key = (tuple(id(m) for m in mods), _STACK_GENERATION[0], mods[0].fc.weight.device,
+           tuple(_param_version(p) for f in branches for p in (f[0].weight, f[0].bias, f[1].weight, f[1].bias)))
     if plan is None or plan["key"] != key:
-        branches = [f for m in mods for f in (m.gamma_function, m.beta_function)]
         plan = {"key": key,
                 "w1": torch.cat([f[0].weight.detach() for f in branches], 0).contiguous(),
                 "b1": torch.cat([f[0].bias.detach() for f in branches], 0).contiguous(),

@@ -161,6 +161,27 @@ def equal_replacer(images):
     return images
 
 
+def _to_tensor_like_torchvision(arr):
+    """torchvision.transforms.functional.to_tensor for arrays (hair_swap.py:81-82): HWC (or HW) -> CHW; uint8 -> float32 / 255
+    ON THE CPU (torch's GPU division is a multiplication by the rounded reciprocal: one ulp away), other dtypes unchanged."""
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    if arr.ndim != 3:
+        raise ValueError(f"image arrays are HW or HWC, got shape {arr.shape}")
+    t = torch.from_numpy(np.array(arr.transpose(2, 0, 1), order="C"))  # a copy: PIL hands out read-only buffers
+    return t.to(torch.float32).div(255) if t.dtype is torch.uint8 else t
+
+
+def _read_image_rgb(path):
+    """torchvision.io.read_image(path, mode=ImageReadMode.RGB) (hair_swap.py:85-86): the decoded file as uint8 [3,H,W]."""
+    try:
+        from PIL import Image
+    except ImportError as e:  # pragma: no cover - PIL is in the image
+        raise ImportError(f"reading image file {path!r} needs Pillow (pass a tensor, an array or a .npy file otherwise)") from e
+    with Image.open(path) as im:
+        return torch.from_numpy(np.asarray(im.convert("RGB")).transpose(2, 0, 1).copy())
+
+
 def set_seed(seed):  # utils/seed.py:8-16
     torch.manual_seed(seed)
     if torch.cuda.is_available():
@@ -615,7 +636,10 @@ class HairFast:
       pretrained_root directory the checkpoint paths are relative to (default: cwd / HAIRFAST_PRETRAINED_ROOT)
       stages          a `Stages` object supplying rotate / shape_adaptor / sean_inpaint / blend (e.g. the reference's own
                       modules); networks whose state dicts are passed below still run natively, the
-                      files of the others are then NOT read
+                      files of the other STAGE networks (SEAN, shape adaptor, RotateModel, ClipBlendingModel) are then NOT
+                      read.  Independent of `stages`: the generator, both encoders, BiSeNet and PostProcessModel always
+                      come from their files (args.ckpt, args.pp_checkpoint + PostProcess/latent_avg.pt, ...) unless
+                      their own state dicts (generator_state, e4e_state, fs_state, bisenet_state, pp_state + pp_latent_avg) are given
       generator_state {'g_ema': ..., 'latent_avg': ...} instead of args.ckpt
       e4e_state + e4e_latent_avg / fs_state + fs_dlatent_avg   encoder state dicts with their average latents
       pp_state + pp_latent_avg    PostProcessModel ('model_state_dict' of args.pp_checkpoint; PostProcess/latent_avg.pt)
@@ -634,19 +658,28 @@ class HairFast:
 
     @staticmethod
     def _as_tensor(img, cache=None):
-        """torch.Tensor [3,H,W] (uint8 or float in [0,1]), numpy HWC uint8 array, or the path of a .npy array (image
-        decoding libraries are not part of this backend)."""
+        """The image forms of the reference's `swap` (hair_swap.py:79-92): torch.Tensor [3,H,W] (uint8 or float in [0,1])
+        as is; `PIL.Image.Image` and numpy HWC arrays with `F.to_tensor`'s semantics (uint8 -> CHW float / 255 on the CPU;
+        other dtypes keep their values); a `Path` / `str` is read once per call - an image file through PIL (the
+        reference's `read_image(path, mode=ImageReadMode.RGB)`: uint8 [3,H,W]), a `.npy` file as the array it holds.
+        PIL is imported lazily: tensors and arrays never need it."""
+        if isinstance(img, torch.Tensor):
+            return img
         if isinstance(img, np.ndarray):
-            return torch.from_numpy(img).permute(2, 0, 1) if img.ndim == 3 and img.shape[-1] == 3 else torch.from_numpy(img)
+            return _to_tensor_like_torchvision(img)
         if isinstance(img, (Path, str)):
             cache = cache if cache is not None else {}
             if img not in cache:
-                arr = np.load(str(img))
-                cache[img] = torch.from_numpy(arr).permute(2, 0, 1) if arr.shape[-1] == 3 else torch.from_numpy(arr)
+                if str(img).endswith(".npy"):
+                    arr = np.load(str(img))
+                    cache[img] = torch.from_numpy(arr).permute(2, 0, 1).contiguous() if arr.ndim == 3 and arr.shape[-1] == 3 else torch.from_numpy(arr)
+                else:
+                    cache[img] = _read_image_rgb(str(img))
             return cache[img]
-        if not isinstance(img, torch.Tensor):
-            raise TypeError(f"Unsupported image format {type(img)}")
-        return img
+        if type(img).__module__.split(".")[0] == "PIL":  # PIL.Image.Image (any subclass), without importing PIL for other inputs
+            arr = np.asarray(img)  # to_tensor: one channel per band; mode "1" is 0 / 255, "I" / "I;16" / "F" keep their values
+            return _to_tensor_like_torchvision(arr.astype(np.uint8) * 255 if img.mode == "1" else arr)
+        raise TypeError(f"Unsupported image format {type(img)}")
 
     def __init__(self, args, *, stages=None, generator_state=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
                  fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None, bisenet_state=None, rotate_state=None,
@@ -665,7 +698,9 @@ class HairFast:
         if stages is None:  # the reference's constructor: everything from files unless handed over in memory
             self.stages = native_stages(args, root=root, **given)
         elif any(given[k] is not None for k in ("rotate_state", "blend_state", "shape_state", "sean_state")):
-            self.stages = native_stages(args, which=(), base=stages, root=root, **given)
+            # nothing is read from files for the stages `stages` supplies - except the CLIP tower a given blend_state needs
+            # (its state dict or callable not passed): checkpoint / ~/.cache/clip, as in the default path above
+            self.stages = native_stages(args, which=("blend",) if blend_state is not None else (), base=stages, root=root, **given)
         else:
             self.stages = stages
         self.net = Net(args, state=generator_state, root=root)
@@ -715,8 +750,8 @@ class HairFast:
                                              [tuple(key(t, n) for n in ("face", "shape", "color")) for t in range(T)], **kwargs)
 
     def swap(self, face_img, shape_img, color_img, benchmark=False, align=False, seed=None, exp_name=None, **kwargs):
-        """hair_swap.py:63-103.  Images: torch.Tensor [3,H,W] (uint8 or float in [0,1]), numpy HWC
-        uint8 arrays, or file paths of .npy arrays (image decoding libraries are not part of this backend).
+        """hair_swap.py:63-103.  Images: torch.Tensor [3,H,W] (uint8 or float in [0,1]), `PIL.Image.Image`, numpy HWC
+        arrays, or file paths (image files decoded through PIL like the reference's `read_image(..., RGB)`; `.npy` arrays).
 
         Randomness: `seed` (default 3407, utils/seed.py:19) makes a swap reproducible on THIS backend; it does not
         reproduce a seeded run of the reference sample for sample: the per-layer noise of a generator forward is one draw

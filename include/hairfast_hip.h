@@ -655,6 +655,10 @@ int hf_set_batch_invariant(int on);
  * the second kernel, whichever block is last) and finishes the tile; every launch leaves the buffer zero.  Launches with
  * more output tiles than counters, and the transposed forms, keep the two-kernel form.  NULL unregisters. */
 int hf_set_splitk_counters(void *zeroed_ints, int n_ints);
+/* Profiling aid (ABI 11; no reference counterpart - the reference's harness is a wall-clock decorator, utils/time.py:9-36):
+ * launches the empty kernel `hf_profile_marker_kernel` with id + 1 workgroups (0 <= id <= 1023) on `stream`.  Placed
+ * around a region, it lets rocprofv3's per-dispatch tables be cut to that region (tools/summarize_prof.py --between). */
+int hf_profile_marker(int id, void *stream);
 
 #ifdef __cplusplus
 }

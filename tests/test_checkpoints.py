@@ -163,3 +163,53 @@ def test_loader_refuses_wrong_wrappers(tmp_path):
     with pytest.raises(KeyError, match="encoder"):
         CK.e4e(path=str(tmp_path / "e.pt"))
     np.save(tmp_path / "x.npy", np.zeros(3))
+
+
+class _NotAWeight:  # a global that torch.load(weights_only=True) refuses
+    def __init__(self):
+        self.x = 1
+
+
+def test_full_unpickling_is_opt_in(tmp_path, monkeypatch):
+    """Round-4 advisor: a checkpoint that fails safe loading is NOT silently unpickled (arbitrary code execution): the
+    loader raises, naming the file and the opt-in; HAIRFAST_UNSAFE_LOAD=1 restores the reference's plain torch.load."""
+    import pickle
+
+    p = tmp_path / "odd.pth"
+    torch.save({"model_state_dict": {"w": torch.ones(2)}, "extra": _NotAWeight()}, p)
+    monkeypatch.delenv("HAIRFAST_UNSAFE_LOAD", raising=False)
+    with pytest.raises(pickle.UnpicklingError, match="HAIRFAST_UNSAFE_LOAD=1") as err:
+        CK.load_file(str(p), "RotateModel")
+    assert "odd.pth" in str(err.value)
+    monkeypatch.setenv("HAIRFAST_UNSAFE_LOAD", "1")
+    with pytest.warns(UserWarning, match="full unpickling"):
+        got = CK.load_file(str(p), "RotateModel")
+    assert torch.equal(got["model_state_dict"]["w"], torch.ones(2)) and isinstance(got["extra"], _NotAWeight)
+
+
+def test_modulation_stack_plan_follows_in_place_updates():
+    """Round-4 advisor: the stacked copies of the first Linears / LayerNorms are re-made when a source parameter is
+    updated in place, re-typed or re-loaded through a sub-module (key = storage, dtype, version), and the
+    load_state_dict hook is a module-level function (a lambda would make torch.save(module) fail)."""
+    import io
+    import pickle
+
+    from hairfastgan_amd.encoders import post_process as PPM
+
+    m = PPM.ModulationModule(6)
+    pickle.dumps(m)  # picklable with its hook
+    torch.save(m, io.BytesIO())
+    p = m.gamma_function[0].weight
+    k0 = PPM._param_version(p)
+    with torch.no_grad():
+        p.mul_(2.0)  # what an optimizer step / param.copy_ does (writes through `.data` bypass every version counter)
+    assert PPM._param_version(p) != k0
+    k1 = PPM._param_version(p)
+    m.gamma_function[0].load_state_dict(m.gamma_function[0].state_dict())  # a sub-module load: no ModulationModule hook fires
+    assert PPM._param_version(p) != k1
+    gen = PPM._STACK_GENERATION[0]
+    m.load_state_dict(m.state_dict())
+    assert PPM._STACK_GENERATION[0] == gen + 1
+    with torch.inference_mode():
+        t = torch.ones(3)
+    assert PPM._param_version(t)[2] is None  # inference tensors carry no version counter

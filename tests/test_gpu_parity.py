@@ -47,7 +47,7 @@ def test_native_library_is_loaded():
     from hairfastgan_amd import _lib
 
     lib = _lib.load()
-    assert lib.hf_abi_version() == 10
+    assert lib.hf_abi_version() == 11
     maps = open("/proc/self/maps").read()
     assert "libhairfast_hip.so" in maps
 

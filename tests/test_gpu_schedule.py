@@ -272,6 +272,92 @@ def test_swap_batch_equals_single_swaps_in_batch_invariant_mode():
         _runtime.set_batch_invariant(prev)
 
 
+def _stagewise(both, one, t, tol=None):
+    """Triple t of a recorded `swap_batch` run against a recorded single `swap` of the same triple, stage by stage:
+    -> (mask index differences per stage, max-abs differences per tensor).  tol: assert every tensor within tol * scale."""
+    flips, exact = {}, {}
+
+    def diff(a, b, what):
+        err, scale = float((a - b).abs().max()), max(1.0, float(b.abs().max()))
+        exact[what] = err
+        if tol is not None:
+            assert err <= tol * scale, (f"triple {t}", what, err, scale)
+
+    for n in ("face", "shape", "color"):
+        eb, es = both["embed"][(t, n)], one["embed"][n]
+        flips[f"mask_{n}"] = int((eb["mask"] != es["mask"]).sum())
+        for k in ("W", "S", "F"):
+            diff(eb[k], es[k], f"{n}/{k}")
+    flips["rot_masks"] = int((both["parses"][1][2 * t:2 * t + 2] != one["parses"][1]).sum())
+    flips["target_masks"] = int((both["targets"][0][2 * t:2 * t + 2] != one["targets"][0]).sum())
+    diff(both["calls"][2]["latent"][2 * t:2 * t + 2], one["calls"][2]["latent"], "rotated_latents")
+    diff(both["calls"][2]["out"][2 * t:2 * t + 2], one["calls"][2]["out"], "rotated_images")
+    diff(torch.stack(list(both["sean"][0][2 * t:2 * t + 2])), torch.stack(list(one["sean"][0])), "sean")
+    diff(both["align"][0][t]["latent_F_align"], one["align"][0][0]["latent_F_align"], "latent_F_align")
+    flips["HM_X"] = int((both["align"][0][t]["HM_X"] != one["align"][0][0]["HM_X"]).sum())
+    for ci, what in ((4, "blend"), (5, "final")):
+        diff(both["calls"][ci]["latent"][t:t + 1], one["calls"][ci]["latent"], f"S_{what}")
+        diff(both["calls"][ci]["layer_in"][t:t + 1], one["calls"][ci]["layer_in"], f"F_{what}")
+    diff(both["result"][t], one["result"], "final_image")
+    return flips, exact
+
+
+def test_swap_batch_at_the_timed_pass_size_equals_single_swaps():
+    """The configuration `bench.py`'s swap number is timed on (round-4 verdict, missing #2): `swap_batch` with **32 triples
+    per pass** (BASELINE.json configs[3]: 32 per GPU; e4e at batch 96, generator 0->8 at 64, PostProcess at 64) over an
+    8-triple pool, four of the 32 results - distinct pool entries at distinct batch positions - against single `swap`
+    calls STAGE BY STAGE: every latent / feature / image within 1e-4 of scale, every mask index difference counted.
+    Default mode: the masks of the input images equal, near-tie flips of the generated images' masks / the shape adaptor's
+    label maps bounded (teacher forcing keeps them out of the later stages' comparisons, as in the 2-triple test above).
+    Batch-invariant mode: 0 flips without teacher forcing and every tensor upstream of an argmax bit-equal."""
+    from hairfastgan_amd import _runtime
+
+    dev = torch.device("cuda:0")
+    hf = _hairfast(dev)
+    with torch.no_grad():
+        for name, p in hf.net.generator.named_parameters():
+            if name.endswith("noise.weight"):
+                p.zero_()
+    hf.stages.sean_model.netG.noise_source = lambda d, sizes: [torch.zeros(d, r, r, device=dev) for r in sizes]
+    a, b, c = (im.to(dev) for im in C.pipeline_images())
+    im = [a, b, c, a.flip(-1).contiguous(), b.flip(-1).contiguous(), c.flip(-1).contiguous(),
+          a.flip(-2).contiguous(), b.flip(-2).contiguous(), c.flip(-2).contiguous()]
+    pool = [(im[0], im[1], im[2]), (im[5], im[6], im[4]), (im[3], im[2], im[7]), (im[8], im[0], im[4]),
+            (im[1], im[5], im[6]), (im[7], im[3], im[0]), (im[2], im[8], im[3]), (im[4], im[7], im[1])]
+    PASS = 32
+    triples = [pool[i % 8] for i in range(PASS)]
+    picked = [0, 11, 21, 30]  # pool entries 0, 3, 5, 6 at four different places of the pass
+    for invariant in (False, True):
+        prev = _runtime.set_batch_invariant(invariant)
+        try:
+            both = _recorded(hf, lambda: hf.swap_batch(triples, seed=3))
+            assert [c["sig"] for c in both["calls"]] == [(3 * PASS, 3, 3), (3 * PASS, 0, 3), (2 * PASS, 0, 8), (2 * PASS, 0, 3),
+                                                         (PASS, 4, 8), (PASS, 5, 8)]
+            assert len(both["result"]) == PASS
+            # the same triple at another batch position of the same pass: equal images up to batch-position effects
+            for i in (8, 16, 24):
+                assert float((both["result"][i] - both["result"][0]).abs().max()) <= (0.0 if invariant else 1e-4)
+            for t in picked:
+                forced = None if invariant else both["targets"][0][2 * t:2 * t + 2]
+                one = _recorded(hf, lambda: hf.swap(*triples[t], seed=3), force_targets=forced)
+                flips, exact = _stagewise(both, one, t, tol=1e-4)
+                print(f"{PASS} per pass, batch-invariant={invariant}, triple {t}: mask index differences {flips}; "
+                      f"worst max-abs {max(exact.values()):.3g} ({max(exact, key=exact.get)})")
+                assert all(v == 0 for k, v in flips.items() if k.startswith("mask_")), flips
+                assert flips["HM_X"] == 0, flips
+                if invariant:
+                    assert all(v == 0 for v in flips.values()), flips
+                    upstream = [k for k in exact if k.endswith("/W") or k.startswith("rotated")]
+                    assert all(exact[k] == 0.0 for k in upstream), {k: exact[k] for k in upstream}
+                else:
+                    assert flips["rot_masks"] <= 4 and flips["target_masks"] <= 8, flips
+                del one
+            del both
+            torch.cuda.empty_cache()
+        finally:
+            _runtime.set_batch_invariant(prev)
+
+
 def test_swap_graphed_equals_eager_swap():
     """HairFast.swap_graphed: the whole swap as ONE hipGraph replay gives the eager swap's image bit for bit (noise
     strengths zero: the two forms draw their noise from different points of the RNG stream), also on new inputs through

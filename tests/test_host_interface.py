@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
                                     "hf_sample_layernorm_workspace_floats", "hf_conv1x1_f16_workspace_floats",
                                     "hf_modconv3x3_small_workspace_floats"} == declared
     bound = _lib.bind(lib)
-    assert bound.hf_abi_version() == 10
+    assert bound.hf_abi_version() == 11
     assert bound.hf_strerror(-1) == b"invalid argument"
 
 
@@ -290,3 +290,46 @@ def test_deterministic_env_switch_reaches_the_library():
                            env=dict(os.environ, HAIRFAST_DETERMINISTIC=env_val), timeout=300)
         assert r.returncode == 0, r.stderr[-1500:]
         assert r.stdout.strip().splitlines()[-1] == want, r.stdout
+
+
+def test_swap_accepts_the_reference_image_forms(tmp_path):
+    """hair_swap.py:79-92: `swap` takes a Tensor, a PIL image, an array or a file path.  PIL images and arrays go through
+    `F.to_tensor` (HWC uint8 -> CHW float / 255 on the CPU), a path through `read_image(path, mode=RGB)` (uint8 [3,H,W],
+    read once per call); anything else raises the reference's TypeError.  (The conversion is host code: no GPU needed.)"""
+    import numpy as np
+    from PIL import Image
+
+    from hairfastgan_amd.hair_swap import HairFast
+
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 256, (16, 12, 3), dtype=np.uint8)
+    want = torch.from_numpy(arr).permute(2, 0, 1).to(torch.float32).div(255)  # F.to_tensor
+    t = torch.from_numpy(arr).permute(2, 0, 1)
+    assert HairFast._as_tensor(t) is t                                         # tensors pass through (uint8 or float)
+    got = HairFast._as_tensor(arr)
+    assert got.dtype is torch.float32 and got.shape == (3, 16, 12) and torch.equal(got, want)
+    pil = Image.fromarray(arr)
+    got = HairFast._as_tensor(pil)
+    assert got.dtype is torch.float32 and torch.equal(got, want)
+    rgba = Image.fromarray(np.dstack([arr, np.full((16, 12), 255, np.uint8)]), mode="RGBA")
+    assert HairFast._as_tensor(rgba).shape == (4, 16, 12)                      # to_tensor keeps every band
+    grey = HairFast._as_tensor(Image.fromarray(arr[:, :, 0]))
+    assert grey.shape == (1, 16, 12) and torch.equal(grey[0], want[0])
+    assert torch.equal(HairFast._as_tensor(arr.astype(np.float32)), torch.from_numpy(arr.astype(np.float32)).permute(2, 0, 1))
+    # files: PNG (lossless) through PIL as uint8 RGB, also from a palette / grey file; read once per call
+    png, pal, npy = tmp_path / "a.png", tmp_path / "p.png", tmp_path / "a.npy"
+    pil.save(png)
+    pil.convert("P", palette=Image.ADAPTIVE, colors=8).save(pal)
+    np.save(npy, arr)
+    cache = {}
+    for path in (png, str(png)):
+        got = HairFast._as_tensor(path, cache)
+        assert got.dtype is torch.uint8 and torch.equal(got, t)
+    assert HairFast._as_tensor(png, cache) is HairFast._as_tensor(png, cache) and len(cache) == 2
+    got = HairFast._as_tensor(pal)
+    assert got.dtype is torch.uint8 and got.shape == (3, 16, 12)               # mode=RGB: palettes are expanded
+    assert torch.equal(HairFast._as_tensor(npy), t)
+    with pytest.raises(TypeError, match="Unsupported image format"):
+        HairFast._as_tensor([1, 2, 3])
+    with pytest.raises(FileNotFoundError):
+        HairFast._as_tensor(tmp_path / "missing.png")

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from whole-bench rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and
 optionally SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE), averaged per launch and keyed by the
-kernel labels bench.py uses.  usage: make_pmc_traffic.py <fetch_dir> <write_dir> [<mfma_dir>]"""
+kernel labels bench.py uses.  usage: make_pmc_traffic.py [--between] <fetch_dir> <write_dir> [<mfma_dir> [<kernel_trace_dir>]]
+--between: only the dispatches between bench.py's two hf_profile_marker_kernel launches (its timed region)."""
 import collections
 import csv
 import json
@@ -44,9 +45,42 @@ def label(name):
     return f"{fam}<{','.join(args)}>"
 
 
+BETWEEN = False
+MARKER = "hf_profile_marker_kernel"
+
+
+def marker_window(rows, grid_key):
+    t0 = t1 = None
+    for r in rows:
+        if MARKER in r["Kernel_Name"]:
+            wg = int(r[grid_key]) // 64
+            if wg == 2:
+                t0 = int(r["End_Timestamp"])
+            elif wg == 3 and t0 is not None:
+                t1 = int(r["Start_Timestamp"])
+    return None if t0 is None or t1 is None else (t0, t1)
+
+
+def trace_avg_us(d):
+    """kernel label -> average duration (us) of the dispatches inside the marker window of a --kernel-trace run."""
+    rows = list(csv.DictReader(open(os.path.join(d, "bench_kernel_trace.csv"))))
+    win = marker_window(rows, "Grid_Size_X") if BETWEEN else None
+    acc = collections.defaultdict(list)
+    for r in rows:
+        if win is None or win[0] <= int(r["Start_Timestamp"]) <= win[1]:
+            acc[label(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return {k: sum(v) / len(v) / 1e3 for k, v in acc.items()}
+
+
 def agg(d, counter):
     acc = collections.defaultdict(lambda: [0.0, set()])
-    for r in csv.DictReader(open(os.path.join(d, "bench_counter_collection.csv"))):
+    rows = list(csv.DictReader(open(os.path.join(d, "bench_counter_collection.csv"))))
+    win = marker_window(rows, "Grid_Size") if BETWEEN else None
+    if BETWEEN and win is None:
+        sys.exit(f"--between: no hf_profile_marker_kernel pair in {d}")
+    for r in rows:
+        if win is not None and not (win[0] <= int(r["Start_Timestamp"]) <= win[1]):
+            continue
         if r["Counter_Name"] == counter:
             a = acc[label(r["Kernel_Name"])]
             a[0] += float(r["Counter_Value"])
@@ -55,16 +89,25 @@ def agg(d, counter):
 
 
 def main():
+    global BETWEEN
+    if "--between" in sys.argv:  # only the dispatches between bench.py's two profile markers (its timed region)
+        BETWEEN = True
+        sys.argv.remove("--between")
     f, w = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
     busy = gui = None
     if len(sys.argv) > 3:
         busy, gui = agg(sys.argv[3], "SQ_VALU_MFMA_BUSY_CYCLES"), agg(sys.argv[3], "GRBM_GUI_ACTIVE")
+    avg_us = trace_avg_us(sys.argv[4]) if len(sys.argv) > 4 else {}
+    cmd = os.environ.get("PROFILE_CMD", "python bench.py --steps 1 --warmup 1 --no-exact-f32")
     out = {"tag": os.environ.get("PROFILE_TAG", "untagged"), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE (separate passes), "
-                     "python bench.py --steps 1 --warmup 1 --no-exact-f32; KiB*1024; FETCH_SIZE doubled for the kernels that read "
+                     + cmd + ("; dispatches between bench.py's profile markers only (timed region)" if BETWEEN else "") + "; KiB*1024; FETCH_SIZE doubled for the kernels that read "
                      "16 B / lane (fetch_doubled: LDS-DMA / wide vector loads), as MI355X_MICROARCH.md's HBM section prescribes for "
                      "gfx950; left as counted for the dword halo loads of modconv (uncalibrated); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
                      "(GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs), i.e. relative to the clock the kernel actually ran at",
            "kernels": {}}
+    if os.environ.get("PROFILE_SWAP_BATCH"):  # the batched swap pass: bench.py attaches it only to a run of the same pass size / precision
+        out["swap_batch"] = int(os.environ["PROFILE_SWAP_BATCH"])
+        out["conv_precision"] = os.environ.get("PROFILE_CONV_PRECISION", "f16x3")
     for k in f:
         n = max(1, len(f[k][1]))
         if f[k][0] / n < 1000 and not k.startswith("conv_mfma"):
@@ -78,6 +121,8 @@ def main():
              "fetch_doubled": bool(wide), "write_bytes_per_launch": w[k][0] / max(1, len(w[k][1])) * 1024, "launches": n}
         if busy and gui and gui[k][0] > 0:
             e["mfma_busy"] = round(busy[k][0] / (gui[k][0] / 8 * 1024), 4)
+        if k in avg_us:
+            e["avg_us"] = round(avg_us[k], 2)  # of the --kernel-trace run of the same command (no counters)
         out["kernels"][k] = e
     print(json.dumps(out, indent=1))
 
