@@ -1,7 +1,14 @@
-# GPU call r05a (run through `gpurun -- bash gpurun_cmd.sh` from the repo root): the 32-per-pass parity test, the batched swap's
-# kernel trace in the default and the batch-invariant mode, the per-rank pass-size probe.
+# GPU call r05b: batch-invariant plans as the default (virtual split-K): the whole GPU suite, the batched swap's kernel trace in
+# both plan modes, the generator line and the single swap in both modes.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_schedule.py -m gpu -q -s -k "timed_pass_size or call_surface" > gpurun_out/r05a_tests.log 2>&1; tail -12 gpurun_out/r05a_tests.log
-bash tools/prof_swap.sh r05a stats det
-timeout 600 python tools/probes/rank_pass_sizes.py > gpurun_out/r05a_pass_sizes.log 2>&1; tail -5 gpurun_out/r05a_pass_sizes.log
+python -m pytest tests -m gpu -q -x --durations=8 > gpurun_out/r05b_tests.log 2>&1; tail -15 gpurun_out/r05b_tests.log
+bash tools/prof_swap.sh r05b stats nodet
+for d in 1 0; do
+  HAIRFAST_DETERMINISTIC=$d python bench.py --no-cpu-baseline --no-exact-f32 --swap-triples 0 --steps 20 --warmup 3 > gpurun_out/r05b_gen_det$d.json 2> gpurun_out/r05b_gen_det$d.err
+  HAIRFAST_DETERMINISTIC=$d python bench.py --workload swap256 --triples 12 --swap-batch 1 --warmup 2 --no-kernel-events --no-verify > gpurun_out/r05b_single_det$d.json 2> gpurun_out/r05b_single_det$d.err
+  python -c "
+import json
+g=json.load(open('gpurun_out/r05b_gen_det$d.json')); s=json.load(open('gpurun_out/r05b_single_det$d.json'))
+print('det=$d generator img/s', g['value'], 'single swap ms', s['ms_per_step'])"
+done

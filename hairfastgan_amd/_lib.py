@@ -91,6 +91,7 @@ SIGNATURES = {
     "hf_set_splitk_counters": [_f, _i],
     "hf_modconv3x3_f16_rgb_slabs": [_i],
     "hf_profile_marker": [_i, _st],
+    "hf_conv2d_f16_split_output_ok": [_i, _i, _i, _i, _i, _i, _i, _i],
 }
 
 

@@ -757,10 +757,10 @@ def conv2d_f16(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None, 
     return out
 
 
-def conv2d_f16_split_supported(lib, b, cin, cout, h, w, stride):
-    """hf_conv2d_f16_split_f32 takes the launch: groups 1 and no split-K plan (the split output is written by the conv kernel's
-    own epilogue)."""
-    return cout % 8 == 0 and lib.hf_conv2d_f16_workspace_floats(b, cin, cout, h, w, stride, 1) == 0
+def conv2d_f16_split_supported(lib, b, cin, cout, h, w, stride, nterms=3, pre=False):
+    """hf_conv2d_f16_split_f32 takes the launch: groups 1 and no K split spread over the grid (the split output is written by
+    the conv kernel's own epilogue; hf_conv2d_f16_split_output_ok).  pre: the input arrives pre-split (SplitActivation)."""
+    return cout % 8 == 0 and lib.hf_conv2d_f16_split_output_ok(b, cin, cout, h, w, stride, nterms, 1 if pre else 0) == 1
 
 
 def conv2d_f16_split(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None, in_shift=None, out_scale=None, bias=None,

@@ -185,14 +185,19 @@ def reference_rng_walk():
 
 
 # ---------------------------------------------------------------------------------------
-# Batch-invariant plans (HAIRFAST_DETERMINISTIC=1 / set_batch_invariant): split-K factors, tile forms and the
-# small-plane / tiled / fp32 dispatch of every conv are chosen from the PER-SAMPLE shape only, so that a sample's result
-# has the same bits whatever it is batched with - `HairFast.swap_batch` then produces exactly the segmentation-mask
-# indices of `HairFast.swap` (north_star: bit-exact mask indices; an argmax near a tie otherwise flips with the batch
-# size because the summation order of the logits follows the plan).  Cost: a batched launch keeps the split-K passes
-# and small tile forms of a batch-1 launch.  Process-wide, like the library's flag
-# (hf_set_batch_invariant), which `lib()` keeps equal to this setting.
-_batch_invariant = os.environ.get("HAIRFAST_DETERMINISTIC", "0") not in ("", "0")
+# Batch-invariant plans - THE DEFAULT since round 5 (HAIRFAST_DETERMINISTIC=0 / set_batch_invariant(False) opt out): every
+# decision that changes a sample's bits - the K partition (split-K factor) and the kernel family (fp32 split-K / tap-GEMM /
+# tiled fp16-core kernels sum in different orders) - is made for a fixed CANONICAL batch (3: the Embedding stage's batch of a
+# single swap), never for the batch a sample happens to run in, so that a sample's result has the same bits whatever it is
+# batched with: `HairFast.swap_batch` produces exactly the segmentation-mask indices of `HairFast.swap` (north_star: bit-exact
+# mask indices; an argmax near a tie otherwise flips with the batch size).  What keeps following the whole launch are the
+# things that do NOT change the K order: tile forms, pre-split vs register-staged input, images per GEMM tile - and HOW a K
+# partition is executed: a launch that fills the chip by itself walks the slabs inside its blocks (ConvParams::vsplit), a
+# batch-1 launch spreads them over the grid and adds them in a second pass, same bits.
+# Process-wide, like the library's flag (hf_set_batch_invariant), which `lib()` keeps equal to this setting;
+# `HairFast(args, batch_invariant=...)` sets it for the duration of that object's calls.
+CANON_BATCH = 3  # conv_common.h kCanonBatch
+_batch_invariant = os.environ.get("HAIRFAST_DETERMINISTIC", "1") not in ("", "0")
 _lib_flag = False  # what the library currently holds
 
 
@@ -208,6 +213,25 @@ def set_batch_invariant(on):
     return prev
 
 
+class batch_invariant_scope:
+    """`with batch_invariant_scope(on):` - batch-invariant plans on / off for the calls inside (None: no change); what
+    `HairFast(args, batch_invariant=...)` wraps its calls in, like conv_precision_scope."""
+
+    def __init__(self, on):
+        self.on, self.prev = on, None
+
+    def __enter__(self):
+        if self.on is not None:
+            self.prev = set_batch_invariant(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on is not None:
+            set_batch_invariant(self.prev)
+        return False
+
+
 def plan_batch(batch):
-    """The batch count host-side dispatch decisions are made with (the library's plan_batch, conv_common.h)."""
-    return 1 if _batch_invariant else batch
+    """The batch count host-side decisions that change a sample's BITS are made with (kernel family: fp32 split-K / tap-GEMM /
+    tiled; the library's plan_batch, conv_common.h).  Bit-neutral choices (pre-splitting an input, tile forms) use the real batch."""
+    return CANON_BATCH if _batch_invariant else batch

@@ -60,6 +60,11 @@ struct ConvParams {
   long long zslab;             // split-K: floats per z slab of `partial` (= groups*batch*cout*oh*ow)
   int splits;                  // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps); 1 = off
   int chunks_per_split;
+  int vsplit;                  // "virtual" split-K (convh_enc.hip, gemm_h.hip; batch-invariant plans): the K partition into `splits`
+                               // slabs is kept - it decides the bits - but ONE block walks all slabs, adding each slab's sum to a
+                               // second accumulator set in z order (exactly what splitk_reduce adds), and runs the epilogue itself:
+                               // no partial slabs in memory, no second launch.  Taken when the launch fills the chip without a
+                               // real K split (a batched pass); a batch-1 launch of the same layer splits for real - same bits.
   float *partial;              // splits > 1: raw accumulators go to partial[z][b][co][oh][ow]
   unsigned int *counters;      // splits > 1, non-null: one arrival counter per (blockIdx.x, blockIdx.y) output tile, zero on entry - the
                                // LAST block of a tile to arrive adds the z slabs in z order and runs the epilogue (no second launch)
@@ -128,6 +133,18 @@ __device__ __forceinline__ float splitk_finish(const ConvParams &P, long long i,
 #pragma clang fp contract(on)
   float v = 0.0f;
   for (int z = 0; z < P.splits; ++z) v += P.partial[(long long)z * P.zslab + i];
+  if (with_epilogue && P.d_bstride == 0 && !P.noise) {
+    // encoder-type launches (per-channel out scale, no noise): the arithmetic of store_tile_rows - ONE fma, then the
+    // activation - so that a layer gives the same bits whether its K split is real (this pass) or virtual (ConvParams::vsplit:
+    // the block's own store_tile_rows epilogue)
+    v = fmaf(v, P.d ? P.d[gc] : 1.0f, P.bias ? P.bias[gc] : 0.0f);
+    if (P.residual && P.residual_pre) v += P.residual[i];
+    const float neg = P.act == ACT_PRELU ? P.slope[gc] : (P.act == ACT_LRELU ? P.alpha : 1.0f);
+    v = (v > 0.0f ? v : v * neg) * (P.act == ACT_LRELU ? P.scale : 1.0f);
+    if (P.act == ACT_QGELU) v = v / (1.0f + expf(-1.702f * v));
+    if (P.residual && !P.residual_pre) v += P.residual[i];
+    return v;
+  }
   if (P.d) v *= P.d[b * P.d_bstride + gc];
   if (with_epilogue) {
     if (P.noise) v = fmaf(nw, P.noise[b * P.noise_bstride + pix], v);
@@ -194,7 +211,7 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
     }
     return;
   }
-  const bool partial = P.splits > 1;  // split-K: raw sums, epilogue runs in splitk_reduce
+  const bool partial = P.splits > 1 && !P.vsplit;  // split-K: raw sums, epilogue runs in splitk_reduce (virtual split: the block holds the finished sums)
   const bool full = !UP && !partial;
   const float nw = (full && P.noise) ? P.noise_w[0] : 0.0f;
 #pragma unroll
@@ -274,7 +291,7 @@ __device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const 
                                                      int ty0, int tx0, int b0) {
   const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
   const long long oplane = (long long)P.out_h * P.out_w;
-  const bool partial = P.splits > 1;
+  const bool partial = P.splits > 1 && !P.vsplit;
   const bool prelu = !partial && P.act == ACT_PRELU, lrelu = !partial && P.act == ACT_LRELU, qgelu = !partial && P.act == ACT_QGELU;
   const float neg_u = lrelu ? P.alpha : 1.0f, sc = lrelu ? P.scale : 1.0f;
   const bool res_pre = RES && P.residual_pre;
@@ -398,7 +415,7 @@ template <int CT_TILES, int PG>
 __device__ __forceinline__ void store_tile_rows(const ConvParams &P, const TileGeom &G, const GroupOfs &go,
                                                 f32x16 (&acc)[1][CT_TILES][PG], int co_wave, int wave_pg, int li, int lh,
                                                 int ty0, int tx0, int b0) {
-  if (P.residual && P.splits <= 1)
+  if (P.residual && (P.splits <= 1 || P.vsplit))
     store_tile_rows_impl<CT_TILES, PG, true>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
   else
     store_tile_rows_impl<CT_TILES, PG, false>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
@@ -457,9 +474,14 @@ int launch_conv_rows(ConvParams &P, int nterms, const void *wt_hi, const void *w
 extern thread_local int g_h_blocks;           // hf_debug_set_persistent_blocks: resident blocks the convh.hip grid is sized for (0 = 256 CUs)
 extern thread_local int g_h_tune;             // hf_debug_set_tuning: bit 0 force early stage DMAs, bit 1 force spread ones (convh.hip)
 extern int g_batch_invariant;                 // hf_set_batch_invariant (process-wide): plans (split-K counts, tile forms) from the per-sample shape only
-// The batch count every PLAN decision (split-K factor, tile form) is made with: the real one, or 1 in batch-invariant mode,
-// where a sample's result must not depend on what it is batched with (summation order is a function of the plan).
-inline int plan_batch(int batch) { return g_batch_invariant ? 1 : batch; }
+// The batch count every decision that changes a sample's BITS is made with - the K partition (split-K factor) and the kernel
+// family (fp32 split-K / tap-GEMM / tiled fp16-core kernels differ in summation order): the real one, or - in batch-invariant
+// mode, where a sample's result must not depend on what it is batched with - a fixed canonical batch: 3, the Embedding stage's
+// batch of a single swap, so that single swaps keep the plans they were tuned with.  TILE FORMS (64 x 128 / 256 / 512 pixels,
+// 51 / 52, images per GEMM tile, pre-split or register-staged input) do not change the K order (bit-identical: tests/
+// test_sim_encoders.py, test_sim_generator.py) and always follow the whole launch.
+constexpr int kCanonBatch = 3;
+inline int plan_batch(int batch) { return g_batch_invariant ? kCanonBatch : batch; }
 extern thread_local int g_force_h;            // hf_debug_set_dispatch same_cfg 51/52: force the convh.hip tile configuration
 void note_path(int path, int cfg);  // records what hf_debug_last_path reports
 // split-K second pass (modconv.hip): out = epilogue(d * sum_z partial[z]), deterministic

@@ -1108,7 +1108,8 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
   //     MFMAs - the HBM-bound high-resolution layers (few chunks per tile)
   cfg = g_force_h;
   if (cfg == 0) {
-    const long long blocks52 = (long long)plan_batch(P.batch) * hf_cdiv(P.h, 16) * hf_cdiv(P.w, 32) * (P.cout / 64);
+    // (a tile FORM: same K order as 51, equal bits - tests/test_sim_kernels.py - so it follows the real launch in every mode)
+    const long long blocks52 = (long long)P.batch * hf_cdiv(P.h, 16) * hf_cdiv(P.w, 32) * (P.cout / 64);
     if (P.cout % 64) cfg = (P.w >= 128) ? 55 : 53;
     else cfg = (P.h * P.w >= 512 && blocks52 >= 256) ? 52 : 51;
   }

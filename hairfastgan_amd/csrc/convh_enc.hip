@@ -53,7 +53,10 @@ constexpr int enc_npix() {
 // Wave tiles: WAVES_CO = 2, CT_TILES = 1 (each wave 32 channels x 64 pixels: small layers, many blocks) or
 // WAVES_CO = 1, CT_TILES = 2 (each wave all 64 channels x 64 pixels, 2 x 2 MFMA tiles: 0.67 instead of 1 LDS
 // fragment read per MFMA - the batched swap's layers, which fill the chip with 512-pixel tiles).
-template <int NTERMS, int PG, int WAVES_PX, int STRIDE, bool PRE, int CT_TILES = 1, int WAVES_CO = 2>
+// VSPLIT: ConvParams::vsplit - the block walks all P.splits K slabs itself; at the end of a slab the slab's sum (what a real
+// split-K block stores to its z slab) is added to a second accumulator set, slabs in z order from 0.0f like splitk_reduce, and
+// the block's own epilogue finishes the tile: the bits of the two-launch form without its slabs and its second launch.
+template <int NTERMS, int PG, int WAVES_PX, int STRIDE, bool PRE, int CT_TILES = 1, int WAVES_CO = 2, bool VSPLIT = false>
 __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
                                                                        const _Float16 *__restrict__ wtl_all) {
   constexpr int NW = WAVES_CO * WAVES_PX;
@@ -222,8 +225,18 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
   }
 
   const int nchunks_all = P.cin / KH;
-  const int c_begin = (P.splits > 1) ? (int)blockIdx.z * P.chunks_per_split : 0;
-  const int c_end = (P.splits > 1) ? min(nchunks_all, c_begin + P.chunks_per_split) : nchunks_all;
+  const int c_begin = (P.splits > 1 && !VSPLIT) ? (int)blockIdx.z * P.chunks_per_split : 0;
+  const int c_end = (P.splits > 1 && !VSPLIT) ? min(nchunks_all, c_begin + P.chunks_per_split) : nchunks_all;
+  f32x16 vsum[VSPLIT ? CT_TILES : 1][VSPLIT ? PG : 1];  // VSPLIT: the slabs added so far
+  int slab_left = P.chunks_per_split;                   // VSPLIT: chunks until the current slab ends
+  if (VSPLIT) {
+#pragma unroll
+    for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+      for (int g = 0; g < PG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vsum[VSPLIT ? ct : 0][VSPLIT ? g : 0][r] = 0.0f;
+  }
   if (PRE) {  // zero the activation regions of both buffers once: DMA-masked units (padding) stay zero
     half8 z;
 #pragma unroll
@@ -309,6 +322,17 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (VSPLIT && (--slab_left == 0 || !more)) {  // a slab ends: its sum (pre-scale undone, exact) joins the earlier slabs'
+      slab_left = P.chunks_per_split;
+#pragma unroll
+      for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+        for (int g = 0; g < PG; ++g) {
+          vsum[VSPLIT ? ct : 0][VSPLIT ? g : 0] += acc[0][ct][g] * w_unscale;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[0][ct][g][r] = 0.0f;
+        }
+    }
     hf_barrier_keep_young<0>();  // next stage complete (DMA landed, conversions written), current one free
   }
 
@@ -316,15 +340,18 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
 #pragma unroll
   for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
-    for (int g = 0; g < PG; ++g)
+    for (int g = 0; g < PG; ++g) {
+      if (VSPLIT) acc[0][ct][g] = vsum[VSPLIT ? ct : 0][VSPLIT ? g : 0];
+      else
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][ct][g][r] *= w_unscale;
+        for (int r = 0; r < 16; ++r) acc[0][ct][g][r] *= w_unscale;
+    }
   if (P.d_bstride == 0 && !P.noise)
     store_tile_rows<CT_TILES, PG>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
   else
     store_tile<CT_TILES, PG, false>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
   // split-K without a second launch: the tile's last block adds the slabs and runs the epilogue (conv_common.h)
-  if (P.splits > 1 && P.counters && splitk_arrive_last(P, reinterpret_cast<int *>(hf_dyn_lds)))
+  if (!VSPLIT && P.splits > 1 && P.counters && splitk_arrive_last(P, reinterpret_cast<int *>(hf_dyn_lds)))
     store_tile<CT_TILES, PG, false, 1, true>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
@@ -338,9 +365,12 @@ inline int enc_splitk_plan(long long blocks, int nchunks) {
   return s < 2 ? 1 : s;
 }
 
+// force_splits > 0 (batch-invariant plans): the K partition is given - the canonical plan of run_enc - and only its
+// execution is decided here: one block per slab (grid.z, partial slabs + splitk_reduce) when the output grid alone leaves
+// the chip empty, else ConvParams::vsplit (every block walks all slabs; same bits).
 template <int NTERMS, int PG, int WAVES_PX, int STRIDE, int CT_TILES = 1, int WAVES_CO = 2>
 int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *workspace, long long workspace_floats,
-               hipStream_t st, bool plan_only = false) {
+               hipStream_t st, bool plan_only = false, int force_splits = 0) {
   constexpr int CT = 32 * CT_TILES * WAVES_CO, NT = 64 * WAVES_CO * WAVES_PX;
   static_assert(CT == 64, "64 output channels per block");
   constexpr int PT = 32 * PG * WAVES_PX;
@@ -359,71 +389,102 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
   P.co_tiles = P.cout / CT;
   const int groups = P.groups > 1 ? P.groups : 1;
   const long long blocks = (long long)geom_blocks(G) * P.co_tiles * groups;
-  // the split-K factor is planned from ONE sample's block count in batch-invariant mode (G.lg_nb == 0: tiles_b = batch)
-  P.splits = enc_splitk_plan(blocks / P.batch * plan_batch(P.batch), P.cin / KH);
+  // what this launch needs to fill the chip by itself (hf_debug_set_tuning bits 24-31: tests lower the block count from which a
+  // launch counts as chip-filling, so that small shapes reach the virtual split)
+  const int fill = (g_h_tune >> 24) & 255;
+  const int own_splits = (fill && blocks >= fill) ? 1 : enc_splitk_plan(blocks, P.cin / KH);
+  P.splits = force_splits > 0 ? force_splits : own_splits;
   P.chunks_per_split = hf_cdiv(P.cin / KH, P.splits);
   P.splits = hf_cdiv(P.cin / KH, P.chunks_per_split);  // no empty split
   P.zslab = (long long)groups * P.batch * P.cout * P.out_h * P.out_w;
+  // virtual split: the encoder-type epilogue only (splitk_finish and store_tile_rows share their arithmetic), and only forms
+  // whose second accumulator set fits the register file (the register-staged 512-pixel form does not)
+  P.vsplit = (force_splits > 0 && P.splits > 1 && own_splits == 1 && P.d_bstride == 0 && !P.noise &&
+              !(CT_TILES == 2 && !P.xh)) ? 1 : 0;
   // the checks that can still reject this tile form come BEFORE the plan-only return: the workspace query must plan with
   // the form the launch will take
-  dim3 grid(geom_blocks(G), P.co_tiles * groups, P.splits);
+  dim3 grid(geom_blocks(G), P.co_tiles * groups, P.vsplit ? 1 : P.splits);
   if (grid.y > 65535) return HF_E_INVALID;
   const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float);
   if (lds > 160 * 1024) return HF_E_INVALID;
   if (plan_only) return HF_OK;
-  if (P.oh && (P.splits > 1 || groups > 1)) return HF_E_INVALID;  // split output: written by this kernel's own epilogue only
-  if (P.splits > 1) {
+  if (P.oh && ((P.splits > 1 && !P.vsplit) || groups > 1)) return HF_E_INVALID;  // split output: written by this kernel's own epilogue only
+  if (P.splits > 1 && !P.vsplit) {
     if (!workspace || workspace_floats < P.splits * P.zslab) return HF_E_WORKSPACE;
     P.partial = workspace;
     P.counters = splitk_counters_for((long long)grid.x * grid.y);
   }
   if (P.xh) {
     if ((long long)2 * P.h * P.w * 16 >= (1LL << 31) || (NTERMS == 3 && !P.xl)) return HF_E_INVALID;
-    hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, true, CT_TILES, WAVES_CO>), grid, dim3(NT), lds, st, P, wth, wtl);
+    if (P.vsplit)
+      hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, true, CT_TILES, WAVES_CO, true>), grid, dim3(NT), lds, st, P, wth, wtl);
+    else
+      hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, true, CT_TILES, WAVES_CO>), grid, dim3(NT), lds, st, P, wth, wtl);
+  } else if (P.vsplit) {
+    if constexpr (CT_TILES == 2) return HF_E_INVALID;  // (never planned: see P.vsplit above)
+    else
+      hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, false, CT_TILES, WAVES_CO, true>), grid, dim3(NT), lds, st, P, wth, wtl);
   } else {
     hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, false, CT_TILES, WAVES_CO>), grid, dim3(NT), lds, st, P, wth, wtl);
   }
   int rc = hf_launch_status();
-  if (rc == HF_OK && P.splits > 1 && !P.counters) rc = launch_splitk_reduce(P, true, st);  // deterministic second pass + epilogue
+  if (rc == HF_OK && P.splits > 1 && !P.vsplit && !P.counters) rc = launch_splitk_reduce(P, true, st);  // deterministic second pass + epilogue
   return rc;
 }
 
-// the tile configuration hf_conv2d_f16_f32 uses for a shape (shared by the workspace query)
+// the tile configuration hf_conv2d_f16_f32 uses for a shape (shared by the workspace query).  Tile forms follow the real
+// launch in every mode: they do not change the K order (equal bits, tests/test_sim_encoders.py).
 template <int NTERMS>
-int run_enc(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *ws, long long wsn, hipStream_t st, bool plan_only) {
+int run_enc_forms(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *ws, long long wsn, hipStream_t st, bool plan_only,
+                  int force_splits) {
   int rc;
   if (P.stride == 2) {
     // 64 co x 128 output px (the halo of a stride-2 tile is 4x its output: a 256-pixel tile does not fit twice in LDS).
     // Eight waves of 1 x 1 MFMA tiles: two waves per SIMD hide the stage latencies, which is worth more here than the
     // 1 instead of 1.33 LDS fragment reads per MFMA of four 1 x 2 waves (tools/probes/stride2.py: 10-25% faster from
     // 64@256^2 to the 11-group style heads, 30-35% on the register-staged path; same accumulation order, equal bits)
-    rc = launch_enc<NTERMS, 1, 4, 2>(P, hi, lo, ws, wsn, st, plan_only);
+    rc = launch_enc<NTERMS, 1, 4, 2>(P, hi, lo, ws, wsn, st, plan_only, force_splits);
     if (rc == HF_OK && !plan_only) note_path(6, 2);
     return rc;
   }
   // 64 co x 512 px (8 waves, 2 x 2 MFMA tiles each) when that fills the chip (batched swaps), else
   // 64 co x 256 px (8 waves, 1 x 2 tiles) when that still does, else 64 co x 128 px (4 waves)
   const int groups = P.groups > 1 ? P.groups : 1;
-  const long long blocks256 = (long long)plan_batch(P.batch) * groups * hf_cdiv((long long)P.out_h * P.out_w, 256) * (P.cout / 64);
-  const long long blocks512 = (long long)plan_batch(P.batch) * groups * hf_cdiv((long long)P.out_h * P.out_w, 512) * (P.cout / 64);
+  const long long blocks256 = (long long)P.batch * groups * hf_cdiv((long long)P.out_h * P.out_w, 256) * (P.cout / 64);
+  const long long blocks512 = (long long)P.batch * groups * hf_cdiv((long long)P.out_h * P.out_w, 512) * (P.cout / 64);
   rc = HF_E_INVALID;
   // hf_debug_set_tuning: bit 2 = never the 512-pixel form, bits 8-15 = its minimum block count / 8 (0: the default),
   // bits 16-23 = the minimum block count / 8 of the 256-pixel form
   const int min512 = ((g_h_tune >> 8) & 255) > 0 ? ((g_h_tune >> 8) & 255) * 8 : 512;
   const int min256 = ((g_h_tune >> 16) & 255) > 0 ? ((g_h_tune >> 16) & 255) * 8 : 384;
   if (NTERMS == 3 && !(g_h_tune & 4) && blocks512 >= min512) {  // plain fp16 operands: staging-bound, measured slower
-    rc = launch_enc<NTERMS, 2, 8, 1, 2, 1>(P, hi, lo, ws, wsn, st, plan_only);
+    rc = launch_enc<NTERMS, 2, 8, 1, 2, 1>(P, hi, lo, ws, wsn, st, plan_only, force_splits);
     if (rc == HF_OK && !plan_only) note_path(6, 4);
   }
   if (rc == HF_E_INVALID && blocks256 >= min256) {
-    rc = launch_enc<NTERMS, 2, 4, 1>(P, hi, lo, ws, wsn, st, plan_only);
+    rc = launch_enc<NTERMS, 2, 4, 1>(P, hi, lo, ws, wsn, st, plan_only, force_splits);
     if (rc == HF_OK && !plan_only) note_path(6, 1);
   }
   if (rc == HF_E_INVALID) {
-    rc = launch_enc<NTERMS, 2, 2, 1>(P, hi, lo, ws, wsn, st, plan_only);
+    rc = launch_enc<NTERMS, 2, 2, 1>(P, hi, lo, ws, wsn, st, plan_only, force_splits);
     if (rc == HF_OK && !plan_only) note_path(6, 3);
   }
   return rc;
+}
+
+// Batch-invariant mode: the K partition - what decides a sample's bits - is the one the CANONICAL launch of this layer
+// (batch kCanonBatch, whatever the real batch) plans for itself; the real launch then runs that partition in its own tile form.
+template <int NTERMS>
+int run_enc(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *ws, long long wsn, hipStream_t st, bool plan_only) {
+  int force = 0;
+  if (g_batch_invariant) {
+    ConvParams C = P;
+    C.batch = kCanonBatch;
+    const int rc = run_enc_forms<NTERMS>(C, hi, lo, nullptr, 0, st, true, 0);
+    if (rc != HF_OK) return rc;
+    force = C.splits;
+  }
+  return run_enc_forms<NTERMS>(P, hi, lo, ws, wsn, st, plan_only, force);
 }
 
 // s*x + t (per input channel; null = identity) split into fp16 (hi, lo) and K-blocked
@@ -489,11 +550,26 @@ extern "C" long long hf_conv2d_f16_workspace_floats(int batch, int cin, int cout
     return 0;
   // both operand modes (their tile forms can differ: nterms 1 never takes the 512-pixel form): the larger plan
   long long need = 0;
-  if (run_enc<3>(P, nullptr, nullptr, nullptr, 0, nullptr, true) == HF_OK && P.splits > 1) need = P.splits * P.zslab;
+  // (planned for register-staged input: a pre-split launch may split virtually where this one splits for real - an upper bound)
+  if (run_enc<3>(P, nullptr, nullptr, nullptr, 0, nullptr, true) == HF_OK && P.splits > 1 && !P.vsplit) need = P.splits * P.zslab;
   ConvParams Q = P;
-  if (run_enc<1>(Q, nullptr, nullptr, nullptr, 0, nullptr, true) == HF_OK && Q.splits > 1 && Q.splits * Q.zslab > need)
+  if (run_enc<1>(Q, nullptr, nullptr, nullptr, 0, nullptr, true) == HF_OK && Q.splits > 1 && !Q.vsplit && Q.splits * Q.zslab > need)
     need = Q.splits * Q.zslab;
   return need;
+}
+
+// 1 when hf_conv2d_f16_split_f32 takes the launch (its epilogue must run in the conv kernel itself: no real split-K; a
+// virtual one - batch-invariant plans, ConvParams::vsplit - is fine, and whether a launch can split virtually depends on
+// how its input arrives), else 0.
+extern "C" int hf_conv2d_f16_split_output_ok(int batch, int cin, int cout, int h, int w, int stride, int nterms, int presplit_input) {
+  ConvParams P{};
+  if ((nterms != 1 && nterms != 3) || (cout & 7) ||
+      enc_fill(P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0.0f, nullptr, batch,
+               cin, cout, h, w, stride, 1, 0) != HF_OK)
+    return 0;
+  if (presplit_input) P.xh = P.xl = &P;  // only tested for NULL while planning
+  const int rc = (nterms == 3) ? run_enc<3>(P, nullptr, nullptr, nullptr, 0, nullptr, true) : run_enc<1>(P, nullptr, nullptr, nullptr, 0, nullptr, true);
+  return (rc == HF_OK && !(P.splits > 1 && !P.vsplit)) ? 1 : 0;
 }
 
 extern "C" int hf_conv2d_f16_f32(float *out, const float *x, const void *x_hi, const void *x_lo, const void *wt_hi,

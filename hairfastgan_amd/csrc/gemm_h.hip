@@ -26,11 +26,15 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KH = 16;   // input channels per MFMA k-step
 constexpr int KS = 32;   // input channels per LDS stage
+// blocks from which a launch fills the chip without a K split (hf_debug_set_tuning bits 24-31 lower it for tests)
+inline int gemm_fill_blocks() { return ((hf_detail::g_h_tune >> 24) & 255) ? ((hf_detail::g_h_tune >> 24) & 255) : 256; }
 
 // PRE: the activations arrive already transformed, split into fp16 (hi, lo) and K-blocked ([image][cin/8][h*w][8 halves]:
 // hf_split_activation_f16 / hf_split_activation_mod_f16; ConvParams::xh / xl) and are staged by LDS-DMA like the weights -
 // an input shared by many output-channel tiles (the tap-GEMM's 72, the CLIP MLP's 48) is converted once, not once per block.
-template <int NTERMS, int PG, bool PRE>
+// VSPLIT (ConvParams::vsplit): the block walks all P.splits K slabs and adds their sums in z order to a second accumulator
+// set - the bits of the split-K form (slabs + splitk_reduce / small_combine) without the slabs (see csrc/convh_enc.hip).
+template <int NTERMS, int PG, bool PRE, bool VSPLIT = false>
 __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
                                                  const _Float16 *__restrict__ wtl_all) {
   constexpr int NT = 256, CT = 64, PT = 64 * PG;
@@ -89,8 +93,8 @@ __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Floa
   }
 
   const int nstages_all = P.cin / KS;
-  const int s_begin = (P.splits > 1) ? (int)blockIdx.z * P.chunks_per_split : 0;
-  const int s_end = (P.splits > 1) ? min(nstages_all, s_begin + P.chunks_per_split) : nstages_all;
+  const int s_begin = (P.splits > 1 && !VSPLIT) ? (int)blockIdx.z * P.chunks_per_split : 0;
+  const int s_end = (P.splits > 1 && !VSPLIT) ? min(nstages_all, s_begin + P.chunks_per_split) : nstages_all;
 
   const unsigned lds_addr0 = hf_lds_addr(lds);
   auto dma_w = [&](int stage, int bufsel) {
@@ -154,10 +158,15 @@ __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Floa
   };
 
   f32x16 acc[1][1][PG];
+  f32x16 vsum[VSPLIT ? PG : 1];        // VSPLIT: the slabs added so far
+  int slab_left = P.chunks_per_split;  // VSPLIT: stages until the current slab ends
 #pragma unroll
   for (int g = 0; g < PG; ++g)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][g][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) {
+      acc[0][0][g][r] = 0.0f;
+      if (VSPLIT) vsum[VSPLIT ? g : 0][r] = 0.0f;
+    }
 
   if (PRE) {  // items outside the image: zero in both buffers, once (the masked DMA never touches them)
     half8 z;
@@ -208,16 +217,28 @@ __global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Floa
       }
     }
     if (more) convert_x(s + 1, nbuf);
+    if (VSPLIT && (--slab_left == 0 || !more)) {  // a slab ends: its sum (pre-scale undone, exact) joins the earlier slabs'
+      slab_left = P.chunks_per_split;
+#pragma unroll
+      for (int g = 0; g < PG; ++g) {
+        vsum[VSPLIT ? g : 0] += acc[0][0][g] * w_unscale;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][g][r] = 0.0f;
+      }
+    }
     hf_barrier_keep_young<0>();
   }
   // epilogue: the weights' power-of-two pre-scale comes out here (exact); split-K launches store raw sums * 2^-k
 #pragma unroll
-  for (int g = 0; g < PG; ++g)
+  for (int g = 0; g < PG; ++g) {
+    if (VSPLIT) acc[0][0][g] = vsum[VSPLIT ? g : 0];
+    else
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][g][r] *= w_unscale;
+      for (int r = 0; r < 16; ++r) acc[0][0][g][r] *= w_unscale;
+  }
   store_tile_rows<1, PG>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, 0, tx0, b0);
   // split-K without a second launch: the tile's last block adds the slabs and runs the epilogue (conv_common.h)
-  if (P.splits > 1 && P.counters && splitk_arrive_last(P, reinterpret_cast<int *>(hf_dyn_lds)))
+  if (!VSPLIT && P.splits > 1 && P.counters && splitk_arrive_last(P, reinterpret_cast<int *>(hf_dyn_lds)))
     reduce_tile_rows<1, PG>(P, G, go, co0 + wave_co, wave_pg, li, lh, 0, tx0, b0);
 }
 
@@ -241,27 +262,31 @@ int launch_gemm(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStre
   const int nblocks = g.tiles_x * g.tiles_b;
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;
   const size_t lds = (size_t)2 * NPART * ((KS / 8) * 64 + (KS / 8) * PT) * 16;
-  dim3 grid(nblocks, P.co_tiles * max(1, P.groups), P.splits);
+  // batch-invariant plans: P.splits is the canonical K partition (gemm_splits at kCanonBatch); a launch whose output grid
+  // fills the chip by itself walks the slabs inside its blocks instead of spreading them over grid.z (same bits)
+  P.vsplit = (g_batch_invariant && P.splits > 1 && (long long)nblocks * P.co_tiles * max(1, P.groups) >= gemm_fill_blocks()) ? 1 : 0;
+  dim3 grid(nblocks, P.co_tiles * max(1, P.groups), P.vsplit ? 1 : P.splits);
   if (grid.y > 65535 || grid.z > 65535) return HF_E_INVALID;
   // split-K of hf_conv1x1_f16_f32 (P.out = the result tensor): the in-kernel second half when a counter buffer is registered;
   // the tap-GEMM of the small-plane convs (P.out = its own slab workspace, combined by small_combine) keeps raw slabs
-  P.counters = (P.splits > 1 && P.out != P.partial) ? splitk_counters_for((long long)grid.x * grid.y) : nullptr;
+  P.counters = (P.splits > 1 && !P.vsplit && P.out != P.partial) ? splitk_counters_for((long long)grid.x * grid.y) : nullptr;
   if (P.xh) {
     if (P.stride != 1 || P.s || P.t || (NTERMS == 3 && !P.xl) || P.groups > 1 ||
         (long long)P.batch * P.cin * P.h * P.w * 2 >= (1LL << 32))
       return HF_E_INVALID;  // 32-bit unit offsets; the affine went into the split
-    hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, true>), grid, dim3(256), lds, st, P, wth, wtl);
+    if (P.vsplit) hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, true, true>), grid, dim3(256), lds, st, P, wth, wtl);
+    else hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, true>), grid, dim3(256), lds, st, P, wth, wtl);
   } else {
-    hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, false>), grid, dim3(256), lds, st, P, wth, wtl);
+    if (P.vsplit) hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, false, true>), grid, dim3(256), lds, st, P, wth, wtl);
+    else hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, false>), grid, dim3(256), lds, st, P, wth, wtl);
   }
   return hf_launch_status();
 }
 
 }  // namespace
 
-// Scratch of hf_conv1x1_f16_f32 in floats (0 = none): small grids split K.
-static int gemm_splits(int batch, int cin, int cout, int oplane, int groups) {
-  batch = hf_detail::plan_batch(batch);  // batch-invariant mode: the K split of ONE sample's grid
+// blocks of the launch (the tile form launch_gemm takes for this batch)
+static long long gemm_blocks(int batch, int cout, int oplane, int groups) {
   const int pt = oplane * (long long)batch <= 128 || oplane <= 128 ? 128 : 256;
   int tw = pt, nb = 1;
   if (oplane < pt && (oplane & (oplane - 1)) == 0) {
@@ -269,7 +294,12 @@ static int gemm_splits(int batch, int cin, int cout, int oplane, int groups) {
     nb = pt / oplane;
     if (nb > pow2_ceil(batch)) nb = pow2_ceil(batch);
   }
-  const long long blocks = (long long)hf_cdiv(oplane, tw) * hf_cdiv(batch, nb) * (cout / 64) * (groups > 1 ? groups : 1);
+  return (long long)hf_cdiv(oplane, tw) * hf_cdiv(batch, nb) * (cout / 64) * (groups > 1 ? groups : 1);
+}
+
+// Split-K plan: small grids split K.  Batch-invariant mode: the K partition of the CANONICAL launch (kCanonBatch)...
+static int gemm_splits(int batch, int cin, int cout, int oplane, int groups) {
+  const long long blocks = gemm_blocks(hf_detail::plan_batch(batch), cout, oplane, groups);
   const int stages = cin / KS;
   int sk = 1;
   if (blocks < 256 && stages >= 4) {
@@ -279,11 +309,16 @@ static int gemm_splits(int batch, int cin, int cout, int oplane, int groups) {
   }
   return sk;
 }
+// ... and whether THIS launch runs it virtually (ConvParams::vsplit: its own output grid fills the chip; launch_gemm's rule)
+static bool gemm_vsplit(int batch, int cout, int oplane, int groups, int sk) {
+  return hf_detail::g_batch_invariant && sk > 1 && gemm_blocks(batch, cout, oplane, groups) >= gemm_fill_blocks();
+}
 
 extern "C" long long hf_conv1x1_f16_workspace_floats(int batch, int cin, int cout, int h, int w, int stride, int groups) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2) || (cin % KS) || (cout % 64)) return 0;
   const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
   const int sk = gemm_splits(batch, cin, cout, oh * ow, groups);
+  if (gemm_vsplit(batch, cout, oh * ow, groups, sk)) return 0;  // the blocks walk the slabs themselves: no slabs in memory
   return sk > 1 ? (long long)sk * (groups > 1 ? groups : 1) * batch * cout * oh * ow : 0;
 }
 
@@ -316,7 +351,7 @@ extern "C" int hf_conv1x1_f16_f32(float *out, const float *x, const void *x_hi, 
   P.splits = sk;
   if (sk > 1) {
     const long long slab = (long long)(groups > 1 ? groups : 1) * batch * cout * oplane;
-    if (!workspace || workspace_floats < sk * slab) return HF_E_WORKSPACE;
+    if (!gemm_vsplit(batch, cout, oplane, groups, sk) && (!workspace || workspace_floats < sk * slab)) return HF_E_WORKSPACE;
     const int stages = cin / KS;
     P.chunks_per_split = (stages + sk - 1) / sk;
     P.splits = (stages + P.chunks_per_split - 1) / P.chunks_per_split;  // no empty split
@@ -330,7 +365,7 @@ extern "C" int hf_conv1x1_f16_f32(float *out, const float *x, const void *x_hi, 
   else rc = (nterms == 3) ? launch_gemm<3, 4>(P, hi, lo, (hipStream_t)stream) : launch_gemm<1, 4>(P, hi, lo, (hipStream_t)stream);
   if (rc != HF_OK) return rc;
   note_path(7, small ? 1 : 2);
-  if (P.splits > 1 && !P.counters) {
+  if (P.splits > 1 && !P.vsplit && !P.counters) {
     P.out_h = 1; P.out_w = oplane;
     return launch_splitk_reduce(P, true, (hipStream_t)stream);
   }
@@ -410,7 +445,8 @@ static int small_gemm(ConvParams &P, const void *w9_hi, const void *w9_lo, int n
   // the modulated input, split once for all 9*cout/64 channel tiles: hi (+ lo) behind the tap slabs in the workspace
   const long long split_floats = (long long)batch * cin * h * w / 2;  // halves -> floats, per part
   {
-    const int sk0 = gemm_splits(batch, cin, 9 * cout, h * w, 1);
+    int sk0 = gemm_splits(batch, cin, 9 * cout, h * w, 1);
+    if (gemm_vsplit(batch, 9 * cout, h * w, 1, sk0)) sk0 = 1;  // virtual split: one slab
     const long long need = (long long)sk0 * batch * 9 * cout * h * w + 2 * split_floats;
     if (!workspace || workspace_floats < need) return HF_E_WORKSPACE;
     float *xs_hi = workspace + (long long)sk0 * batch * 9 * cout * h * w, *xs_lo = xs_hi + split_floats;
@@ -431,7 +467,7 @@ static int small_gemm(ConvParams &P, const void *w9_hi, const void *w9_lo, int n
   sk = (stages + P.chunks_per_split - 1) / P.chunks_per_split;
   P.splits = sk;
   const long long slab = (long long)batch * 9 * cout * oplane;
-  if (!workspace || workspace_floats < (long long)sk * slab) return HF_E_WORKSPACE;
+  if (!workspace || workspace_floats < (long long)(gemm_vsplit(batch, 9 * cout, oplane, 1, sk) ? 1 : sk) * slab) return HF_E_WORKSPACE;
   // the GEMM always stores through the split-K path (raw sums into the workspace, one slab per split)
   P.partial = workspace;
   P.zslab = slab;
@@ -445,7 +481,8 @@ static int small_gemm(ConvParams &P, const void *w9_hi, const void *w9_lo, int n
 
 extern "C" long long hf_modconv3x3_small_workspace_floats(int batch, int cin, int cout, int h, int w) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (cin % KS) || (cout % 64)) return 0;
-  const int sk = gemm_splits(batch, cin, 9 * cout, h * w, 1);
+  int sk = gemm_splits(batch, cin, 9 * cout, h * w, 1);
+  if (gemm_vsplit(batch, 9 * cout, h * w, 1, sk)) sk = 1;
   return (long long)sk * batch * 9 * cout * h * w + (long long)batch * cin * h * w;  // tap slabs + the split input (hi, lo)
 }
 
@@ -465,7 +502,7 @@ extern "C" int hf_modconv3x3_small_f16_f32(float *out, const float *x, const voi
   const long long total = (long long)batch * cout * out_h * pitch;
   long long g = (total + 255) / 256;
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(small_combine, dim3((int)g), dim3(256), 0, (hipStream_t)stream, out, workspace, P.splits, P.zslab, d, noise,
+  hipLaunchKernelGGL(small_combine, dim3((int)g), dim3(256), 0, (hipStream_t)stream, out, workspace, P.vsplit ? 1 : P.splits, P.zslab, d, noise,
                      noise_w, noise_bstride, bias, batch, cout, h, w, upsample ? 1 : 0, out_h, pitch, wv, alpha, scale);
   note_path(7, upsample ? 4 : 3);
   return hf_launch_status();

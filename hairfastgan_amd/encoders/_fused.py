@@ -197,14 +197,16 @@ def _conv_unpadded(x, w, k, stride=1, presplit=False, split_out=None, **kw):
     h, wd = x.shape[-2], x.shape[-1]
     if split_out is not None:
         b = x.shape[0]
+        nterms = 3 if mode == "f16x3" else 1
+        out_px = b * ((h - 1) // stride + 1) * ((wd - 1) // stride + 1)  # (bit-neutral: the real batch in every mode)
+        to_split = (not isinstance(x, M.SplitActivation) and PRESPLIT == "all"
+                    and (w.cout // 64 >= 8 or (w.cin >= 128 and out_px >= 12288)))
         if (kw.get("groups", 1) == 1 and takes_f16_conv(w, h, wd, k, stride, **kw)
-                and M.conv2d_f16_split_supported(lib(), b, w.cin, w.cout, h, wd, stride)):
+                and M.conv2d_f16_split_supported(lib(), b, w.cin, w.cout, h, wd, stride, nterms,
+                                                 pre=to_split or isinstance(x, M.SplitActivation))):
             hi, lo = w.f16()
-            nterms = 3 if mode == "f16x3" else 1
-            if not isinstance(x, M.SplitActivation):
-                out_px = plan_batch(b) * ((h - 1) // stride + 1) * ((wd - 1) // stride + 1)
-                if PRESPLIT == "all" and (w.cout // 64 >= 8 or (w.cin >= 128 and out_px >= 12288)):
-                    x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None), want_lo=nterms == 3)
+            if to_split:
+                x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None), want_lo=nterms == 3)
             return M.conv2d_f16_split(lib(), stream(), x, hi, lo, nterms, w.cout, stride, next_scale=split_out.get("next_scale"),
                                       next_shift=split_out.get("next_shift"), want_f32=split_out.get("want_f32", False), **kw)
         return None, _conv_unpadded(x, w, k, stride, presplit, **kw)
@@ -220,7 +222,7 @@ def _conv_unpadded(x, w, k, stride=1, presplit=False, split_out=None, **kw):
         # GEMM then stages it by LDS-DMA instead of converting it in every block column
         # (from 32 tiles already at 128 pixels: SEAN's table GEMM - 288 channel tiles over 304 label columns - spent 3/4 of its
         # 160 us converting the same 512 x 304 input in every block column)
-        px = plan_batch(x.shape[0]) * h * wd  # batch-invariant mode: the same launches at any batch (results are equal either way)
+        px = x.shape[0] * h * wd  # pre-split or register-staged input: equal results, so the whole launch decides in every mode
         if (PRESPLIT == "all" and stride == 1 and kw.get("groups", 1) == 1 and w.cin % 8 == 0
                 and ((w.cout // 64 >= 8 and px >= 512) or (w.cout // 64 >= 32 and px >= 128))):
             x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None), want_lo=nterms == 3)
@@ -241,7 +243,7 @@ def _conv_unpadded(x, w, k, stride=1, presplit=False, split_out=None, **kw):
         # worth a separate pass when the same input tile is converted by many (group, 64-channel) block columns -
         # or, from 128 input channels, when a batched pass (HairFast.swap_batch) makes the extra launch negligible
         # (tools/bench_enc_layers.py, ENC_BATCH_MULT=8: 256->256 @32^2 128 -> 111 us, 512->512 stride 2 340 -> 160 us)
-        out_px = plan_batch(x.shape[0]) * ((h - 1) // stride + 1) * ((wd - 1) // stride + 1)
+        out_px = x.shape[0] * ((h - 1) // stride + 1) * ((wd - 1) // stride + 1)  # (bit-neutral: the real batch)
         many = groups * (w.cout // 64) >= 8 or (w.cin >= 128 and out_px >= 12288)
         if not isinstance(x, M.SplitActivation) and ((PRESPLIT == "all" and many) or (presplit and PRESPLIT in ("all", "heads"))):
             x = M.split_activation_f16(lib(), stream(), x, kw.pop("in_scale", None), kw.pop("in_shift", None),

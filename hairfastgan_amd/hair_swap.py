@@ -46,7 +46,7 @@ from torch import nn
 
 from . import _marshal as M
 from . import checkpoints as ckpt_files
-from ._runtime import batch_invariant, configured_conv_precision, conv_precision_scope, lib, reference_rng_walk, require_gpu, run_guarded, stream
+from ._runtime import batch_invariant, batch_invariant_scope, configured_conv_precision, conv_precision_scope, lib, reference_rng_walk, require_gpu, run_guarded, stream
 from .encoders import ClipBlendingModel, Encoder4Editing, FSEncoder, PostProcessModel, RotateModel, get_latents
 from .face_parsing import BiSeNet, get_segmentation
 from .net import Net
@@ -652,6 +652,9 @@ class HairFast:
       conv_precision  this object's matrix-core mode ("f16x3" | "f32" | "f16" | "auto"; _runtime.CONV_PRECISIONS): set for
                       the duration of each swap / swap_batch / swap_graphed call and restored, so that two HairFast objects
                       of one process can differ (default None: the process-wide HAIRFAST_CONV_PRECISION / set_conv_precision)
+      batch_invariant this object's plan mode (None: the process-wide HAIRFAST_DETERMINISTIC / set_batch_invariant, ON by
+                      default): True = `swap_batch` gives every triple the bits - and mask indices - `swap` gives it alone;
+                      False = plans from the whole launch (a few per cent faster batched, near-tie argmax flips possible)
       sean_state + sean_mean_codes   SEAN generator (…/CelebA-HQ_pretrained/latest_net_G.pth) and the [19,512] per-label
                       median style codes (models/sean_codes/styles_test/mean_style_code/median/<label>/ACE.npy)
     """
@@ -684,9 +687,10 @@ class HairFast:
     def __init__(self, args, *, stages=None, generator_state=None, e4e_state=None, fs_state=None, e4e_latent_avg=None,
                  fs_dlatent_avg=None, pp_state=None, pp_latent_avg=None, bisenet_state=None, rotate_state=None,
                  blend_state=None, clip_image_embed=None, shape_state=None, sean_state=None, sean_mean_codes=None,
-                 clip_state=None, pretrained_root=None, conv_precision=None):
+                 clip_state=None, pretrained_root=None, conv_precision=None, batch_invariant=None):
         self.args = args
         self.conv_precision = conv_precision  # None: the process-wide mode; else this object's own (set per call)
+        self.batch_invariant = batch_invariant  # None: the process-wide setting (default on); True / False: this object's own
         conv_precision_scope(conv_precision)  # validates
         if getattr(args, "save_all", False):
             raise NotImplementedError(
@@ -776,7 +780,7 @@ class HairFast:
             set_seed(seed_)
             return self._swap_from_tensors(*images, exp_name=exp_name, **kwargs)
 
-        with conv_precision_scope(self.conv_precision):
+        with conv_precision_scope(self.conv_precision), batch_invariant_scope(self.batch_invariant):
             final_image = run_guarded(run)
         if benchmark:
             torch.cuda.current_stream().synchronize()
@@ -799,7 +803,7 @@ class HairFast:
         if len({id(im) for im in images}) != 3 or getattr(self.args, "save_all", False):
             return self.swap(*images, seed=seed)
         images = [im.float().contiguous() for im in images]
-        with conv_precision_scope(self.conv_precision):
+        with conv_precision_scope(self.conv_precision), batch_invariant_scope(self.batch_invariant):
             return self._swap_graphed(images, seed)
 
     def _swap_graphed(self, images, seed):
@@ -838,7 +842,7 @@ class HairFast:
                     res[t] = self._swap_from_tensors(*tr, **kwargs)
             return res
 
-        with conv_precision_scope(self.conv_precision):
+        with conv_precision_scope(self.conv_precision), batch_invariant_scope(self.batch_invariant):
             return run_guarded(run)
 
 

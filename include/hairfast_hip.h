@@ -367,6 +367,12 @@ int hf_conv2d_f16_split_f32(float *out, void *out_hi, void *out_lo, const float 
                             int nterms, const float *in_scale, const float *in_shift, const float *out_scale,
                             const float *bias, int act, const float *slope, float alpha, const float *residual, int batch,
                             int cin, int cout, int h, int w, int stride, void *stream);
+/* 1 when hf_conv2d_f16_split_f32 takes a launch of this shape (ABI 11): the split output is written by the conv kernel's own
+ * epilogue, so a launch that spreads its K loop over the grid (hf_conv2d_f16_workspace_floats != 0 for it) cannot produce it.
+ * In batch-invariant mode a launch that fills the chip by itself runs its K partition inside the blocks instead (same bits),
+ * which the register-staged 512-pixel tile form has no registers for: the answer depends on `presplit_input`
+ * (x_hi / x_lo given) and `nterms`. */
+int hf_conv2d_f16_split_output_ok(int batch, int cin, int cout, int h, int w, int stride, int nterms, int presplit_input);
 /* hf_conv2d_f32 for k = 1 on the fp16 matrix cores (csrc/gemm_h.hip): a GEMM over the pixels,
  *   y = act( out_scale[co] * sum_ci W[co,ci] * (in_scale[ci]*x + in_shift[ci]) + bias[co] ) + residual,
  * stride in {1, 2} (the source pixel of output (oy, ox) is (oy*stride, ox*stride)), operand modes as hf_conv2d_f16_f32.
@@ -636,7 +642,9 @@ int hf_debug_set_persistent_blocks(int blocks);
  * stage's LDS-DMA copies in the stage's first tap-step instead of spreading them one per tap-step (the default,
  * measured 0-8 % faster on every generator layer); bit 2 = hf_conv2d_f16_f32 never uses its 512-pixel tile form,
  * bits 8-15 = the minimum number of 512-pixel blocks / 8 for that form (0 = the default, 512), bits 16-23 = the
- * same for the 256-pixel form (default 384).  Results of the generator
+ * same for the 256-pixel form (default 384), bits 24-31 = the block count from which a launch counts as filling the
+ * chip by itself (0 = the default, 256; batch-invariant plans: such a launch runs its K partition inside its blocks instead
+ * of spreading it over the grid - tests reach that form on small shapes with it).  Results of the generator
  * kernels do not depend on it; tile forms of hf_conv2d_f16_f32 differ in summation order only. */
 int hf_debug_set_tuning(int bits);
 /* Batch-invariant plans (process-wide; returns the previous setting; set it while no other thread is launching).  Split-K factors and tile forms are normally chosen

@@ -173,66 +173,21 @@ def _recorded(hf, fn, force_targets=None):
     return rec
 
 
-def test_swap_batch_equals_single_swaps():
+@pytest.mark.parametrize("invariant", [True, False], ids=["default-batch-invariant", "whole-launch-plans"])
+def test_swap_batch_equals_single_swaps(invariant):
     """HairFast.swap_batch: two triples as ONE batched pass (every hot-path call with the batch of both triples) against
-    two separate swaps, STAGE BY STAGE: latents and feature maps at the fp32 tolerance (what remains between the two forms
-    are summation-order differences of batch-dependent tile plans), every segmentation mask index equal (counted
-    separately; a near-tie flip would show here, not hide in an image-level bound), final images at 1e-4.  Noise strengths
-    are zeroed (the batched and the single calls draw different noise otherwise)."""
-    dev = torch.device("cuda:0")
-    hf = _hairfast(dev)
-    with torch.no_grad():
-        for name, p in hf.net.generator.named_parameters():
-            if name.endswith("noise.weight"):
-                p.zero_()
-    hf.stages.sean_model.netG.noise_source = lambda d, sizes: [torch.zeros(d, r, r, device=dev) for r in sizes]
-    a, b, c = (im.to(dev) for im in C.pipeline_images())  # smooth patterns + noise: parsing maps with regions, few near-ties
-    triples = [(a, b, c), (c.flip(-1).contiguous(), a.flip(-2).contiguous(), b.flip(-1).contiguous())]
-    both = _recorded(hf, lambda: hf.swap_batch(triples, seed=3))
-    assert [c["sig"] for c in both["calls"]] == [(6, 3, 3), (6, 0, 3), (4, 0, 8), (4, 0, 3), (2, 4, 8), (2, 5, 8)]
-    assert len(both["result"]) == 2
+    two separate swaps, STAGE BY STAGE.  Noise strengths are zeroed (the batched and the single calls draw different
+    noise otherwise).
 
-    def close(a, b, what, tol=1e-4):
-        err, scale = float((a - b).abs().max()), max(1.0, float(b.abs().max()))
-        assert err <= tol * scale, (what, err, scale)
+    Default (batch-invariant plans; north_star "bit-exact segmentation-mask indices"): the K partition and the kernel
+    family of every layer are those of the canonical batch-3 launch whatever the real batch, so `swap_batch` and `swap` give
+    EQUAL mask indices everywhere - the BiSeNet masks of the input images, of the generated (rotated) 1024^2 images, the
+    shape adaptor's label maps - with NO teacher forcing, every tensor upstream of an argmax (e4e latents, rotated
+    latents, rotated images) bit-equal, the rest within 1e-4 (CLIP / SEAN GEMMs fold the batch into their pixel axis).
 
-    flips = {}
-    for t, triple in enumerate(triples):
-        one = _recorded(hf, lambda: hf.swap(*triple, seed=3), force_targets=both["targets"][0][2 * t:2 * t + 2])
-        for n in ("face", "shape", "color"):
-            eb, es = both["embed"][(t, n)], one["embed"][n]
-            for k in ("W", "S", "F"):
-                close(eb[k], es[k], f"triple {t} {n} {k}")
-            flips[f"{t}/mask_{n}"] = int((eb["mask"] != es["mask"]).sum())
-        flips[f"{t}/rot_masks"] = int((both["parses"][1][2 * t:2 * t + 2] != one["parses"][1]).sum())
-        flips[f"{t}/target_masks"] = int((both["targets"][0][2 * t:2 * t + 2] != one["targets"][0]).sum())
-        close(both["calls"][2]["latent"][2 * t:2 * t + 2], one["calls"][2]["latent"], f"triple {t} rotated latents")
-        close(torch.stack(list(both["sean"][0][2 * t:2 * t + 2])), torch.stack(list(one["sean"][0])), f"triple {t} SEAN renderings")
-        close(both["align"][0][t]["latent_F_align"], one["align"][0][0]["latent_F_align"], f"triple {t} latent_F_align")
-        assert torch.equal(both["align"][0][t]["HM_X"], one["align"][0][0]["HM_X"])
-        for ci, what in ((4, "S_blend / I_blend"), (5, "S_final / I_final")):
-            close(both["calls"][ci]["latent"][t:t + 1], one["calls"][ci]["latent"], f"triple {t} {what} latent")
-            close(both["calls"][ci]["layer_in"][t:t + 1], one["calls"][ci]["layer_in"], f"triple {t} {what} layer_in")
-        close(both["result"][t], one["result"], f"triple {t} final image")
-    print("swap_batch vs single swaps, mask index differences:", flips)
-    # BiSeNet masks of the INPUT images: equal.  The masks of the GENERATED (rotated) images and the shape adaptor's label
-    # maps are argmaxes downstream of kernels whose tile / split-K plans depend on the batch size (a batch-4 and a batch-2
-    # generator forward take different small-plane kernels): a handful of near-tie pixels may differ - counted, bounded,
-    # and, by teacher forcing above, kept out of the later stages' comparisons.
-    assert all(v == 0 for k, v in flips.items() if "/mask_" in k), flips
-    assert all(v <= 4 for k, v in flips.items() if "rot_masks" in k), flips
-    assert all(v <= 8 for k, v in flips.items() if "target" in k), flips
-    # a triple that repeats an image takes the single path (the reference's shortcuts), the other one the batched path
-    mixed = hf.swap_batch([triples[0], (triples[1][0], triples[1][1], triples[1][1].clone())], seed=3)
-    assert len(mixed) == 2 and all(torch.isfinite(m).all() for m in mixed)
-
-
-def test_swap_batch_equals_single_swaps_in_batch_invariant_mode():
-    """HAIRFAST_DETERMINISTIC=1 (`_runtime.set_batch_invariant`; round-3 verdict item 6, north_star "bit-exact
-    segmentation-mask indices"): split-K factors, tile forms and the small-plane dispatch are planned from the per-sample
-    shape, so `swap_batch` and `swap` of the same triple give EQUAL mask indices everywhere - the BiSeNet masks of the input
-    images, of the generated (rotated) 1024^2 images and the shape adaptor's label maps - with NO teacher forcing, and every
-    tensor upstream of an argmax (e4e latents, rotated latents, the rotated images) equal bit for bit."""
+    HAIRFAST_DETERMINISTIC=0 / set_batch_invariant(False) (plans from the whole launch): latents and feature maps at the fp32
+    tolerance, the masks of the input images equal, a handful of near-tie flips of the downstream argmaxes tolerated
+    (counted; teacher forcing keeps them out of the later stages' comparisons)."""
     from hairfastgan_amd import _runtime
 
     dev = torch.device("cuda:0")
@@ -242,32 +197,35 @@ def test_swap_batch_equals_single_swaps_in_batch_invariant_mode():
             if name.endswith("noise.weight"):
                 p.zero_()
     hf.stages.sean_model.netG.noise_source = lambda d, sizes: [torch.zeros(d, r, r, device=dev) for r in sizes]
-    a, b, c = (im.to(dev) for im in C.pipeline_images())
+    a, b, c = (im.to(dev) for im in C.pipeline_images())  # smooth patterns + noise: parsing maps with regions, few near-ties
     triples = [(a, b, c), (c.flip(-1).contiguous(), a.flip(-2).contiguous(), b.flip(-1).contiguous())]
-    prev = _runtime.set_batch_invariant(True)
+    assert _runtime.batch_invariant(), "batch-invariant plans are the default"
+    prev = _runtime.set_batch_invariant(invariant)
     try:
         both = _recorded(hf, lambda: hf.swap_batch(triples, seed=3))
-        flips, exact = {}, {}
+        assert [c["sig"] for c in both["calls"]] == [(6, 3, 3), (6, 0, 3), (4, 0, 8), (4, 0, 3), (2, 4, 8), (2, 5, 8)]
+        assert len(both["result"]) == 2
         for t, triple in enumerate(triples):
-            one = _recorded(hf, lambda: hf.swap(*triple, seed=3))  # no force_targets: the single swap runs on its own label maps
-            for n in ("face", "shape", "color"):
-                eb, es = both["embed"][(t, n)], one["embed"][n]
-                flips[f"{t}/mask_{n}"] = int((eb["mask"] != es["mask"]).sum())
-                for k in ("W", "S", "F"):
-                    exact[f"{t}/{n}/{k}"] = float((eb[k] - es[k]).abs().max())
-            flips[f"{t}/rot_masks"] = int((both["parses"][1][2 * t:2 * t + 2] != one["parses"][1]).sum())
-            flips[f"{t}/target_masks"] = int((both["targets"][0][2 * t:2 * t + 2] != one["targets"][0]).sum())
-            exact[f"{t}/rotated_latents"] = float((both["calls"][2]["latent"][2 * t:2 * t + 2] - one["calls"][2]["latent"]).abs().max())
-            exact[f"{t}/rotated_images"] = float((both["calls"][2]["out"][2 * t:2 * t + 2] - one["calls"][2]["out"]).abs().max())
-            exact[f"{t}/sean"] = float((torch.stack(list(both["sean"][0][2 * t:2 * t + 2])) - torch.stack(list(one["sean"][0]))).abs().max())
-            exact[f"{t}/final"] = float((both["result"][t] - one["result"]).abs().max())
-            assert torch.equal(both["align"][0][t]["HM_X"], one["align"][0][0]["HM_X"])
-        print("batch-invariant mode: mask index differences", flips)
-        print("batch-invariant mode: max-abs differences", exact)
-        assert all(v == 0 for v in flips.values()), flips
-        upstream = [k for k in exact if k.endswith("/W") or "rotated" in k]
-        assert all(exact[k] == 0.0 for k in upstream), {k: exact[k] for k in upstream}
-        assert all(v <= 1e-4 for v in exact.values()), exact  # downstream of the masks: CLIP / SEAN GEMMs fold the batch into pixels
+            forced = None if invariant else both["targets"][0][2 * t:2 * t + 2]
+            one = _recorded(hf, lambda: hf.swap(*triple, seed=3), force_targets=forced)
+            flips, exact = _stagewise(both, one, t, tol=1e-4)
+            print(f"swap_batch vs single swap, batch-invariant={invariant}, triple {t}: mask index differences {flips}; "
+                  f"worst max-abs {max(exact.values()):.3g} ({max(exact, key=exact.get)})")
+            assert all(v == 0 for k, v in flips.items() if k.startswith("mask_")) and flips["HM_X"] == 0, flips
+            if invariant:
+                assert all(v == 0 for v in flips.values()), flips
+                upstream = [k for k in exact if k.endswith("/W") or k.startswith("rotated")]
+                assert all(exact[k] == 0.0 for k in upstream), {k: exact[k] for k in upstream}
+            else:
+                assert flips["rot_masks"] <= 4 and flips["target_masks"] <= 8, flips
+        # a triple that repeats an image takes the single path (the reference's shortcuts), the other one the batched path
+        mixed = hf.swap_batch([triples[0], (triples[1][0], triples[1][1], triples[1][1].clone())], seed=3)
+        assert len(mixed) == 2 and all(torch.isfinite(m).all() for m in mixed)
+        # the object's own switch (HairFast(args, batch_invariant=...)) is set for the duration of its calls and restored
+        hf.batch_invariant = not invariant
+        hf.swap(*triples[0], seed=3)
+        hf.batch_invariant = None
+        assert _runtime.batch_invariant() == invariant
     finally:
         _runtime.set_batch_invariant(prev)
 

@@ -251,43 +251,54 @@ def test_equal_replacer_matches_the_reference_rule():
     assert r[1] is not r[0]
 
 
-def test_batch_invariant_plans_scale_with_the_batch():
-    """hf_set_batch_invariant (HAIRFAST_DETERMINISTIC=1): split-K plans are made from ONE sample's grid, so the workspace of
-    a batch-B launch is exactly B times the batch-1 workspace - whereas the default plan splits a batch-8 launch less (or not
-    at all) than a batch-1 launch.  Host-side planning code of the product library: runs without a GPU."""
+def test_batch_invariant_plans_do_not_follow_the_batch():
+    """hf_set_batch_invariant (the default since round 5; HAIRFAST_DETERMINISTIC=0 opts out): the K partition of a layer is the
+    canonical batch-3 launch's whatever the real batch - a launch that leaves the chip empty spreads it over the grid
+    (workspace = B x the batch-1 workspace: the same number of slabs per sample), a launch that fills the chip by itself runs it
+    inside its blocks (no workspace at all) - whereas whole-launch plans split a batch-48 launch less than a batch-1 launch.
+    Host-side planning code of the product library: runs without a GPU."""
     from hairfastgan_amd import _lib, _runtime
 
     L = _lib.load()
     shapes = [(256, 64, 16, 16, 1), (256, 256, 32, 32, 1), (512, 512, 32, 32, 2)]
     try:
         assert L.hf_set_batch_invariant(1) in (0, 1)
-        for cin, cout, h, w, stride in shapes:
+        for k, (cin, cout, h, w, stride) in enumerate(shapes):
             one = L.hf_conv2d_f16_workspace_floats(1, cin, cout, h, w, stride, 1)
-            assert one > 0, "batch 1 must plan split-K for these shapes"
-            for b in (2, 3, 8, 48):
-                assert L.hf_conv2d_f16_workspace_floats(b, cin, cout, h, w, stride, 1) == b * one
-            g1 = L.hf_conv1x1_f16_workspace_floats(1, 768, 3072, 1, 50, 1, 1)
-            assert L.hf_conv1x1_f16_workspace_floats(4, 768, 3072, 1, 50, 1, 1) == 4 * g1 > 0
+            assert one > 0, "the canonical plan must split K for these shapes"
+            for b in (2, 3, 8):
+                assert L.hf_conv2d_f16_workspace_floats(b, cin, cout, h, w, stride, 1) in (b * one, 0)
+            assert L.hf_conv2d_f16_workspace_floats(3, cin, cout, h, w, stride, 1) == 3 * one
+            big = L.hf_conv2d_f16_workspace_floats(48, cin, cout, h, w, stride, 1)
+            assert big == (48 * one if k == 0 else 0)  # 96 blocks: still spread over the grid; 768 blocks: virtual
+            # a split output needs the conv's own epilogue: only the virtual form offers it
+            assert L.hf_conv2d_f16_split_output_ok(1, cin, cout, h, w, stride, 3, 1) == 0
+            assert L.hf_conv2d_f16_split_output_ok(48, cin, cout, h, w, stride, 3, 1) == (0 if k == 0 else 1)
+        g1 = L.hf_conv1x1_f16_workspace_floats(1, 768, 3072, 1, 50, 1, 1)
+        assert L.hf_conv1x1_f16_workspace_floats(4, 768, 3072, 1, 50, 1, 1) == 4 * g1 > 0
+        assert L.hf_conv1x1_f16_workspace_floats(64, 768, 3072, 1, 50, 1, 1) == 0
         L.hf_set_batch_invariant(0)
         cin, cout, h, w, stride = shapes[1]
         one = L.hf_conv2d_f16_workspace_floats(1, cin, cout, h, w, stride, 1)
-        assert L.hf_conv2d_f16_workspace_floats(48, cin, cout, h, w, stride, 1) < 48 * one  # the default plan follows the launch
+        assert L.hf_conv2d_f16_workspace_floats(8, cin, cout, h, w, stride, 1) < 8 * one  # whole-launch plans follow the launch
     finally:
         L.hf_set_batch_invariant(1 if _runtime.batch_invariant() else 0)
-    assert _runtime.plan_batch(7) == (1 if _runtime.batch_invariant() else 7)
+    assert _runtime.plan_batch(7) == (_runtime.CANON_BATCH if _runtime.batch_invariant() else 7)
 
 
 def test_deterministic_env_switch_reaches_the_library():
-    """HAIRFAST_DETERMINISTIC=1 is read at import and applied to the library by the first `_runtime.lib()` call (plans are
-    made inside C calls: the flag must be there before the first launch, not after the first host-side predicate)."""
+    """HAIRFAST_DETERMINISTIC (default: on) is read at import and applied to the library by the first `_runtime.lib()` call
+    (plans are made inside C calls: the flag must be there before the first launch, not after the first host-side predicate)."""
     import subprocess
     import sys
 
     code = ("from hairfastgan_amd import _runtime; L = _runtime.lib(); "
             "print(int(_runtime.batch_invariant()), L.hf_set_batch_invariant(1), _runtime.plan_batch(9))")
-    for env_val, want in (("1", "1 1 1"), ("0", "0 0 9")):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
-                           env=dict(os.environ, HAIRFAST_DETERMINISTIC=env_val), timeout=300)
+    for env_val, want in (("1", "1 1 3"), ("0", "0 0 9"), (None, "1 1 3")):
+        env = {k: v for k, v in os.environ.items() if k != "HAIRFAST_DETERMINISTIC"}
+        if env_val is not None:
+            env["HAIRFAST_DETERMINISTIC"] = env_val
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
         assert r.returncode == 0, r.stderr[-1500:]
         assert r.stdout.strip().splitlines()[-1] == want, r.stdout
 

@@ -458,3 +458,88 @@ def test_conv2d_f16_split_output(simlib, stride, nterms):
     z1 = M.conv2d_f16(simlib, None, sp2, hi2, lo2, nterms, 64, 1)
     z2 = M.conv2d_f16(simlib, None, want2, hi2, lo2, nterms, 64, 1)
     assert torch.equal(z1, z2)
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
+@pytest.mark.parametrize("stride,pre", [(1, False), (1, True), (2, True)])
+def test_conv2d_f16_virtual_split_k_equals_the_two_launch_form(simlib, nterms, stride, pre):
+    """Batch-invariant plans (the default): the K partition of a layer is the canonical launch's (batch 3), whatever the real
+    batch; a launch that fills the chip by itself walks the slabs INSIDE its blocks (ConvParams::vsplit: a second
+    accumulator set, slabs added in z order, the block's own store_tile_rows epilogue) - bit for bit what the batch-1
+    launch of the same layer gives with its slabs in memory and the splitk_reduce pass.  Also: the 512-pixel tile form,
+    the split output (available again, since the epilogue runs in the conv kernel), PReLU + residual in the epilogue."""
+    torch.manual_seed(41 + stride)
+    cin, cout, H, W = 256, 64, 16 * stride, 32 * stride
+    form512 = stride == 1 and nterms == 3 and pre  # also the 64 x 512 tile form: 13 images = 13 such tiles (> the canonical launch's 12 blocks)
+    B = 13 if form512 else 6
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    hi, lo = M.conv_split_weights_f16(simlib, None, M.conv_prepare(simlib, None, w))
+    a, t = torch.rand(cin) + 0.5, torch.randn(cin) * 0.2
+    g, bsh, slope = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2, torch.rand(cout) * 0.5
+    res = torch.randn(B, cout, H // stride, W // stride)
+    kw = dict(out_scale=g, bias=bsh, act=M.ACT_PRELU, slope=slope)
+    src = lambda xx: (M.split_activation_f16(simlib, None, xx, a, t, want_lo=nterms == 3), {}) if pre else (xx, dict(in_scale=a, in_shift=t))  # noqa: E731
+    prev = simlib.hf_set_batch_invariant(1)
+    try:
+        # one sample at a time: 4 (stride 2: 4) output tiles x 16 stages -> the canonical plan splits K, for real
+        assert simlib.hf_conv2d_f16_workspace_floats(1, cin, cout, H, W, stride, 1) > 0
+        assert not M.conv2d_f16_split_supported(simlib, 1, cin, cout, H, W, stride, nterms, pre=pre)
+        singles = []
+        for b in range(B):
+            xin, kin = src(x[b:b + 1])
+            singles.append(M.conv2d_f16(simlib, None, xin, hi, lo, nterms, cout, stride, residual=res[b:b + 1], **kw, **kin))
+        ref = torch.cat(singles)
+        # the whole batch (>= 24 output tiles) with "the chip" shrunk to 13 blocks - the canonical batch-3 launch (12 tiles) still
+        # splits, this one fills it: virtual split, no workspace, same bits
+        simlib.hf_debug_set_tuning(13 << 24)
+        assert simlib.hf_conv2d_f16_workspace_floats(B, cin, cout, H, W, stride, 1) == 0  # (the query plans register-staged input)
+        xin, kin = src(x)
+        y = M.conv2d_f16(simlib, None, xin, hi, lo, nterms, cout, stride, residual=res, **kw, **kin)
+        assert torch.equal(y, ref)
+        if form512:  # (pre-split input only: the register-staged 512-pixel form has no registers left for the second accumulator set)
+            simlib.hf_debug_set_tuning((13 << 24) | (1 << 8))
+            y512 = M.conv2d_f16(simlib, None, xin, hi, lo, nterms, cout, stride, residual=res, **kw, **kin)
+            assert simlib.hf_debug_last_path() == 604 and torch.equal(y512, ref)
+            simlib.hf_debug_set_tuning(13 << 24)
+        # the split output of the virtual form = the split of the fp32 result
+        assert M.conv2d_f16_split_supported(simlib, B, cin, cout, H, W, stride, nterms, pre=pre)
+        sp, y2 = M.conv2d_f16_split(simlib, None, xin, hi, lo, nterms, cout, stride, want_f32=True, **kw, **kin)
+        noresid = torch.cat([M.conv2d_f16(simlib, None, src(x[b:b + 1])[0], hi, lo, nterms, cout, stride, **kw, **src(x[b:b + 1])[1])
+                             for b in range(B)])
+        assert torch.equal(y2, noresid)
+        want = M.split_activation_f16(simlib, None, noresid, want_lo=nterms == 3)
+        assert torch.equal(sp.hi, want.hi) and (nterms == 1 or torch.equal(sp.lo, want.lo))
+    finally:
+        simlib.hf_debug_set_tuning(0)
+        simlib.hf_set_batch_invariant(prev)
+    ref32 = F.prelu(F.conv2d(x * a.view(1, -1, 1, 1) + t.view(1, -1, 1, 1), w, stride=stride, padding=1) * g.view(1, -1, 1, 1)
+                    + bsh.view(1, -1, 1, 1), slope) + res
+    assert maxdiff(y, ref32) < (TOL if nterms == 3 else 4e-3) * max(1.0, float(ref32.abs().max()))
+
+
+def test_conv1x1_f16_virtual_split_k_equals_the_two_launch_form(simlib):
+    """gemm_h.hip under batch-invariant plans: hf_conv1x1_f16_f32 of a batch that fills "the chip" runs the canonical K
+    partition inside its blocks - the bits of the one-sample launches with their slabs and splitk_reduce; and the tap-GEMM
+    of the small-plane modulated conv (raw slabs + small_combine) likewise."""
+    torch.manual_seed(43)
+    B, cin, cout, H, W = 8, 512, 64, 8, 8
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 1, 1) / cin ** 0.5
+    a, t = torch.rand(cin) + 0.5, torch.randn(cin) * 0.2
+    g, bsh = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2
+    hi, lo = M.conv_split_weights_f16(simlib, None, M.conv_prepare(simlib, None, w))
+    prev = simlib.hf_set_batch_invariant(1)
+    try:
+        assert simlib.hf_conv1x1_f16_workspace_floats(1, cin, cout, H, W, 1, 1) > 0
+        kw = dict(in_scale=a, in_shift=t, out_scale=g, bias=bsh, act=M.ACT_LRELU, alpha=0.2)
+        ref = torch.cat([M.conv1x1_f16(simlib, None, x[b:b + 1], hi, lo, 3, cout, 1, **kw) for b in range(B)])
+        simlib.hf_debug_set_tuning(3 << 24)  # canonical batch 3: 2 blocks (two 8 x 8 images per tile) - splits; batch 8: 4 blocks
+        assert simlib.hf_conv1x1_f16_workspace_floats(B, cin, cout, H, W, 1, 1) == 0
+        y = M.conv1x1_f16(simlib, None, x, hi, lo, 3, cout, 1, **kw)
+        assert torch.equal(y, ref)
+    finally:
+        simlib.hf_debug_set_tuning(0)
+        simlib.hf_set_batch_invariant(prev)
+    want = F.leaky_relu(F.conv2d(x * a.view(1, -1, 1, 1) + t.view(1, -1, 1, 1), w) * g.view(1, -1, 1, 1) + bsh.view(1, -1, 1, 1), 0.2)
+    assert maxdiff(y, want) < TOL * max(1.0, float(want.abs().max()))

@@ -632,3 +632,59 @@ def test_conv_rows_pipeline_equals_tiled_kernel(simlib, B, H, W):
     out1, raw1 = M.modconv3x3_f16_pre(simlib, None, act1, hi, lo, 1, dm, nz, nw, bias, rgb=(rgb_w, rgb_s))
     assert simlib.hf_debug_last_path() == 579
     assert torch.equal(out1, ref1_out) and torch.equal(raw1, ref1_raw) and not torch.equal(out1, out)
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
+def test_modconv_f16_tile_forms_51_and_52_give_equal_bits(simlib, nterms):
+    """The two same-resolution tile forms of csrc/convh.hip (51: 64 co x 256 px, 2 x 4 waves of 1 x 2 MFMA tiles; 52: 64 co x
+    512 px, 8 waves of 2 x 2 tiles) walk K in the same order - chunk, tap, (hi*hi, hi*lo, lo*hi) - so a sample's bits do
+    not depend on which one a launch takes: the choice follows the whole launch also under batch-invariant plans.  Ragged
+    plane, odd chunk count, fp32 and pre-split input, noise + bias + lrelu epilogue."""
+    B, cin, cout, H, W = 2, 48, 64, 36, 40
+    torch.manual_seed(23)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    s, dm = torch.rand(B, cin) + 0.5, torch.rand(B, cout) + 0.5
+    nz, nw, bias = torch.randn(B, 1, H, W), torch.tensor([0.3]), torch.randn(cout)
+    wt, _ = M.prepare_weights(simlib, None, wgt)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    act = M.SplitActivation(*M.split_activation_reference(x, s), None)
+    out = {}
+    try:
+        for cfg in (51, 52):
+            simlib.hf_debug_set_dispatch(cfg, 0)
+            out[cfg] = M.modconv3x3_f16(simlib, None, x, hi, lo, nterms, s, dm, nz, nw, bias)
+            assert simlib.hf_debug_last_path() == 500 + cfg
+            out[cfg, "pre"] = M.modconv3x3_f16_pre(simlib, None, act, hi, lo, nterms, dm, nz, nw, bias)
+            assert simlib.hf_debug_last_path() == 520 + cfg
+    finally:
+        simlib.hf_debug_set_dispatch(0, 0)
+    assert torch.equal(out[51], out[52]) and torch.equal(out[51, "pre"], out[52, "pre"]) and torch.equal(out[51], out[51, "pre"])
+
+
+def test_small_plane_tap_gemm_virtual_split_k(simlib):
+    """hf_modconv3x3_small_f16_f32 (the tap GEMM of the generator's small planes + small_combine) under batch-invariant
+    plans: a batch that fills "the chip" keeps the canonical K partition inside its blocks (one slab instead of `splits`) -
+    the bits of the one-sample launches."""
+    torch.manual_seed(29)
+    B, cin, cout, H, W = 4, 256, 64, 8, 8
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    s, dm = torch.rand(B, cin) + 0.5, torch.rand(B, cout) + 0.5
+    nz, nw, bias = torch.randn(B, 1, H, W), torch.tensor([0.3]), torch.randn(cout)
+    wt, _ = M.prepare_weights(simlib, None, wgt)
+    w9 = M.split_weights_small(simlib, None, wt)
+    prev = simlib.hf_set_batch_invariant(1)
+    try:
+        ref = torch.cat([M.modconv3x3_small(simlib, None, x[b:b + 1], w9, 3, s[b:b + 1], dm[b:b + 1], nz[b:b + 1], nw, bias, cout)
+                         for b in range(B)])
+        n1 = simlib.hf_modconv3x3_small_workspace_floats(B, cin, cout, H, W)
+        # canonical batch 3: 2 pixel tiles (two 8 x 8 images each) x 9 channel tiles = 18 blocks -> splits; batch 4: 18 too...
+        simlib.hf_debug_set_tuning(18 << 24)
+        y = M.modconv3x3_small(simlib, None, x, w9, 3, s, dm, nz, nw, bias, cout)
+        n2 = simlib.hf_modconv3x3_small_workspace_floats(B, cin, cout, H, W)
+    finally:
+        simlib.hf_debug_set_tuning(0)
+        simlib.hf_set_batch_invariant(prev)
+    assert torch.equal(y, ref)
+    assert n2 < n1  # one slab instead of `splits`: the virtual form ran

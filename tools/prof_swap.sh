@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over the batched swap at the pass size the bench line is timed on (run on the GPU box from the repo root):
 #   tools/prof_swap.sh <tag> [stats|pmc|det ...]     (default: stats)
-# stats: --kernel-trace --stats;  det: the same with HAIRFAST_DETERMINISTIC=1;  pmc: FETCH_SIZE / WRITE_SIZE / MFMA-busy in
+# stats: --kernel-trace --stats;  det / nodet: the same with HAIRFAST_DETERMINISTIC=1 / 0;  pmc: FETCH_SIZE / WRITE_SIZE / MFMA-busy in
 # separate runs (counters never together with other trace domains).  bench.py brackets its timed region with
 # hf_profile_marker_kernel launches; tools/summarize_prof.py --between / tools/make_pmc_traffic.py --between cut to it.
 tag=$1; shift
@@ -17,6 +17,9 @@ for w in $what; do
     det)
       HAIRFAST_DETERMINISTIC=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_swapdet_stats -o bench -- $B > $R/gpurun_out/prof_${tag}_swapdet_stats.log 2>&1
       echo "swap det stats rc=$?" ;;
+    nodet)  # plans from the whole launch (the opt-out of the batch-invariant default)
+      HAIRFAST_DETERMINISTIC=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_swapnodet_stats -o bench -- $B > $R/gpurun_out/prof_${tag}_swapnodet_stats.log 2>&1
+      echo "swap nodet stats rc=$?" ;;
     pmc)
       for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
         name=$(echo $set | cut -d' ' -f1); [ "$name" = "SQ_VALU_MFMA_BUSY_CYCLES" ] && name=MFMA
