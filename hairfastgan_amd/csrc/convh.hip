@@ -40,6 +40,9 @@ using namespace hf_detail;
 #ifndef HF_H_SPLIT_STORE16
 #define HF_H_SPLIT_STORE16 0  // fused upsampling epilogue: 1 = split output as ONE 16-byte store per lane (v_permlane32_swap of the half-waves) instead of two 8-byte stores; measured equal (587 vs 595 us on the 1024^2 layer): the epilogue is not store-bound
 #endif
+#ifndef HF_H_PINGPONG
+#define HF_H_PINGPONG 1  // 0: the one-phase K loop (side work of a tap-step, then its MFMAs, all eight waves in lock-step) for A/B builds
+#endif
 #ifndef HF_H_ABLATE
 #define HF_H_ABLATE 0  // timing experiments only: 1 no activation loads, 2 no epilogue stores, 4 no weight DMA, 8 no activation DMA
 #endif
@@ -733,6 +736,18 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
 
   // (s_setprio 1 for the second-dispatched half of the block - MI355X_MICROARCH.md, "two waves per SIMD", item 4 -
   // measured no effect on any generator layer)
+  // PP ("ping-pong"; pre-split input = all staging is LDS-DMA, eight waves = two per SIMD): the two waves of a SIMD (w and
+  // w + 4: a workgroup's waves go round the four SIMDs) take TURNS on the matrix pipe.  Phase A of a K stage: waves 0-3 run the
+  // stage's MFMAs back to back while waves 4-7 issue their LDS-DMA copies of the next stage; s_barrier; phase B: roles swapped;
+  // s_barrier.  In the one-phase form every wave alternates a tap's side work with its MFMAs and all eight run in lock-step:
+  // the pipe idles while both waves of a SIMD sit in their DMA issues (100-185 cycles each for an in-order wave; a tap-step took
+  // 1.2-1.5 k cycles for 768 cycles of MFMA time, profiles/r04a_trace_fused.txt) - here the partner's MFMAs cover them
+  // (MI355X_MICROARCH.md, "Two waves per SIMD": matrix beside memory pays, matrix beside matrix does not).  Per wave the K order
+  // is unchanged: equal bits.  Hazards: stage c is complete since the end-of-stage barrier of stage c-1 (every wave drained its
+  // copies, vmcnt(0)); the copies of stage c+1 go to the buffer stage c-1 was read from, whose last readers (phase B of c-1)
+  // passed that barrier too; the mid-stage barrier only swaps the roles (copies stay in flight across it).
+  constexpr bool PP = PRE && NW == 8 && HF_H_PINGPONG;
+  const int pp_half = wave >> 2;
   int stage = 0;  // LDS buffer = stage & 1, running across tiles
   int trace_n = 0;
   (void)trace_n;
@@ -813,6 +828,15 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
           nzf[g][0] = n0.x; nzf[g][1] = n0.y; nzf[g][2] = n1.x; nzf[g][3] = n1.y;
         }
       }
+      if (PP && pp_half == 1) {  // phase A of the second half: its copies of the next stage, then the role swap
+        if (more1) {
+#pragma unroll
+          for (int j = 0; j < ND; ++j) dma_piece(j, cpf, cb ^ 1);
+#pragma unroll
+          for (int e = 0; e < XE; ++e) dma_x(e, cpf, cb ^ 1);
+        }
+        hf_barrier_lds();
+      }
       const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT + ct*32
       const half8 *b_hi = buf + OFF_XH + lh * NPIX;      // + pixrow + tap column
       // fragments of tap+1 are fetched from LDS while the MFMAs of tap run
@@ -867,13 +891,13 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
           // the next group's activation fragment, as soon as its slot is free (= when this group starts)
           if (group_first<UP>(grp) == i && group_first<UP>(grp + 1) < 9) fetch_b(sb ^ 1, tap_at<UP>(group_first<UP>(grp + 1)));
         }
-        // ---- side work of this step ----
-        if (more1) {
+        // ---- side work of this step (PP: none - the copies are issued in the wave's other phase) ----
+        if (!PP && more1) {
 #pragma unroll
           for (int j = 0; j < ND; ++j)
             if ((early ? 0 : j / DMA_PER_STEP) == i) dma_piece(j, cpf, cb ^ 1);
         }
-        if (PRE && more1) {  // activation DMAs in tap-steps 1, 3, 5, ...
+        if (!PP && PRE && more1) {  // activation DMAs in tap-steps 1, 3, 5, ...
 #pragma unroll
           for (int e = 0; e < XE; ++e)
             if (i == (early ? 0 : ((2 * XE <= 9) ? 1 + 2 * e : 1 + e))) dma_x(e, cpf, cb ^ 1);
@@ -910,6 +934,15 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
         __builtin_amdgcn_sched_barrier(0);
       }
       HF_TRACE_POINT(2);  // chunk MFMAs issued, before the barrier
+      if (PP && pp_half == 0) {  // phase B of the first half: role swap, then its copies of the next stage
+        hf_barrier_lds();
+        if (more1) {
+#pragma unroll
+          for (int j = 0; j < ND; ++j) dma_piece(j, cpf, cb ^ 1);
+#pragma unroll
+          for (int e = 0; e < XE; ++e) dma_x(e, cpf, cb ^ 1);
+        }
+      }
       // next stage complete (DMA landed, conversions written), current one free
       HF_H_BARRIER();
       HF_TRACE_POINT(3);  // after the barrier

@@ -36,6 +36,9 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KH = 16;  // input channels per stage = K of one MFMA
+#ifndef HF_ENC_PINGPONG
+#define HF_ENC_PINGPONG 1  // 0: the one-phase K loop for every form (A/B builds: tools/build_variant.sh -DHF_ENC_PINGPONG=0)
+#endif
 
 // 16-byte units of one activation part per kgroup that the LDS tile is sized for
 template <int PT, int STRIDE>
@@ -260,13 +263,107 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
   }
   hf_barrier_keep_young<0>();
 
+  // ---- K loop.  PP ("ping-pong", pre-split input, eight waves = two per SIMD): the two waves of a SIMD (w and w + 4: a
+  // workgroup's waves go round the four SIMDs) take TURNS on the matrix pipe - phase A: the first half of the block runs its
+  // 108 MFMAs of the stage back to back while the second half issues its LDS-DMA copies of the next stage; s_barrier; phase B:
+  // roles swapped; s_barrier.  In the one-phase form (every wave: a tap's side work, then its MFMAs, all eight in lock-step)
+  // the pipe idles while both waves of a SIMD sit in their DMA issues (100-185 cycles each, in-order waves: a tap-step took
+  // 1.2-1.5 k cycles for 768 cycles of MFMA time, profiles/r04a_trace_fused.txt); here the partner's MFMAs cover them
+  // (MI355X_MICROARCH.md, "Two waves per SIMD": matrix beside memory).  Same K order per wave: equal bits.
+  constexpr bool PP = PRE && NW == 8 && HF_ENC_PINGPONG;
+  const int half = wave >> 2;  // PP: 0 computes in phase A, 1 in phase B
+  half8 ah[2][CT_TILES], al[2][CT_TILES], bh[2][PG], bl[2][PG];
+  auto compute_stage = [&](const half8 *buf) {  // the 9 taps of one K stage: fragments of tap+1 fetched under the MFMAs of tap
+    const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT
+    const half8 *b_hi = buf + OFF_XH + lh * NPIX;
+    auto fetch = [&](int slot, int tap) {
+      const int ky = tap / 3, kx = tap % 3;
+      const int toff = (STRIDE == 1) ? ky * wp + kx : ky * wp + (kx & 1) * wp2 + (kx >> 1);
+#pragma unroll
+      for (int ct = 0; ct < CT_TILES; ++ct) {
+        ah[slot][ct] = a_hi[tap * 2 * CT + ct * 32];
+        if (NTERMS == 3) al[slot][ct] = a_hi[OFF_WL + tap * 2 * CT + ct * 32];
+      }
+#pragma unroll
+      for (int g = 0; g < PG; ++g) {
+        bh[slot][g] = b_hi[pix0[g] + toff];
+        if (NTERMS == 3) bl[slot][g] = b_hi[X_UNITS + pix0[g] + toff];
+      }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int s_ = tap & 1;
+      if (tap + 1 < 9) fetch(s_ ^ 1, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+        for (int g = 0; g < PG; ++g)
+          acc[0][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_][ct], bh[s_][g], acc[0][ct][g], 0, 0, 0);
+      if (NTERMS == 3) {
+#pragma unroll
+        for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+          for (int g = 0; g < PG; ++g)
+            acc[0][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_][ct], bl[s_][g], acc[0][ct][g], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+          for (int g = 0; g < PG; ++g)
+            acc[0][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s_][ct], bh[s_][g], acc[0][ct][g], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto stage_dma = [&](int chunk, int bufsel) {  // PP: this wave's share of a stage's copies, issued back to back
+#pragma unroll
+    for (int i = 0; i < ND; ++i) dma_piece(i, chunk, bufsel);
+#pragma unroll
+    for (int e = 0; e < XE; ++e) dma_x(e, chunk, bufsel);
+  };
+  auto slab_end = [&](bool more) {  // VSPLIT: a slab ends - its sum (pre-scale undone, exact) joins the earlier slabs'
+    if (VSPLIT && (--slab_left == 0 || !more)) {
+      slab_left = P.chunks_per_split;
+#pragma unroll
+      for (int ct = 0; ct < CT_TILES; ++ct)
+#pragma unroll
+        for (int g = 0; g < PG; ++g) {
+          vsum[VSPLIT ? ct : 0][VSPLIT ? g : 0] += acc[0][ct][g] * w_unscale;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[0][ct][g][r] = 0.0f;
+        }
+    }
+  };
+
   for (int c = c_begin; c < c_end; ++c) {
     const int cb = (c - c_begin) & 1;
     half8 *buf = lds + cb * BUF_UNITS, *nbuf = lds + (cb ^ 1) * BUF_UNITS;
     const bool more = c + 1 < c_end;
+    if constexpr (PP) {
+      // Hazards: stage c is complete since the end-of-stage barrier of stage c-1 (every wave drained its copies: vmcnt(0)); the
+      // copies of stage c+1 go to the buffer stage c-1 was read from, whose last readers (second half, phase B of c-1) passed
+      // that barrier too.  The mid-stage barrier only swaps the roles (copies stay in flight across it).  The last stage
+      // has no end barrier: the first half's epilogue runs under the second half's MFMAs.
+      if (half == 0) {
+        compute_stage(buf);
+        slab_end(more);
+        hf_barrier_lds();
+        if (more) {
+          stage_dma(c + 1, cb ^ 1);
+          hf_barrier_keep_young<0>();
+        }
+      } else {
+        if (more) stage_dma(c + 1, cb ^ 1);
+        hf_barrier_lds();
+        compute_stage(buf);
+        slab_end(more);
+        if (more) hf_barrier_keep_young<0>();
+      }
+      continue;
+    }
     const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT
     const half8 *b_hi = buf + OFF_XH + lh * NPIX;
-    half8 ah[2][CT_TILES], al[2][CT_TILES], bh[2][PG], bl[2][PG];
     auto fetch = [&](int slot, int tap) {
       const int ky = tap / 3, kx = tap % 3;
       const int toff = (STRIDE == 1) ? ky * wp + kx : ky * wp + (kx & 1) * wp2 + (kx >> 1);
@@ -322,17 +419,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (VSPLIT && (--slab_left == 0 || !more)) {  // a slab ends: its sum (pre-scale undone, exact) joins the earlier slabs'
-      slab_left = P.chunks_per_split;
-#pragma unroll
-      for (int ct = 0; ct < CT_TILES; ++ct)
-#pragma unroll
-        for (int g = 0; g < PG; ++g) {
-          vsum[VSPLIT ? ct : 0][VSPLIT ? g : 0] += acc[0][ct][g] * w_unscale;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[0][ct][g][r] = 0.0f;
-        }
-    }
+    slab_end(more);
     hf_barrier_keep_young<0>();  // next stage complete (DMA landed, conversions written), current one free
   }
 

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _marshal as M
-from ._runtime import lib, plan_batch, require_gpu, stream
+from ._runtime import batch_invariant, lib, require_gpu, stream
 from .encoders._fused import FrozenPlanMixin, PreparedConv, conv, patches
 
 HAIR_IDX = 13  # models/CtrlHair/global_value_utils.py:49-52 (PARSING_LABEL_LIST.index('hair'))
@@ -113,9 +113,10 @@ class Conv2dBlock(nn.Module):  # my_torchlib/module.py:64-131 (pad_type 'zero', 
             # would stream 2.25x the weights (its zero taps) through the general 3x3 path: 0.95 ms per layer at batch 16.
             b, _, h, w_ = x.shape
             cols = patches(x, 4, 2, 1, tap_major=False).flatten(2)                     # [B, cin*16, L], rows ordered like F.unfold's
-            # batch-invariant mode (_runtime.plan_batch): the GEMM form folds the batch into its pixel axis, so its split-K plan
-            # - the summation order of every sample - would follow the batch; the row-wise GEMV form is taken at any batch
-            rows_planned = plan_batch(b) * cols.shape[2]
+            # batch-invariant plans (the default): the GEMM form folds the batch into its PIXEL axis - the library cannot plan
+            # it for a canonical batch, its K split (the summation order of every sample, upstream of the label-map argmax)
+            # would follow the real one - so the row-wise GEMV form is taken at any batch
+            rows_planned = (1 if batch_invariant() else b) * cols.shape[2]
             if rows_planned > 32 and "gemm" not in p:  # the MFMA-GEMM form's weights: only when that branch runs
                 w2 = self.conv.weight.detach().reshape(cout, -1, 1, 1)
                 p["gemm"] = PreparedConv(M.conv_prepare(L, st, w2.contiguous()), 1)

@@ -502,11 +502,21 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
         assert up_pre == [32, 64] and up_fused == [128, 256, 512]
         # finishing passes on the raw slabs (8, 4, 2, 1, 1 slabs of 3 channels); the layers below 64^2 run the stand-alone ToRGB
         assert plain_rgb == [512, 512, 512, 512, 24, 12, 6, 3, 3], plain_rgb
-        # batch 1: the 32^2 block (1024 pixels per launch: 32 blocks that would each walk the whole K loop) stays on the
-        # fp32 split-K kernels (M.modconv3x3_f16_supported(batch=)), the hand-over chain starts at 64^2
+        # batch 1 under batch-invariant plans (the default): the kernel families of the canonical batch-3 launch - the same chain
         fused.clear(); presplit.clear(); up_pre.clear(); up_fused.clear(); plain_rgb.clear()
         g([lat[:1]], input_is_latent=True, noise=nz)
-        assert presplit == [64, 128, 256, 512, 1024] and up_pre == [64] and up_fused == [128, 256, 512], (presplit, up_pre)
+        assert presplit == [32, 64, 128, 256, 512, 1024] and up_pre == [32, 64] and up_fused == [128, 256, 512], (presplit, up_pre)
+        # ... and with plans from the whole launch (HAIRFAST_DETERMINISTIC=0): the 32^2 block of a batch-1 forward (1024 pixels per
+        # launch: 32 blocks that would each walk the whole K loop) stays on the fp32 split-K kernels
+        # (M.modconv3x3_f16_supported(batch=)), the hand-over chain starts at 64^2
+        from hairfastgan_amd import _runtime
+        prev_mode = _runtime.set_batch_invariant(False)
+        try:
+            fused.clear(); presplit.clear(); up_pre.clear(); up_fused.clear(); plain_rgb.clear()
+            g([lat[:1]], input_is_latent=True, noise=nz)
+            assert presplit == [64, 128, 256, 512, 1024] and up_pre == [64] and up_fused == [128, 256, 512], (presplit, up_pre)
+        finally:
+            _runtime.set_batch_invariant(prev_mode)
         # module API: forward_rgb's explicit (out, raw) pair finished by ToRGB.finish equals the stand-alone ToRGB
         x32 = torch.randn(1, 32, 1024, 1024, device=dev)
         l1 = lat[:1]
