@@ -54,6 +54,12 @@ F16_CORE_KERNELS = ("conv_mfma_h", "conv_enc_h", "gemm_h", "conv_rows_h", "stem 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_f16: 32768 FLOP / 32 cycles / SIMD, 1024 SIMDs x 2.4 GHz
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (~6.3 TB/s achievable)
+# What a loop of NOTHING BUT back-to-back v_mfma_f32_32x32x16_f16 (the conv kernels' 2 x 2 tiles, three MFMAs per tile and tap,
+# operands constant in registers) sustains on this chip: every SIMD issues one MFMA per 32.0 shader cycles (s_memtime) - the pipe
+# is saturated - but the chip clocks at ~1.7 GHz under that load (DVFS: power), not 2.4.  tools/probes/mfma_rate.hip, run on the
+# GPU box: profiles/r05_mfma_rate.txt (1788 TFLOP/s MFMA only, 1651-1661 with the kernels' 8 ds_read_b128 per 12 MFMAs).
+# `roofline.frac` stays against the nominal peak (the contract); `frac_of_sustained_mfma` is the same number against this one.
+SUSTAINED_F16_MFMA_TFLOPS = 1788.0
 DTYPES = {
     "f16x3": "f32 tensors + f32 accumulate; conv products as 3 fp16 MFMAs on (hi,lo)-split operands (fp32-class)",
     "f32": "f32 (fp32 MFMA)",
@@ -375,18 +381,23 @@ def kernel_report(prof, elapsed, precision, sampled=1.0, pmc=True):
         dom = max(mfma, key=lambda k: mfma[k][1])
         d = mfma[dom]
         ach = d[0] / d[1] / 1e12
+        sustained = None
         if dom.startswith(F16_CORE_KERNELS):
             terms = 3 if precision == "f16x3" else 1
             peak = PEAK_F16_MFMA_TFLOPS / terms
+            sustained = SUSTAINED_F16_MFMA_TFLOPS / terms
             peak_note = (f"fp16 dense MFMA peak {PEAK_F16_MFMA_TFLOPS} TFLOP/s / {terms} MFMA per product; "
-                         f"MFMA FLOPs issued = {terms} x algorithmic = {round(ach * terms, 1)} TFLOP/s")
+                         f"MFMA FLOPs issued = {terms} x algorithmic = {round(ach * terms, 1)} TFLOP/s; an MFMA-only loop sustains "
+                         f"{SUSTAINED_F16_MFMA_TFLOPS} TFLOP/s on this chip (pipe saturated at 32 cycles per MFMA, clock ~1.7 GHz under "
+                         f"load: profiles/r05_mfma_rate.txt) = {round(sustained, 1)} for this operand mode")
         else:
             peak, peak_note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA peak"
         # the committed PMC passes were collected in the headline configuration (f16x3, batch 8, generator workload) only
         traffic, busy, tag = pmc_profile(dom) if pmc else (None, None, None)
         alg_bytes = d[3] / d[2] if d[3] > 0 else None
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1),
-                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                           "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                           "frac_of_sustained_mfma": None if sustained is None else round(ach / sustained, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": None if alg_bytes is None else round(alg_bytes),
                            "traffic_over_algorithmic": None if (traffic is None or not alg_bytes) else round(traffic / alg_bytes, 3),
                            "traffic_source": (f"{PMC_PROFILE} (tag {tag}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -404,7 +415,9 @@ def kernel_report(prof, elapsed, precision, sampled=1.0, pmc=True):
         else:
             pk = PEAK_FP32_MFMA_TFLOPS
         a = v[0] / v[1] / 1e12
-        fam_roof[k] = {"achieved": round(a, 2), "peak": round(pk, 1), "frac": round(a / pk, 4), "avg_launch_ms": round(v[1] / v[2] * 1e3, 4),
+        fam_roof[k] = {"achieved": round(a, 2), "peak": round(pk, 1), "frac": round(a / pk, 4),
+                       "frac_of_sustained_mfma": round(a / (pk * SUSTAINED_F16_MFMA_TFLOPS / PEAK_F16_MFMA_TFLOPS), 4) if k.startswith(F16_CORE_KERNELS) else None,
+                       "avg_launch_ms": round(v[1] / v[2] * 1e3, 4),
                        "launches": v[2], "share_of_timed_region": round(v[1] / elapsed, 4)}
     if fam_roof:
         out["roofline_families"] = {"bound": "mfma", "unit": "TFLOP/s", "kernels": fam_roof}

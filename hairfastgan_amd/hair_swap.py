@@ -161,6 +161,34 @@ def equal_replacer(images):
     return images
 
 
+def equal_replacer_many(triples, _any_device=False):
+    """`equal_replacer` for the T triples of a batched pass with ONE device synchronisation instead of up to 3 T: when every
+    image is an 8-bit image of one shape on one device (what `parallel.swap_many` feeds), the 3 T pair comparisons are three
+    batched `!=` / `any` reductions over stacked images and one copy of their T x 3 flags to the host.  Anything else
+    (float images, mixed shapes / devices, repeated objects) takes the per-triple form.  Same results."""
+    flat = [im for tr in triples for im in tr]
+    first = flat[0] if flat else None
+    batched = (len(triples) > 1 and all(len(tr) == 3 for tr in triples) and first is not None and (first.is_cuda or _any_device)
+               and all(torch.is_tensor(im) and im.dtype is torch.uint8 and im.shape == first.shape and im.device == first.device for im in flat)
+               and len({id(im) for im in flat}) == len(flat))
+    if not batched:
+        return [tuple(equal_replacer(list(tr))) for tr in triples]
+    cols = [torch.stack([tr[k] for tr in triples]) for k in range(3)]
+    differ = torch.stack([(cols[i] != cols[j]).flatten(1).any(1) for i, j in ((0, 1), (0, 2), (1, 2))], 1).cpu()  # [T, 3]: the one sync
+    out = []
+    for t, tr in enumerate(triples):
+        images = [im / 255 for im in tr]
+        d01, d02, d12 = (bool(v) for v in differ[t])
+        if not d01:
+            images[1] = images[0]
+        if not d02:
+            images[2] = images[0]
+        elif not d12:
+            images[2] = images[1]
+        out.append(tuple(images))
+    return out
+
+
 def _to_tensor_like_torchvision(arr):
     """torchvision.transforms.functional.to_tensor for arrays (hair_swap.py:81-82): HWC (or HW) -> CHW; uint8 -> float32 / 255
     ON THE CPU (torch's GPU division is a multiplication by the rounded reciprocal: one ulp away), other dtypes unchanged."""
@@ -824,7 +852,7 @@ class HairFast:
         (tensors / arrays).  Returns a list of [3, size, size] images in [0, 1], one per triple, equal to what
         `swap` returns for each triple given the same per-layer noise."""
         cache = {}
-        prepared = [tuple(equal_replacer([self._as_tensor(img, cache) for img in triple])) for triple in triples]
+        prepared = equal_replacer_many([[self._as_tensor(img, cache) for img in triple] for triple in triples])
         set_seed(3407 if seed is None else seed)
         # a triple that repeats an image takes the reference's shortcuts (no mixing / no second Rotate): one by one
         plain = [t for t, tr in enumerate(prepared) if len({id(x) for x in tr}) == 3]

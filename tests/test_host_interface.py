@@ -344,3 +344,23 @@ def test_swap_accepts_the_reference_image_forms(tmp_path):
         HairFast._as_tensor([1, 2, 3])
     with pytest.raises(FileNotFoundError):
         HairFast._as_tensor(tmp_path / "missing.png")
+
+
+def test_equal_replacer_many_equals_the_per_triple_form():
+    """`equal_replacer_many` (one host synchronisation per batched pass instead of one per image pair): the same objects are
+    identified as `equal_replacer` (utils/image_utils.py:14-24) identifies them triple by triple."""
+    from hairfastgan_amd.hair_swap import equal_replacer, equal_replacer_many
+
+    g = torch.Generator().manual_seed(0)
+    mk = lambda: torch.randint(0, 256, (3, 8, 8), dtype=torch.uint8, generator=g)  # noqa: E731
+    a, b, c = mk(), mk(), mk()
+    triples = [[a, b, c], [a.clone(), a.clone(), c.clone()], [b.clone(), c.clone(), c.clone()], [a.clone(), b.clone(), a.clone()],
+               [c.clone(), c.clone(), c.clone()]]
+    for forced in (False, True):  # the per-triple fallback (CPU tensors) and the batched comparison
+        got = equal_replacer_many(triples, _any_device=forced)
+        for tr, out in zip(triples, got):
+            ref = equal_replacer(list(tr))
+            same = lambda ims: [ims[i] is ims[j] for i in range(3) for j in range(3)]  # noqa: E731
+            assert same(out) == same(ref)
+            assert all(torch.equal(o, r) for o, r in zip(out, ref)) and out[0].dtype is torch.float32
+    assert len(equal_replacer_many([[a, b, b]], _any_device=True)) == 1  # a repeated object: per-triple form

@@ -16,5 +16,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE";
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/prof_${tag}_$name -o bench -- $B --steps 1 --warmup 1 --no-kernel-events > $R/gpurun_out/prof_${tag}_$name.log 2>&1
   echo "pmc $name rc=$?"
 done
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_swap -o bench -- python $R/bench.py --workload swap256 --triples 16 --warmup 1 --no-kernel-events > $R/gpurun_out/prof_${tag}_swap.log 2>&1
-echo "swap stats rc=$?"
+# (the batched swap: tools/prof_swap.sh)
+
