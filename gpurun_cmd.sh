@@ -1,11 +1,12 @@
-# GPU call r05g (round check): GPU parity suite, smoke, the default bench line, rocprofv3 stats + PMC passes of the generator
-# workload and of the batched swap at its timed pass size.
+# GPU call r05h: unit -> unit hand-off (HAIRFAST_UNIT_CHAIN) A/B on the batched and the single swap, then the whole GPU suite.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q --durations=5 > gpurun_out/tests_gpu.log 2>&1; tail -6 gpurun_out/tests_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; python -c "
-import json; d=json.load(open('gpurun_out/bench.json')); p=d['swap_pipeline']
-print(d['value'], d['f16_mode']['value'], p['value'], p['single_swap']['ms_per_swap'], p['single_swap_graph'], p.get('verified'))"
-bash tools/profile_bench.sh r05a
-bash tools/prof_swap.sh r05a stats pmc
+for c in 1 0; do
+  HAIRFAST_UNIT_CHAIN=$c python bench.py --workload swap256 --triples 64 --swap-batch 32 --warmup 1 --no-kernel-events > gpurun_out/r05h_swap_chain$c.json 2> gpurun_out/r05h_swap_chain$c.err
+  HAIRFAST_UNIT_CHAIN=$c python bench.py --workload swap256 --triples 12 --swap-batch 1 --warmup 2 --no-kernel-events --no-verify > gpurun_out/r05h_single_chain$c.json 2> gpurun_out/r05h_single_chain$c.err
+  python -c "
+import json
+a=json.load(open('gpurun_out/r05h_swap_chain$c.json')); s=json.load(open('gpurun_out/r05h_single_chain$c.json'))
+print('chain=$c batched', a['value'], 'triples/s', a['verified']['equal'], 'single swap ms', s['ms_per_step'])"
+done
+python -m pytest tests -m gpu -q > gpurun_out/r05h_tests.log 2>&1; tail -5 gpurun_out/r05h_tests.log

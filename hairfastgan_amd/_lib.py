@@ -92,6 +92,7 @@ SIGNATURES = {
     "hf_modconv3x3_f16_rgb_slabs": [_i],
     "hf_profile_marker": [_i, _st],
     "hf_conv2d_f16_split_output_ok": [_i, _i, _i, _i, _i, _i, _i, _i],
+    "hf_scale_shortcut_add_split_f16": [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _st],
 }
 
 

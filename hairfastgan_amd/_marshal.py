@@ -822,6 +822,20 @@ def scale_shortcut_add(lib, st, r, gate, shortcut, sc_stride=1):
     return out
 
 
+def scale_shortcut_add_split(lib, st, r, gate, shortcut, sc_stride=1, next_scale=None, next_shift=None, want_lo=True):
+    """hf_scale_shortcut_add_split_f16: scale_shortcut_add whose result also leaves as the SplitActivation of
+    next_scale * out + next_shift (the next unit's first conv input) -> (out fp32, SplitActivation)."""
+    r, shortcut = _c(r), _c(shortcut)
+    b, c, oh, ow = r.shape
+    sh, sw = shortcut.shape[2], shortcut.shape[3]
+    out = torch.empty_like(r)
+    hi = torch.empty((b, c // 8, oh, ow, 8), dtype=torch.float16, device=r.device)
+    lo = torch.empty_like(hi) if want_lo else None
+    check(lib, lib.hf_scale_shortcut_add_split_f16(_p(out), _p(hi), _p(lo), _p(_c(next_scale)), _p(_c(next_shift)), _p(r), _p(gate),
+                                                   _p(shortcut), sc_stride, b, c, oh, ow, sh, sw, st), "hf_scale_shortcut_add_split_f16")
+    return out, SplitActivation(hi, lo, None)
+
+
 def upsample_bilinear_add(lib, st, x, y):
     x, y = _c(x), _c(y)
     b, c, h, w = x.shape

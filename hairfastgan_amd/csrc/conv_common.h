@@ -60,6 +60,10 @@ struct ConvParams {
   long long zslab;             // split-K: floats per z slab of `partial` (= groups*batch*cout*oh*ow)
   int splits;                  // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps); 1 = off
   int chunks_per_split;
+  int swap_xy;                 // convh_enc.hip: the grid is (columns, tiles) instead of (tiles, columns) - blocks are dispatched
+                               // x-fastest, so consecutive blocks then share an INPUT tile and walk the (group, channel-tile)
+                               // columns: the input tile stays in L2 while the weights stream from the Infinity Cache
+                               // (run_enc picks the order with the smaller beyond-L2 traffic)
   int vsplit;                  // "virtual" split-K (convh_enc.hip, gemm_h.hip; batch-invariant plans): the K partition into `splits`
                                // slabs is kept - it decides the bits - but ONE block walks all slabs, adding each slab's sum to a
                                // second accumulator set in z order (exactly what splitk_reduce adds), and runs the epilogue itself:
@@ -100,10 +104,11 @@ struct GroupOfs {
   int co_tile;
 };
 __device__ __forceinline__ GroupOfs group_offsets(const ConvParams &P) {
-  GroupOfs go{0, 0, 0, 0, (int)blockIdx.y};
+  const int col = P.swap_xy ? (int)blockIdx.x : (int)blockIdx.y;  // (group, channel tile) column of the block
+  GroupOfs go{0, 0, 0, 0, col};
   if (P.groups > 1) {
-    const int g = blockIdx.y / P.co_tiles;
-    go.co_tile = blockIdx.y - g * P.co_tiles;
+    const int g = col / P.co_tiles;
+    go.co_tile = col - g * P.co_tiles;
     go.x = (long long)g * P.x_gstride;
     go.wt = (long long)g * P.wt_gstride;
     go.o = (long long)g * P.batch * P.cout * P.out_h * P.out_w;

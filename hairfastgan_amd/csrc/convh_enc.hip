@@ -36,6 +36,9 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KH = 16;  // input channels per stage = K of one MFMA
+#ifndef HF_ENC_SWAP_XY
+#define HF_ENC_SWAP_XY 1  // 0: always the (tiles, columns) grid (A/B builds)
+#endif
 #ifndef HF_ENC_PINGPONG
 #define HF_ENC_PINGPONG 1  // 0: the one-phase K loop for every form (A/B builds: tools/build_variant.sh -DHF_ENC_PINGPONG=0)
 #endif
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
   float *tl = sl + cin4;
 
   const GroupOfs go = group_offsets(P);
-  const int grp = (P.groups > 1) ? (int)blockIdx.y / P.co_tiles : 0;
+  const int grp = (P.groups > 1) ? (P.swap_xy ? (int)blockIdx.x : (int)blockIdx.y) / P.co_tiles : 0;
   const long long wn = 9LL * P.cin * P.cout;
   const _Float16 *wth = wth_all + (long long)grp * (wn + 8);  // [weights | trailer] per group
   const _Float16 *wtl = wtl_all ? wtl_all + (long long)grp * wn : nullptr;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
 
   // ---- tile (uniform): OUTPUT pixels [ty0, ty0+th) x [tx0, tx0+tw) of image b0 ----
   const TileGeom G = P.g[0];
-  int t = blockIdx.x;
+  int t = P.swap_xy ? blockIdx.y : blockIdx.x;
   const int tx = t % G.tiles_x;
   t /= G.tiles_x;
   const int ty = t % G.tiles_y;
@@ -492,6 +495,23 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
   // the form the launch will take
   dim3 grid(geom_blocks(G), P.co_tiles * groups, P.vsplit ? 1 : P.splits);
   if (grid.y > 65535) return HF_E_INVALID;
+  // Block order (blocks are dispatched x-fastest, 256 at a time): tiles-fastest keeps a column's weights in L2 and re-reads every
+  // input tile once per column from beyond L2 (columns x input bytes); columns-fastest keeps ~256 / columns input tiles in L2 and
+  // re-reads the weights once per such group (weights fit the 256 MB Infinity Cache; the input of a batched pass does not).
+  // Taken when it moves fewer bytes from beyond L2 and no counters are keyed by (x, y) (real split-K keeps tiles-fastest).
+  P.swap_xy = 0;
+  if (HF_ENC_SWAP_XY && (P.vsplit || P.splits == 1) && grid.x <= 65535 && grid.y > 1) {
+    const double col_in = (double)P.batch * P.cin * P.h * P.w * 4.0;   // input bytes one column reads (hi + lo, or fp32)
+    const double in_bytes = col_in * (P.x_gstride ? groups : 1);       // all inputs once
+    const double w_bytes = 9.0 * P.cin * P.cout * 4.0 * groups;        // all weights once (hi + lo)
+    const double tiles_fast = (double)grid.y * col_in + w_bytes;
+    const double resident = grid.y >= 256 ? 1.0 : 256.0 / grid.y;      // input tiles in flight at a time
+    const double cols_fast = in_bytes + w_bytes * ((double)grid.x / resident);
+    if ((g_h_tune & 32) || (in_bytes > 64e6 && cols_fast < 0.5 * tiles_fast)) {  // hf_debug_set_tuning bit 5: tests force the order
+      P.swap_xy = 1;
+      grid = dim3(grid.y, grid.x, grid.z);
+    }
+  }
   const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float);
   if (lds > 160 * 1024) return HF_E_INVALID;
   if (plan_only) return HF_OK;
@@ -604,7 +624,65 @@ __global__ __launch_bounds__(256) void split_activation(half8 *__restrict__ hi, 
   }
 }
 
+// The tail of a bottleneck_IR_SE unit (helpers.py:118-120: res * gate + shortcut, shortcut optionally MaxPool2d(1, stride)) that
+// ALSO leaves as the pre-split input of the next unit's first conv: out = r * gate + shortcut (fp32, the next unit's shortcut), and
+// s*out + t (the next unit's BatchNorm) split into fp16 (hi, lo), K-blocked - bit for bit what hf_scale_shortcut_add_f32 followed by
+// hf_split_activation_f16 write.  One thread per (image, channel block of 8, pixel): 8 coalesced plane loads of r and of the shortcut.
+__global__ __launch_bounds__(256) void scale_shortcut_add_split(float *__restrict__ out, half8 *__restrict__ hi, half8 *__restrict__ lo,
+                                                                const float *__restrict__ r, const float *__restrict__ gate,
+                                                                const float *__restrict__ shortcut, const float *__restrict__ s,
+                                                                const float *__restrict__ t, int sc_stride, int channels, int oh,
+                                                                int ow, int sh, int sw, long long total) {
+#pragma clang fp contract(on)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int cblocks = channels >> 3, oplane = oh * ow;
+  const long long splane = (long long)sh * sw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int pix = (int)(i % oplane);
+    const long long q = i / oplane;
+    const int cb = (int)(q % cblocks);
+    const long long im = q / cblocks;
+    const int y = pix / ow, x = pix - y * ow;
+    const long long pl0 = im * channels + cb * 8;
+    const float *rp = r + pl0 * oplane + pix;
+    const float *sp = shortcut + pl0 * splane + (long long)(y * sc_stride) * sw + x * sc_stride;
+    float *op = out + pl0 * oplane + pix;
+    half8 h8, l8;
+    bool ovf = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = cb * 8 + k;
+      float v = rp[(long long)k * oplane];
+      if (gate) v *= gate[pl0 + k];
+      v += sp[(long long)k * splane];
+      op[(long long)k * oplane] = v;
+      const float u = fmaf(v, s ? s[c] : 1.0f, t ? t[c] : 0.0f);
+      _Float16 hv, lv;
+      hf_split_f16(u, hv, lv, ovf);
+      h8[k] = hv;
+      l8[k] = lv;
+    }
+    hf_note_overflow(ovf);
+    hi[i] = h8;
+    if (lo) lo[i] = l8;
+  }
+}
+
 }  // namespace
+
+extern "C" int hf_scale_shortcut_add_split_f16(float *out, void *out_hi, void *out_lo, const float *next_scale,
+                                               const float *next_shift, const float *r, const float *gate, const float *shortcut,
+                                               int sc_stride, int batch, int channels, int oh, int ow, int sh, int sw, void *stream) {
+  if (!out || !out_hi || !r || !shortcut || sc_stride < 1 || batch <= 0 || channels <= 0 || (channels & 7) || oh <= 0 || ow <= 0)
+    return HF_E_INVALID;
+  if ((oh - 1) * sc_stride >= sh || (ow - 1) * sc_stride >= sw) return HF_E_INVALID;
+  const long long total = (long long)batch * (channels >> 3) * oh * ow;
+  long long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(scale_shortcut_add_split, dim3((int)g), dim3(256), 0, (hipStream_t)stream, out, static_cast<half8 *>(out_hi),
+                     static_cast<half8 *>(out_lo), r, gate, shortcut, next_scale, next_shift, sc_stride, channels, oh, ow, sh, sw, total);
+  return hf_launch_status();
+}
 
 extern "C" unsigned long long hf_f16_overflow_count_enc(int reset) { return hf_f16_overflow_read_tu(reset); }
 

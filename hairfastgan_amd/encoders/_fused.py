@@ -252,15 +252,34 @@ def _conv_unpadded(x, w, k, stride=1, presplit=False, split_out=None, **kw):
     return M.conv2d(lib(), stream(), x, w.wt, k, stride, **kw)
 
 
-def conv_pair(x, w1, kw1, w2, stride2, kw2, stride1=1):
+# unit -> unit hand-off (round 5): the LAST conv / tail kernel of a residual unit also writes the next unit's first-conv input in
+# its pre-split layout (with that unit's BatchNorm applied): no split pass at the unit boundary, and the next unit's first conv
+# stages by LDS-DMA whatever its width.  "0" = every unit converts its own input.  Same bits either way.
+USE_CHAIN = os.environ.get("HAIRFAST_UNIT_CHAIN", "1") != "0"
+
+
+def conv_pair(x, w1, kw1, w2, stride2, kw2, stride1=1, out_split=None):
     """conv3x3(x, w1, stride1, **kw1) -> conv3x3(., w2, stride2, **kw2): the two convolutions of an IR-SE / IBasicBlock unit
     (helpers.py:99-115, iresnet.py:44-56; stride on the second) or of a ResNet BasicBlock (resnet.py:36-45; stride on the
     first).  When both run on the tiled fp16-core kernel the first one's epilogue writes its result straight in the second
     one's pre-split input layout (hf_conv2d_f16_split_f32): no fp32 tensor in between, no split pass, and the second conv
-    stages by LDS-DMA."""
+    stages by LDS-DMA.
+    x may be a SplitActivation (kw1 then carries no input affine: it went into the split).
+    out_split = {"next_scale", "next_shift"}: the second conv's result is ALSO wanted as the pre-split input of a following
+    fp16-core conv -> returns (SplitActivation | None, fp32 result)."""
     h, wd = x.shape[-2], x.shape[-1]
     h1, w1d = (h - 1) // stride1 + 1, (wd - 1) // stride1 + 1
     if USE_PAIR and takes_f16_conv(w2, h1, w1d, 3, stride2, **kw2):
         mid, mid32 = conv(x, w1, 3, stride1, split_out={}, **kw1)
-        return conv(mid if mid is not None else mid32, w2, 3, stride2, **kw2)
-    return conv(conv(x, w1, 3, stride1, **kw1), w2, 3, stride2, **kw2)
+        mid = mid if mid is not None else mid32
+    else:
+        mid = conv(x, w1, 3, stride1, **kw1)
+    if out_split is None:
+        return conv(mid, w2, 3, stride2, **kw2)
+    return conv(mid, w2, 3, stride2, split_out=dict(out_split, want_f32=True), **kw2)
+
+
+def chain_takes_split(w1, h, wd, **kw1):
+    """Will the first 3x3 conv of a unit accept a pre-split input handed over by its predecessor (the tiled fp16-core kernel
+    runs it)?"""
+    return USE_CHAIN and takes_f16_conv(w1, h, wd, 3, 1, **kw1)

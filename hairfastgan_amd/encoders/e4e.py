@@ -16,8 +16,8 @@ import torch
 from torch import nn
 
 from .. import _marshal as M
-from .._runtime import lib, require_gpu, stream
-from ._fused import FrozenPlanMixin, PreparedConv, conv, conv_pair, fold_bn, prep_conv
+from .._runtime import conv_precision, lib, require_gpu, stream
+from ._fused import FrozenPlanMixin, PreparedConv, chain_takes_split, conv, conv_pair, fold_bn, prep_conv
 
 # get_blocks(50): (in_channel, depth, stride) per unit (helpers.py:30-37)
 _IR50 = ([(64, 64, 2)] + [(64, 64, 1)] * 2 + [(64, 128, 2)] + [(128, 128, 1)] * 3 +
@@ -60,16 +60,33 @@ class bottleneck_IR_SE(FrozenPlanMixin, nn.Module):  # helpers.py:93-120
         return self._plan
 
     def forward(self, x):
+        return self.forward_chain(x, None, None)[0]
+
+    def takes_split(self, h, wd):
+        """Would this unit's first conv accept its input pre-split (handed over by the previous unit's tail)?"""
+        p = self._prepared()
+        return chain_takes_split(p["w1"], h, wd, act=M.ACT_PRELU, slope=p["slope"])
+
+    def forward_chain(self, x, xs, nxt):
+        """The unit on x [B,C,H,W]; xs: x already in the first conv's pre-split layout with THIS unit's BatchNorm applied
+        (the previous unit's hand-over) or None; nxt: the next unit when its first conv takes such a hand-over, else None.
+        -> (out, SplitActivation of the next unit's BatchNorm(out) | None).  Same bits as unit after unit."""
         require_gpu(x)
         p = self._prepared()
         if "wsc" in p:
             shortcut, sc_stride = conv(x, p["wsc"], 1, self.stride, out_scale=p["sc"][0], bias=p["sc"][1]), 1
         else:
             shortcut, sc_stride = x, self.stride  # MaxPool2d(1, stride) == strided identity
-        r = conv_pair(x, p["w1"], dict(in_scale=p["in"][0], in_shift=p["in"][1], act=M.ACT_PRELU, slope=p["slope"]),
-                      p["w2"], self.stride, dict(out_scale=p["out"][0], bias=p["out"][1]))
+        kw1 = dict(act=M.ACT_PRELU, slope=p["slope"])
+        if xs is None:
+            kw1.update(in_scale=p["in"][0], in_shift=p["in"][1])
+        r = conv_pair(xs if xs is not None else x, p["w1"], kw1, p["w2"], self.stride, dict(out_scale=p["out"][0], bias=p["out"][1]))
         gate = M.se_gate(lib(), stream(), M.plane_mean(lib(), stream(), r), p["fc1"], p["fc2"])
-        return M.scale_shortcut_add(lib(), stream(), r, gate, shortcut, sc_stride)
+        if nxt is not None and r.shape[1] % 8 == 0:
+            n_in = nxt._prepared()["in"]
+            return M.scale_shortcut_add_split(lib(), stream(), r, gate, shortcut, sc_stride, n_in[0], n_in[1],
+                                              want_lo=conv_precision() == "f16x3")
+        return M.scale_shortcut_add(lib(), stream(), r, gate, shortcut, sc_stride), None
 
 
 class EqualLinear(nn.Module):  # e4e's stylegan2 copy, model.py:128-157 (lr_mul = 1, no activation here)
@@ -136,8 +153,11 @@ class Encoder4Editing(FrozenPlanMixin, nn.Module):  # psp_encoders.py:124-200
         p = self._plan
         x = conv(x, p["w_in"], 3, 1, out_scale=p["bn_in"][0], bias=p["bn_in"][1], act=M.ACT_PRELU, slope=p["slope_in"])
         taps = {}
+        xs = None
         for i, unit in enumerate(self.body):
-            x = unit(x)
+            nxt = self.body[i + 1] if i + 1 < len(self.body) else None
+            oh, ow = (x.shape[2] - 1) // unit.stride + 1, (x.shape[3] - 1) // unit.stride + 1
+            x, xs = unit.forward_chain(x, xs, nxt if (nxt is not None and nxt.takes_split(oh, ow)) else None)
             if i in (6, 20, 23):
                 taps[i] = x
         c1, c2, c3 = taps[6], taps[20], taps[23]

@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import _marshal as M
 from .._runtime import lib, reference_rng_walk, require_gpu, stream
-from ._fused import FrozenPlanMixin, conv, conv_pair, fold_bn, prep_conv
+from ._fused import FrozenPlanMixin, chain_takes_split, conv, conv_pair, fold_bn, prep_conv
 
 _IRESNET50 = [(64, 3), (128, 4), (256, 14), (512, 3)]  # (planes, blocks) per layer, arcface/iresnet.py iresnet50
 
@@ -37,8 +37,7 @@ class IBasicBlock(FrozenPlanMixin, nn.Module):  # iresnet.py:28-57
         self.stride = stride
         self._plan = None
 
-    def forward(self, x):
-        require_gpu(x)
+    def _prepared(self):
         if self._plan is None:
             p = {"bn1": fold_bn(self.bn1), "w1": prep_conv(self.conv1), "bn2": fold_bn(self.bn2),
                  "slope": self.prelu.weight.detach(), "w2": prep_conv(self.conv2), "bn3": fold_bn(self.bn3)}
@@ -46,13 +45,47 @@ class IBasicBlock(FrozenPlanMixin, nn.Module):  # iresnet.py:28-57
                 p["wd"] = prep_conv(self.downsample[0])
                 p["bnd"] = fold_bn(self.downsample[1])
             self._plan = p
-        p = self._plan
+        return self._plan
+
+    def forward(self, x):
+        return self.forward_chain(x, None, None)[0]
+
+    def takes_split(self, h, wd):
+        """Would this block's first conv accept its input pre-split (handed over by the previous block's second conv)?"""
+        p = self._prepared()
+        return chain_takes_split(p["w1"], h, wd, out_scale=p["bn2"][0], bias=p["bn2"][1], act=M.ACT_PRELU, slope=p["slope"])
+
+    def forward_chain(self, x, xs, nxt):
+        """The block on x; xs: x in the first conv's pre-split layout with THIS block's bn1 applied (the previous block's
+        hand-over) or None; nxt: the next block when its first conv takes such a hand-over.  -> (out, SplitActivation of the
+        next block's bn1(out) | None): the second conv's epilogue (bn3 + residual) writes both.  Same bits as block after block."""
+        require_gpu(x)
+        p = self._prepared()
         identity = x
         if "wd" in p:
             identity = conv(x, p["wd"], 1, self.stride, out_scale=p["bnd"][0], bias=p["bnd"][1])
-        return conv_pair(x, p["w1"], dict(in_scale=p["bn1"][0], in_shift=p["bn1"][1], out_scale=p["bn2"][0], bias=p["bn2"][1],
-                                          act=M.ACT_PRELU, slope=p["slope"]),
-                         p["w2"], self.stride, dict(out_scale=p["bn3"][0], bias=p["bn3"][1], residual=identity))
+        kw1 = dict(out_scale=p["bn2"][0], bias=p["bn2"][1], act=M.ACT_PRELU, slope=p["slope"])
+        if xs is None:
+            kw1.update(in_scale=p["bn1"][0], in_shift=p["bn1"][1])
+        kw2 = dict(out_scale=p["bn3"][0], bias=p["bn3"][1], residual=identity)
+        if nxt is None:
+            return conv_pair(xs if xs is not None else x, p["w1"], kw1, p["w2"], self.stride, kw2), None
+        n_bn = nxt._prepared()["bn1"]
+        split, out = conv_pair(xs if xs is not None else x, p["w1"], kw1, p["w2"], self.stride, kw2,
+                               out_split=dict(next_scale=n_bn[0], next_shift=n_bn[1]))
+        return out, split
+
+
+def run_block_chain(blocks, x, xs=None, after=None):
+    """`for b in blocks: x = b(x)` with the unit -> unit hand-off: every block's second conv also writes the next block's
+    first-conv input pre-split.  after: the block that follows the chain (its first conv receives the last hand-over).
+    -> (x, hand-over for `after` | None)."""
+    blocks = list(blocks)
+    for i, blk in enumerate(blocks):
+        nxt = blocks[i + 1] if i + 1 < len(blocks) else after
+        oh, ow = (x.shape[2] - 1) // blk.stride + 1, (x.shape[3] - 1) // blk.stride + 1
+        x, xs = blk.forward_chain(x, xs, nxt if (nxt is not None and nxt.takes_split(oh, ow)) else None)
+    return x, xs
 
 
 def _make_layer(inplanes, planes, blocks):
@@ -102,8 +135,10 @@ class fs_encoder_v2(FrozenPlanMixin, nn.Module):  # feature_style_encoder.py:12-
         b = x.shape[0]
         pooled = x.new_empty((b, 960, 3, 3))
         c_off, content = 0, None
+        xs = None
         for li in range(4):
-            x = getattr(self, f"block_{li + 1}")(x)
+            nxt_layer = getattr(self, f"block_{li + 2}", None) if li < 3 else None
+            x, xs = run_block_chain(getattr(self, f"block_{li + 1}"), x, xs, after=None if nxt_layer is None else nxt_layer[0])
             if li == 2:
                 content = conv_pair(x, p["c_w1"], dict(in_scale=p["c_bn0"][0], in_shift=p["c_bn0"][1], out_scale=p["c_bn2"][0],
                                                        bias=p["c_bn2"][1], act=M.ACT_PRELU, slope=p["c_slope"]),

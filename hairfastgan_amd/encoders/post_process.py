@@ -27,7 +27,7 @@ from torch import nn
 from .. import _marshal as M
 from .._runtime import lib, require_gpu, stream
 from ._fused import FrozenPlanMixin, conv, conv_pair, fold_bn, prep_conv
-from .fs_encoder import _IRESNET50, IBasicBlock, _make_layer
+from .fs_encoder import _IRESNET50, IBasicBlock, _make_layer, run_block_chain
 
 
 class FeatureEncoderMult(FrozenPlanMixin, nn.Module):  # models/Net.py:396-477 with fs_layers=[9], ranks=None
@@ -66,8 +66,10 @@ class FeatureEncoderMult(FrozenPlanMixin, nn.Module):  # models/Net.py:396-477 w
         b = x.shape[0]
         pooled = x.new_empty((b, 960, 3, 3))
         c_off, content = 0, None
+        xs = None
         for li in range(4):
-            x = getattr(self, f"block_{li + 1}")(x)
+            nxt_layer = getattr(self, f"block_{li + 2}") if li < 3 else None
+            x, xs = run_block_chain(getattr(self, f"block_{li + 1}"), x, xs, after=None if nxt_layer is None else nxt_layer[0])
             if li == 1:
                 content = conv_pair(x, p["c_w1"], dict(in_scale=p["c_bn0"][0], in_shift=p["c_bn0"][1], out_scale=p["c_bn2"][0],
                                                        bias=p["c_bn2"][1], act=M.ACT_PRELU, slope=p["c_slope"]),
@@ -183,9 +185,7 @@ class FeatureiResnet(nn.Module):  # models/Encoders.py:35-57
         self.res_blocks = nn.ModuleDict(res_blocks)
 
     def forward(self, x):
-        for module in self.res_blocks.values():
-            x = module(x)
-        return x
+        return run_block_chain(self.res_blocks.values(), x)[0]  # block -> block hand-over of the pre-split first-conv input
 
 
 class PostProcessModel(nn.Module):  # models/Encoders.py:106-137

@@ -22,7 +22,10 @@ from torch import nn
 
 from . import _marshal as M
 from ._runtime import conv_precision, lib, require_gpu, stream
-from .encoders._fused import FrozenPlanMixin, conv, conv_pair, fold_bn, prep_conv
+from .encoders._fused import FrozenPlanMixin, chain_takes_split, conv, conv_pair, fold_bn, prep_conv, takes_f16_conv
+from .encoders import _fused
+
+USE_CHAIN_STRIDED = True  # hand-over into a stride-2 first conv (pre-split stride-2 form)
 
 # FaceParsing_tensor.label_list order -> index in PARSING_LABEL_LIST (global_value_utils.py:49-51); 13 = hair
 _BISENET_LABELS = ["background", "skin_other", "l_brow", "r_brow", "l_eye", "r_eye", "eye_g", "l_ear", "r_ear", "ear_r",
@@ -86,12 +89,26 @@ class BasicBlock(nn.Module):  # resnet.py:19-46
         return p
 
     def run(self, p, x):
+        return self.run_chain(p, x, None, False)[0]
+
+    def takes_split(self, p, h, wd):
+        """Would this block's first conv accept its input pre-split (handed over by the previous block's second conv)?"""
+        return chain_takes_split(p["w1"], h, wd, out_scale=p["bn1"][0], bias=p["bn1"][1], **RELU) if self.stride == 1 else \
+            (USE_CHAIN_STRIDED and _fused.USE_CHAIN and takes_f16_conv(p["w1"], h, wd, 3, self.stride, out_scale=p["bn1"][0], bias=p["bn1"][1], **RELU))
+
+    def run_chain(self, p, x, xs, hand_over):
+        """xs: x in conv1's pre-split layout (the previous block's hand-over) or None; hand_over: also return the result
+        pre-split for the next block's conv1 (no affine: a BasicBlock's conv1 takes its input as it is).  -> (out, split | None)."""
         sc = x if "wd" not in p else conv(x, p["wd"], 1, self.stride, out_scale=p["bnd"][0], bias=p["bnd"][1])
         # relu(shortcut + bn2(conv2(r))): the residual joins BEFORE the activation (resnet.py:41-45); conv1's result goes to
         # conv2 in its pre-split input layout when both run on the fp16 matrix cores (conv_pair)
-        return conv_pair(x, p["w1"], dict(out_scale=p["bn1"][0], bias=p["bn1"][1], **RELU),
-                         p["w2"], 1, dict(out_scale=p["bn2"][0], bias=p["bn2"][1], act=M.ACT_LRELU | M.ACT_RESIDUAL_FIRST,
-                                          alpha=0.0, residual=sc), stride1=self.stride)
+        first = xs if xs is not None else x
+        kw1 = dict(out_scale=p["bn1"][0], bias=p["bn1"][1], **RELU)
+        kw2 = dict(out_scale=p["bn2"][0], bias=p["bn2"][1], act=M.ACT_LRELU | M.ACT_RESIDUAL_FIRST, alpha=0.0, residual=sc)
+        if not hand_over:
+            return conv_pair(first, p["w1"], kw1, p["w2"], 1, kw2, stride1=self.stride), None
+        split, out = conv_pair(first, p["w1"], kw1, p["w2"], 1, kw2, stride1=self.stride, out_split={})
+        return out, split
 
 
 def _layer(in_chan, out_chan, stride):
@@ -174,10 +191,16 @@ class BiSeNet(FrozenPlanMixin, nn.Module):  # model.py:230-253
             x = conv(x, w, 7, 2, out_scale=s, bias=t, **RELU)
             x = M.maxpool3x3s2(L, st, x)
         feats = []
-        for li in (1, 2, 3, 4):
-            for j in (0, 1):
-                x = getattr(r, f"layer{li}")[j].run(p[f"l{li}.{j}"], x)
-            feats.append(x)
+        order = [(li, j) for li in (1, 2, 3, 4) for j in (0, 1)]
+        xs = None
+        for k, (li, j) in enumerate(order):  # block -> block hand-over of the pre-split conv1 input (encoders/_fused.py USE_CHAIN)
+            blk = getattr(r, f"layer{li}")[j]
+            nxt = order[k + 1] if k + 1 < len(order) else None
+            oh, ow = (x.shape[2] - 1) // blk.stride + 1, (x.shape[3] - 1) // blk.stride + 1
+            hand = nxt is not None and getattr(r, f"layer{nxt[0]}")[nxt[1]].takes_split(p[f"l{nxt[0]}.{nxt[1]}"], oh, ow)
+            x, xs = blk.run_chain(p[f"l{li}.{j}"], x, xs, hand)
+            if j == 1:
+                feats.append(x)
         feat8, feat16, feat32 = feats[1], feats[2], feats[3]
 
         def arm(name, f):

@@ -367,6 +367,14 @@ int hf_conv2d_f16_split_f32(float *out, void *out_hi, void *out_lo, const float 
                             int nterms, const float *in_scale, const float *in_shift, const float *out_scale,
                             const float *bias, int act, const float *slope, float alpha, const float *residual, int batch,
                             int cin, int cout, int h, int w, int stride, void *stream);
+/* hf_scale_shortcut_add_f32 (the tail of bottleneck_IR_SE.forward, helpers.py:118-120: res * gate + shortcut, shortcut optionally
+ * MaxPool2d(1, stride), :95-96) whose result ALSO leaves as the pre-split input of the next unit's first 3x3 conv (ABI 11):
+ * out = r * gate + shortcut [batch, channels, oh, ow] fp32, and next_scale[c] * out + next_shift[c] (the next unit's BatchNorm,
+ * helpers.py:99; NULL = identity) as fp16 (hi, lo; out_lo NULL = plain fp16 consumer) in hf_split_activation_f16's layout - bit for
+ * bit what the two separate passes write.  channels % 8 == 0. */
+int hf_scale_shortcut_add_split_f16(float *out, void *out_hi, void *out_lo, const float *next_scale, const float *next_shift,
+                                    const float *r, const float *gate, const float *shortcut, int sc_stride, int batch, int channels,
+                                    int oh, int ow, int sh, int sw, void *stream);
 /* 1 when hf_conv2d_f16_split_f32 takes a launch of this shape (ABI 11): the split output is written by the conv kernel's own
  * epilogue, so a launch that spreads its K loop over the grid (hf_conv2d_f16_workspace_floats != 0 for it) cannot produce it.
  * In batch-invariant mode a launch that fills the chip by itself runs its K partition inside the blocks instead (same bits),
@@ -642,7 +650,8 @@ int hf_debug_set_persistent_blocks(int blocks);
  * stage's LDS-DMA copies in the stage's first tap-step instead of spreading them one per tap-step (the default,
  * measured 0-8 % faster on every generator layer); bit 2 = hf_conv2d_f16_f32 never uses its 512-pixel tile form,
  * bits 8-15 = the minimum number of 512-pixel blocks / 8 for that form (0 = the default, 512), bits 16-23 = the
- * same for the 256-pixel form (default 384), bits 24-31 = the block count from which a launch counts as filling the
+ * same for the 256-pixel form (default 384), bit 5 = hf_conv2d_f16_f32 launches its grid columns-fastest whenever that is
+ * legal (by default only when it moves fewer bytes from beyond L2; results do not depend on the block order), bits 24-31 = the block count from which a launch counts as filling the
  * chip by itself (0 = the default, 256; batch-invariant plans: such a launch runs its K partition inside its blocks instead
  * of spreading it over the grid - tests reach that form on small shapes with it).  Results of the generator
  * kernels do not depend on it; tile forms of hf_conv2d_f16_f32 differ in summation order only. */

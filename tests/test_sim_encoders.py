@@ -460,8 +460,7 @@ def test_conv2d_f16_split_output(simlib, stride, nterms):
     assert torch.equal(z1, z2)
 
 
-@pytest.mark.parametrize("nterms", [3, 1])
-@pytest.mark.parametrize("stride,pre", [(1, False), (1, True), (2, True)])
+@pytest.mark.parametrize("stride,pre,nterms", [(1, False, 3), (1, True, 3), (2, True, 3), (1, True, 1)])
 def test_conv2d_f16_virtual_split_k_equals_the_two_launch_form(simlib, nterms, stride, pre):
     """Batch-invariant plans (the default): the K partition of a layer is the canonical launch's (batch 3), whatever the real
     batch; a launch that fills the chip by itself walks the slabs INSIDE its blocks (ConvParams::vsplit: a second
@@ -469,7 +468,7 @@ def test_conv2d_f16_virtual_split_k_equals_the_two_launch_form(simlib, nterms, s
     launch of the same layer gives with its slabs in memory and the splitk_reduce pass.  Also: the 512-pixel tile form,
     the split output (available again, since the epilogue runs in the conv kernel), PReLU + residual in the epilogue."""
     torch.manual_seed(41 + stride)
-    cin, cout, H, W = 256, 64, 16 * stride, 32 * stride
+    cin, cout, H, W = 128, 64, 16 * stride, 32 * stride  # 8 K stages: the canonical plan makes two slabs of them
     form512 = stride == 1 and nterms == 3 and pre  # also the 64 x 512 tile form: 13 images = 13 such tiles (> the canonical launch's 12 blocks)
     B = 13 if form512 else 6
     x = torch.randn(B, cin, H, W)
@@ -543,3 +542,97 @@ def test_conv1x1_f16_virtual_split_k_equals_the_two_launch_form(simlib):
         simlib.hf_set_batch_invariant(prev)
     want = F.leaky_relu(F.conv2d(x * a.view(1, -1, 1, 1) + t.view(1, -1, 1, 1), w) * g.view(1, -1, 1, 1) + bsh.view(1, -1, 1, 1), 0.2)
     assert maxdiff(y, want) < TOL * max(1.0, float(want.abs().max()))
+
+
+def test_unit_chain_hand_over_equals_unit_after_unit(sim_backend, simlib, monkeypatch):
+    """Round 5, unit -> unit hand-off: the tail of a residual unit (IR-SE: hf_scale_shortcut_add_split_f16; IBasicBlock: the second
+    conv's epilogue with bn3 + residual) also writes the NEXT unit's first-conv input pre-split with that unit's BatchNorm -
+    no split pass at the boundary, the next conv stages by LDS-DMA.  Bit for bit the result of running unit after unit, across a
+    stride-2 unit with a conv shortcut, and the hand-over really happens."""
+    import sys
+
+    from torch import nn
+
+    from hairfastgan_amd.encoders.e4e import bottleneck_IR_SE
+    from hairfastgan_amd.encoders.fs_encoder import IBasicBlock, run_block_chain
+
+    fused = sys.modules["hairfastgan_amd.encoders._fused"]
+    torch.manual_seed(3)
+
+    def randomize(mod):
+        for name, p_ in mod.named_parameters():
+            p_.data.normal_(0, 0.2)
+        for name, b_ in mod.named_buffers():
+            if name.endswith("running_var"):
+                b_.uniform_(0.5, 1.5)
+            elif name.endswith("running_mean"):
+                b_.normal_(0, 0.2)
+        return mod.eval()
+
+    x = torch.randn(2, 64, 32, 32)
+    # --- IR-SE units (e4e): 64 -> 64, 64 -> 128 stride 2 (conv shortcut), 128 -> 128
+    units = [randomize(bottleneck_IR_SE(64, 64, 1)), randomize(bottleneck_IR_SE(64, 128, 2)), randomize(bottleneck_IR_SE(128, 128, 1))]
+    calls = []
+    real = M.scale_shortcut_add_split
+    monkeypatch.setattr(M, "scale_shortcut_add_split", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.inference_mode():
+        ref = x
+        for u in units:
+            ref = u(ref)
+        assert not calls
+        y, xs = x, None
+        for i, u in enumerate(units):
+            nxt = units[i + 1] if i + 1 < len(units) else None
+            oh, ow = (y.shape[2] - 1) // u.stride + 1, (y.shape[3] - 1) // u.stride + 1
+            y, xs = u.forward_chain(y, xs, nxt if (nxt is not None and nxt.takes_split(oh, ow)) else None)
+    assert len(calls) == 2 and xs is None and torch.equal(y, ref)
+    # the tail kernel alone against its two-pass form
+    r, gate, sc = torch.randn(2, 64, 16, 16), torch.rand(2, 64), torch.randn(2, 64, 32, 32)
+    a, t = torch.rand(64) + 0.5, torch.randn(64) * 0.3
+    out, sp = real(simlib, None, r, gate, sc, 2, a, t)
+    want = M.scale_shortcut_add(simlib, None, r, gate, sc, 2)
+    wsp = M.split_activation_f16(simlib, None, want, a, t)
+    assert torch.equal(out, want) and torch.equal(sp.hi, wsp.hi) and torch.equal(sp.lo, wsp.lo)
+    # --- IBasicBlocks (FS encoder / PostProcess trunk): 64 -> 64, 64 -> 64 stride 2 with its downsample branch, 64 -> 64 (four K
+    # stages: no launch here spreads its K loop over the grid - such a launch cannot write the hand-over and the chain falls back)
+    ds = nn.Sequential(nn.Conv2d(64, 64, 1, 2, bias=False), nn.BatchNorm2d(64, eps=1e-05))
+    blocks = [randomize(IBasicBlock(64, 64)), randomize(IBasicBlock(64, 64, 2, ds)), randomize(IBasicBlock(64, 64))]
+    handed = []
+    real_split = M.conv2d_f16_split
+    monkeypatch.setattr(M, "conv2d_f16_split", lambda *a, **k: (handed.append(k.get("want_f32", False)), real_split(*a, **k))[1])
+    with torch.inference_mode():
+        monkeypatch.setattr(fused, "USE_CHAIN", False)
+        ref = x
+        for b_ in blocks:
+            ref = b_(ref)
+        assert not any(handed)
+        monkeypatch.setattr(fused, "USE_CHAIN", True)
+        y, xs = run_block_chain(blocks, x)
+    assert sum(handed) == 2 and xs is None and torch.equal(y, ref)
+
+
+def test_conv2d_f16_block_order_does_not_change_results(simlib):
+    """hf_conv2d_f16_f32 launches its grid tiles-fastest or columns-fastest (ConvParams::swap_xy: which of the input tile and the
+    weight column stays in L2) - forced here through hf_debug_set_tuning bit 5: identical results for a plain launch, a
+    grouped launch on a shared pre-split input (the e4e style heads) and a stride-2 launch."""
+    torch.manual_seed(51)
+    for B, cin, cout, H, W, stride, G in ((2, 32, 128, 16, 32, 1, 1), (2, 16, 64, 32, 32, 2, 3), (1, 32, 192, 32, 32, 2, 1)):
+        x = torch.randn(B, cin, H, W)
+        ws = torch.randn(G, cout, cin, 3, 3) / (cin * 9) ** 0.5
+        wt = torch.stack([M.conv_prepare(simlib, None, ws[g]) for g in range(G)]).contiguous()
+        hi, lo = M.conv_split_weights_f16(simlib, None, wt if G > 1 else wt[0])
+        bias = torch.randn(G, cout) if G > 1 else torch.randn(cout)
+        xs = M.split_activation_f16(simlib, None, x)
+        kw = dict(bias=bias, act=M.ACT_LRELU, alpha=0.01, groups=G)
+        try:
+            simlib.hf_debug_set_tuning(0)
+            ref = M.conv2d_f16(simlib, None, xs, hi, lo, 3, cout, stride, **kw)
+            simlib.hf_debug_set_tuning(32)
+            y = M.conv2d_f16(simlib, None, xs, hi, lo, 3, cout, stride, **kw)
+            y32 = M.conv2d_f16(simlib, None, x, hi, lo, 3, cout, stride, **kw)
+        finally:
+            simlib.hf_debug_set_tuning(0)
+        assert torch.equal(y, ref) and torch.equal(y32, ref)
+        for g in range(G):
+            want = F.leaky_relu(F.conv2d(x, ws[g], (bias[g] if G > 1 else bias), stride=stride, padding=1), 0.01)
+            assert maxdiff(y[g] if G > 1 else y, want) < TOL * max(1.0, float(want.abs().max()))

@@ -166,10 +166,19 @@ def test_shape_adaptor_blocks_and_layout(simlib, monkeypatch, golden):
     # deep-layer form: 8x8 input -> patches + GEMM on the 1x1 conv kernel
     blk8 = SAP.Conv2dBlock(6, 10, 4, 2, padding=1, norm="none", activation="none")
     x8 = torch.randn(3, 6, 8, 8)
-    with torch.inference_mode():
-        y8 = blk8(x8)
+    from hairfastgan_amd import _runtime
     with torch.no_grad():
         r8 = F.conv2d(F.pad(x8, (1, 1, 1, 1)), blk8.conv.weight, blk8.conv.bias, stride=2)
+    with torch.inference_mode():  # batch-invariant plans (the default): the row-wise GEMV form at any batch (the GEMM folds the batch)
+        y8 = blk8(x8)
+    assert "gemm" not in blk8._plan and y8.shape == r8.shape and float((y8 - r8).abs().max()) < 2e-5
+    prev = _runtime._batch_invariant
+    _runtime._batch_invariant = False  # (host-side predicate only: the simulated library is called directly)
+    try:
+        with torch.inference_mode():
+            y8 = blk8(x8)
+    finally:
+        _runtime._batch_invariant = prev
     assert "gemm" in blk8._plan and y8.shape == r8.shape and float((y8 - r8).abs().max()) < 2e-5
     with torch.inference_mode():  # few patch rows (a single swap): the weight-streaming linear kernel
         y8s = blk8(x8[:1, :, :4, :4].contiguous())
