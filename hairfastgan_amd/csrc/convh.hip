@@ -40,6 +40,9 @@ using namespace hf_detail;
 #ifndef HF_H_SPLIT_STORE16
 #define HF_H_SPLIT_STORE16 0  // fused upsampling epilogue: 1 = split output as ONE 16-byte store per lane (v_permlane32_swap of the half-waves) instead of two 8-byte stores; measured equal (587 vs 595 us on the 1024^2 layer): the epilogue is not store-bound
 #endif
+#ifndef HF_H_SWAP_XY
+#define HF_H_SWAP_XY 1  // 0: always the (tile walkers, cout tiles) grid (A/B builds)
+#endif
 #ifndef HF_H_PINGPONG
 #define HF_H_PINGPONG 1  // 0: the one-phase K loop (side work of a tap-step, then its MFMAs, all eight waves in lock-step) for A/B builds
 #endif
@@ -162,7 +165,12 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   const int lh = lane >> 5;  // k group of the lane: input channels 8*lh .. 8*lh+7 of the stage
   const int wave_co = (wave / WAVES_PX) * (32 * CT_TILES);
   const int wave_pg = (wave % WAVES_PX) * PG;
-  const int co0 = blockIdx.y * CT;
+  // grid = (tile walkers, cout tiles), or - ConvParams::swap_xy - (cout tiles, tile walkers): blocks are dispatched x-fastest, so
+  // consecutive blocks then share an input tile and differ in the cout tile (block b runs on XCD b % 8: with 8 cout tiles every
+  // XCD keeps ONE cout tile's weights in its L2 and the input tiles stream through) - see launch_h
+  const int blk_x = P.swap_xy ? (int)blockIdx.y : (int)blockIdx.x, blk_y = P.swap_xy ? (int)blockIdx.x : (int)blockIdx.y;
+  const int grid_x = P.swap_xy ? (int)gridDim.y : (int)gridDim.x, grid_y = P.swap_xy ? (int)gridDim.x : (int)gridDim.y;
+  const int co0 = blk_y * CT;
 
   const long long plane = (long long)P.h * P.w;
   const int iplane = (int)plane;
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   };
   zero_acc();
 
-  int t_cur = blockIdx.x;
+  int t_cur = blk_x;
   Tile cur = locate(t_cur);
   locate_items(cur, e_src);
   xb = P.x + (long long)cur.b0 * P.cin * plane;
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
         // the two half-waves hold the other channels of the same pixels: add, the low half stores.  A wave covers
         // 32*CT_TILES of the cout channels: its sum goes to slab (blockIdx.y*WAVES_CO + co-wave) of the
         // [B][slabs*3][H][W] raw tensor; ToRGB's finishing pass adds the slabs in a fixed order (deterministic)
-        const int slabs = (int)gridDim.y * WAVES_CO, slab = (int)blockIdx.y * WAVES_CO + wave / WAVES_PX;
+        const int slabs = grid_y * WAVES_CO, slab = blk_y * WAVES_CO + wave / WAVES_PX;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           rgb[c] += __shfl_xor(rgb[c], 32, 64);
@@ -776,7 +784,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     HF_TRACE_POINT(7);  // tile geometry done
     // the block's next tile, and its image's s into the other slot (read only after
     // the barriers of this tile's first nchunks-1 stages; nchunks >= 2)
-    const int t_next = t_cur + gridDim.x;
+    const int t_next = t_cur + grid_x;
     const bool has_next = t_next < P.n_tiles;
     Tile nxt = cur;
     int nxt_sl_off = sl_off;
@@ -1085,6 +1093,21 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
   const int gx = (walk && nblocks > resident) ? resident : nblocks;
   dim3 grid(gx, co_tiles);
   if (grid.y > 65535) return HF_E_INVALID;
+  // Block order (see csrc/convh_enc.hip launch_enc): tiles-fastest re-reads every input tile once per cout tile from beyond L2,
+  // cout-tiles-fastest streams the weights once per group of resident input tiles instead - taken when that moves fewer bytes
+  P.swap_xy = 0;
+  if (HF_H_SWAP_XY && co_tiles > 1 && gx <= 65535) {
+    const double in_bytes = (double)P.batch * P.cin * P.h * P.w * 4.0, w_bytes = 9.0 * P.cin * P.cout * 4.0;
+    const double tiles_fast = co_tiles * in_bytes + w_bytes;
+    const double resident_tiles = co_tiles >= 256 ? 1.0 : 256.0 / co_tiles;
+    const double cols_fast = in_bytes + w_bytes * ((double)nblocks / resident_tiles);
+    // (inputs that fit the 256 MB Infinity Cache beside everything else are re-read from there either way: measured neutral at
+    // batch 8 - tools/probes/gen_layers.py, r05j - so only from half of it upward, i.e. in the batched swap's generator calls)
+    if ((g_h_tune & 32) || (in_bytes > 128e6 && cols_fast < 0.5 * tiles_fast)) {
+      P.swap_xy = 1;
+      grid = dim3(co_tiles, gx);
+    }
+  }
   if (PRE) {
     if (!P.xh || (NTERMS == 3 && !P.xl) || P.s || (P.cin & 15)) return HF_E_INVALID;
     if ((long long)2 * P.h * P.w * 16 >= (1LL << 31)) return HF_E_INVALID;  // 32-bit offsets inside a stage

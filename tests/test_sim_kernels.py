@@ -688,3 +688,38 @@ def test_small_plane_tap_gemm_virtual_split_k(simlib):
         simlib.hf_set_batch_invariant(prev)
     assert torch.equal(y, ref)
     assert n2 < n1  # one slab instead of `splits`: the virtual form ran
+
+
+@pytest.mark.parametrize("up", [False, True])
+def test_modconv_f16_block_order_does_not_change_results(simlib, up):
+    """csrc/convh.hip launches (tile walkers, cout tiles) or - ConvParams::swap_xy, forced here by hf_debug_set_tuning bit 5 -
+    (cout tiles, tile walkers): which of the input tile and the cout tile's weights stays in an XCD's L2.  Identical results:
+    same-resolution conv with split output and the transposed conv, several cout tiles, a persistent tile walk."""
+    B, cin, cout, H, W = 2, 32, 128, 16, 32
+    torch.manual_seed(37)
+    x = torch.randn(B, cin, H, W)
+    wgt = torch.randn(1, cout, cin, 3, 3)
+    s, dm, s2 = torch.rand(B, cin) + 0.5, torch.rand(B, cout) + 0.5, torch.rand(B, cout) + 0.5
+    nz, nw, bias = torch.randn(B, 1, H, W), torch.tensor([0.3]), torch.randn(cout)
+    wt, _ = M.prepare_weights(simlib, None, wgt)
+    hi, lo = M.split_weights_f16(simlib, None, wt)
+    act = M.SplitActivation(*M.split_activation_reference(x, s), None)
+    nz2 = torch.randn(B, 1, 2 * H, 2 * W)
+    outs = []
+    try:
+        for tune in (0, 32):
+            simlib.hf_debug_set_tuning(tune)
+            simlib.hf_debug_set_persistent_blocks(4)  # 4 resident blocks over 2 cout tiles: every block walks several tiles
+            if up:
+                outs.append(M.modconv3x3_up(simlib, None, act, wt, None, dm, O.blur_kernel_1d_to_2d(gain=4.0), nz2, nw, bias, f16=(hi, lo, 3)))
+            else:
+                y = M.modconv3x3_f16_pre(simlib, None, act, hi, lo, 3, dm, nz, nw, bias, split_for=s2)
+                parts = y if isinstance(y, (tuple, list)) else (y,)
+                flat = []
+                for t_ in parts:
+                    flat += [t_.hi.float().flatten(), t_.lo.float().flatten()] if isinstance(t_, M.SplitActivation) else ([t_.flatten()] if torch.is_tensor(t_) else [])
+                outs.append(torch.cat(flat))
+    finally:
+        simlib.hf_debug_set_tuning(0)
+        simlib.hf_debug_set_persistent_blocks(0)
+    assert outs[0].numel() > 0 and torch.equal(outs[0], outs[1])
