@@ -1103,7 +1103,7 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
     const double cols_fast = in_bytes + w_bytes * ((double)nblocks / resident_tiles);
     // (inputs that fit the 256 MB Infinity Cache beside everything else are re-read from there either way: measured neutral at
     // batch 8 - tools/probes/gen_layers.py, r05j - so only from half of it upward, i.e. in the batched swap's generator calls)
-    if ((g_h_tune & 32) || (in_bytes > 128e6 && cols_fast < 0.5 * tiles_fast)) {
+    if ((g_h_tune & 8) || (in_bytes > 128e6 && cols_fast < 0.5 * tiles_fast)) {
       P.swap_xy = 1;
       grid = dim3(co_tiles, gx);
     }

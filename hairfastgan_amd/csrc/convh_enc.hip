@@ -508,8 +508,8 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
     const double resident = grid.y >= 256 ? 1.0 : 256.0 / grid.y;      // input tiles in flight at a time
     const double cols_fast = in_bytes + w_bytes * ((double)grid.x / resident);
     // (an input that fits the 256 MB Infinity Cache beside the rest is re-read from there either way: from half of it upward;
-    // hf_debug_set_tuning bit 5: tests force the order)
-    if ((g_h_tune & 32) || (col_in > 128e6 && cols_fast < 0.5 * tiles_fast)) {
+    // hf_debug_set_tuning bit 3: tests force the order)
+    if ((g_h_tune & 8) || (col_in > 128e6 && cols_fast < 0.5 * tiles_fast)) {
       P.swap_xy = 1;
       grid = dim3(grid.y, grid.x, grid.z);
     }

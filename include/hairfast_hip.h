@@ -650,8 +650,9 @@ int hf_debug_set_persistent_blocks(int blocks);
  * stage's LDS-DMA copies in the stage's first tap-step instead of spreading them one per tap-step (the default,
  * measured 0-8 % faster on every generator layer); bit 2 = hf_conv2d_f16_f32 never uses its 512-pixel tile form,
  * bits 8-15 = the minimum number of 512-pixel blocks / 8 for that form (0 = the default, 512), bits 16-23 = the
- * same for the 256-pixel form (default 384), bit 5 = hf_conv2d_f16_f32 launches its grid columns-fastest whenever that is
- * legal (by default only when it moves fewer bytes from beyond L2; results do not depend on the block order), bits 24-31 = the block count from which a launch counts as filling the
+ * same for the 256-pixel form (default 384), bit 3 = the fp16-core conv kernels launch their grid columns-fastest whenever that is
+ * legal (by default only when it moves fewer bytes from beyond L2; results do not depend on the block order; bits 5-7 are
+ * timing ablations of the row-pipeline kernel), bits 24-31 = the block count from which a launch counts as filling the
  * chip by itself (0 = the default, 256; batch-invariant plans: such a launch runs its K partition inside its blocks instead
  * of spreading it over the grid - tests reach that form on small shapes with it).  Results of the generator
  * kernels do not depend on it; tile forms of hf_conv2d_f16_f32 differ in summation order only. */

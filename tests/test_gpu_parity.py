@@ -939,3 +939,25 @@ def test_conv_rows_pipeline_equals_tiled_kernel_on_hardware(B, H, W):
     if B * H * W <= 1 << 20:
         exact = M.modconv3x3(lib, st, x, wt, s, dm, nz, nw, bias)
         assert float((out - exact).abs().max()) <= 2e-5 * max(1.0, float(exact.abs().max()))
+
+
+def test_generator1024_block_order_does_not_change_the_image():
+    """The cout-tiles-fastest block order of the generator's fp16-core kernels (ConvParams::swap_xy; by default only from 128 MB of
+    layer input, i.e. in a batched swap's batch-64 calls) forced on a batch-8 forward through hf_debug_set_tuning bit 3: the
+    image - every layer form: same-resolution, fused upsampling, two-pass upsampling, fused ToRGB slabs - is bit-identical."""
+    from hairfastgan_amd._runtime import lib
+
+    dev = _dev()
+    g, shapes, size, _, _ = _gpu_generator("g1024", dev)
+    lat2, nz, _ = C.generator_inputs(size, 2, 0)
+    lat = torch.cat([lat2, lat2.flip(0), lat2 * 0.5, lat2 * 0.25]).to(dev)
+    nz = [n.to(dev) for n in nz]
+    L = lib()
+    try:
+        with torch.inference_mode():
+            ref, _ = g([lat], input_is_latent=True, noise=nz)
+            L.hf_debug_set_tuning(8)
+            y, _ = g([lat], input_is_latent=True, noise=nz)
+    finally:
+        L.hf_debug_set_tuning(0)
+    assert torch.isfinite(ref).all() and torch.equal(y, ref)

@@ -692,7 +692,7 @@ def test_small_plane_tap_gemm_virtual_split_k(simlib):
 
 @pytest.mark.parametrize("up", [False, True])
 def test_modconv_f16_block_order_does_not_change_results(simlib, up):
-    """csrc/convh.hip launches (tile walkers, cout tiles) or - ConvParams::swap_xy, forced here by hf_debug_set_tuning bit 5 -
+    """csrc/convh.hip launches (tile walkers, cout tiles) or - ConvParams::swap_xy, forced here by hf_debug_set_tuning bit 3 -
     (cout tiles, tile walkers): which of the input tile and the cout tile's weights stays in an XCD's L2.  Identical results:
     same-resolution conv with split output and the transposed conv, several cout tiles, a persistent tile walk."""
     B, cin, cout, H, W = 2, 32, 128, 16, 32
@@ -707,7 +707,7 @@ def test_modconv_f16_block_order_does_not_change_results(simlib, up):
     nz2 = torch.randn(B, 1, 2 * H, 2 * W)
     outs = []
     try:
-        for tune in (0, 32):
+        for tune in (0, 8):
             simlib.hf_debug_set_tuning(tune)
             simlib.hf_debug_set_persistent_blocks(4)  # 4 resident blocks over 2 cout tiles: every block walks several tiles
             if up:

@@ -69,13 +69,18 @@ for n in dir(M):
         setattr(M, n, (lambda name, fn: (lambda *a, **k: bracket("hf", name, fn, a, k)))(n, f))
 
 dev = torch.device("cuda:0")
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+GEN = len(sys.argv) > 1 and sys.argv[1] == "gen"  # `time_sites.py gen [rows]`: one generator 0->8 forward at batch 8 instead of a swap
+T = 8 if GEN else (int(sys.argv[1]) if len(sys.argv) > 1 else 32)
 ROWS = int(sys.argv[2]) if len(sys.argv) > 2 else 70
 g, sd = bench.build_generator(dev)
-hf = bench.build_hairfast(sd, dev)
-load = bench.make_triple_loader(4)
-trip = [tuple(t.to(dev) for t in load(i)) for i in range(max(T, 2))]
-run = (lambda: hf.swap(*trip[0])) if T == 1 else (lambda: hf.swap_batch(trip[:T]))
+if GEN:
+    lat = torch.randn(T, 18, 512, device=dev)
+    run = lambda: g([lat], input_is_latent=True)  # noqa: E731
+else:
+    hf = bench.build_hairfast(sd, dev)
+    load = bench.make_triple_loader(4)
+    trip = [tuple(t.to(dev) for t in load(i)) for i in range(max(T, 2))]
+    run = (lambda: hf.swap(*trip[0])) if T == 1 else (lambda: hf.swap_batch(trip[:T]))
 with torch.inference_mode():
     for _ in range(2):
         run()
@@ -96,7 +101,8 @@ by_name = collections.Counter()
 for (kind, name, site, shape), (ms, n) in acc.items():
     by_kind[kind] += ms
     by_name[(kind, name)] += ms
-print(f"{len(EVENTS)} bracketed calls, {total:.1f} ms of bracketed GPU time in one {'swap' if T == 1 else f'swap_batch of {T}'} (event overhead included)")
+print(f"{len(EVENTS)} bracketed calls, {total:.1f} ms of bracketed GPU time in one "
+      f"{'generator forward at batch 8' if GEN else ('swap' if T == 1 else f'swap_batch of {T}')} (event overhead included)")
 print("by kind:", {k: round(v, 1) for k, v in by_kind.items()})
 print("by operation:", [(k[1], round(v, 2)) for k, v in by_name.most_common(40)])
 for (kind, name, site, shape), (ms, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:ROWS]:
