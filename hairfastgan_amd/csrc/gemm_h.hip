@@ -26,6 +26,12 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KH = 16;   // input channels per MFMA k-step
 constexpr int KS = 32;   // input channels per LDS stage
+// Two blocks per CU: the 64 x 256 form's two stage buffers are exactly 80 KiB - half of a CU's 160 KiB - but without a register bound
+// hipcc spends 290 registers on it (one wave per SIMD, every LDS / DMA latency exposed); bounded to two waves per SIMD it needs
+// 226-240 and no scratch (round 5; -DHF_GEMM_MIN_WAVES=1 = the old build for A/B).
+#ifndef HF_GEMM_MIN_WAVES
+#define HF_GEMM_MIN_WAVES 2
+#endif
 // blocks from which a launch fills the chip without a K split (hf_debug_set_tuning bits 24-31 lower it for tests)
 inline int gemm_fill_blocks() { return ((hf_detail::g_h_tune >> 24) & 255) ? ((hf_detail::g_h_tune >> 24) & 255) : 256; }
 
@@ -35,7 +41,7 @@ inline int gemm_fill_blocks() { return ((hf_detail::g_h_tune >> 24) & 255) ? ((h
 // VSPLIT (ConvParams::vsplit): the block walks all P.splits K slabs and adds their sums in z order to a second accumulator
 // set - the bits of the split-K form (slabs + splitk_reduce / small_combine) without the slabs (see csrc/convh_enc.hip).
 template <int NTERMS, int PG, bool PRE, bool VSPLIT = false>
-__global__ __launch_bounds__(256) void gemm1x1_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
+__global__ __launch_bounds__(256, HF_GEMM_MIN_WAVES) void gemm1x1_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
                                                  const _Float16 *__restrict__ wtl_all) {
   constexpr int NT = 256, CT = 64, PT = 64 * PG;
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;
