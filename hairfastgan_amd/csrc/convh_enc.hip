@@ -445,14 +445,35 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
     store_tile<CT_TILES, PG, false, 1, true>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
-// split-K plan: fill the chip (>= ~1.5 blocks per CU) when the output grid alone cannot, keeping at
-// least 4 K stages per block; 1 = off
+// split-K plan.  The tile forms that small launches take hold 100-117 KB of LDS: ONE block per CU, so a launch runs in
+// ceil(blocks / 256) rounds of resident blocks and a K split only pays while it does not add a round.  Cost model (us; round 5,
+// from the batch-3 layers of a single swap - a block's fixed cost of ~3 us: LDS zero fill, first stage's DMA latency, epilogue;
+// ~0.9 us per 16-channel K stage; ~6 us for the second pass incl. its launch):
+//   T(s) = ceil(blocks * s / 256) * (3 + 0.9 * ceil(nchunks / s)) + (s > 1 ? 6 : 0),   s <= nchunks / 4, s <= 16
+// e.g. 96 blocks x 16 stages (256 -> 256 @ 32^2, batch 3): s = 2 (16.2; s = 1: 17.4, the old plan's s = 4 - 384 blocks, two rounds -
+// 19.2); 48 blocks x 32 stages (512 @ 16^2): s = 5; 192 blocks x 8 stages (128 @ 64^2): no split (the old plan: 2).
+// -DHF_ENC_PLAN_OLD: the round-2 rule (>= 1.5 blocks per CU) for A/B builds.
 inline int enc_splitk_plan(long long blocks, int nchunks) {
   if (blocks >= 256 || nchunks < 8) return 1;
+#ifdef HF_ENC_PLAN_OLD
   int s = (int)((384 + blocks - 1) / blocks);
   if (s > nchunks / 4) s = nchunks / 4;
   if (s > 16) s = 16;
   return s < 2 ? 1 : s;
+#else
+  int best = 1;
+  double best_t = 1e30;
+  const int smax = nchunks / 4 < 16 ? nchunks / 4 : 16;
+  for (int s = 1; s <= smax; ++s) {
+    const double rounds = (double)((blocks * s + 255) / 256);
+    const double t = rounds * (3.0 + 0.9 * ((nchunks + s - 1) / s)) + (s > 1 ? 6.0 : 0.0);
+    if (t < best_t - 1e-9) {
+      best_t = t;
+      best = s;
+    }
+  }
+  return best;
+#endif
 }
 
 // force_splits > 0 (batch-invariant plans): the K partition is given - the canonical plan of run_enc - and only its

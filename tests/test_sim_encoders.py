@@ -468,7 +468,7 @@ def test_conv2d_f16_virtual_split_k_equals_the_two_launch_form(simlib, nterms, s
     launch of the same layer gives with its slabs in memory and the splitk_reduce pass.  Also: the 512-pixel tile form,
     the split output (available again, since the epilogue runs in the conv kernel), PReLU + residual in the epilogue."""
     torch.manual_seed(41 + stride)
-    cin, cout, H, W = 128, 64, 16 * stride, 32 * stride  # 8 K stages: the canonical plan makes two slabs of them
+    cin, cout, H, W = 192, 64, 16 * stride, 32 * stride  # 12 K stages over 12 blocks: the canonical plan makes three slabs of them
     form512 = stride == 1 and nterms == 3 and pre  # also the 64 x 512 tile form: 13 images = 13 such tiles (> the canonical launch's 12 blocks)
     B = 13 if form512 else 6
     x = torch.randn(B, cin, H, W)
