@@ -350,10 +350,12 @@ def verify_gathered(hf, images, load, dev, n_total, rank, world, pass_size, grou
 
 
 def auto_swap_batch(n_total, world, cap=32):
-    """Triples per batched pass when --swap-batch 0: half the rank's shard (so that every rank has at least two passes - the
-    H2D prefetch of pass 2 and the all-gather of pass 1 then overlap compute), capped at the throughput plateau (32)."""
+    """Triples per batched pass when --swap-batch 0: the rank's whole shard, capped at the throughput plateau (32).  Measured on one
+    rank's 32-triple shard with RCCL initialised (tools/probes/rank_pass_sizes.py): one pass of 32 = 443.6 ms,
+    two passes of 16 = 457.3 ms - what the second pass's copy-in / the first pass's gather would hide (~5 ms) is less than what the
+    smaller batch loses (13.7 ms)."""
     per_rank = -(-n_total // world)
-    return max(1, min(cap, -(-per_rank // 2)))
+    return max(1, min(cap, per_rank))
 
 
 def kernel_report(prof, elapsed, precision, sampled=1.0, pmc=True):
@@ -513,8 +515,8 @@ def main():
     ap.add_argument("--triples", type=int, default=256, help="swap256: triples of the whole job")
     ap.add_argument("--swap-batch", type=int, default=0,
                     help="swap256: triples per batched pass over the hot path (HairFast.swap_batch); 1 = one HairFast.swap per triple; "
-                         "0 (default) = auto: min(32, half the rank's shard) - 32 on 1-4 GPUs for 256 triples, 16 on 8 (two passes "
-                         "per rank, so that copy-in and gather overlap compute). "
+                         "0 (default) = auto: min(32, the rank's shard) - one pass of 32 beats two of 16 even with nothing to overlap "
+                         "its copy-in and gather with (DESIGN.md section 7). "
                          "Measured on resident inputs (tools/probes/swap_batch_sizes.py, round 4): 1: 29 triples/s, 4: 54, 8: 64, "
                          "16: 70.6 (22.6 GiB), 32: 72.9 (32.1 GiB), 48: 72.4, 64: 72.8 (50.9 GiB) - a plateau from 32, which is "
                          "also one pass per rank for 256 triples on 8 GPUs")
