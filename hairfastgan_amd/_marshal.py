@@ -37,6 +37,7 @@ KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modc
     573: "conv_mfma_h<1,2,1,8,up,fuse>", 593: "conv_mfma_h<1,2,1,8,up,pre,fuse>",
     # csrc/convh_enc.hip (encoder convs on the fp16 matrix cores)
     601: "conv_enc_h<64x256>", 602: "conv_enc_h<64x128,stride2>", 603: "conv_enc_h<64x128>", 604: "conv_enc_h<64x512>",
+    605: "conv_enc_h<64x128,stride2,x4 tiles>",
 }
 
 

@@ -36,6 +36,9 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KH = 16;  // input channels per stage = K of one MFMA
+#ifndef HF_ENC_S2MT
+#define HF_ENC_S2MT 4  // pixel tiles per resident weight stage of the stride-2 multi-tile form (1 = off: A/B builds)
+#endif
 #ifndef HF_ENC_SWAP_XY
 #define HF_ENC_SWAP_XY 1  // 0: always the (tiles, columns) grid (A/B builds)
 #endif
@@ -445,6 +448,210 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
     store_tile<CT_TILES, PG, false, 1, true>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
 }
 
+// ---- stride 2, several pixel tiles per resident weight stage (round 5) -------------------------------------------------------
+// A stride-2 conv reads four input pixels per output pixel: its 64 co x 128 px blocks move 36.9 KB of weights + 38 KB of
+// activations per 216 MFMAs - four times the bytes per MFMA of the stride-1 512-pixel form - and are bound by that L2 -> LDS
+// traffic (8.2 TB/s = 16 B/clk/CU on the e4e heads' first level).  A 256-pixel tile does not fit LDS twice; what does fit is
+// to keep a K stage's WEIGHTS for MT consecutive 128-pixel tiles: the block holds MT accumulator tiles per wave (16 registers
+// each), walks step (chunk c, tile j) with the activations of the next step and a share of the next chunk's weights arriving by
+// LDS-DMA meanwhile (two activation buffers by step parity, two weight buffers by chunk parity: the same 150 KB), one barrier per
+// step as before.  Bytes per MFMA: (38 + 36.9 / MT) KB per 216 instead of 75.  Per output the K order is that of conv_enc_h:
+// equal bits (tests/test_sim_encoders.py).  Pre-split input only; real split-K launches keep the one-tile form.
+template <int NTERMS, int MT, bool VSPLIT>
+__global__ __launch_bounds__(512) void conv_enc_s2mt_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
+                                                       const _Float16 *__restrict__ wtl_all) {
+  constexpr int WAVES_PX = 4, NW = 8, NT = 64 * NW, CT = 64, PT = 128;
+  constexpr int NPIX = enc_npix<PT, 2>();
+  constexpr int NPART = (NTERMS == 3) ? 2 : 1;
+  constexpr int W_UNITS = 9 * 2 * CT, X_UNITS = 2 * NPIX;
+  constexpr int BUF_UNITS = NPART * (W_UNITS + X_UNITS);
+  constexpr int N_WPIECE = NPART * W_UNITS / 64;
+  constexpr int ND = (N_WPIECE + NW - 1) / NW;
+  constexpr int XE = (X_UNITS + NT - 1) / NT;
+  constexpr int OFF_WL = W_UNITS, OFF_XH = NPART * W_UNITS, OFF_XL = NPART * W_UNITS + X_UNITS;
+
+  HF_DYN_LDS;
+  half8 *lds = reinterpret_cast<half8 *>(hf_dyn_lds);  // [2][BUF_UNITS]: W of chunk parity b | X of step parity b
+
+  const GroupOfs go = group_offsets(P);
+  const int grp = (P.groups > 1) ? (P.swap_xy ? (int)blockIdx.x : (int)blockIdx.y) / P.co_tiles : 0;
+  const long long wn = 9LL * P.cin * P.cout;
+  const _Float16 *wth = wth_all + (long long)grp * (wn + 8);
+  const _Float16 *wtl = wtl_all ? wtl_all + (long long)grp * wn : nullptr;
+  const float w_unscale = *reinterpret_cast<const float *>(wth + wn);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wave_co = (wave / WAVES_PX) * 32;
+  const int wave_pg = wave % WAVES_PX;
+  const int co0 = go.co_tile * CT;
+
+  const TileGeom G = P.g[0];
+  const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
+  const int hp = (th - 1) * 2 + 3, wcols = (tw - 1) * 2 + 3;
+  const int wp2 = tw + 1, wp = 2 * wp2;
+  const int n_tiles = G.tiles_x * G.tiles_y * G.tiles_b;
+  const int t_first = (P.swap_xy ? (int)blockIdx.y : (int)blockIdx.x) * MT;
+  const long long plane = (long long)P.h * P.w;
+  const int iplane = (int)plane;
+
+  // the MT tiles of this block: origin, image and - per staging item - the input pixel of its 16-byte unit
+  int tx0[MT], ty0[MT], b0[MT], e_src[MT][XE];
+  bool valid[MT];
+  const char *xh_b[MT], *xl_b[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    int t = t_first + j;
+    valid[j] = t < n_tiles;
+    if (!valid[j]) t = n_tiles - 1;  // (computes the last tile again, stores nothing: uniform barriers)
+    const int tx = t % G.tiles_x;
+    t /= G.tiles_x;
+    const int ty = t % G.tiles_y;
+    b0[j] = t / G.tiles_y;
+    ty0[j] = ty * th;
+    tx0[j] = tx * tw;
+    const long long img = (long long)(P.x_gstride ? grp * P.batch : 0) + b0[j];
+    xh_b[j] = static_cast<const char *>(P.xh) + img * (P.cin / 8) * plane * 16;
+    xl_b[j] = (NTERMS == 3) ? static_cast<const char *>(P.xl) + img * (P.cin / 8) * plane * 16 : nullptr;
+#pragma unroll
+    for (int e = 0; e < XE; ++e) {
+      const int i = tid + e * NT;
+      const int kg = i / NPIX, u = i - kg * NPIX;
+      e_src[j][e] = -2;
+      if (i < X_UNITS && u < hp * wp) {
+        const int hr = u / wp, r = u - hr * wp;
+        const int hc = 2 * (r % wp2) + (r / wp2);
+        if (hc < wcols) {
+          const int ys = ty0[j] * 2 - 1 + hr, xc = tx0[j] * 2 - 1 + hc;
+          e_src[j][e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
+        }
+      }
+    }
+  }
+
+  const unsigned lds_addr0 = hf_lds_addr(lds);
+  auto dma_piece = [&](int i, int chunk, int wbuf) {
+    const int pc = wave + i * NW;
+    if (pc < N_WPIECE) {
+      const int part = pc / (W_UNITS / 64), q = pc % (W_UNITS / 64);
+      const int u = q * 64 + lane;
+      const int row = u / CT, col = u % CT;
+      int off = (row * P.cout + co0 + col) * 16;
+      HF_OPAQUE_I32(off);
+      const _Float16 *src = (part ? wtl : wth) + (long long)chunk * 18 * P.cout * 8;
+      hf_glds16_raw_s(src, (unsigned)off, lds_addr0 + (unsigned)(wbuf * BUF_UNITS + part * W_UNITS + q * 64) * 16u);
+    }
+  };
+  // activations of (chunk, tile j) into the X region of buffer xbuf; halo units outside the image are written as zeros by
+  // their lanes (the tiles of a block differ in which units those are: nothing can be zeroed once and for all)
+  auto dma_x = [&](int j, int e, int chunk, int xbuf) {
+    const int i = tid + e * NT;
+    if (i - lane >= X_UNITS) return;
+    const int kg = i / NPIX;
+    const bool inside = e_src[j][e] >= 0;
+    int off = inside ? (kg * iplane + e_src[j][e]) * 16 : 0;
+    HF_OPAQUE_I32(off);
+    const long long cofs = (long long)chunk * 2 * plane * 16;
+    const unsigned dst = lds_addr0 + (unsigned)(xbuf * BUF_UNITS + OFF_XH + (i - lane)) * 16u;
+    hf_glds16_raw_s_if(inside, xh_b[j] + cofs, (unsigned)off, dst);
+    if (NTERMS == 3) hf_glds16_raw_s_if(inside, xl_b[j] + cofs, (unsigned)off, dst + (unsigned)X_UNITS * 16u);
+    if (e_src[j][e] == -1) {
+      half8 z;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.0f;
+      lds[xbuf * BUF_UNITS + OFF_XH + i] = z;
+      if (NTERMS == 3) lds[xbuf * BUF_UNITS + OFF_XL + i] = z;
+    }
+  };
+
+  f32x16 acc[MT][1][1][1];
+  f32x16 vsum[VSPLIT ? MT : 1];
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[j][0][0][0][r] = 0.0f;
+      if (VSPLIT) vsum[VSPLIT ? j : 0][r] = 0.0f;
+    }
+  int slab_left = P.chunks_per_split;
+
+  const int p = wave_pg * 32 + li;
+  const int pix0 = ((p >> G.lg_tw) & (th - 1)) * 2 * wp + (p & (tw - 1));
+  const int nchunks = P.cin / KH;
+
+  // prologue: weights of chunk 0, activations of step (0, tile 0)
+#pragma unroll
+  for (int i = 0; i < ND; ++i) dma_piece(i, 0, 0);
+#pragma unroll
+  for (int e = 0; e < XE; ++e) dma_x(0, e, 0, 0);
+  hf_barrier_keep_young<0>();
+
+  half8 ah[2], al[2], bh[2], bl[2];
+  int step = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const int wb = c & 1;
+    const bool more_c = c + 1 < nchunks;
+#pragma unroll
+    for (int j = 0; j < MT; ++j, ++step) {
+      const int xb = step & 1;
+      // the next step's activations, a share of the next chunk's weights
+      if (j + 1 < MT) {
+#pragma unroll
+        for (int e = 0; e < XE; ++e) dma_x(j + 1 < MT ? j + 1 : 0, e, c, xb ^ 1);
+      } else if (more_c) {
+#pragma unroll
+        for (int e = 0; e < XE; ++e) dma_x(0, e, c + 1, xb ^ 1);
+      }
+      if (more_c) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+          if (i % MT == j) dma_piece(i, c + 1, wb ^ 1);
+      }
+      const half8 *a_hi = lds + wb * BUF_UNITS + lh * CT + wave_co + li;
+      const half8 *b_hi = lds + xb * BUF_UNITS + OFF_XH + lh * NPIX;
+      auto fetch = [&](int slot, int tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const int toff = ky * wp + (kx & 1) * wp2 + (kx >> 1);
+        ah[slot] = a_hi[tap * 2 * CT];
+        if (NTERMS == 3) al[slot] = a_hi[OFF_WL + tap * 2 * CT];
+        bh[slot] = b_hi[pix0 + toff];
+        if (NTERMS == 3) bl[slot] = b_hi[X_UNITS + pix0 + toff];
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int s_ = tap & 1;
+        if (tap + 1 < 9) fetch(s_ ^ 1, tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[j][0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bh[s_], acc[j][0][0][0], 0, 0, 0);
+        if (NTERMS == 3) {
+          acc[j][0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bl[s_], acc[j][0][0][0], 0, 0, 0);
+          acc[j][0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s_], bh[s_], acc[j][0][0][0], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      hf_barrier_keep_young<0>();  // next step's copies landed, this step's buffers free
+    }
+    if (VSPLIT && (--slab_left == 0 || !more_c)) {  // a slab ends (see conv_enc_h)
+      slab_left = P.chunks_per_split;
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        vsum[VSPLIT ? j : 0] += acc[j][0][0][0] * w_unscale;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][0][0][0][r] = 0.0f;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    if (VSPLIT) acc[j][0][0][0] = vsum[VSPLIT ? j : 0];
+    else
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][0][0][0][r] *= w_unscale;
+    if (valid[j]) store_tile_rows<1, 1>(P, G, go, acc[j], co0 + wave_co, wave_pg, li, lh, ty0[j], tx0[j], b0[j]);
+  }
+}
+
 // split-K plan.  The tile forms that small launches take hold 100-117 KB of LDS: ONE block per CU, so a launch runs in
 // ceil(blocks / 256) rounds of resident blocks and a K split only pays while it does not add a round.  Cost model (us; round 5,
 // from the batch-3 layers of a single swap - a block's fixed cost of ~3 us: LDS zero fill, first stage's DMA latency, epilogue;
@@ -479,6 +686,8 @@ inline int enc_splitk_plan(long long blocks, int nchunks) {
 // force_splits > 0 (batch-invariant plans): the K partition is given - the canonical plan of run_enc - and only its
 // execution is decided here: one block per slab (grid.z, partial slabs + splitk_reduce) when the output grid alone leaves
 // the chip empty, else ConvParams::vsplit (every block walks all slabs; same bits).
+thread_local int g_s2mt_last = 0;  // 1: the last stride-2 launch took the multi-tile form (hf_debug_last_path 605)
+
 template <int NTERMS, int PG, int WAVES_PX, int STRIDE, int CT_TILES = 1, int WAVES_CO = 2>
 int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *workspace, long long workspace_floats,
                hipStream_t st, bool plan_only = false, int force_splits = 0) {
@@ -544,8 +753,22 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
     P.partial = workspace;
     P.counters = splitk_counters_for((long long)grid.x * grid.y);
   }
+  g_s2mt_last = 0;
   if (P.xh) {
     if ((long long)2 * P.h * P.w * 16 >= (1LL << 31) || (NTERMS == 3 && !P.xl)) return HF_E_INVALID;
+    if constexpr (STRIDE == 2 && HF_ENC_S2MT > 1) {
+      // several pixel tiles per resident weight stage (conv_enc_s2mt_h) when the launch still fills the chip with MT times
+      // fewer blocks (hf_debug_set_tuning bits 24-31 lower "the chip" for tests) and its K loop is not spread over the grid
+      constexpr int MT = HF_ENC_S2MT;
+      const long long fill_blocks = fill ? fill : 256;
+      if ((P.vsplit || P.splits == 1) && blocks / MT >= fill_blocks) {
+        dim3 g2 = P.swap_xy ? dim3(grid.x, hf_cdiv((int)grid.y, MT), 1) : dim3(hf_cdiv((int)grid.x, MT), grid.y, 1);
+        if (P.vsplit) hipLaunchKernelGGL((conv_enc_s2mt_h<NTERMS, MT, true>), g2, dim3(NT), lds, st, P, wth, wtl);
+        else hipLaunchKernelGGL((conv_enc_s2mt_h<NTERMS, MT, false>), g2, dim3(NT), lds, st, P, wth, wtl);
+        g_s2mt_last = 1;
+        return hf_launch_status();
+      }
+    }
     if (P.vsplit)
       hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, true, CT_TILES, WAVES_CO, true>), grid, dim3(NT), lds, st, P, wth, wtl);
     else
@@ -574,7 +797,7 @@ int run_enc_forms(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *
     // 1 instead of 1.33 LDS fragment reads per MFMA of four 1 x 2 waves (tools/probes/stride2.py: 10-25% faster from
     // 64@256^2 to the 11-group style heads, 30-35% on the register-staged path; same accumulation order, equal bits)
     rc = launch_enc<NTERMS, 1, 4, 2>(P, hi, lo, ws, wsn, st, plan_only, force_splits);
-    if (rc == HF_OK && !plan_only) note_path(6, 2);
+    if (rc == HF_OK && !plan_only) note_path(6, g_s2mt_last ? 5 : 2);
     return rc;
   }
   // 64 co x 512 px (8 waves, 2 x 2 MFMA tiles each) when that fills the chip (batched swaps), else

@@ -636,3 +636,58 @@ def test_conv2d_f16_block_order_does_not_change_results(simlib):
         for g in range(G):
             want = F.leaky_relu(F.conv2d(x, ws[g], (bias[g] if G > 1 else bias), stride=stride, padding=1), 0.01)
             assert maxdiff(y[g] if G > 1 else y, want) < TOL * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
+def test_conv2d_f16_stride2_multi_tile_form(simlib, nterms):
+    """conv_enc_s2mt_h (round 5): a stride-2 block keeps a K stage's weights for four consecutive 128-pixel tiles (four
+    accumulator tiles per wave, the next step's activations and a share of the next chunk's weights arriving meanwhile) - the
+    bits of the one-tile form: ragged planes (tiles past the end, halo units outside the image that differ from tile to
+    tile), two images, a grouped launch on per-group inputs, a virtual split-K, PReLU + residual, the split output."""
+    torch.manual_seed(61)
+    for B, cin, cout, H, W, G in ((2, 48, 64, 40, 72, 1), (1, 32, 128, 64, 64, 2)):
+        x = torch.randn(*((G, B) if G > 1 else (B,)), cin, H, W)
+        ws = torch.randn(G, cout, cin, 3, 3) / (cin * 9) ** 0.5
+        wt = torch.stack([M.conv_prepare(simlib, None, ws[g]) for g in range(G)]).contiguous()
+        hi, lo = M.conv_split_weights_f16(simlib, None, wt if G > 1 else wt[0])
+        bias = torch.randn(G, cout) if G > 1 else torch.randn(cout)
+        slope = torch.rand(G, cout) if G > 1 else torch.rand(cout)
+        oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        res = torch.randn(*((G, B) if G > 1 else (B,)), cout, oh, ow)
+        xs = M.split_activation_f16(simlib, None, x, want_lo=nterms == 3)
+        kw = dict(bias=bias, act=M.ACT_PRELU, slope=slope, residual=res, groups=G, x_shared=False)
+        try:
+            simlib.hf_debug_set_tuning(0)
+            ref = M.conv2d_f16(simlib, None, xs, hi, lo, nterms, cout, 2, **kw)
+            assert simlib.hf_debug_last_path() == 602
+            simlib.hf_debug_set_tuning(2 << 24)  # "the chip" = 2 blocks: the launch fills it with a quarter of its blocks
+            y = M.conv2d_f16(simlib, None, xs, hi, lo, nterms, cout, 2, **kw)
+            assert simlib.hf_debug_last_path() == 605
+            if G == 1:
+                sp, y2 = M.conv2d_f16_split(simlib, None, xs, hi, lo, nterms, cout, 2, want_f32=True, bias=bias, act=M.ACT_PRELU, slope=slope)
+                assert simlib.hf_debug_last_path() == 605
+        finally:
+            simlib.hf_debug_set_tuning(0)
+        assert torch.equal(y, ref)
+        if G == 1:
+            noresid = M.conv2d_f16(simlib, None, xs, hi, lo, nterms, cout, 2, bias=bias, act=M.ACT_PRELU, slope=slope)
+            want = M.split_activation_f16(simlib, None, noresid, want_lo=nterms == 3)
+            assert torch.equal(y2, noresid) and torch.equal(sp.hi, want.hi) and (nterms == 1 or torch.equal(sp.lo, want.lo))
+    # virtual split-K inside the multi-tile form (batch-invariant plans): 12 K stages, canonical batch 3 splits them
+    B, cin, cout, H, W = 14, 192, 64, 32, 64
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    hi, lo = M.conv_split_weights_f16(simlib, None, M.conv_prepare(simlib, None, w))
+    bias = torch.randn(cout)
+    prev = simlib.hf_set_batch_invariant(1)
+    try:
+        assert simlib.hf_conv2d_f16_workspace_floats(1, cin, cout, H, W, 2, 1) > 0
+        ref = torch.cat([M.conv2d_f16(simlib, None, M.split_activation_f16(simlib, None, x[b:b + 1], want_lo=nterms == 3), hi, lo, nterms,
+                                      cout, 2, bias=bias) for b in range(B)])
+        simlib.hf_debug_set_tuning(13 << 24)  # canonical launch: 3 x 4 tiles = 12 blocks, split; this one: 56 blocks / 4 = 14: virtual, multi-tile
+        y = M.conv2d_f16(simlib, None, M.split_activation_f16(simlib, None, x, want_lo=nterms == 3), hi, lo, nterms, cout, 2, bias=bias)
+        assert simlib.hf_debug_last_path() == 605
+    finally:
+        simlib.hf_debug_set_tuning(0)
+        simlib.hf_set_batch_invariant(prev)
+    assert torch.equal(y, ref)
