@@ -1,14 +1,12 @@
-# Round check on the GPU box (run through `gpurun -- bash gpurun_cmd.sh` from the repo root): GPU parity suite, smoke, the default
-# bench line, rocprofv3 stats + PMC passes of the generator workload and of the batched swap at its timed pass size, the swap
-# workload once more with RCCL initialised at world 1.
+# GPU call r05r: stride-2 multi-tile form with the rounds rule (x4 / x2 / one tile) A/B per layer and on the batched swap; GPU tests
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q --durations=5 > gpurun_out/tests_gpu.log 2>&1; tail -4 gpurun_out/tests_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; python -c "
-import json; d=json.load(open('gpurun_out/bench.json')); p=d['swap_pipeline']
-print(d['value'], d['f16_mode']['value'], p['value'], p['single_swap']['ms_per_swap'], p['single_swap_graph'], p.get('verified',{}).get('equal'))"
-bash tools/profile_bench.sh r05c
-bash tools/prof_swap.sh r05c stats pmc
-HF_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29671 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 python bench.py --workload swap256 --triples 64 --no-kernel-events 2> gpurun_out/bench_dist.err | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('forced RCCL world 1:', d['value'], 'triples/s', d['config']['gather'], d['verified']['equal'], d['balance'])"
+python tools/probes/enc_layers_pre.py 2>&1 | grep -E "s2|lib" > gpurun_out/r05r_layers_mt.log
+HAIRFAST_HIP_LIB=$GRAFT_REPO_ROOT/hairfastgan_amd/csrc/libhairfast_mt1.so python tools/probes/enc_layers_pre.py 2>&1 | grep -E "s2|lib" > gpurun_out/r05r_layers_mt1.log
+paste -d'\n' gpurun_out/r05r_layers_mt.log gpurun_out/r05r_layers_mt1.log
+for v in hip mt1 hip mt1; do
+  HAIRFAST_HIP_LIB=$GRAFT_REPO_ROOT/hairfastgan_amd/csrc/libhairfast_$v.so python bench.py --workload swap256 --triples 64 --swap-batch 32 --warmup 1 --no-kernel-events > gpurun_out/r05r_swap_$v.json 2> gpurun_out/r05r_swap_$v.err
+  python -c "
+import json; d=json.load(open('gpurun_out/r05r_swap_$v.json')); print('$v', d['value'], 'triples/s', d['verified']['equal'])"
+done
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3

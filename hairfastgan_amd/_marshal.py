@@ -38,6 +38,7 @@ KERNEL_NAMES = {  # hf_debug_last_path() code -> kernel instantiation (csrc/modc
     # csrc/convh_enc.hip (encoder convs on the fp16 matrix cores)
     601: "conv_enc_h<64x256>", 602: "conv_enc_h<64x128,stride2>", 603: "conv_enc_h<64x128>", 604: "conv_enc_h<64x512>",
     605: "conv_enc_h<64x128,stride2,x4 tiles>",
+    606: "conv_enc_h<64x128,stride2,x2 tiles>",
 }
 
 

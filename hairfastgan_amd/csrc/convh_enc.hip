@@ -686,7 +686,7 @@ inline int enc_splitk_plan(long long blocks, int nchunks) {
 // force_splits > 0 (batch-invariant plans): the K partition is given - the canonical plan of run_enc - and only its
 // execution is decided here: one block per slab (grid.z, partial slabs + splitk_reduce) when the output grid alone leaves
 // the chip empty, else ConvParams::vsplit (every block walks all slabs; same bits).
-thread_local int g_s2mt_last = 0;  // 1: the last stride-2 launch took the multi-tile form (hf_debug_last_path 605)
+thread_local int g_s2mt_last = 0;  // 4 / 2: the last stride-2 launch took the multi-tile form with that many tiles (hf_debug_last_path 605 / 606)
 
 template <int NTERMS, int PG, int WAVES_PX, int STRIDE, int CT_TILES = 1, int WAVES_CO = 2>
 int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *workspace, long long workspace_floats,
@@ -759,13 +759,29 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
     if constexpr (STRIDE == 2 && HF_ENC_S2MT > 1) {
       // several pixel tiles per resident weight stage (conv_enc_s2mt_h) when the launch still fills the chip with MT times
       // fewer blocks (hf_debug_set_tuning bits 24-31 lower "the chip" for tests) and its K loop is not spread over the grid
-      constexpr int MT = HF_ENC_S2MT;
+      // MT = 4, else 2: the largest one whose blocks still fill the chip's rounds of 256 resident blocks (512 @ 32^2 at batch 96:
+      // 1536 one-tile blocks = 6 full rounds, 384 four-tile blocks = 1.5 - measured 17 % slower; 768 two-tile blocks = 3)
       const long long fill_blocks = fill ? fill : 256;
-      if ((P.vsplit || P.splits == 1) && blocks / MT >= fill_blocks) {
-        dim3 g2 = P.swap_xy ? dim3(grid.x, hf_cdiv((int)grid.y, MT), 1) : dim3(hf_cdiv((int)grid.x, MT), grid.y, 1);
-        if (P.vsplit) hipLaunchKernelGGL((conv_enc_s2mt_h<NTERMS, MT, true>), g2, dim3(NT), lds, st, P, wth, wtl);
-        else hipLaunchKernelGGL((conv_enc_s2mt_h<NTERMS, MT, false>), g2, dim3(NT), lds, st, P, wth, wtl);
-        g_s2mt_last = 1;
+      const int cols = P.co_tiles * groups, tiles = geom_blocks(G);
+      int mt = 0;
+      if (P.vsplit || P.splits == 1) {
+        for (int m = HF_ENC_S2MT; m >= 2 && !mt; m >>= 1) {
+          const long long nb = (long long)hf_cdiv(tiles, m) * cols;
+          const long long rounds = (nb + fill_blocks - 1) / fill_blocks;
+          if (nb >= fill_blocks && (double)nb >= 0.85 * (double)(rounds * fill_blocks)) mt = m;
+        }
+      }
+      if (mt) {
+        const int tb = hf_cdiv(tiles, mt);
+        dim3 g2 = P.swap_xy ? dim3(cols, tb, 1) : dim3(tb, cols, 1);
+        if (mt == 4) {
+          if (P.vsplit) hipLaunchKernelGGL((conv_enc_s2mt_h<NTERMS, 4, true>), g2, dim3(NT), lds, st, P, wth, wtl);
+          else hipLaunchKernelGGL((conv_enc_s2mt_h<NTERMS, 4, false>), g2, dim3(NT), lds, st, P, wth, wtl);
+        } else {
+          if (P.vsplit) hipLaunchKernelGGL((conv_enc_s2mt_h<NTERMS, 2, true>), g2, dim3(NT), lds, st, P, wth, wtl);
+          else hipLaunchKernelGGL((conv_enc_s2mt_h<NTERMS, 2, false>), g2, dim3(NT), lds, st, P, wth, wtl);
+        }
+        g_s2mt_last = mt;
         return hf_launch_status();
       }
     }
@@ -797,7 +813,7 @@ int run_enc_forms(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *
     // 1 instead of 1.33 LDS fragment reads per MFMA of four 1 x 2 waves (tools/probes/stride2.py: 10-25% faster from
     // 64@256^2 to the 11-group style heads, 30-35% on the register-staged path; same accumulation order, equal bits)
     rc = launch_enc<NTERMS, 1, 4, 2>(P, hi, lo, ws, wsn, st, plan_only, force_splits);
-    if (rc == HF_OK && !plan_only) note_path(6, g_s2mt_last ? 5 : 2);
+    if (rc == HF_OK && !plan_only) note_path(6, g_s2mt_last == 4 ? 5 : g_s2mt_last ? 6 : 2);
     return rc;
   }
   // 64 co x 512 px (8 waves, 2 x 2 MFMA tiles each) when that fills the chip (batched swaps), else

@@ -361,7 +361,7 @@ def _fp64_conv_rows(x, w, rows, stride, in_scale, in_shift, out_scale, bias, slo
     (48, 256, 256, 32, 32, 1, 601),      # 256-channel 32^2 units, pre-split: 384 blocks of 512 px do not fill the chip -> the 64 x 256 form
     (32, 1024, 1024, 64, 64, 1, 604),    # PostProcess trunk at 16 triples (source + target)
     (48, 64, 64, 256, 256, 2, 602),      # stride 2, eight-wave form, parity-split halo tile
-    (48, 128, 128, 128, 128, 2, 602),
+    (48, 128, 128, 128, 128, 2, 605),    # ... pre-split: four pixel tiles per resident weight stage (conv_enc_s2mt_h)
     (48, 512, 512, 32, 32, 2, 602),
 ])
 def test_batched_kernel_forms_vs_fp64_oracle(B, cin, cout, H, W, stride, want_path):

@@ -645,7 +645,8 @@ def test_conv2d_f16_stride2_multi_tile_form(simlib, nterms):
     bits of the one-tile form: ragged planes (tiles past the end, halo units outside the image that differ from tile to
     tile), two images, a grouped launch on per-group inputs, a virtual split-K, PReLU + residual, the split output."""
     torch.manual_seed(61)
-    for B, cin, cout, H, W, G in ((2, 48, 64, 40, 72, 1), (1, 32, 128, 64, 64, 2)):
+    # f4 / f2: "chips" (blocks per round) that the launch's blocks / 4 and / 2 fill in whole rounds (20 and 32 one-tile blocks)
+    for B, cin, cout, H, W, G, f4, f2 in ((2, 48, 64, 40, 72, 1, 5, 10), (1, 32, 128, 64, 64, 2, 4, 6)):
         x = torch.randn(*((G, B) if G > 1 else (B,)), cin, H, W)
         ws = torch.randn(G, cout, cin, 3, 3) / (cin * 9) ** 0.5
         wt = torch.stack([M.conv_prepare(simlib, None, ws[g]) for g in range(G)]).contiguous()
@@ -660,7 +661,10 @@ def test_conv2d_f16_stride2_multi_tile_form(simlib, nterms):
             simlib.hf_debug_set_tuning(0)
             ref = M.conv2d_f16(simlib, None, xs, hi, lo, nterms, cout, 2, **kw)
             assert simlib.hf_debug_last_path() == 602
-            simlib.hf_debug_set_tuning(2 << 24)  # "the chip" = 2 blocks: the launch fills it with a quarter of its blocks
+            simlib.hf_debug_set_tuning(f2 << 24)
+            yb = M.conv2d_f16(simlib, None, xs, hi, lo, nterms, cout, 2, **kw)
+            assert simlib.hf_debug_last_path() == 606 and torch.equal(yb, ref)
+            simlib.hf_debug_set_tuning(f4 << 24)
             y = M.conv2d_f16(simlib, None, xs, hi, lo, nterms, cout, 2, **kw)
             assert simlib.hf_debug_last_path() == 605
             if G == 1:
@@ -674,7 +678,7 @@ def test_conv2d_f16_stride2_multi_tile_form(simlib, nterms):
             want = M.split_activation_f16(simlib, None, noresid, want_lo=nterms == 3)
             assert torch.equal(y2, noresid) and torch.equal(sp.hi, want.hi) and (nterms == 1 or torch.equal(sp.lo, want.lo))
     # virtual split-K inside the multi-tile form (batch-invariant plans): 12 K stages, canonical batch 3 splits them
-    B, cin, cout, H, W = 14, 192, 64, 32, 64
+    B, cin, cout, H, W = 13, 192, 64, 32, 64
     x = torch.randn(B, cin, H, W)
     w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
     hi, lo = M.conv_split_weights_f16(simlib, None, M.conv_prepare(simlib, None, w))
@@ -684,9 +688,15 @@ def test_conv2d_f16_stride2_multi_tile_form(simlib, nterms):
         assert simlib.hf_conv2d_f16_workspace_floats(1, cin, cout, H, W, 2, 1) > 0
         ref = torch.cat([M.conv2d_f16(simlib, None, M.split_activation_f16(simlib, None, x[b:b + 1], want_lo=nterms == 3), hi, lo, nterms,
                                       cout, 2, bias=bias) for b in range(B)])
-        simlib.hf_debug_set_tuning(13 << 24)  # canonical launch: 3 x 4 tiles = 12 blocks, split; this one: 56 blocks / 4 = 14: virtual, multi-tile
-        y = M.conv2d_f16(simlib, None, M.split_activation_f16(simlib, None, x, want_lo=nterms == 3), hi, lo, nterms, cout, 2, bias=bias)
+        simlib.hf_debug_set_tuning(13 << 24)  # canonical launch: 3 x 4 tiles = 12 blocks, split; this one: 52 blocks / 4 = 13, one full round: virtual, x4
+        xs = M.split_activation_f16(simlib, None, x, want_lo=nterms == 3)
+        y = M.conv2d_f16(simlib, None, xs, hi, lo, nterms, cout, 2, bias=bias)
         assert simlib.hf_debug_last_path() == 605
+        # a "chip" of 26 blocks per round: 13 four-tile blocks do not fill it, 26 two-tile blocks are exactly one round -> x2
+        simlib.hf_debug_set_tuning(26 << 24)
+        y2t = M.conv2d_f16(simlib, None, xs, hi, lo, nterms, cout, 2, bias=bias)
+        assert simlib.hf_debug_last_path() == 606
+        assert torch.equal(y2t, y)
     finally:
         simlib.hf_debug_set_tuning(0)
         simlib.hf_set_batch_invariant(prev)
