@@ -457,6 +457,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
 // LDS-DMA meanwhile (two activation buffers by step parity, two weight buffers by chunk parity: the same 150 KB), one barrier per
 // step as before.  Bytes per MFMA: (38 + 36.9 / MT) KB per 216 instead of 75.  Per output the K order is that of conv_enc_h:
 // equal bits (tests/test_sim_encoders.py).  Pre-split input only; real split-K launches keep the one-tile form.
+#ifndef HF_ENC_S2MT_AREG
+#define HF_ENC_S2MT_AREG 1
+#endif
 template <int NTERMS, int MT, bool VSPLIT>
 __global__ __launch_bounds__(512) void conv_enc_s2mt_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
                                                        const _Float16 *__restrict__ wtl_all) {
@@ -586,7 +589,13 @@ __global__ __launch_bounds__(512) void conv_enc_s2mt_h(const ConvParams P, const
   for (int e = 0; e < XE; ++e) dma_x(0, e, 0, 0);
   hf_barrier_keep_young<0>();
 
-  half8 ah[2], al[2], bh[2], bl[2];
+  // HF_ENC_S2MT_AREG: the chunk's weight fragments (9 taps x hi / lo, 72 registers) are read from LDS during the chunk's first
+  // tile and stay in registers for its other MT - 1 tiles: 36 -> 18 ds_read_b128 per tile step for those (the 128-pixel form has
+  // ONE accumulator tile per wave, 1.33 LDS reads per MFMA - twice the 512-pixel form's - and 8 waves' reads take longer than
+  // their MFMAs)
+  // (not with four tiles AND the virtual split-K's second accumulator set: 256 registers + scratch)
+  constexpr bool AREG = HF_ENC_S2MT_AREG && !(VSPLIT && MT == 4 && NTERMS == 3);
+  half8 wh[AREG ? 9 : 2], wl[AREG ? 9 : 2], bh[2], bl[2];
   int step = 0;
   for (int c = 0; c < nchunks; ++c) {
     const int wb = c & 1;
@@ -609,11 +618,15 @@ __global__ __launch_bounds__(512) void conv_enc_s2mt_h(const ConvParams P, const
       }
       const half8 *a_hi = lds + wb * BUF_UNITS + lh * CT + wave_co + li;
       const half8 *b_hi = lds + xb * BUF_UNITS + OFF_XH + lh * NPIX;
+      const bool load_w = !AREG || j == 0;
       auto fetch = [&](int slot, int tap) {
         const int ky = tap / 3, kx = tap % 3;
         const int toff = ky * wp + (kx & 1) * wp2 + (kx >> 1);
-        ah[slot] = a_hi[tap * 2 * CT];
-        if (NTERMS == 3) al[slot] = a_hi[OFF_WL + tap * 2 * CT];
+        if (load_w) {
+          const int ws = AREG ? tap : slot;
+          wh[ws] = a_hi[tap * 2 * CT];
+          if (NTERMS == 3) wl[ws] = a_hi[OFF_WL + tap * 2 * CT];
+        }
         bh[slot] = b_hi[pix0 + toff];
         if (NTERMS == 3) bl[slot] = b_hi[X_UNITS + pix0 + toff];
       };
@@ -621,12 +634,13 @@ __global__ __launch_bounds__(512) void conv_enc_s2mt_h(const ConvParams P, const
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int s_ = tap & 1;
+        const int ws = AREG ? tap : s_;
         if (tap + 1 < 9) fetch(s_ ^ 1, tap + 1);
         __builtin_amdgcn_sched_barrier(0);
-        acc[j][0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bh[s_], acc[j][0][0][0], 0, 0, 0);
+        acc[j][0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ws], bh[s_], acc[j][0][0][0], 0, 0, 0);
         if (NTERMS == 3) {
-          acc[j][0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bl[s_], acc[j][0][0][0], 0, 0, 0);
-          acc[j][0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s_], bh[s_], acc[j][0][0][0], 0, 0, 0);
+          acc[j][0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ws], bl[s_], acc[j][0][0][0], 0, 0, 0);
+          acc[j][0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ws], bh[s_], acc[j][0][0][0], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }

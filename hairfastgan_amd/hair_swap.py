@@ -138,6 +138,12 @@ class DilateErosion:
         return M.dilate_erode(lib(), stream(), mask.float(), self.dilate_erosion)
 
 
+def _cat(tensors):
+    """torch.cat(tensors, 0) without the copy for a single tensor (one triple: no launch added to the unbatched swap)."""
+    tensors = list(tensors)
+    return tensors[0] if len(tensors) == 1 else torch.cat(tensors, 0)
+
+
 def _same_content(a, b, fa, fb):
     """torch.allclose(fa, fb) of utils/image_utils.py:21 without its ten elementwise launches where the answer is exact:
     the same storage, or two 8-bit images (distinct 8-bit values differ by 1/255 after the division, far above allclose's
@@ -174,11 +180,14 @@ def equal_replacer_many(triples, _any_device=False):
     if not batched:
         return [tuple(equal_replacer(list(tr))) for tr in triples]
     cols = [torch.stack([tr[k] for tr in triples]) for k in range(3)]
-    differ = torch.stack([(cols[i] != cols[j]).flatten(1).any(1) for i, j in ((0, 1), (0, 2), (1, 2))], 1).cpu()  # [T, 3]: the one sync
+    # eight bytes per compared element where the rows allow it (the comparison is for equality only)
+    wide = [c.view(torch.int64) if c.shape[-1] % 8 == 0 else c for c in cols]
+    differ = torch.stack([(wide[i] != wide[j]).flatten(1).any(1) for i, j in ((0, 1), (0, 2), (1, 2))], 1).cpu()  # [T, 3]: the one sync
+    scaled = [c / 255 for c in cols]  # three launches for the 3 T divisions; a triple's images are rows of them (same bits)
     out = []
-    for t, tr in enumerate(triples):
-        images = [im / 255 for im in tr]
-        d01, d02, d12 = (bool(v) for v in differ[t])
+    for t in range(len(triples)):
+        images = [scaled[k][t] for k in range(3)]
+        d01, d02, d12 = differ[t].tolist()
         if not d01:
             images[1] = images[0]
         if not d02:
@@ -523,22 +532,38 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
         targets = self.stages.shape_adaptor(torch.cat([name_to_embed[a]["mask"] for a, _ in todo], 0), masks)
         return {key: (I_rot[k:k + 1], masks[k:k + 1], targets[k:k + 1]) for k, key in enumerate(todo)}
 
+    def _target_mask(self, im_name1, im_name2, name_to_embed, rotated=None):
+        """The target parse of a pair (:58-83): the shape adaptor's output on the rotated image, or the face's own parse
+        when both names hold the same image."""
+        e1, e2 = name_to_embed[im_name1], name_to_embed[im_name2]
+        if e1["image_256"] is e2["image_256"]:
+            return e1["mask"]
+        rot = (rotated or {}).get((im_name1, im_name2))
+        if rot is None:
+            rot = self.rotate_images([(im_name1, im_name2)], name_to_embed)[(im_name1, im_name2)]
+        return rot[2]
+
     @torch.inference_mode()
     def shape_module(self, im_name1, im_name2, name_to_embed, only_target=True, rotated=None, **kwargs):  # :40-99
         e1, e2 = name_to_embed[im_name1], name_to_embed[im_name2]
         inp_mask1, inp_mask2 = e1["mask"], e2["mask"]
-        if e1["image_256"] is not e2["image_256"]:
-            rot = (rotated or {}).get((im_name1, im_name2))
-            if rot is None:
-                rot = self.rotate_images([(im_name1, im_name2)], name_to_embed)[(im_name1, im_name2)]
-            target_mask = rot[2]
-        else:
-            target_mask = inp_mask1
+        target_mask = self._target_mask(im_name1, im_name2, name_to_embed, rotated)
         hair_mask_target = (target_mask == 13).to(target_mask.dtype)
         if only_target:
             return {"HM_X": hair_mask_target}
         return (inp_mask1, (inp_mask1 == 13).to(inp_mask1.dtype), inp_mask2, (inp_mask2 == 13).to(inp_mask2.dtype),
                 target_mask, hair_mask_target)
+
+    @torch.inference_mode()
+    def shape_modules(self, pairs, name_to_embed, rotated=None, **kwargs):
+        """`shape_module(..., only_target=True)` for several pairs: the hair masks of all target parses from one comparison
+        (two launches instead of two per pair; elementwise, so every pair's mask has the bits of its own call)."""
+        if not pairs:
+            return []
+        targets = [self._target_mask(a, b, name_to_embed, rotated) for a, b in pairs]
+        stacked = _cat(targets)
+        hair = (stacked == 13).to(stacked.dtype)
+        return [{"HM_X": hair[j:j + 1]} for j in range(len(pairs))]
 
     @torch.inference_mode()
     def align_images(self, im_name1, im_name2, name_to_embed, **kwargs):  # :101-175
@@ -550,41 +575,49 @@ class Alignment(nn.Module):  # models/Alignment.py:15-175
         out-of-scope stages run per pair, everything on the hot path once for all pairs (the SEAN outputs of all
         pairs are ONE e4e batch + ONE generator 0->3 forward, the masks one dilation / erosion call)."""
         results = [None] * len(pairs)
-        work = []  # (index, e1, e2, masks of the pair)
+        work = []  # (index, e1, e2, target parse of the pair)
         for k, (n1, n2) in enumerate(pairs):
             e1, e2 = name_to_embed[n1], name_to_embed[n2]
             if e1["image_256"] is e2["image_256"]:
                 hm = self.shape_module(n1, n2, name_to_embed, only_target=True, **kwargs)["HM_X"]
                 results[k] = {"latent_F_align": e1["F"], "HM_X": hm}
             else:
-                work.append((k, e1, e2, self.shape_module(n1, n2, name_to_embed, only_target=False, **kwargs)))
+                work.append((k, e1, e2, self._target_mask(n1, n2, name_to_embed, kwargs.get("rotated"))))
         if not work:
             return results
-        sean, masks = [], []
-        batched_sean = getattr(self.stages, "sean_inpaint_pairs", None)
-        for k, e1, e2, (inp_mask1, hair_mask1, inp_mask2, hair_mask2, target_mask, hair_mask_target) in work:
-            if batched_sean is None:
-                images = torch.cat([e1["image_256"], e2["image_256"]], dim=0)
-                labels = torch.cat([inp_mask1, inp_mask2], dim=0)
-                sean += list(self.stages.sean_inpaint(images, labels, target_mask))  # SEAN for inpaint (per pair)
-            masks.append(torch.cat([1 - (1 - hair_mask1) * (1 - hair_mask_target), hair_mask_target, hair_mask2 * hair_mask_target], 0))
+        # the masks of every pair from whole-batch launches (:84-99, :133-141 are elementwise: same bits as pair by pair)
+        P = len(work)
+        parses = _cat([w[1]["mask"] for w in work] + [w[2]["mask"] for w in work])  # [2P,1,h,w]: the faces' parses, then the shapes'
+        targets = _cat([w[3] for w in work])
+        hair, hair_target = (parses == 13).to(parses.dtype), (targets == 13).to(targets.dtype)
+        hair1, hair2 = hair[:P], hair[P:]
+        masks = torch.stack([1 - (1 - hair1) * (1 - hair_target), hair_target, hair2 * hair_target], dim=1).reshape(3 * P, *hair.shape[1:])
         _mark("align: shape module, masks")
+        batched_sean = getattr(self.stages, "sean_inpaint_pairs", None)
         if batched_sean is not None:  # SEAN for inpaint: every pair in one batched pass (hairfastgan_amd.sean)
             sean = batched_sean(torch.cat([e["image_256"] for _, e1, e2, _m in work for e in (e1, e2)], dim=0),
-                                torch.cat([m_ for _, _e1, _e2, m in work for m_ in (m[0], m[2])], dim=0),
-                                torch.cat([m[4] for _, _e1, _e2, m in work], dim=0))
+                                torch.cat([e["mask"] for _, e1, e2, _m in work for e in (e1, e2)], dim=0),
+                                targets)
+        else:
+            sean = []
+            for _, e1, e2, target_mask in work:  # SEAN for inpaint (per pair)
+                sean += list(self.stages.sean_inpaint(torch.cat([e1["image_256"], e2["image_256"]], dim=0),
+                                                      torch.cat([e1["mask"], e2["mask"]], dim=0), target_mask))
         _mark("align: SEAN encode + decodes")
         enc_F = self.latent_encoder(sean)["F"]                                   # e4e batch 2P + generator 0->3
-        dilate, erosion = self.dilate_erosion.mask(torch.cat(masks, 0))          # [3P, 1, 256, 256] each
+        dilate, erosion = self.dilate_erosion.mask(masks)                        # [3P, 1, 256, 256] each
         free_mask = torch.stack([dilate[0::3], erosion[1::3], erosion[2::3]], dim=1).reshape(-1, *dilate.shape[1:])
         low = 1 - F.interpolate(free_mask.float(), size=(32, 32), mode="bicubic")  # [3P, 1, 32, 32]
-        for j, (k, e1, e2, m) in enumerate(work):
-            intermediate_align, latent_F_out_new = enc_F[2 * j:2 * j + 1], enc_F[2 * j + 1:2 * j + 2]
-            il = low[3 * j:3 * j + 3]
-            latent_F_align = intermediate_align + il[0] * (e1["F"] - intermediate_align)
-            latent_F_align = latent_F_out_new + il[1] * (latent_F_align - latent_F_out_new)
-            latent_F_align = e2["F"] + il[2] * (latent_F_align - e2["F"])
-            results[k] = {"latent_F_align": latent_F_align, "HM_X": m[5]}
+        # the three interpolations of F (:160-172) for all pairs at once
+        enc_F = enc_F.reshape(P, 2, *enc_F.shape[1:])
+        intermediate_align, latent_F_out_new = enc_F[:, 0], enc_F[:, 1]
+        il = low.reshape(P, 3, *low.shape[1:])
+        F_1, F_2 = _cat([e1["F"] for _, e1, _e2, _m in work]), _cat([e2["F"] for _, _e1, e2, _m in work])
+        latent_F_align = intermediate_align + il[:, 0] * (F_1 - intermediate_align)
+        latent_F_align = latent_F_out_new + il[:, 1] * (latent_F_align - latent_F_out_new)
+        latent_F_align = F_2 + il[:, 2] * (latent_F_align - F_2)
+        for j, (k, _e1, _e2, _m) in enumerate(work):
+            results[k] = {"latent_F_align": latent_F_align[j:j + 1], "HM_X": hair_target[j:j + 1]}
         return results
 
 
@@ -621,21 +654,25 @@ class Blending(nn.Module):  # models/Blending.py:11-82
         emb = [[name_to_embed[k] for k in key] for key in keys]
         mask_de = self.dilate_erosion.hair_from_mask(torch.cat([e[i]["mask"] for e in emb for i in (0, 2)], dim=0))  # [2T,...]
         HM_XD, _ = self.dilate_erosion.mask(torch.cat([a["HM_X"] for a in aligns_color], dim=0))
-        S_blend, todo, args_ = [None] * T, [], []
-        for t, (ef, es, ec) in enumerate(emb):
-            I_1, I_2, I_3 = ef["image_norm_256"], es["image_norm_256"], ec["image_norm_256"]
-            HM_1D = mask_de[0][2 * t].unsqueeze(0)
-            HM_3D, HM_3E = mask_de[0][2 * t + 1].unsqueeze(0), mask_de[1][2 * t + 1].unsqueeze(0)
-            latent_S_1, latent_S_3 = ef["S"], ec["S"]
-            target_mask = (1 - HM_1D) * (1 - HM_3D) * (1 - HM_XD[t:t + 1])
-            if I_1 is not I_3 or I_1 is not I_2:
-                todo.append(t)
-                args_.append((latent_S_1[:, 6:], latent_S_3[:, 6:], I_1 * target_mask, I_3 * HM_3E))
-            else:
-                S_blend[t] = latent_S_1
+        # the blending encoder's inputs (:50-58) for all triples from whole-batch launches (elementwise: the bits of the per-triple form)
+        HM_1D, HM_3D, HM_3E = mask_de[0][0::2], mask_de[0][1::2], mask_de[1][1::2]           # [T, 1, 256, 256] each
+        target_mask = (1 - HM_1D) * (1 - HM_3D) * (1 - HM_XD)
+        I_1_all = _cat([e[0]["image_norm_256"] for e in emb])
+        I_3_all = _cat([e[2]["image_norm_256"] for e in emb])
+        face_in, color_in = I_1_all * target_mask, I_3_all * HM_3E
+        S_blend = [None] * T
+        todo = [t for t, (ef, es, ec) in enumerate(emb)
+                if ef["image_norm_256"] is not ec["image_norm_256"] or ef["image_norm_256"] is not es["image_norm_256"]]
+        for t, (ef, _es, _ec) in enumerate(emb):
+            if t not in todo:
+                S_blend[t] = ef["S"]
         _mark("blend: masks")
         if todo:  # the blending encoder once for all triples that need it
-            S_6_18 = self.stages.blend(*(torch.cat([a[j] for a in args_], 0) for j in range(4)))
+            if len(todo) < T:
+                rows = torch.tensor(todo, device=face_in.device)
+                face_in, color_in = face_in.index_select(0, rows), color_in.index_select(0, rows)
+            S_6_18 = self.stages.blend(_cat([emb[t][0]["S"][:, 6:] for t in todo]), _cat([emb[t][2]["S"][:, 6:] for t in todo]),
+                                       face_in, color_in)
             _mark("blend: ClipBlendingModel incl. CLIP tower")
             for j, t in enumerate(todo):
                 S_blend[t] = torch.cat((emb[t][0]["S"][:, :6], S_6_18[j:j + 1]), dim=1)
@@ -644,7 +681,6 @@ class Blending(nn.Module):  # models/Blending.py:11-82
                                         end_layer=8, layer_in=latent_F_align)
         I_blend_256 = self.downsample_256(I_blend)
         _mark("blend: generator 4->8")
-        I_1_all = torch.cat([e[0]["image_norm_256"] for e in emb], dim=0)
         S_final, F_final = self.post_process(I_1_all, I_blend_256)  # Post Process (native: encoders/post_process.py)
         _mark("blend: PostProcessModel")
         I_final, _ = self.net.generator([S_final], input_is_latent=True, return_latents=False, start_layer=5, end_layer=8,
@@ -774,9 +810,9 @@ class HairFast:
         _mark("rotate: RotateModel, generator 0->8, BiSeNet @1024, shape adaptor")
         aligns_shape = self.align.align_images_batch([(key(t, "face"), key(t, "shape")) for t in range(T)], name_to_embed,
                                                      rotated=rotated, **kwargs)
-        aligns_color = [aligns_shape[t] if same[t] else
-                        self.align.shape_module(key(t, "face"), key(t, "color"), name_to_embed, rotated=rotated, **kwargs)
-                        for t in range(T)]
+        color_targets = iter(self.align.shape_modules([(key(t, "face"), key(t, "color")) for t in range(T) if not same[t]],
+                                                      name_to_embed, rotated=rotated, **kwargs))
+        aligns_color = [aligns_shape[t] if same[t] else next(color_targets) for t in range(T)]
         _mark("align: e4e of the SEAN renderings, generator 0->3, F alignment")
         return self.blend.blend_images_batch(aligns_shape, aligns_color, name_to_embed,
                                              [tuple(key(t, n) for n in ("face", "shape", "color")) for t in range(T)], **kwargs)

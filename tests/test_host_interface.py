@@ -352,15 +352,84 @@ def test_equal_replacer_many_equals_the_per_triple_form():
     from hairfastgan_amd.hair_swap import equal_replacer, equal_replacer_many
 
     g = torch.Generator().manual_seed(0)
-    mk = lambda: torch.randint(0, 256, (3, 8, 8), dtype=torch.uint8, generator=g)  # noqa: E731
-    a, b, c = mk(), mk(), mk()
-    triples = [[a, b, c], [a.clone(), a.clone(), c.clone()], [b.clone(), c.clone(), c.clone()], [a.clone(), b.clone(), a.clone()],
-               [c.clone(), c.clone(), c.clone()]]
-    for forced in (False, True):  # the per-triple fallback (CPU tensors) and the batched comparison
-        got = equal_replacer_many(triples, _any_device=forced)
-        for tr, out in zip(triples, got):
-            ref = equal_replacer(list(tr))
-            same = lambda ims: [ims[i] is ims[j] for i in range(3) for j in range(3)]  # noqa: E731
-            assert same(out) == same(ref)
-            assert all(torch.equal(o, r) for o, r in zip(out, ref)) and out[0].dtype is torch.float32
+    for shape in ((3, 8, 8), (3, 8, 12)):  # rows compared eight bytes at a time / byte by byte
+        mk = lambda: torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)  # noqa: E731
+        a, b, c = mk(), mk(), mk()
+        d = c.clone()
+        d[2, 7, -1] ^= 1  # one bit of the last byte
+        triples = [[a, b, c], [a.clone(), a.clone(), c.clone()], [b.clone(), c.clone(), c.clone()], [a.clone(), b.clone(), a.clone()],
+                   [c.clone(), c.clone(), c.clone()], [c.clone(), d, c.clone()]]
+        for forced in (False, True):  # the per-triple fallback (CPU tensors) and the batched comparison
+            got = equal_replacer_many(triples, _any_device=forced)
+            for tr, out in zip(triples, got):
+                ref = equal_replacer(list(tr))
+                same = lambda ims: [ims[i] is ims[j] for i in range(3) for j in range(3)]  # noqa: E731
+                assert same(out) == same(ref)
+                assert all(torch.equal(o, r) for o, r in zip(out, ref)) and out[0].dtype is torch.float32
     assert len(equal_replacer_many([[a, b, b]], _any_device=True)) == 1  # a repeated object: per-triple form
+
+
+def test_batched_stage_glue_equals_the_glue_of_each_triple_alone():
+    """Alignment.align_images_batch / shape_modules and Blending.blend_images_batch build the masks, the three interpolations of F
+    and the blending encoder's inputs for all triples with whole-batch launches: every triple gets the values - bit for bit -
+    its own call produces.  The networks in between are per-sample stand-ins here (the GPU suite runs the real ones,
+    tests/test_gpu_schedule.py); this test is about the index bookkeeping of the batched form."""
+    import types
+
+    from hairfastgan_amd import hair_swap as hs
+
+    g = torch.Generator().manual_seed(5)
+    T, hw = 4, 64
+    rnd = lambda *shape: torch.randn(*shape, generator=g)  # noqa: E731
+    parse = lambda: torch.randint(10, 16, (1, 1, hw, hw), generator=g).float()  # noqa: E731
+
+    def entry():
+        im = rnd(1, 3, hw, hw)
+        return {"W": rnd(1, 18, 8), "F": rnd(1, 8, 32, 32), "S": rnd(1, 18, 8), "mask": parse(), "image_256": im, "image_norm_256": im * 2 - 1}
+
+    name_to_embed, rotated, triples = {}, {}, []
+    for t in range(T):
+        face, shape = entry(), entry()
+        color = shape if t == 1 else entry()          # triple 1: shape is color
+        if t == 2:
+            shape = face                              # triple 2: the face is its own shape (no SEAN, no mixing of F)
+        for n, e in zip(("face", "shape", "color"), (face, shape, color)):
+            name_to_embed[(t, n)] = e
+        for n in ("shape", "color"):
+            if name_to_embed[(t, n)]["image_256"] is not face["image_256"]:
+                rotated[((t, "face"), (t, n))] = rotated[((t, "face"), (t, "shape"))] if n == "color" and color is shape else (None, None, parse())
+        triples.append(t)
+
+    per_sample = lambda x: x.flatten(1).mean(1)  # noqa: E731
+    de = types.SimpleNamespace(mask=lambda m: (m * 0.5 + 0.125, m * 0.25), hair_from_mask=lambda m: ((m == 13).float() * 0.5 + 0.25, (m == 13).float() * 0.75))
+    stages = types.SimpleNamespace(
+        sean_inpaint_pairs=lambda im, lab, tgt: im + 0.01 * lab + 0.001 * tgt.repeat_interleave(2, 0),
+        blend=lambda s1, s3, a, b: s1 * per_sample(a).reshape(-1, 1, 1) + s3 * per_sample(b).reshape(-1, 1, 1))
+    align = hs.Alignment.__new__(hs.Alignment)
+    torch.nn.Module.__init__(align)
+    align.stages, align.dilate_erosion = stages, de
+    align.latent_encoder = lambda ims: {"F": torch.stack([per_sample(i[None]).reshape(1, 1, 1).expand(8, 32, 32) * 1.0 for i in ims])}
+    blend = hs.Blending.__new__(hs.Blending)
+    torch.nn.Module.__init__(blend)
+    blend.stages, blend.dilate_erosion = stages, de
+    blend.downsample_256 = lambda x: x * 0.5
+    blend.post_process = lambda a, b: (per_sample(a).reshape(-1, 1, 1).expand(-1, 18, 8) + per_sample(b).reshape(-1, 1, 1), per_sample(a).reshape(-1, 1, 1, 1) + b[:, :1])
+    gen = lambda styles, layer_in=None, **kw: (torch.sin(1e3 * (per_sample(styles[0]) + per_sample(layer_in))).reshape(-1, 1, 1, 1) * torch.linspace(0.1, 1, 192).reshape(1, 3, 8, 8), None)  # noqa: E731
+    blend.net = types.SimpleNamespace(generator=gen)
+
+    def run(ts):
+        same = [name_to_embed[(t, "shape")] is name_to_embed[(t, "color")] for t in ts]
+        a_shape = align.align_images_batch([((t, "face"), (t, "shape")) for t in ts], name_to_embed, rotated=rotated)
+        targets = iter(align.shape_modules([((t, "face"), (t, "color")) for t, sm in zip(ts, same) if not sm], name_to_embed, rotated=rotated))
+        a_color = [a_shape[j] if sm else next(targets) for j, sm in enumerate(same)]
+        images = blend.blend_images_batch(a_shape, a_color, name_to_embed, [tuple((t, n) for n in ("face", "shape", "color")) for t in ts])
+        return a_shape, a_color, images
+
+    b_shape, b_color, b_images = run(triples)
+    for j, t in enumerate(triples):
+        s_shape, s_color, s_images = run([t])
+        one = align.shape_module((t, "face"), (t, "color"), name_to_embed, only_target=True, rotated=rotated)
+        assert torch.equal(b_color[j]["HM_X"], one["HM_X"]) and torch.equal(b_color[j]["HM_X"], s_color[0]["HM_X"])
+        assert torch.equal(b_shape[j]["HM_X"], s_shape[0]["HM_X"]) and torch.equal(b_shape[j]["latent_F_align"], s_shape[0]["latent_F_align"])
+        assert torch.equal(b_images[j], s_images[0])
+    assert not torch.equal(b_images[0], b_images[3])
