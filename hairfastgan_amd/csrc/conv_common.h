@@ -290,14 +290,20 @@ __device__ __forceinline__ void store_tile(const ConvParams &P, const TileGeom &
 // waits for the store's acknowledgement), the activation is one select + multiply (negative slope 1 = identity),
 // and the run-time options are tested per tile, not per element (store_tile spends ~100 cycles per element on them: as long as the
 // whole K loop of a 64-channel layer).  split-K launches store the raw sums.
-template <int CT_TILES, int PG, bool RES>
+// MODE (round 5): the per-launch switches as compile-time constants - bit 0 = an fp32 output, bit 1 = a split output, bit 2 =
+// QuickGELU; -1 = read from P (the residual variants).  With run-time switches every ELEMENT paid three taken scalar branches
+// (over the QuickGELU code, around its store, around the split) and a 64-bit multiply for its address: 12-13 k cycles per block of
+// the 512-pixel form whatever the layer - 1.6 K stages, a quarter of a 64-channel layer's blocks (tools/probes/trace_enc_layer.py).
+// The channel rows of a pixel are now walked by pointer increments.  Same arithmetic, same bits.
+template <int CT_TILES, int PG, bool RES, int MODE = -1>
 __device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const TileGeom &G, const GroupOfs &go,
                                                      f32x16 (&acc)[1][CT_TILES][PG], int co_wave, int wave_pg, int li, int lh,
                                                      int ty0, int tx0, int b0) {
   const int tw = 1 << G.lg_tw, th = 1 << G.lg_th;
   const long long oplane = (long long)P.out_h * P.out_w;
   const bool partial = P.splits > 1 && !P.vsplit;
-  const bool prelu = !partial && P.act == ACT_PRELU, lrelu = !partial && P.act == ACT_LRELU, qgelu = !partial && P.act == ACT_QGELU;
+  const bool prelu = !partial && P.act == ACT_PRELU, lrelu = !partial && P.act == ACT_LRELU;
+  const bool qgelu = MODE >= 0 ? (MODE & 4) != 0 : (!partial && P.act == ACT_QGELU);
   const float neg_u = lrelu ? P.alpha : 1.0f, sc = lrelu ? P.scale : 1.0f;
   const bool res_pre = RES && P.residual_pre;
   long long pofs[PG], uofs[PG];  // fp32 element / split 16-byte unit of (image, channel 0, Y, X)
@@ -313,7 +319,8 @@ __device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const 
   }
   float *obase = (partial ? P.partial + (long long)blockIdx.z * P.zslab : P.out) + go.o;
   // split output (launcher: groups == 1, no split-K): unit (b, channel block, Y, X) of 16 bytes, the lane's 4 channels = its half lh
-  const bool split = !partial && P.oh != nullptr, store32 = partial || P.out != nullptr;
+  const bool split = MODE >= 0 ? (MODE & 2) != 0 : (!partial && P.oh != nullptr);
+  const bool store32 = MODE >= 0 ? (MODE & 1) != 0 : (partial || P.out != nullptr);
   bool ovf_tile = false;
   (void)ovf_tile;
   // one 32-channel tile at a time (register budget: some callers run two blocks per CU): its per-channel vectors
@@ -349,14 +356,14 @@ __device__ __forceinline__ void store_tile_rows_impl(const ConvParams &P, const 
         float *ob = obase + pofs[g] + (long long)(co_wave + ct * 32 + 8 * q + 4 * lh) * oplane;
         float vq[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4; ++k, ob += oplane) {
           const int r = 4 * q + k;
           float v = fmaf(acc[0][ct][g][r], dmv[k], bsv[k]);
           if (RES && res_pre) v += rv[RES ? g : 0][r];
           v = (v > 0.0f ? v : v * slv[k]) * sc;
           if (qgelu) v = v / (1.0f + expf(-1.702f * v));  // uniform branch (per launch)
           if (RES && !res_pre) v += rv[RES ? g : 0][r];
-          if (store32) HF_STORE_OUT(ob + k * oplane, v);
+          if (store32) HF_STORE_OUT(ob, v);
           vq[k] = v;
         }
 #ifdef HF_WANT_F16_SPLIT
@@ -420,10 +427,25 @@ template <int CT_TILES, int PG>
 __device__ __forceinline__ void store_tile_rows(const ConvParams &P, const TileGeom &G, const GroupOfs &go,
                                                 f32x16 (&acc)[1][CT_TILES][PG], int co_wave, int wave_pg, int li, int lh,
                                                 int ty0, int tx0, int b0) {
-  if (P.residual && (P.splits <= 1 || P.vsplit))
-    store_tile_rows_impl<CT_TILES, PG, true>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
-  else
-    store_tile_rows_impl<CT_TILES, PG, false>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
+  const bool partial = P.splits > 1 && !P.vsplit;
+  const bool split = !partial && P.oh != nullptr, store32 = partial || P.out != nullptr;
+  if (P.residual && !partial) {
+    if (store32 && !split && P.act != ACT_QGELU)
+      store_tile_rows_impl<CT_TILES, PG, true, 1>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
+    else
+      store_tile_rows_impl<CT_TILES, PG, true>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
+    return;
+  }
+  if (!partial && P.act == ACT_QGELU) {
+    if (split) store_tile_rows_impl<CT_TILES, PG, false>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
+    else store_tile_rows_impl<CT_TILES, PG, false, 5>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
+  } else if (store32 && !split) {
+    store_tile_rows_impl<CT_TILES, PG, false, 1>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
+  } else if (store32) {
+    store_tile_rows_impl<CT_TILES, PG, false, 3>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
+  } else if (split) {
+    store_tile_rows_impl<CT_TILES, PG, false, 2>(P, G, go, acc, co_wave, wave_pg, li, lh, ty0, tx0, b0);
+  }
 }
 
 inline int ilog2(int v) {

@@ -29,6 +29,7 @@
 // level by level; every group's weights are a self-contained [9*cin*cout halves | 16-byte trailer].
 #define HF_WANT_F16_SPLIT
 #include "conv_common.h"
+#include <type_traits>
 
 using namespace hf_detail;
 
@@ -47,6 +48,24 @@ constexpr int KH = 16;  // input channels per stage = K of one MFMA
 #endif
 
 // 16-byte units of one activation part per kgroup that the LDS tile is sized for
+#ifndef HF_ENC_FAST_PROLOGUE
+#define HF_ENC_FAST_PROLOGUE 1
+#endif
+#ifdef HF_ENC_TRACE
+// kernel-development build only (tools/probes/trace_enc_layer.py): where a block of conv_enc_h spends its time - s_memtime stamps of
+// waves 0 and 7 in three blocks of the launch (the 1st, one of the 3rd round, one of a late round)
+__device__ unsigned long long hf_enc_trace_buf[3 * 2 * 8];
+#define HF_ENC_TRACE_POINT(id)                                                                                              \
+  do {                                                                                                                      \
+    const unsigned lin_ = blockIdx.x + blockIdx.y * gridDim.x;                                                              \
+    const int sel_ = lin_ == 0 ? 0 : lin_ == 700 ? 1 : lin_ == 2000 ? 2 : -1;                                               \
+    if (sel_ >= 0 && (threadIdx.x == 0 || threadIdx.x == 448))                                                              \
+      hf_enc_trace_buf[(sel_ * 2 + (threadIdx.x ? 1 : 0)) * 8 + (id)] = __builtin_readcyclecounter();                       \
+  } while (0)
+#else
+#define HF_ENC_TRACE_POINT(id) ((void)0)
+#endif
+
 template <int PT, int STRIDE>
 constexpr int enc_npix() {
   // tw = 32: th = PT/32;  tw = 16: th = PT/16
@@ -84,6 +103,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
   static_assert(XE <= 8, "conversion schedule: one item per tap-step");
 
   HF_DYN_LDS;
+  HF_ENC_TRACE_POINT(0);
   half8 *lds = reinterpret_cast<half8 *>(hf_dyn_lds);  // [2][BUF_UNITS]
   float *sl = reinterpret_cast<float *>(lds + 2 * BUF_UNITS);  // in_scale [cin], in_shift [cin]
   const int cin4 = (P.cin + 3) & ~3;
@@ -126,45 +146,6 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
   const char *xh_b = PRE ? static_cast<const char *>(P.xh) + img * (P.cin / 8) * plane * 16 : nullptr;
   const char *xl_b = (PRE && NTERMS == 3) ? static_cast<const char *>(P.xl) + img * (P.cin / 8) * plane * 16 : nullptr;
 
-  // ---- per-thread staging items (stage invariant): plane offset of the input pixel (-1 zero fill,
-  // -2 none) and the 16-byte LDS unit (incl. kgroup) it goes to.  Register staging enumerates the
-  // halo in input order (coalesced loads); PRE enumerates LDS units (a DMA piece fills 64 consecutive
-  // units, each lane fetching its own pixel's 16-byte unit) ----
-  int e_src[XE], e_dst[XE], e_kg[XE];
-#pragma unroll
-  for (int e = 0; e < XE; ++e) {
-    const int i = tid + e * NT;
-    e_src[e] = -2;
-    e_dst[e] = 0;
-    if (!PRE) {
-      const int kg = i / n_items, v = i - kg * n_items;
-      e_kg[e] = kg;
-      if (kg < 2) {
-        const int hr = v / wcols, hc = v - hr * wcols;
-        const int ys = ty0 * STRIDE - 1 + hr, xc = tx0 * STRIDE - 1 + hc;
-        e_src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
-        e_dst[e] = kg * NPIX + ((STRIDE == 1) ? hr * wp + hc : hr * wp + (hc & 1) * wp2 + (hc >> 1));
-      }
-    } else {
-      const int kg = i / NPIX, u = i - kg * NPIX;
-      e_kg[e] = kg;
-      e_dst[e] = i;
-      if (i < X_UNITS && u < hp * wp) {
-        const int hr = u / wp, r = u - hr * wp;
-        const int hc = (STRIDE == 1) ? r : 2 * (r % wp2) + (r / wp2);
-        if (hc < wcols) {
-          const int ys = ty0 * STRIDE - 1 + hr, xc = tx0 * STRIDE - 1 + hc;
-          e_src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
-        }
-      }
-    }
-  }
-  if (!PRE)
-    for (int i = tid; i < P.cin; i += NT) {
-      sl[i] = P.s ? P.s[i] : 1.0f;
-      tl[i] = P.t ? P.t[i] : 0.0f;
-    }
-
   const unsigned lds_addr0 = hf_lds_addr(lds);
   auto dma_piece = [&](int i, int chunk, int bufsel) {
     const int pc = wave + i * NW;
@@ -178,6 +159,61 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
       hf_glds16_raw_s(src, (unsigned)off, lds_addr0 + (unsigned)(bufsel * BUF_UNITS + part * W_UNITS + q * 64) * 16u);
     }
   };
+  // HF_ENC_FAST_PROLOGUE (round 5; tools/probes/trace_enc_layer.py: index arithmetic 2.4-3.3 k cycles, zero fill 1-1.5 k, first
+  // stage 3-7.7 k - together 1.3 K stages per block, whatever the layer): the first stage's weights leave at once (they depend on
+  // nothing below), its activations as soon as their addresses exist; only the halo units OUTSIDE the image are zeroed (by the
+  // lanes that own them; the masked DMA never writes them) instead of both activation regions, and the divisions by the halo
+  // pitch are divisions by its two possible values.
+  const int c_first = (P.splits > 1 && !VSPLIT) ? (int)blockIdx.z * P.chunks_per_split : 0;
+  constexpr bool FASTP = PRE && HF_ENC_FAST_PROLOGUE;
+  if (FASTP) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) dma_piece(i, c_first, 0);
+  }
+  const bool tw32 = tw == 32;
+  auto div_wp = [&](int u) { return STRIDE == 1 ? (tw32 ? u / 34 : u / 18) : (tw32 ? u / 66 : u / 34); };  // wp: tw + 2 | 2 (tw + 1)
+  auto div_wp2 = [&](int r) { return tw32 ? r / 33 : r / 17; };                                              // wp2 = tw + 1
+  auto div_wcols = [&](int v) { return STRIDE == 1 ? (tw32 ? v / 34 : v / 18) : (tw32 ? v / 65 : v / 33); };  // (tw - 1) STRIDE + 3
+  // ---- per-thread staging items (stage invariant): plane offset of the input pixel (-1 zero fill,
+  // -2 none) and the 16-byte LDS unit (incl. kgroup) it goes to.  Register staging enumerates the
+  // halo in input order (coalesced loads); PRE enumerates LDS units (a DMA piece fills 64 consecutive
+  // units, each lane fetching its own pixel's 16-byte unit) ----
+  int e_src[XE], e_dst[XE], e_kg[XE];
+#pragma unroll
+  for (int e = 0; e < XE; ++e) {
+    const int i = tid + e * NT;
+    e_src[e] = -2;
+    e_dst[e] = 0;
+    if (!PRE) {
+      const int kg = (i >= n_items) + (i >= 2 * n_items) + (i >= 3 * n_items), v = i - kg * n_items;  // (kg >= 2: no item)
+      e_kg[e] = kg;
+      if (kg < 2) {
+        const int hr = div_wcols(v), hc = v - hr * wcols;
+        const int ys = ty0 * STRIDE - 1 + hr, xc = tx0 * STRIDE - 1 + hc;
+        e_src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
+        e_dst[e] = kg * NPIX + ((STRIDE == 1) ? hr * wp + hc : hr * wp + (hc & 1) * wp2 + (hc >> 1));
+      }
+    } else {
+      const int kg = i / NPIX, u = i - kg * NPIX;
+      e_kg[e] = kg;
+      e_dst[e] = i;
+      if (i < X_UNITS && u < hp * wp) {
+        const int hr = div_wp(u), r = u - hr * wp;
+        const int rq = div_wp2(r);
+        const int hc = (STRIDE == 1) ? r : 2 * (r - rq * wp2) + rq;
+        if (hc < wcols) {
+          const int ys = ty0 * STRIDE - 1 + hr, xc = tx0 * STRIDE - 1 + hc;
+          e_src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
+        }
+      }
+    }
+  }
+  if (!PRE)
+    for (int i = tid; i < P.cin; i += NT) {
+      sl[i] = P.s ? P.s[i] : 1.0f;
+      tl[i] = P.t ? P.t[i] : 0.0f;
+    }
+
   // PRE: item e of stage `chunk` straight into LDS (units of pixels outside the image were zeroed once)
   auto dma_x = [&](int e, int chunk, int bufsel) {
     const int i = tid + e * NT;
@@ -246,7 +282,24 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
 #pragma unroll
         for (int r = 0; r < 16; ++r) vsum[VSPLIT ? ct : 0][VSPLIT ? g : 0][r] = 0.0f;
   }
-  if (PRE) {  // zero the activation regions of both buffers once: DMA-masked units (padding) stay zero
+  HF_ENC_TRACE_POINT(1);  // index arithmetic done
+  if (FASTP) {
+#pragma unroll
+    for (int e = 0; e < XE; ++e) dma_x(e, c_begin, 0);
+    half8 z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.0f;
+#pragma unroll
+    for (int e = 0; e < XE; ++e)
+      if (e_src[e] == -1) {  // a halo unit outside the image: zero in both buffers, for every stage
+        lds[OFF_XH + e_dst[e]] = z;
+        lds[BUF_UNITS + OFF_XH + e_dst[e]] = z;
+        if (NTERMS == 3) {
+          lds[OFF_XL + e_dst[e]] = z;
+          lds[BUF_UNITS + OFF_XL + e_dst[e]] = z;
+        }
+      }
+  } else if (PRE) {  // zero the activation regions of both buffers once: DMA-masked units (padding) stay zero
     half8 z;
 #pragma unroll
     for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.0f;
@@ -255,10 +308,14 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
       lds[BUF_UNITS + OFF_XH + i] = z;
     }
   }
-  __syncthreads();  // sl / tl (or the zero fill) visible
+  if (!FASTP) __syncthreads();  // sl / tl (or the zero fill) visible
+  HF_ENC_TRACE_POINT(2);  // LDS zero fill done
+  if (!FASTP) {
 #pragma unroll
-  for (int i = 0; i < ND; ++i) dma_piece(i, c_begin, 0);
-  if (PRE) {
+    for (int i = 0; i < ND; ++i) dma_piece(i, c_begin, 0);
+  }
+  if (FASTP) {
+  } else if (PRE) {
 #pragma unroll
     for (int e = 0; e < XE; ++e) dma_x(e, c_begin, 0);
   } else {
@@ -268,6 +325,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
     for (int e = 0; e < XE; ++e) convert_item(e, c_begin, lds);
   }
   hf_barrier_keep_young<0>();
+  HF_ENC_TRACE_POINT(3);  // first stage landed
 
   // ---- K loop.  PP ("ping-pong", pre-split input, eight waves = two per SIMD): the two waves of a SIMD (w and w + 4: a
   // workgroup's waves go round the four SIMDs) take TURNS on the matrix pipe - phase A: the first half of the block runs its
@@ -429,6 +487,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
     hf_barrier_keep_young<0>();  // next stage complete (DMA landed, conversions written), current one free
   }
 
+  HF_ENC_TRACE_POINT(4);  // K loop done
   // undo the weights' power-of-two pre-scale (exact), then the shared epilogue
 #pragma unroll
   for (int ct = 0; ct < CT_TILES; ++ct)
@@ -443,6 +502,11 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
     store_tile_rows<CT_TILES, PG>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
   else
     store_tile<CT_TILES, PG, false>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+  HF_ENC_TRACE_POINT(5);  // epilogue issued
+#ifdef HF_ENC_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HF_ENC_TRACE_POINT(6);  // stores acknowledged
+#endif
   // split-K without a second launch: the tile's last block adds the slabs and runs the epilogue (conv_common.h)
   if (!VSPLIT && P.splits > 1 && P.counters && splitk_arrive_last(P, reinterpret_cast<int *>(hf_dyn_lds)))
     store_tile<CT_TILES, PG, false, 1, true>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
@@ -522,8 +586,9 @@ __global__ __launch_bounds__(512) void conv_enc_s2mt_h(const ConvParams P, const
       const int kg = i / NPIX, u = i - kg * NPIX;
       e_src[j][e] = -2;
       if (i < X_UNITS && u < hp * wp) {
-        const int hr = u / wp, r = u - hr * wp;
-        const int hc = 2 * (r % wp2) + (r / wp2);
+        const int hr = (tw == 32) ? u / 66 : u / 34, r = u - hr * wp;  // wp = 2 (tw + 1), tw 16 | 32 (launch_enc)
+        const int rq = (tw == 32) ? r / 33 : r / 17;
+        const int hc = 2 * (r - rq * wp2) + rq;
         if (hc < wcols) {
           const int ys = ty0[j] * 2 - 1 + hr, xc = tx0[j] * 2 - 1 + hc;
           e_src[j][e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
@@ -656,14 +721,22 @@ __global__ __launch_bounds__(512) void conv_enc_s2mt_h(const ConvParams P, const
       }
     }
   }
-#pragma unroll
-  for (int j = 0; j < MT; ++j) {
+  // (one epilogue per tile with a constant index: a loop the compiler does not unroll puts the per-tile arrays into scratch)
+  auto finish = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
     if (VSPLIT) acc[j][0][0][0] = vsum[VSPLIT ? j : 0];
     else
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][0][0][0][r] *= w_unscale;
     if (valid[j]) store_tile_rows<1, 1>(P, G, go, acc[j], co0 + wave_co, wave_pg, li, lh, ty0[j], tx0[j], b0[j]);
+  };
+  finish(std::integral_constant<int, 0>{});
+  finish(std::integral_constant<int, 1>{});
+  if constexpr (MT == 4) {
+    finish(std::integral_constant<int, 2>{});
+    finish(std::integral_constant<int, 3>{});
   }
+  static_assert(MT == 2 || MT == 4, "tiles per resident weight stage");
 }
 
 // split-K plan.  The tile forms that small launches take hold 100-117 KB of LDS: ONE block per CU, so a launch runs in
@@ -1073,3 +1146,9 @@ extern "C" int hf_split_activation_mod_f16(void *out_hi, void *out_lo, const flo
                      static_cast<half8 *>(out_lo), x, scale, (const float *)nullptr, channels, plane, total, scale ? channels : 0);
   return hf_launch_status();
 }
+
+#ifdef HF_ENC_TRACE
+extern "C" int hf_debug_read_enc_trace(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hf_enc_trace_buf), sizeof(unsigned long long) * n);
+}
+#endif
