@@ -64,6 +64,8 @@ struct ConvParams {
                                // x-fastest, so consecutive blocks then share an INPUT tile and walk the (group, channel-tile)
                                // columns: the input tile stays in L2 while the weights stream from the Infinity Cache
                                // (run_enc picks the order with the smaller beyond-L2 traffic)
+  int persist;                 // convh_enc.hip (conv_enc_h): the launch is `persist` resident blocks that walk the (lin_x x lin_y) block
+  int lin_x, lin_y;            // grid of the plain form in dispatch order, block b taking b, b + persist, ... (0 = one block per tile)
   int vsplit;                  // "virtual" split-K (convh_enc.hip, gemm_h.hip; batch-invariant plans): the K partition into `splits`
                                // slabs is kept - it decides the bits - but ONE block walks all slabs, adding each slab's sum to a
                                // second accumulator set in z order (exactly what splitk_reduce adds), and runs the epilogue itself:
@@ -103,8 +105,8 @@ struct GroupOfs {
   int c;               // offset into bias / slope / d
   int co_tile;
 };
-__device__ __forceinline__ GroupOfs group_offsets(const ConvParams &P) {
-  const int col = P.swap_xy ? (int)blockIdx.x : (int)blockIdx.y;  // (group, channel tile) column of the block
+__device__ __forceinline__ GroupOfs group_offsets(const ConvParams &P, int bx, int by) {
+  const int col = P.swap_xy ? bx : by;  // (group, channel tile) column of the block
   GroupOfs go{0, 0, 0, 0, col};
   if (P.groups > 1) {
     const int g = col / P.co_tiles;
@@ -116,6 +118,7 @@ __device__ __forceinline__ GroupOfs group_offsets(const ConvParams &P) {
   }
   return go;
 }
+__device__ __forceinline__ GroupOfs group_offsets(const ConvParams &P) { return group_offsets(P, (int)blockIdx.x, (int)blockIdx.y); }
 
 // (`#pragma clang fp contract(on)` at the head of the two bodies below: clang applies FP contraction lexically, so a
 // pragma in the CALLER does not reach these inlined bodies - without it hipcc's default `fast` contraction may fuse

@@ -51,13 +51,16 @@ constexpr int KH = 16;  // input channels per stage = K of one MFMA
 #ifndef HF_ENC_FAST_PROLOGUE
 #define HF_ENC_FAST_PROLOGUE 1
 #endif
+#ifndef HF_ENC_PERSIST
+#define HF_ENC_PERSIST 1
+#endif
 #ifdef HF_ENC_TRACE
 // kernel-development build only (tools/probes/trace_enc_layer.py): where a block of conv_enc_h spends its time - s_memtime stamps of
 // waves 0 and 7 in three blocks of the launch (the 1st, one of the 3rd round, one of a late round)
 __device__ unsigned long long hf_enc_trace_buf[3 * 2 * 8];
 #define HF_ENC_TRACE_POINT(id)                                                                                              \
   do {                                                                                                                      \
-    const unsigned lin_ = blockIdx.x + blockIdx.y * gridDim.x;                                                              \
+    const unsigned lin_ = persist ? (unsigned)lin : blockIdx.x + blockIdx.y * gridDim.x;                                        \
     const int sel_ = lin_ == 0 ? 0 : lin_ == 700 ? 1 : lin_ == 2000 ? 2 : -1;                                               \
     if (sel_ >= 0 && (threadIdx.x == 0 || threadIdx.x == 448))                                                              \
       hf_enc_trace_buf[(sel_ * 2 + (threadIdx.x ? 1 : 0)) * 8 + (id)] = __builtin_readcyclecounter();                       \
@@ -84,6 +87,9 @@ constexpr int enc_npix() {
 // VSPLIT: ConvParams::vsplit - the block walks all P.splits K slabs itself; at the end of a slab the slab's sum (what a real
 // split-K block stores to its z slab) is added to a second accumulator set, slabs in z order from 0.0f like splitk_reduce, and
 // the block's own epilogue finishes the tile: the bits of the two-launch form without its slabs and its second launch.
+template <int NTERMS, int CT_TILES, bool VSPLIT>
+__host__ __device__ constexpr bool enc_persist_ok() { return !(VSPLIT && CT_TILES == 2 && NTERMS == 3); }
+
 template <int NTERMS, int PG, int WAVES_PX, int STRIDE, bool PRE, int CT_TILES = 1, int WAVES_CO = 2, bool VSPLIT = false>
 __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
                                                                        const _Float16 *__restrict__ wtl_all) {
@@ -103,20 +109,34 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
   static_assert(XE <= 8, "conversion schedule: one item per tap-step");
 
   HF_DYN_LDS;
-  HF_ENC_TRACE_POINT(0);
   half8 *lds = reinterpret_cast<half8 *>(hf_dyn_lds);  // [2][BUF_UNITS]
   float *sl = reinterpret_cast<float *>(lds + 2 * BUF_UNITS);  // in_scale [cin], in_shift [cin]
   const int cin4 = (P.cin + 3) & ~3;
   float *tl = sl + cin4;
 
-  const GroupOfs go = group_offsets(P);
-  const int grp = (P.groups > 1) ? (P.swap_xy ? (int)blockIdx.x : (int)blockIdx.y) / P.co_tiles : 0;
+  // Persistent form (ConvParams::persist; round 5): a block of the 512-pixel form is resident alone on its CU (158 KB of LDS), so
+  // the ~5 us between the end of one block and the first instruction of the next - wave launch, LDS allocation, kernel arguments
+  // - were spent with the CU empty, once per TILE: 12 times in a 64-channel layer of 430 us (tools/probes/trace_enc_layer.py:
+  // 31 us per block inside, 36 us per block from outside).  The launch is now one resident block per CU that walks the plain
+  // form's blocks b, b + persist, ... in their dispatch order (the same neighbours in L2 at any time); a tile's code is unchanged.
+  // (not the 512-pixel form with the virtual split-K's second accumulator set: the loop costs it registers it does not have)
+  const int persist = enc_persist_ok<NTERMS, CT_TILES, VSPLIT>() ? P.persist : 0;
+  const int lin_n = persist ? P.lin_x * P.lin_y : 1;
+  for (int lin = persist ? (int)blockIdx.x : 0; lin < lin_n; lin += persist ? persist : 1) {
+  const int bx = persist ? lin % P.lin_x : (int)blockIdx.x, by = persist ? lin / P.lin_x : (int)blockIdx.y;
+  HF_ENC_TRACE_POINT(0);
+  const GroupOfs go = group_offsets(P, bx, by);
+  const int grp = (P.groups > 1) ? (P.swap_xy ? bx : by) / P.co_tiles : 0;
   const long long wn = 9LL * P.cin * P.cout;
   const _Float16 *wth = wth_all + (long long)grp * (wn + 8);  // [weights | trailer] per group
   const _Float16 *wtl = wtl_all ? wtl_all + (long long)grp * wn : nullptr;
   const float w_unscale = *reinterpret_cast<const float *>(wth + wn);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (opaque per tile: what derives from the thread index is recomputed for every tile instead of being hoisted out of the tile
+  // loop and kept in registers through the epilogue - the 512-pixel forms are at the 256-register limit there)
+  int tid_ = threadIdx.x;
+  if (enc_persist_ok<NTERMS, CT_TILES, VSPLIT>()) HF_OPAQUE_I32(tid_);
+  const int tid = tid_, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wave_co = (wave / WAVES_PX) * 32 * CT_TILES;
   const int wave_pg = (wave % WAVES_PX) * PG;
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
 
   // ---- tile (uniform): OUTPUT pixels [ty0, ty0+th) x [tx0, tx0+tw) of image b0 ----
   const TileGeom G = P.g[0];
-  int t = P.swap_xy ? blockIdx.y : blockIdx.x;
+  int t = P.swap_xy ? by : bx;
   const int tx = t % G.tiles_x;
   t /= G.tiles_x;
   const int ty = t % G.tiles_y;
@@ -510,6 +530,8 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
   // split-K without a second launch: the tile's last block adds the slabs and runs the epilogue (conv_common.h)
   if (!VSPLIT && P.splits > 1 && P.counters && splitk_arrive_last(P, reinterpret_cast<int *>(hf_dyn_lds)))
     store_tile<CT_TILES, PG, false, 1, true>(P, G, go, acc, co0 + wave_co, wave_pg, li, lh, ty0, tx0, b0);
+  if (persist) __syncthreads();  // every wave is done with the stage buffers (and sl / tl): the next tile's copies may land
+  }
 }
 
 // ---- stride 2, several pixel tiles per resident weight stage (round 5) -------------------------------------------------------
@@ -872,6 +894,21 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
         return hf_launch_status();
       }
     }
+  }
+  // persistent form: one resident block per CU walks the grid (forms whose LDS leaves room for one block per CU only)
+  P.persist = 0;
+  {
+    static const int on = [] { const char *e = getenv("HAIRFAST_ENC_PERSIST"); return e ? atoi(e) : HF_ENC_PERSIST; }();
+    const int resident = g_h_blocks > 0 ? g_h_blocks : 256;
+    const bool ok = P.vsplit ? enc_persist_ok<NTERMS, CT_TILES, true>() : enc_persist_ok<NTERMS, CT_TILES, false>();
+    if (on && ok && (P.vsplit || P.splits == 1) && lds > 80 * 1024 && blocks > resident) {
+      P.persist = resident;
+      P.lin_x = (int)grid.x;
+      P.lin_y = (int)grid.y;
+      grid = dim3(resident, 1, 1);
+    }
+  }
+  if (P.xh) {
     if (P.vsplit)
       hipLaunchKernelGGL((conv_enc_h<NTERMS, PG, WAVES_PX, STRIDE, true, CT_TILES, WAVES_CO, true>), grid, dim3(NT), lds, st, P, wth, wtl);
     else
