@@ -115,7 +115,7 @@ def main():
         # MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B / lane)
         # coalesced streaming read, `global_load` and `buffer_load ... lds` alike: the kernels whose reads are 16-byte
         # LDS-DMA units (pre-split activations + weights) or 16-byte vector loads get their FETCH doubled
-        wide = (",pre" in k and (k.startswith("conv_mfma_h") or k.startswith("conv_enc_h"))) or k in ("blur4x4_split8", "torgb_kernel", "blur4x4_noise_bias_act") or k.startswith("conv_rows_h")
+        wide = (",pre" in k and (k.startswith("conv_mfma_h") or k.startswith("conv_enc_h"))) or k in ("blur4x4_split8", "torgb_kernel", "blur4x4_noise_bias_act") or k.startswith("conv_rows_h") or k.startswith("conv_enc_s2mt_h")
         raw_fetch = f[k][0] / n * 1024
         e = {"fetch_bytes_per_launch": raw_fetch * (2.0 if wide else 1.0), "fetch_size_counter_bytes": raw_fetch,
              "fetch_doubled": bool(wide), "write_bytes_per_launch": w[k][0] / max(1, len(w[k][1])) * 1024, "launches": n}
