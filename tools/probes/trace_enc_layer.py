@@ -1,5 +1,9 @@
 """Where a block of conv_enc_h<...,pre> spends its time (HF_ENC_TRACE build of csrc/convh_enc.hip through HAIRFAST_HIP_LIB):
-python trace_enc_layer.py B cin cout H W [stride]  ->  cycles between the stamps of waves 0 / 7 in three blocks of the launch."""
+python trace_enc_layer.py B cin cout H W [stride]  ->  shader clocks between the stamps of waves 0 / 7 in three tiles of the launch.
+Build (from hairfastgan_amd/csrc, after build.sh):
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DHF_ENC_TRACE -c convh_enc.hip -o /tmp/enc_trace.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o libhairfast_enctrace.so $(ls *.o | grep -v convh_enc.o) /tmp/enc_trace.o
+Results of round 5: profiles/r05v_trace_enc_block_before.txt, profiles/r05x_trace_enc_block.txt (lesson 24)."""
 import ctypes
 import os
 import sys
