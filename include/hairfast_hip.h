@@ -644,7 +644,8 @@ int hf_debug_set_dispatch(int same_cfg, int up_cfg);
 int hf_debug_last_path(void);
 /* The fp16 matrix-core kernels launch one resident block per CU and let it walk several tiles
  * as one software pipeline; `blocks` overrides the resident-block count the grid is sized for
- * (0 = the MI355X's 256 CUs).  Tests use small values to exercise the tile hand-over. */
+ * (0 = the MI355X's 256 CUs).  Tests use small values to exercise the tile hand-over.  Round 5: hf_conv2d_f16_f32's tile forms
+ * that are alone on a CU walk their grid the same way (csrc/convh_enc.hip, ConvParams::persist) and size it by this count too. */
 int hf_debug_set_persistent_blocks(int blocks);
 /* Tuning switches of the fp16 matrix-core kernels (per thread, like the other debug hooks): bit 0 = issue every
  * stage's LDS-DMA copies in the stage's first tap-step instead of spreading them one per tap-step (the default,
