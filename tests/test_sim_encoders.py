@@ -704,14 +704,14 @@ def test_conv2d_f16_stride2_multi_tile_form(simlib, nterms):
 
 
 def test_conv2d_f16_persistent_blocks_walk_the_grid(simlib):
-    """conv_enc_h's persistent form (round 5): `hf_debug_set_persistent_blocks(n)` resident blocks walk the plain form's grid in
+    """conv_enc_h's persistent form (round 5): `hf_debug_set_persistent_blocks(3)`: three resident blocks walk the plain form's grid in
     its dispatch order, tile after tile through the same stage buffers - the bits of the one-block-per-tile launch: the 512-pixel
     form on fp32 and on pre-split input (ragged planes: border tiles follow interior ones, so halo units that were data become
     zero padding and back), a grouped launch in the columns-fastest order, the stride-2 one-tile form, the split output."""
     torch.manual_seed(77)
     try:
-        for B, cin, cout, H, W, stride, G, tuning in ((3, 48, 128, 40, 72, 1, 1, 1 << 8), (2, 32, 64, 32, 64, 1, 3, (1 << 8) | 8),
-                                                     (3, 32, 64, 40, 72, 2, 1, 0), (5, 32, 64, 16, 32, 1, 1, 0)):
+        for B, cin, cout, H, W, stride, G, tuning in ((2, 32, 128, 24, 72, 1, 1, 1 << 8), (2, 16, 64, 32, 32, 1, 3, (1 << 8) | 8),
+                                                     (2, 32, 64, 40, 40, 2, 1, 0), (5, 16, 64, 16, 32, 1, 1, 0)):
             x = torch.randn(*((G, B) if G > 1 else (B,)), cin, H, W)
             ws = torch.randn(G, cout, cin, 3, 3) / (cin * 9) ** 0.5
             wt = torch.stack([M.conv_prepare(simlib, None, ws[g]) for g in range(G)]).contiguous()
@@ -722,7 +722,7 @@ def test_conv2d_f16_persistent_blocks_walk_the_grid(simlib):
             kw = dict(bias=bias, act=M.ACT_PRELU, slope=slope, groups=G, x_shared=False)
             simlib.hf_debug_set_tuning(tuning)
             outs = {}
-            for blocks in (0, 3, 2):  # 0: the default 256 resident blocks - more than these launches have: one block per tile
+            for blocks in (0, 3):  # 0: the default 256 resident blocks - more than these launches have: one block per tile
                 simlib.hf_debug_set_persistent_blocks(blocks)
                 y32 = M.conv2d_f16(simlib, None, x, hi, lo, 3, cout, stride, **kw) if stride == 1 else None
                 ys = M.conv2d_f16(simlib, None, xs, hi, lo, 3, cout, stride, **kw)
@@ -733,7 +733,7 @@ def test_conv2d_f16_persistent_blocks_walk_the_grid(simlib):
                 outs[blocks] = (y32, ys, sp, path)
             ref = outs[0]
             assert ref[3] == (604 if tuning & (1 << 8) else 602 if stride == 2 else ref[3])
-            for blocks in (3, 2):
+            for blocks in (3,):
                 y32, ys, sp, path = outs[blocks]
                 assert path == ref[3]
                 assert torch.equal(ys, ref[1]) and (y32 is None or torch.equal(y32, ref[0]))
