@@ -1,9 +1,9 @@
-# GPU call r05zb: nontemporal stores in the encoder conv's epilogue (-DHF_NT_STORES in convh_enc.hip) on the batched swap
+# GPU call r06j: ping-pong copy roles (activations by the half that idles first) on the fused and same-resolution kernels + parity
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+PROBE_REPS=2 python tools/probes/fuse_ab.py r0 hip > gpurun_out/r06j_roles.txt 2>&1
+cat gpurun_out/r06j_roles.txt
 C=$GRAFT_REPO_ROOT/hairfastgan_amd/csrc
-for v in hip nt hip nt; do
-  HAIRFAST_HIP_LIB=$C/libhairfast_$v.so python bench.py --workload swap256 --triples 64 --swap-batch 32 --warmup 1 --no-kernel-events > gpurun_out/r05zb_swap_$v.json 2> gpurun_out/r05zb_swap_$v.err
-  python -c "
-import json; d=json.load(open('gpurun_out/r05zb_swap_$v.json')); print('$v', d['value'], 'triples/s', d['verified']['equal'])"
-done
+for v in r0 hip r0 hip; do echo "== $v"; HAIRFAST_HIP_LIB=$C/libhairfast_$v.so PROBE_TUNE=0 python tools/probes/gen_layers.py 2>&1 | grep -v amdgpu | grep "same\|upfu\|512->256\|512->512" ; done > gpurun_out/r06j_gen_layers.txt
+cat gpurun_out/r06j_gen_layers.txt
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3

@@ -40,11 +40,20 @@ using namespace hf_detail;
 #ifndef HF_H_SPLIT_STORE16
 #define HF_H_SPLIT_STORE16 0  // fused upsampling epilogue: 1 = split output as ONE 16-byte store per lane (v_permlane32_swap of the half-waves) instead of two 8-byte stores; measured equal (587 vs 595 us on the 1024^2 layer): the epilogue is not store-bound
 #endif
+#ifndef HF_H_SPLIT_STORE_PAIR
+#define HF_H_SPLIT_STORE_PAIR 1  // fused upsampling epilogue: the half-waves trade their halves of the two pixels (2X, 2X+1) of a position (v_permlane32_swap), every lane then owns ONE whole 16-byte unit: a store instruction writes 1 KiB contiguous instead of every other 8 bytes of it (half the write requests, half the store instructions); 0 = two 8-byte stores per pixel (A/B builds)
+#endif
 #ifndef HF_H_SWAP_XY
 #define HF_H_SWAP_XY 1  // 0: always the (tile walkers, cout tiles) grid (A/B builds)
 #endif
 #ifndef HF_H_PINGPONG
 #define HF_H_PINGPONG 1  // 0: the one-phase K loop (side work of a tap-step, then its MFMAs, all eight waves in lock-step) for A/B builds
+#endif
+#ifndef HF_H_EPI_ABLATE
+#define HF_H_EPI_ABLATE 0  // timing experiments on the fused upsampling epilogue only (WRONG results): 1 no output stores, 2 no lo part (one conversion per element), 4 no cross-wave exchange (no LDS round trip, no barriers), 8 no vertical taps
+#endif
+#ifndef HF_H_PP_ROLES
+#define HF_H_PP_ROLES 0  // ping-pong K loop (measured neutral: fused layers 552-569 vs 592 us, 512->512 @64^2 425 vs 410, r06j - off): 1 = the half that idles FIRST in a stage (waves 4-7, phase A) issues ALL activation copies of the next stage (HBM / Infinity-Cache latency: they get the whole stage to land), the other half (phase B) only the weight copies (L2 hits); 0 = every wave issues its share of both in its idle phase (A/B builds)
 #endif
 #ifndef HF_H_ABLATE
 #define HF_H_ABLATE 0  // timing experiments only: 1 no activation loads, 2 no epilogue stores, 4 no weight DMA, 8 no activation DMA
@@ -55,7 +64,7 @@ using namespace hf_detail;
 __device__ unsigned long long hf_trace_buf[8 * 512];
 #define HF_TRACE_POINT(id)                                                                    \
   do {                                                                                         \
-    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && trace_n < 510) {                    \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && wave < 8 && trace_n < 510) {                    \
       hf_trace_buf[wave * 512 + trace_n++] = ((unsigned long long)(id) << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffULL); \
     }                                                                                          \
   } while (0)
@@ -124,8 +133,9 @@ __host__ __device__ constexpr int group_first(int g) {  // first position of gro
   return !UP ? g : (g == 0 ? 0 : g == 1 ? 4 : g == 2 ? 6 : g == 3 ? 8 : 9);
 }
 
+// (second launch bound = waves per SIMD the register allocation must admit: a 16-wave block is four per SIMD, 128 registers)
 template <int NTERMS, int CT_TILES, int PG, int WAVES_CO, int WAVES_PX, bool MOD, bool UP, int TWMAX, bool PRE, bool FUSE = false>
-__global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const ConvParams P,
+__global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 16 ? 4 : 2)) void conv_mfma_h(const ConvParams P,
                                                                           const _Float16 *__restrict__ wth,
                                                                           const _Float16 *__restrict__ wtl) {
   constexpr int NW = WAVES_CO * WAVES_PX;
@@ -140,17 +150,24 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   constexpr int X_UNITS = 2 * NPIX;                     // 16-byte units of one activation part per stage
   // FUSE: the epilogue's vertical exchange (NW * 6 slots of 64 lanes x 16 B) lives in the free stage buffer - with plain
   // fp16 operands (one part) a stage is smaller than that, the buffer is sized for the exchange
-  constexpr int BUF_UNITS = (FUSE && NPART * (W_UNITS + X_UNITS) < NW * 6 * 64) ? NW * 6 * 64 : NPART * (W_UNITS + X_UNITS);
+  // (one row per wave, PG == 1: the row's four phases once - 4 slots; two rows per wave: the upper row's four + the lower row's two)
+  constexpr int XSLOTS = (PG == 1) ? 4 : 6;
+  constexpr int BUF_UNITS = (FUSE && NPART * (W_UNITS + X_UNITS) < NW * XSLOTS * 64) ? NW * XSLOTS * 64 : NPART * (W_UNITS + X_UNITS);
   constexpr int N_WPIECE = NPART * W_UNITS / 64;        // 1 KiB DMA pieces per stage
-  constexpr int ND = (N_WPIECE + NW - 1) / NW;          // per wave
+  // PP: the ping-pong K loop (below); PPR: its copy roles - activations by waves NW/2.., weights by waves 0..NW/2-1
+  constexpr bool PP = PRE && NW == 8 && HF_H_PINGPONG;
+  constexpr bool PPR = PP && HF_H_PP_ROLES;
+  constexpr int WNW = PPR ? NW / 2 : NW;                // waves that issue weight copies
+  constexpr int XNT = PPR ? NT / 2 : NT;                // threads that issue activation copies
+  constexpr int ND = (N_WPIECE + WNW - 1) / WNW;        // per issuing wave
   // weight DMAs: all in the first three tap-steps when activations are staged through registers
   // (their loads must be issued first thing); one per tap-step when everything is DMA (PRE) -
   // spreading the arrivals over the chunk measured +1..3 %
   constexpr int DMA_PER_STEP = PRE ? 1 : (ND + 2) / 3;
-  constexpr int XE = (X_UNITS + NT - 1) / NT;           // (pixel, kgroup) items per thread per stage
+  constexpr int XE = (X_UNITS + XNT - 1) / XNT;         // (pixel, kgroup) items per issuing thread per stage
   static_assert(W_UNITS % 64 == 0, "weight part must be whole 1 KiB pieces");
   static_assert(!FUSE || (UP && CT_TILES == 1 && WAVES_CO == 1 && TWMAX == 32), "FUSE: 32 co x (PG*WAVES_PX rows of 32 positions)");
-  static_assert(!FUSE || BUF_UNITS * 16 >= NW * 6 * 64 * 16, "FUSE: the exchange of one channel quad must fit a stage buffer");
+  static_assert(!FUSE || BUF_UNITS * 16 >= NW * XSLOTS * 64 * 16, "FUSE: the exchange of one channel quad must fit a stage buffer");
   static_assert(!PRE || (ND <= 9 && XE <= 8), "PRE issue schedule: one weight DMA per tap-step, activations in odd steps (or every step)");
 
   HF_DYN_LDS;
@@ -163,6 +180,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   const int wave = tid >> 6;
   const int li = lane & 31;
   const int lh = lane >> 5;  // k group of the lane: input channels 8*lh .. 8*lh+7 of the stage
+  const int xtid = PPR ? tid - NT / 2 : tid;  // index among the threads that stage activations (negative: none)
   const int wave_co = (wave / WAVES_PX) * (32 * CT_TILES);
   const int wave_pg = (wave % WAVES_PX) * PG;
   // grid = (tile walkers, cout tiles), or - ConvParams::swap_xy - (cout tiles, tile walkers): blocks are dispatched x-fastest, so
@@ -230,10 +248,10 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
     const int wp = (1 << G.lg_tw) + HALO, xs = ((1 << G.lg_th) + HALO) * wp;
 #pragma unroll
     for (int e = 0; e < XE; ++e) {
-      const int i = tid + e * NT;
+      const int i = xtid + e * XNT;
       const int kg = i / NPIX, pix = i - kg * NPIX;
       src[e] = -2;
-      if (i < X_UNITS && pix < xs) {
+      if (i >= 0 && i < X_UNITS && pix < xs) {
         const int hy = pix / wp, hx = pix - hy * wp;
         const int ys = T.ty0 + hy - 1, xc = T.tx0 + hx - 1;
         src[e] = (ys >= 0 && ys < P.h && xc >= 0 && xc < P.w) ? ys * P.w + xc : -1;
@@ -279,8 +297,8 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   // weight stage of `chunk`: uniform base + per-lane byte offset ((tap*2+kg)*cout + co0 + col)*16
   const unsigned lds_addr0 = hf_lds_addr(lds);
   auto dma_piece = [&](int i, int chunk, int bufsel) {
-    const int pc = wave + i * NW;
-    if (pc < N_WPIECE && !(HF_H_ABLATE & 4)) {
+    const int pc = wave + i * WNW;
+    if (wave < WNW && pc < N_WPIECE && !(HF_H_ABLATE & 4)) {
       const int part = pc / (W_UNITS / 64), q = pc % (W_UNITS / 64);
       const int u = q * 64 + lane;            // unit inside the part: (tap*2 + kg)*CT + co
       const int row = u / CT, col = u % CT;   // row = tap*2 + kg
@@ -295,9 +313,10 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   // the image are masked out of the DMA and zero-filled by the same lane
   const char *xh_b = nullptr, *xl_b = nullptr;  // image base of the pre-split tensors (uniform)
   auto dma_x = [&](int e, int chunk, int bufsel) {
-    const int i = tid + e * NT;
+    const int i = xtid + e * XNT;
     const int kg = i / NPIX;
     if (HF_H_ABLATE & 8) return;  // timing experiments: no activation DMA
+    if (PPR && wave < NW / 2) return;  // (uniform per wave)
     const bool inside = e_src[e] >= 0;
     int off = inside ? (kg * iplane + e_src[e]) * 16 : 0;
     HF_OPAQUE_I32(off);
@@ -386,6 +405,8 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   }
   HF_H_BARRIER();
 
+  int trace_n = 0;  // HF_H_TRACE builds: events recorded by this wave
+  (void)trace_n;
   // Epilogue of one tile.  MFMA D layout: row (= co) = (r&3) + 8*(r>>2) + 4*lh, col (= pixel) = li:
   // the lane's 4 channels of register group q = r>>2 are consecutive -> one ds_read_b128 each of
   // d and bias.  Same-res: v = lrelu(acc*d + noise_w*noise + bias)*scale (bias NULL: v = acc*d);
@@ -648,15 +669,23 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
       // 4..5 = phase 1 of the last row for the wave BELOW (index pc); values are read back right where they are
       // used (nothing but the current output pixel's operands is live: the epilogue must not spill - a scratch
       // reload waits for every output store issued before it)
+      HF_TRACE_POINT(30);  // fused epilogue: horizontal pass of the quad done
       float4 *xq = reinterpret_cast<float4 *>(xch);  // [wave][6][64 lanes]
-      float4 *mine = xq + (wv * 6) * 64 + lane;
+      float4 *mine = xq + (wv * XSLOTS) * 64 + lane;
+      if (!(HF_H_EPI_ABLATE & 4)) {
 #pragma unroll
-      for (int ph = 0; ph < 4; ++ph) mine[ph * 64] = make_float4(H[ph][0][0], H[ph][0][1], H[ph][0][2], H[ph][0][3]);
+        for (int ph = 0; ph < 4; ++ph) mine[ph * 64] = make_float4(H[ph][0][0], H[ph][0][1], H[ph][0][2], H[ph][0][3]);
+        if (PG > 1) {
 #pragma unroll
-      for (int pc = 0; pc < 2; ++pc)
-        mine[(4 + pc) * 64] = make_float4(H[2 + pc][PG - 1][0], H[2 + pc][PG - 1][1], H[2 + pc][PG - 1][2], H[2 + pc][PG - 1][3]);
-      hf_barrier_lds();
-      const float4 *above = xq + (max(wv - 1, 0) * 6) * 64 + lane, *below = xq + (min(wv + 1, NW - 1) * 6) * 64 + lane;
+          for (int pc = 0; pc < 2; ++pc)
+            mine[(4 + pc) * 64] = make_float4(H[2 + pc][PG - 1][0], H[2 + pc][PG - 1][1], H[2 + pc][PG - 1][2], H[2 + pc][PG - 1][3]);
+        }
+      }
+      HF_TRACE_POINT(31);  // rows published, before the barrier
+      if (!(HF_H_EPI_ABLATE & 4)) hf_barrier_lds();
+      HF_TRACE_POINT(32);  // after the barrier
+      const float4 *above = xq + (max(wv - 1, 0) * XSLOTS) * 64 + lane, *below = xq + (min(wv + 1, NW - 1) * XSLOTS) * 64 + lane;
+      constexpr int ABOVE_P1 = (PG == 1) ? 2 : 4;  // slot of phase (1, pc) of the LAST row of the wave above
       const int c4 = 8 * q + 4 * lh_o;  // first of the lane's 4 channels (tile relative)
       // the lane's 4 channels are one half (lh) of the 16-byte unit of channel block q
       const long long cb_ofs = (long long)q * oplane * 16 + lh_o * 8;
@@ -665,13 +694,21 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
         const int rr = row0 + g, Y = Y0 + g;
         const bool pv = colv && rr >= 1 && rr <= PT / 32 - 2 && Y >= 0 && Y < P.h;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          u32x2 hq[2], lq[2];  // HF_H_SPLIT_STORE_PAIR: the split results of the pixels (2X, 2X+1), stored after the pc loop
+          bool ovf_a = false;
 #pragma unroll
           for (int pc = 0; pc < 2; ++pc) {
             // the H rows 2Y+a-1 .. 2Y+a+2 of this column: (Y-1, 1), (Y, 0), (Y, 1), (Y+1, 0), (Y+1, 1)
             float hm1[4], h2[4], h3[4];
+            if (HF_H_EPI_ABLATE & 4) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) hm1[k] = H[pc][g][k], h2[k] = H[2 + pc][g][k], h3[k] = H[pc][g][k];
+            } else {
             if (g == 0 && a == 0) {
-              const float4 u = above[(4 + pc) * 64];
+              const float4 u = above[(ABOVE_P1 + pc) * 64];
               hm1[0] = u.x; hm1[1] = u.y; hm1[2] = u.z; hm1[3] = u.w;
             }
             if (g == PG - 1) {
@@ -682,6 +719,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
                 h3[0] = d1.x; h3[1] = d1.y; h3[2] = d1.z; h3[3] = d1.w;
               }
             }
+            }
             const float4 dm = *reinterpret_cast<const float4 *>(ep + c4), bs = *reinterpret_cast<const float4 *>(ep + CT + c4);
             const float dmv[4] = {dm.x, dm.y, dm.z, dm.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
             float v[4];
@@ -691,8 +729,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
               const float h_0 = H[pc][g][k], h_1 = H[2 + pc][g][k];
               const float h_2 = (g == PG - 1) ? h2[k] : H[pc][g == PG - 1 ? g : g + 1][k];
               const float h_3 = (g == PG - 1) ? h3[k] : H[2 + pc][g == PG - 1 ? g : g + 1][k];
-              float o = (a == 0) ? fmaf(kyf[3], h_2, fmaf(kyf[2], h_1, fmaf(kyf[1], h_0, kyf[0] * h_m1)))
-                                 : fmaf(kyf[3], h_3, fmaf(kyf[2], h_2, fmaf(kyf[1], h_1, kyf[0] * h_0)));
+              float o = (HF_H_EPI_ABLATE & 8) ? (a == 0 ? h_0 : h_1)
+                        : (a == 0) ? fmaf(kyf[3], h_2, fmaf(kyf[2], h_1, fmaf(kyf[1], h_0, kyf[0] * h_m1)))
+                                   : fmaf(kyf[3], h_3, fmaf(kyf[2], h_2, fmaf(kyf[1], h_1, kyf[0] * h_0)));
               o = fmaf(o, dmv[k], fmaf(nw_f, nz[g][a * 2 + pc], bsv[k]));  // d and bias carry the output scale (ep_fold)
               v[k] = fmaxf(o, o * P.alpha);
             }
@@ -709,7 +748,13 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
               const float vs[4] = {v[0] * sn.x, v[1] * sn.y, v[2] * sn.z, v[3] * sn.w};
               hf_half4 h4, l4;
               bool ovf = false;
-              hf_split4_f16(vs, h4, l4, ovf);
+              if (HF_H_EPI_ABLATE & 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h4[k] = (_Float16)vs[k];
+                l4 = h4;
+              } else {
+                hf_split4_f16(vs, h4, l4, ovf);
+              }
 #if HF_H_SPLIT_STORE16
               static_assert(NTERMS == 3, "HF_H_SPLIT_STORE16 pairs the hi and lo units of a pixel");
               // one 16-byte store per lane: the half-waves trade halves, lanes 0-31 write the hi unit of the pixel,
@@ -726,8 +771,12 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
                 unit.x = a0; unit.y = a1; unit.z = b0; unit.w = b1;
                 *reinterpret_cast<u32x4 *>((lh_o ? ol_b : oh_b) + (long long)q * oplane * 16 + (long long)pix * 16) = unit;
               }
+#elif HF_H_SPLIT_STORE_PAIR
+              hq[pc] = __builtin_bit_cast(u32x2, h4);
+              lq[pc] = __builtin_bit_cast(u32x2, l4);
+              ovf_a = ovf_a || ovf;
 #else
-              if (pv) {
+              if (pv && !((HF_H_EPI_ABLATE & 1) && P.alpha != 77.0f)) {
                 ovf_tile = ovf_tile || ovf;
                 *reinterpret_cast<hf_half4 *>(oh_b + cb_ofs + (long long)pix * 16) = h4;
                 if (NTERMS == 3) *reinterpret_cast<hf_half4 *>(ol_b + cb_ofs + (long long)pix * 16) = l4;  // plain fp16 consumer: no lo part
@@ -736,8 +785,36 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
             }
             __builtin_amdgcn_sched_barrier(0);
           }
+#if HF_H_SPLIT_STORE_PAIR && !HF_H_SPLIT_STORE16
+          if (SPLIT) {
+            // lanes i / i+32 hold channels 0-3 / 4-7 of the same two pixels: after the swap the low half-wave owns the whole unit
+            // of pixel 2X, the high half-wave that of pixel 2X+1 - (a0, a1) = channels 0-3, (b0, b1) = channels 4-7 in both
+            const long long unit_ofs = (long long)q * oplane * 16 + (long long)(pix00 + (2 * g + a) * (2 * P.w) + lh_o) * 16;
+            unsigned a0 = hq[0].x, b0 = hq[1].x, a1 = hq[0].y, b1 = hq[1].y;
+            hf_half_swap(a0, b0);
+            hf_half_swap(a1, b1);
+            u32x4 uh;
+            uh.x = a0; uh.y = a1; uh.z = b0; uh.w = b1;
+            u32x4 ul = uh;
+            if (NTERMS == 3) {  // plain fp16 consumer: no lo part
+              unsigned c0 = lq[0].x, d0 = lq[1].x, c1 = lq[0].y, d1 = lq[1].y;
+              hf_half_swap(c0, d0);
+              hf_half_swap(c1, d1);
+              ul.x = c0; ul.y = c1; ul.z = d0; ul.w = d1;
+            }
+            if (pv && !((HF_H_EPI_ABLATE & 1) && P.alpha != 77.0f)) {
+              ovf_tile = ovf_tile || ovf_a;
+              *reinterpret_cast<u32x4 *>(oh_b + unit_ofs) = uh;
+              if (NTERMS == 3) *reinterpret_cast<u32x4 *>(ol_b + unit_ofs) = ul;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
+        }
       }
-      hf_barrier_lds();  // everyone has read: the region may be overwritten (next quad / next tile's DMA)
+      HF_TRACE_POINT(33);  // vertical pass + tail + stores of the quad issued
+      if (!(HF_H_EPI_ABLATE & 4) || q == 3) hf_barrier_lds();  // everyone has read: the region may be overwritten (next quad / next tile's DMA)
+      HF_TRACE_POINT(34);
     }
     hf_note_overflow(ovf_tile);
   };
@@ -754,11 +831,8 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, 2) void conv_mfma_h(const
   // is unchanged: equal bits.  Hazards: stage c is complete since the end-of-stage barrier of stage c-1 (every wave drained its
   // copies, vmcnt(0)); the copies of stage c+1 go to the buffer stage c-1 was read from, whose last readers (phase B of c-1)
   // passed that barrier too; the mid-stage barrier only swaps the roles (copies stay in flight across it).
-  constexpr bool PP = PRE && NW == 8 && HF_H_PINGPONG;
   const int pp_half = wave >> 2;
   int stage = 0;  // LDS buffer = stage & 1, running across tiles
-  int trace_n = 0;
-  (void)trace_n;
   while (true) {
     HF_TRACE_POINT(1);  // tile start
     const TileGeom G = geom(cur.gi);
@@ -1067,7 +1141,8 @@ int launch_h(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_
     if (geom_xs(P.g[i], 1, UP ? 1 : 2) > NPIX) return HF_E_INVALID;
   }
   constexpr int NW_ = WAVES_CO * WAVES_PX;
-  constexpr int BUF_UNITS = (FUSE && NPART * (9 * 2 * CT + 2 * NPIX) < NW_ * 6 * 64) ? NW_ * 6 * 64 : NPART * (9 * 2 * CT + 2 * NPIX);
+  constexpr int XSLOTS = (PG == 1) ? 4 : 6;
+  constexpr int BUF_UNITS = (FUSE && NPART * (9 * 2 * CT + 2 * NPIX) < NW_ * XSLOTS * 64) ? NW_ * XSLOTS * 64 : NPART * (9 * 2 * CT + 2 * NPIX);
   const size_t lds = (size_t)2 * BUF_UNITS * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float) +
                      2 * 3 * CT * sizeof(float) + (P.rgb_out ? 2 * 3 * CT * sizeof(float) : 0);
   // stages + s[2][cin] + epilogue d/bias/s_next [2][3][CT] (+ fused ToRGB weights [2][3][CT])
@@ -1289,7 +1364,9 @@ extern "C" int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *s
   // 752 vs 602 us on the 1024^2 layer, 546 vs 432, 449 vs 424: every block stages the full weight stage - twice the LDS-DMA
   // issues per wave - and recomputes 43 % instead of 22 % halo.  Not kept.)
   int rc;
-  if (nterms == 3)
+  if (nterms == 3 && x_hi && (hf_detail::g_h_tune & 32))  // <1,1,1,16>: the same tile, SIXTEEN waves x one row - four waves per SIMD
+    rc = launch_h<3, 1, 1, 1, 16, true, 32, true, true>(P, hi, lo, (hipStream_t)stream);
+  else if (nterms == 3)
     rc = x_hi ? launch_h<3, 1, 2, 1, 8, true, 32, true, true>(P, hi, lo, (hipStream_t)stream)
               : launch_h<3, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
   else

@@ -164,11 +164,23 @@ __device__ __forceinline__ void hf_split4_f16(const float (&vin)[4], hf_half4 &h
       l[k] = lv;
     }
   } else {
+    // on channel PAIRS: v_cvt_pk_f16_f32, two v_cvt_f32_f16 (the upper half by SDWA), v_pk_add_f32, v_cvt_pk_f16_f32 - 2.5 VALU
+    // issues per element and the halves already packed (element-wise hipcc spent 5.5 incl. v_bfi / v_perm packing; same bits:
+    // the packed conversion rounds to nearest even like the scalar one)
+    typedef _Float16 hf_half2_ __attribute__((ext_vector_type(2)));
+    typedef float hf_float2_ __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const _Float16 hv = (_Float16)v[k];
-      h[k] = hv;
-      l[k] = (_Float16)(v[k] - (float)hv);
+    for (int p = 0; p < 2; ++p) {
+      hf_float2_ x;
+      x.x = v[2 * p];
+      x.y = v[2 * p + 1];
+      const hf_half2_ hh = __builtin_convertvector(x, hf_half2_);
+      const hf_float2_ r = x - __builtin_convertvector(hh, hf_float2_);
+      const hf_half2_ ll = __builtin_convertvector(r, hf_half2_);
+      h[2 * p] = hh.x;
+      h[2 * p + 1] = hh.y;
+      l[2 * p] = ll.x;
+      l[2 * p + 1] = ll.y;
     }
   }
 }
@@ -176,14 +188,16 @@ __device__ __forceinline__ void hf_split4_f16(const float (&vin)[4], hf_half4 &h
 
 // Value of the neighbouring lane (lane-1 / lane+1) by a DPP wavefront shift: one VALU instruction, no LDS
 // round trip (the __shfl_* forms are ds_bpermute with an address register and ~100 cycles of latency each).
-// Lane 0 (up) / lane 63 (down) receive 0.
+// Lane 0 (up) / lane 63 (down) receive 0 (bound_ctrl: an out-of-range source lane reads as 0 - with the `old` operand form instead,
+// hipcc initialises the destination with a v_mov_b32 0 in front of every shift: 1.5 extra VALU issues per output of the fused
+// upsampling epilogue, which is bound by VALU issue - tools/probes/valu_rate.hip).
 #ifndef HF_LANE_SHIFT_DEFINED
 #define HF_LANE_SHIFT_DEFINED
 __device__ __forceinline__ float hf_lane_up(float v) {  // from lane-1: DPP wave_shr:1 (0x138)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float hf_lane_down(float v) {  // from lane+1: DPP wave_shl:1 (0x130)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 #endif
 

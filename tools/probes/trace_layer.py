@@ -1,5 +1,5 @@
 """Timeline of block 0 (HF_H_TRACE build of csrc/convh.hip, loaded through HAIRFAST_HIP_LIB):
-python trace_layer.py cin cout res [batch] [mode]   mode: '' | pre | prergb (fused ToRGB, no fp32 output) | up | uppre | fuse"""
+python trace_layer.py cin cout res [batch] [mode]   mode: '' | pre | presplit (split output only) | prergb (fused ToRGB, no fp32 output) | up | uppre | fuse"""
 import ctypes, sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hairfastgan_amd import _marshal as M
@@ -8,7 +8,7 @@ cin, cout, r = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 mode = sys.argv[5] if len(sys.argv) > 5 else ''
 up = mode.startswith('up')
-pre = mode.endswith('pre') or mode in ('prergb', 'fuse')
+pre = mode.endswith('pre') or mode in ('prergb', 'fuse', 'presplit')
 L = lib(); st = stream(); dev = torch.device("cuda:0")
 x = torch.randn(B, cin, r, r, device=dev)
 wt, wsq = M.prepare_weights(L, st, torch.randn(1, cout, cin, 3, 3, device=dev))
@@ -25,6 +25,9 @@ for _ in range(2):
     elif mode == 'prergb':
         rgbp = (torch.randn(cout, 3, device=dev), torch.rand(B, cout, device=dev) + 0.5)
         y = M.modconv3x3_f16_pre(L, st, xin, hi, lo, 3, d, nz, nw, bias, rgb=rgbp, want_out=False)
+    elif mode == 'presplit':
+        s2 = torch.rand(B, cout, device=dev) + 0.5
+        y = M.modconv3x3_f16_pre(L, st, xin, hi, lo, 3, d, nz, nw, bias, want_out=False, split_for=s2)
     elif up:
         y = M.modconv3x3_up(L, st, xin, wt, None if pre else s, d, k4, nz, nw, bias, f16=(hi, lo, 3))
     elif pre:
