@@ -669,6 +669,9 @@ def main():
     prof = None if args.no_kernel_events else []
     every = max(1, args.event_every)
     n_bracketed = len(range(0, args.steps, every))
+    # (hf_profile_marker_kernel dispatches bracket the timed region: tools/summarize_prof.py --between / make_pmc_traffic.py --between
+    # cut rocprofv3's per-dispatch tables to it - the synthetic fill's copies and the one-off weight preparation stay outside)
+    _runtime.lib().hf_profile_marker(1, _runtime.stream())
     t0 = time.perf_counter()
     for i in range(args.steps):
         # per-kernel HIP events (the `roofline` durations) on every `every`-th step of the timed region: an event pair costs
@@ -680,6 +683,7 @@ def main():
         pending[1].wait()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    _runtime.lib().hf_profile_marker(2, _runtime.stream())
     overflow = _marshal.f16_overflow_count(_runtime.lib())
 
     # comparison runs (outside the timed region): the same forward with every conv on the exact-fp32

@@ -1,9 +1,14 @@
-# GPU call r06j: ping-pong copy roles (activations by the half that idles first) on the fused and same-resolution kernels + parity
+# GPU call r06n: full GPU test suite + bench line at the current state
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-PROBE_REPS=2 python tools/probes/fuse_ab.py r0 hip > gpurun_out/r06j_roles.txt 2>&1
-cat gpurun_out/r06j_roles.txt
-C=$GRAFT_REPO_ROOT/hairfastgan_amd/csrc
-for v in r0 hip r0 hip; do echo "== $v"; HAIRFAST_HIP_LIB=$C/libhairfast_$v.so PROBE_TUNE=0 python tools/probes/gen_layers.py 2>&1 | grep -v amdgpu | grep "same\|upfu\|512->256\|512->512" ; done > gpurun_out/r06j_gen_layers.txt
-cat gpurun_out/r06j_gen_layers.txt
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3
+python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+python bench.py > gpurun_out/r06n_bench.json 2> gpurun_out/r06n_bench.err
+python - <<'PY'
+import json
+d = json.load(open('gpurun_out/r06n_bench.json'))
+print({k: d.get(k) for k in ['value', 'ms_per_step']})
+print('fam', {k: (v['avg_launch_ms'], v['frac']) for k, v in d['roofline_families'].items()} if 'roofline_families' in d else None)
+sp = d.get('swap_pipeline') or {}
+print('swap', sp.get('value'), sp.get('single_swap'), {k: sp.get(k) for k in ['ms_per_triple']})
+print('f16', (d.get('f16_mode') or {}).get('value'), 'f32', (d.get('exact_f32') or {}).get('value'))
+PY

@@ -55,6 +55,9 @@ using namespace hf_detail;
 #ifndef HF_H_PP_ROLES
 #define HF_H_PP_ROLES 0  // ping-pong K loop (measured neutral: fused layers 552-569 vs 592 us, 512->512 @64^2 425 vs 410, r06j - off): 1 = the half that idles FIRST in a stage (waves 4-7, phase A) issues ALL activation copies of the next stage (HBM / Infinity-Cache latency: they get the whole stage to land), the other half (phase B) only the weight copies (L2 hits); 0 = every wave issues its share of both in its idle phase (A/B builds)
 #endif
+#ifndef HF_H_PP_PREFETCH
+#define HF_H_PP_PREFETCH 1  // ping-pong K loop: the half that computes second fetches its first tap's fragments BEFORE the role-swap barrier (0 = after: A/B builds)
+#endif
 #ifndef HF_H_ABLATE
 #define HF_H_ABLATE 0  // timing experiments only: 1 no activation loads, 2 no epilogue stores, 4 no weight DMA, 8 no activation DMA
 #endif
@@ -550,7 +553,9 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
       HF_OPAQUE_F32(nzv);  // a product of its own in every instantiation (no contraction into the add below): the
                            // tile configurations must agree bit for bit
       float rgb[3] = {0.0f, 0.0f, 0.0f};
-      if (pv) {
+      // every lane runs the arithmetic (the split's range vote is wave-wide; lanes outside the image hold finite sums of zero
+      // padding), lanes of valid pixels store
+      {
         const unsigned pix4 = (unsigned)(Y * P.out_w + X) * 4u;
 #pragma unroll
         for (int ct = 0; ct < CT_TILES; ++ct)
@@ -566,26 +571,25 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
               const float o = fmaf(acc[0][ct][g][4 * q + k], dmv[k], nzv + bsv[k]);
               v[k] = fmaxf(o, o * P.alpha);
             }
-            if (OUT) {
+            if (OUT && pv) {
               unsigned off = (unsigned)c4 * oplane4 + pix4;
 #pragma unroll
               for (int k = 0; k < 4; ++k, off += oplane4) *reinterpret_cast<float *>(ob0 + off) = v[k];
             }
             if (SPLIT) {  // the lane's 4 channels = one half (lh) of the 16-byte unit of pixel (Y, X), channel block (co0+c4)/8
               const float4 sn = *reinterpret_cast<const float4 *>(ep + 2 * CT + c4);
-              const float snv[4] = {sn.x, sn.y, sn.z, sn.w};
-              typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-              half4 h4, l4;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                _Float16 hv, lv;
-                hf_split_f16(v[k] * snv[k], hv, lv, ovf_tile);
-                h4[k] = hv;
-                l4[k] = lv;
+              const float vs[4] = {v[0] * sn.x, v[1] * sn.y, v[2] * sn.z, v[3] * sn.w};
+              // one range vote per four values, packed conversions (hf_split4_f16: 2.5 VALU issues per element; the element-wise
+              // saturating form this replaced spent 9 - the epilogue is bound by VALU issue; same bits)
+              hf_half4 h4, l4;
+              bool ovf = false;
+              hf_split4_f16(vs, h4, l4, ovf);
+              if (pv) {
+                ovf_tile = ovf_tile || ovf;
+                const long long unit = (((long long)T.b0 * (P.cout >> 3) + ((co0 + c4) >> 3)) * P.out_h + Y) * P.out_w + X;
+                *reinterpret_cast<hf_half4 *>(static_cast<char *>(P.oh) + unit * 16 + ((co0 + c4) & 4) * 2) = h4;
+                if (P.ol) *reinterpret_cast<hf_half4 *>(static_cast<char *>(P.ol) + unit * 16 + ((co0 + c4) & 4) * 2) = l4;
               }
-              const long long unit = (((long long)T.b0 * (P.cout >> 3) + ((co0 + c4) >> 3)) * P.out_h + Y) * P.out_w + X;
-              *reinterpret_cast<half4 *>(static_cast<char *>(P.oh) + unit * 16 + ((co0 + c4) & 4) * 2) = h4;
-              if (P.ol) *reinterpret_cast<half4 *>(static_cast<char *>(P.ol) + unit * 16 + ((co0 + c4) & 4) * 2) = l4;
             }
             if (RGB) {
 #pragma unroll
@@ -910,15 +914,6 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
           nzf[g][0] = n0.x; nzf[g][1] = n0.y; nzf[g][2] = n1.x; nzf[g][3] = n1.y;
         }
       }
-      if (PP && pp_half == 1) {  // phase A of the second half: its copies of the next stage, then the role swap
-        if (more1) {
-#pragma unroll
-          for (int j = 0; j < ND; ++j) dma_piece(j, cpf, cb ^ 1);
-#pragma unroll
-          for (int e = 0; e < XE; ++e) dma_x(e, cpf, cb ^ 1);
-        }
-        hf_barrier_lds();
-      }
       const half8 *a_hi = buf + lh * CT + wave_co + li;  // + tap*2*CT + ct*32
       const half8 *b_hi = buf + OFF_XH + lh * NPIX;      // + pixrow + tap column
       // fragments of tap+1 are fetched from LDS while the MFMAs of tap run
@@ -948,8 +943,24 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
           if (NTERMS == 3) bl[slot][g] = b_hi[X_UNITS + pixrow[g][brow] + bcol];
         }
       };
-      fetch_a(0, tap_at<UP>(0));
-      fetch_b(0, tap_at<UP>(0));
+      if (PP && pp_half == 1) {  // phase A of the second half: its copies of the next stage, then the role swap
+        if (more1) {
+#pragma unroll
+          for (int j = 0; j < ND; ++j) dma_piece(j, cpf, cb ^ 1);
+#pragma unroll
+          for (int e = 0; e < XE; ++e) dma_x(e, cpf, cb ^ 1);
+        }
+        if (HF_H_PP_PREFETCH) {  // the stage has been complete since the last end-of-stage barrier: the first tap's fragments
+                                 // travel while the other half still computes, not after the role swap
+          fetch_a(0, tap_at<UP>(0));
+          fetch_b(0, tap_at<UP>(0));
+        }
+        hf_barrier_lds();
+      }
+      if (!(PP && pp_half == 1 && HF_H_PP_PREFETCH)) {
+        fetch_a(0, tap_at<UP>(0));
+        fetch_b(0, tap_at<UP>(0));
+      }
       if (NSLOT == 3) {
         fetch_a(1, 1);
         fetch_b(1, 1);
