@@ -85,6 +85,24 @@ def emit(out):
     print(json.dumps(out), flush=True)
 
 
+def summary_tail(out):
+    """The few scalars of the line that matter, as its last object (< 600 bytes): headline, the swap half of the metric, single-swap
+    latency, the fp16 / exact-fp32 runs and the roofline fractions of the three dominant kernels."""
+    def g(d, *keys):
+        for k in keys:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+    sp = out.get("swap_pipeline") or {}
+    return {"generator_images_per_s": out.get("value"), "ms_per_step": out.get("ms_per_step"),
+            "swap_triples_per_s": sp.get("value"), "single_swap_ms": g(sp, "single_swap", "ms_per_swap"),
+            "single_swap_graph_ms": g(sp, "single_swap_graph", "ms_per_swap"),
+            "f16_b16_images_per_s": g(out, "f16_mode", "value"), "exact_f32_images_per_s": g(out, "exact_f32", "value"),
+            "frac_generator_dominant": g(out, "roofline", "frac"), "frac_swap_dominant": g(sp, "roofline", "frac"),
+            "frac_f16_dominant": g(out, "f16_mode", "roofline", "frac"), "frac_exact_f32_dominant": g(out, "exact_f32", "roofline", "frac"),
+            "mfma_busy_pmc_generator": g(out, "roofline", "mfma_busy_pmc"), "mfma_busy_pmc_swap": g(sp, "roofline", "mfma_busy_pmc"),
+            "cpu_images_per_s": g(out, "cpu_baseline", "value"), "swap_verified": g(sp, "verified", "equal")}
+
+
 def synth_state(prefix, shapes):
     import numpy as np
 
@@ -492,10 +510,33 @@ def launch_check(args):
     if world > 1:
         dist.all_reduce(sec, op=dist.ReduceOp.MAX)
     ok = got.shape[0] == 2 * world and all(int(got[2 * r, 0, 0, 0]) == (r * 16 + args.steps - 1) % 256 for r in range(world))
+    # the rest of what an N-rank bench run does around its GPU work, at THIS rank count: the per-rank core slice
+    # (len(cpus) // local world) and a ragged block partition through parallel.swap_many (3 * world + 5 triples: shards of
+    # different lengths, padded gather rounds, results in triple order on every rank) - with a stand-in for HairFast.swap
+    cpu_slice = parallel.pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    n_tr = 3 * world + 5
+    load = lambda i: tuple(torch.full((3, 4, 4), (i * 3 + j) % 251, dtype=torch.uint8) for j in range(3))  # noqa: E731
+    fake_swap = lambda a, b, c: (a.float() + b.float() + c.float()) / 765.0  # noqa: E731
+    st = {}
+    imgs, n_local = parallel.swap_many(fake_swap, n_tr, load, device=dev if cuda else None, chunk=2, batch=2,
+                                       swap_batch_fn=lambda trs: [fake_swap(*t) for t in trs], stats=st)
+    want = torch.stack([parallel.to_uint8_image(fake_swap(*load(i)) * 2.0 - 1.0) for i in range(n_tr)])
+    ragged_ok = tuple(imgs.shape) == (n_tr, 3, 4, 4) and bool(torch.equal(imgs.cpu(), want))
+    slices = [None] * world
+    if world > 1:
+        dist.all_gather_object(slices, (n_local, None if cpu_slice is None else (cpu_slice[0], cpu_slice[-1], len(cpu_slice))))
+    else:
+        slices = [(n_local, None)]
+    shards = [s[0] for s in slices]
+    cores = [s[1] for s in slices]
+    disjoint = all(c is None for c in cores) or all(cores[i][1] < cores[i + 1][0] for i in range(world - 1) if cores[i] and cores[i + 1])
+    ok = ok and ragged_ok and sum(shards) == n_tr and disjoint
     if rank == 0:
         print(json.dumps({"metric": "launch_check", "value": int(ones.item()), "unit": "ranks", "n_gpus": world,
                           "ranks_observed": int(ones.item()), "steps": args.steps, "warmup": 0,
                           "ms_per_step": round(float(sec.item()) / max(args.steps, 1) * 1e3, 4), "gather_ok": bool(ok),
+                          "ragged_swap_many_ok": bool(ragged_ok), "triples": n_tr, "shards": shards,
+                          "core_slices_first_last_count": cores, "core_slices_disjoint": bool(disjoint),
                           "backend": dist.get_backend() if world > 1 else None, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                           "config": {"workload": "launcher / process-group check (no GPU work)"}}), flush=True)
@@ -887,6 +928,7 @@ def main():
             out["swap_schedule"] = swap_info
         if pipeline_info is not None:
             out["swap_pipeline"] = pipeline_info
+        out["summary"] = summary_tail(out)  # LAST key: a reader that only keeps the end of the line still sees the scalars that matter
         emit(out)
 
     if use_dist:

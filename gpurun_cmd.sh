@@ -1,14 +1,18 @@
-# GPU call r06n: full GPU test suite + bench line at the current state
+# GPU call r06p: clock / power telemetry of OUR GPU (PCI address of HIP device 0)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests -x -q -m gpu 2>&1 | tail -5
-python bench.py > gpurun_out/r06n_bench.json 2> gpurun_out/r06n_bench.err
-python - <<'PY'
-import json
-d = json.load(open('gpurun_out/r06n_bench.json'))
-print({k: d.get(k) for k in ['value', 'ms_per_step']})
-print('fam', {k: (v['avg_launch_ms'], v['frac']) for k, v in d['roofline_families'].items()} if 'roofline_families' in d else None)
-sp = d.get('swap_pipeline') or {}
-print('swap', sp.get('value'), sp.get('single_swap'), {k: sp.get(k) for k in ['ms_per_triple']})
-print('f16', (d.get('f16_mode') or {}).get('value'), 'f32', (d.get('exact_f32') or {}).get('value'))
-PY
+O=gpurun_out/r06p_clock_power.txt
+{
+echo "# sysfs telemetry (tools/probes/clock_power.py) of HIP device 0 - one MI355X box"
+python -c "import torch; p = torch.cuda.get_device_properties(0); print(p)"
+timeout 60 rocm-smi --showbus 2>&1 | grep -i "GPU\[" | head
+echo "== MFMA-only probe, 200000 iterations (0.4-0.8 s per mode), non-zero operands"
+python tools/probes/clock_power.py --interval 0.02 --label mfma200k -- tools/probes/bin/mfma_rate 200000 0
+echo "== MFMA-only probe, 200000 iterations, ZERO operands"
+python tools/probes/clock_power.py --interval 0.02 --label mfma200k-zero -- tools/probes/bin/mfma_rate 200000 1
+echo "== bench.py generator workload, 300 timed steps, no per-kernel events"
+python tools/probes/clock_power.py --interval 0.02 --label bench-generator -- python bench.py --no-cpu-baseline --no-exact-f32 --swap-triples 0 --steps 300 --warmup 5 --no-kernel-events
+echo "== bench.py swap256 workload, 64 triples at 32 per pass"
+python tools/probes/clock_power.py --interval 0.02 --label bench-swap -- python bench.py --workload swap256 --triples 64 --swap-batch 32 --warmup 1 --no-kernel-events --no-cpu-baseline
+} > $O 2>&1
+grep -v "^{\|MFMA only\|ds_read" $O | cut -c1-250

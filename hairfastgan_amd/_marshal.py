@@ -693,13 +693,17 @@ def conv1x1_f16(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None,
             raise ValueError(f"residual {tuple(residual.shape)} != output {tuple(out.shape)}")
     n = lib.hf_conv1x1_f16_workspace_floats(b, cin, cout, h, w, stride, groups)
     ws = torch.empty((n,), dtype=torch.float32, device=proto.device) if n > 0 else None
+    nparts = 2 if nterms == 3 else 1  # algorithmic HBM bytes: the pixels the GEMM reads, the output, a residual, the weights - each once
+    n_in = b * (1 if (groups == 1 or x_gstride == 0) else groups)
+    nb = (float(n_in) * cin * oh * ow * (2.0 * nparts if pre else 4.0) + float(b) * groups * cout * oh * ow * (4.0 + (4.0 if residual is not None else 0.0))
+          + 2.0 * nparts * cin * cout * groups)
     code = _launch_profiled(
         lib, 2.0 * cin * cout * oh * ow * b * groups,
         lambda: lib.hf_conv1x1_f16_f32(_p(out), None if pre else _p(x), _p(x.hi) if pre else None, _p(x.lo) if pre else None,
                                        _p(wt_hi), _p(wt_lo), nterms, _p(_c(in_scale)), _p(_c(in_shift)),
                                        _p(_c(out_scale)), _p(_c(bias)), act, _p(_c(slope)), float(alpha), _p(residual), b, cin, cout,
                                        h, w, stride, groups, x_gstride, _p(ws), max(n, 0), st),
-        label="gemm_h")
+        label="gemm_h", nbytes=nb)
     check(lib, code, "hf_conv1x1_f16_f32")
     return out
 
@@ -749,12 +753,18 @@ def conv2d_f16(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=None, 
             raise ValueError(f"residual {tuple(residual.shape)} != output {tuple(out.shape)}")
     n = lib.hf_conv2d_f16_workspace_floats(b, cin, cout, h, w, stride, groups)
     ws = torch.empty((n,), dtype=torch.float32, device=dev) if n > 0 else None
+    # algorithmic HBM bytes (bench.py: traffic / algorithmic): the input once (a shared input of a grouped launch once), the
+    # output once, a residual once, the weights once
+    nparts = 2 if nterms == 3 else 1
+    n_in = b * (1 if (groups == 1 or x_gstride == 0) else groups)
+    nb = (float(n_in) * cin * h * w * (2.0 * nparts if pre else 4.0) + float(b) * groups * cout * oh * ow * (4.0 + (4.0 if residual is not None else 0.0))
+          + 2.0 * nparts * 9 * cin * cout * groups)
     code = _launch_profiled(
         lib, 2.0 * cin * cout * 9 * oh * ow * b * groups,
         lambda: lib.hf_conv2d_f16_f32(_p(out), None if pre else _p(x), _p(x.hi) if pre else None, _p(x.lo) if pre else None,
                                       _p(wt_hi), _p(wt_lo), nterms, _p(in_scale), _p(in_shift), _p(_c(out_scale)),
                                       _p(_c(bias)), act, _p(_c(slope)), float(alpha), _p(residual), b, cin, cout, h, w, stride,
-                                      groups, x_gstride, _p(ws), max(n, 0), st), tag=",pre" if pre else "")
+                                      groups, x_gstride, _p(ws), max(n, 0), st), tag=",pre" if pre else "", nbytes=nb)
     check(lib, code, "hf_conv2d_f16_f32")
     return out
 
@@ -787,13 +797,17 @@ def conv2d_f16_split(lib, st, x, wt_hi, wt_lo, nterms, cout, stride=1, in_scale=
         residual = _c(residual)
         if tuple(residual.shape) != (b, cout, oh, ow):
             raise ValueError(f"residual {tuple(residual.shape)} != output {(b, cout, oh, ow)}")
+    nparts = 2 if nterms == 3 else 1  # algorithmic HBM bytes: input, split output (+ the fp32 one), residual, weights - each once
+    nb = (float(b) * cin * h * w * (2.0 * nparts if pre else 4.0)
+          + float(b) * cout * oh * ow * (2.0 * nparts + (4.0 if want_f32 else 0.0) + (4.0 if residual is not None else 0.0))
+          + 2.0 * nparts * 9 * cin * cout)
     code = _launch_profiled(
         lib, 2.0 * cin * cout * 9 * oh * ow * b,
         lambda: lib.hf_conv2d_f16_split_f32(_p(out), _p(hi), _p(lo), _p(_c(next_scale)), _p(_c(next_shift)), None if pre else _p(x),
                                             _p(x.hi) if pre else None, _p(x.lo) if pre else None, _p(wt_hi), _p(wt_lo), nterms,
                                             _p(in_scale), _p(in_shift), _p(_c(out_scale)), _p(_c(bias)), act, _p(_c(slope)),
                                             float(alpha), _p(residual), b, cin, cout, h, w, stride, st),
-        tag=",pre,split-out" if pre else ",split-out")
+        tag=",pre,split-out" if pre else ",split-out", nbytes=nb)
     check(lib, code, "hf_conv2d_f16_split_f32")
     return SplitActivation(hi, lo, None), out
 

@@ -168,3 +168,28 @@ def test_bench_gpus2_self_launches_two_ranks():
         r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                             text=True, timeout=300)
         assert r3.returncode != 0 and "GPU(s) visible" in r3.stderr
+
+
+def test_bench_gpus8_dry_run_under_gloo():
+    """The rank count the driver's scaling run uses, before any 8-GPU node exists for it: `python bench.py --gpus 8
+    --workload launch-check` self-launches EIGHT gloo ranks on this container's cores - rendezvous on 127.0.0.1, the max-over-ranks
+    clock, every rank's core slice (len(cpus) // 8, disjoint), and a ragged 29-triple block partition gathered in triple
+    order through parallel.swap_many (shards of 4 and 3, padded gather rounds of 2)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "launch-check", "--steps", "2"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 8 and doc["ranks_observed"] == 8 and doc["gather_ok"] and doc["ragged_swap_many_ok"]
+    assert doc["triples"] == 29 and doc["shards"] == [4, 4, 4, 4, 4, 3, 3, 3] and doc["core_slices_disjoint"]
+    n_cpu = len(os.sched_getaffinity(0))
+    if n_cpu >= 8:
+        assert all(c is not None and c[2] == n_cpu // 8 for c in doc["core_slices_first_last_count"])

@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_rate tools/probes/mfma_rate.hip && ./mfma_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -17,12 +18,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // MODE 2: + 8 ds_read_b128 per 12 MFMAs (double-buffered fragment slots, as the conv kernels), compiler's acc
 // MODE 3: as 2, accumulators in AGPRs
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned long long *cyc) {
+__global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned long long *cyc, int zero) {
   extern __shared__ half8 lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 4096; i += blockDim.x) {
     half8 v;
-    for (int k_ = 0; k_ < 8; ++k_) v[k_] = (_Float16)(0.001f * ((i * 8 + k_) % 97));
+    for (int k_ = 0; k_ < 8; ++k_) v[k_] = zero ? (_Float16)0.0f : (_Float16)(0.001f * ((i * 8 + k_) % 97));
     lds[i] = v;
   }
   __syncthreads();
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, unsigned long
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+static int g_zero = 0;
 template <int MODE>
 void run(const char *name, int threads, int iters) {
   float *out;
@@ -105,10 +107,10 @@ void run(const char *name, int threads, int iters) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 64 * 1024, 0, out, iters, cyc);
+  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 64 * 1024, 0, out, iters, cyc, g_zero);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 64 * 1024, 0, out, iters, cyc);
+  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 64 * 1024, 0, out, iters, cyc, g_zero);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms;
@@ -124,8 +126,12 @@ void run(const char *name, int threads, int iters) {
   hipFree(cyc);
 }
 
-int main() {
-  const int iters = 2000;
+// usage: mfma_rate [iters = 2000] [zero = 0]   zero = 1: all-zero operands (MI355X_MICROARCH.md, DVFS give-back: the chip clocks higher
+// on zero data); iters sets the loop's duration (2000 = 4-8 ms; 50 = 0.1-0.2 ms, before the power management reacts; 200000 = 0.4-0.8 s)
+int main(int argc, char **argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 2000;
+  g_zero = argc > 2 ? atoi(argv[2]) : 0;
+  printf("iters %d, %s operands\n", iters, g_zero ? "ZERO" : "non-zero");
   for (int threads : {512, 256}) {
     run<0>("MFMA only, acc by the compiler", threads, iters);
     run<1>("MFMA only, acc in AGPRs", threads, iters);
