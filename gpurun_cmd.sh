@@ -1,18 +1,11 @@
-# GPU call r06p: clock / power telemetry of OUR GPU (PCI address of HIP device 0)
+# GPU call r06r: the pipeline golden's target-mask flips with the shape adaptor's decoders in exact fp32 (tail 2 / all 8) and with the whole swap in f32
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-O=gpurun_out/r06p_clock_power.txt
-{
-echo "# sysfs telemetry (tools/probes/clock_power.py) of HIP device 0 - one MI355X box"
-python -c "import torch; p = torch.cuda.get_device_properties(0); print(p)"
-timeout 60 rocm-smi --showbus 2>&1 | grep -i "GPU\[" | head
-echo "== MFMA-only probe, 200000 iterations (0.4-0.8 s per mode), non-zero operands"
-python tools/probes/clock_power.py --interval 0.02 --label mfma200k -- tools/probes/bin/mfma_rate 200000 0
-echo "== MFMA-only probe, 200000 iterations, ZERO operands"
-python tools/probes/clock_power.py --interval 0.02 --label mfma200k-zero -- tools/probes/bin/mfma_rate 200000 1
-echo "== bench.py generator workload, 300 timed steps, no per-kernel events"
-python tools/probes/clock_power.py --interval 0.02 --label bench-generator -- python bench.py --no-cpu-baseline --no-exact-f32 --swap-triples 0 --steps 300 --warmup 5 --no-kernel-events
-echo "== bench.py swap256 workload, 64 triples at 32 per pass"
-python tools/probes/clock_power.py --interval 0.02 --label bench-swap -- python bench.py --workload swap256 --triples 64 --swap-batch 32 --warmup 1 --no-kernel-events --no-cpu-baseline
-} > $O 2>&1
-grep -v "^{\|MFMA only\|ds_read" $O | cut -c1-250
+O=gpurun_out/r06r_target_mask_flips.txt
+: > $O
+for cfg in "default" "HAIRFAST_SHAPE_EXACT_TAIL=2" "HAIRFAST_SHAPE_EXACT_TAIL=8" "HAIRFAST_CONV_PRECISION=f32"; do
+  echo "== $cfg" >> $O
+  if [ "$cfg" = default ]; then e=""; else e="$cfg"; fi
+  env $e python -m pytest tests/test_gpu_pipeline.py -x -q -m gpu -s -k "stage_classes" 2>&1 | grep -i "mask index\|target mask\|passed\|failed\|Error" >> $O
+done
+cat $O

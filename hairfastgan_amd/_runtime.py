@@ -215,7 +215,10 @@ def set_batch_invariant(on):
 
 class batch_invariant_scope:
     """`with batch_invariant_scope(on):` - batch-invariant plans on / off for the calls inside (None: no change); what
-    `HairFast(args, batch_invariant=...)` wraps its calls in, like conv_precision_scope."""
+    `HairFast(args, batch_invariant=...)` wraps its calls in, like conv_precision_scope.  NOT thread-safe either: the flag is
+    process-wide (this module's global and the library's g_batch_invariant) - two HairFast objects with different settings
+    running in different threads would change each other's plans mid-call and silently lose batch invariance; run such
+    objects from one thread (the per-thread split-K counter registration does not change that)."""
 
     def __init__(self, on):
         self.on, self.prev = on, None

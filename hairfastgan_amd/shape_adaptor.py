@@ -21,15 +21,19 @@ How the layers run:
 Inference only; the VAE resampling branch of the hair encoder is not used at test time (solver.py:254, testing=True).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from . import _marshal as M
-from ._runtime import batch_invariant, lib, require_gpu, stream
+from ._runtime import batch_invariant, conv_precision_scope, lib, require_gpu, stream
 from .encoders._fused import FrozenPlanMixin, PreparedConv, conv, patches
 
+# Trailing MaskDecoder convolutions (of eight) that run with exact fp32 products whatever the process-wide mode
+# (HAIRFAST_SHAPE_EXACT_TAIL; tools/probes/shape_adaptor_flips.py measures the label-map flips against the reference golden)
+EXACT_TAIL = int(os.environ.get("HAIRFAST_SHAPE_EXACT_TAIL", "0"))
 HAIR_IDX = 13  # models/CtrlHair/global_value_utils.py:49-52 (PARSING_LABEL_LIST.index('hair'))
 
 
@@ -209,9 +213,20 @@ class MaskDecoder(FrozenPlanMixin, nn.Module):  # model.py:118-146
     def forward(self, input_vector):
         L, st = lib(), stream()
         x = self.in_layer(input_vector).reshape(-1, self.in_channel, self.input_size, self.input_size)
+        # EXACT_TAIL: the last n of the decoder's eight convolutions (seven blocks + the logit layer) with exact fp32 products
+        # (fp32 MFMA) whatever the process-wide mode: what feeds the label-map argmax directly
+        convs = [m for m in self.layers if not isinstance(m, nn.Upsample)]
+        exact_from = len(convs) + 1 - EXACT_TAIL
+        seen = 0
         for layer in self.layers:
-            x = M.upsample_nearest(L, st, x, 2 * x.shape[2], 2 * x.shape[3]) if isinstance(layer, nn.Upsample) else layer(x)
-        return self.out_layer(x)
+            if isinstance(layer, nn.Upsample):
+                x = M.upsample_nearest(L, st, x, 2 * x.shape[2], 2 * x.shape[3])
+            else:
+                with conv_precision_scope("f32" if seen >= exact_from else None):
+                    x = layer(x)
+                seen += 1
+        with conv_precision_scope("f32" if EXACT_TAIL >= 1 else None):
+            return self.out_layer(x)
 
 
 class MaskGenerator(nn.Module):

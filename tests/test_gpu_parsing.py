@@ -143,8 +143,10 @@ def test_shape_adaptor_vs_reference_golden(golden):
         margin = torch.from_numpy(G[f"margin_{b}"].astype("float32")).to(dev)
         for lab in (out[b, 0], get_new_shape(gen, face_code, hair_code)):
             flips = lab != ref_lab
-            assert float(flips.float().mean()) < 1e-3
-            assert int(flips.sum()) == 0 or float(margin[flips].max()) < 2e-3 * max(1.0, abs(scale)), (int(flips.sum()), float(margin[flips].max()))
+            # (observed: 0 flips in f16x3 - the default -, 1 in f32 mode at a reference margin of 1.7e-5: tools/probes/shape_adaptor_flips.py,
+            # profiles/r06q_shape_adaptor_flips.txt)
+            assert int(flips.sum()) <= 2
+            assert int(flips.sum()) == 0 or float(margin[flips].max()) < 1e-4 * max(1.0, abs(scale)), (int(flips.sum()), float(margin[flips].max()))
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 256, 256), (1, 203, 317)])

@@ -127,16 +127,18 @@ def test_swap_vs_reference_stage_classes(golden):
         flips[f"target_mask_{nm}"] = int((targets[row, 0].cpu() != torch.from_numpy(G[f"target_mask_{nm}"].astype(np.int64))).sum())
     print("mask index differences vs the reference:", flips)
     # BiSeNet's five masks (3 x 512^2 inputs, 2 x 1024^2 generated images): every index equal.  The shape adaptor's label maps
-    # are an argmax over the mask generator's 19 class scores: observed 1 of 65 536 indices different per map, allowed only
-    # where the REFERENCE's own top-1 / top-2 score margin is a near-tie (<= 2e-3), and never on the hair / non-hair decision
-    # (HM_X, the only thing the rest of the swap derives from these maps, must be bit-equal).
+    # are an argmax over the mask generator's 19 class scores: observed 1 of 65 536 indices different per map - at a pixel where
+    # the REFERENCE's own top-1 / top-2 scores are an exact tie (margin 0.0; profiles/r06r_target_mask_flips.txt: the same one
+    # pixel per map with the adaptor's decoders, or the whole swap, on exact fp32 products - only the reference's own summation
+    # order would reproduce its tie-break).  Allowed: <= 2 per map, only at margins <= 1e-4, and never on the hair / non-hair
+    # decision (HM_X, the only thing the rest of the swap derives from these maps, must be bit-equal).
     assert DEBUG or all(v == 0 for k, v in flips.items() if not k.startswith("target_")), flips
     for row, nm in enumerate(("shape", "color")):
         diff = targets[row, 0].cpu() != torch.from_numpy(G[f"target_mask_{nm}"].astype(np.int64))
         if bool(diff.any()):
             margin = torch.from_numpy(G[f"target_margin_{nm}"].astype(np.float32))[diff]
             print(f"  target mask {nm}: {int(diff.sum())} index(es) differ, reference margin(s) {[round(float(m_), 5) for m_ in margin]}")
-            assert DEBUG or (int(diff.sum()) <= 4 and float(margin.max()) <= 2e-3), (nm, int(diff.sum()), float(margin.max()))
+            assert DEBUG or (int(diff.sum()) <= 2 and float(margin.max()) <= 1e-4), (nm, int(diff.sum()), float(margin.max()))
     al = rec["align"][0][0]
     hm = np.packbits((al["HM_X"][0, 0] > 0.5).cpu().numpy().astype(np.uint8))
     assert np.array_equal(hm, G["HM_X_shape"])
