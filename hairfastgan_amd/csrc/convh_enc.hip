@@ -855,8 +855,11 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
   }
   const size_t lds = (size_t)2 * NPART * (9 * 2 * CT + 2 * NPIX) * 16 + 2 * ((P.cin + 3) & ~3) * sizeof(float);
   if (lds > 160 * 1024) return HF_E_INVALID;
-  if (plan_only) return HF_OK;
+  // (every rejection of the tile form sits above the plan-only return: a query - hf_conv2d_f16_workspace_floats,
+  // hf_conv2d_f16_split_output_ok, which plans with P.oh set - walks the same fall-through chain as the launch)
   if (P.oh && ((P.splits > 1 && !P.vsplit) || groups > 1)) return HF_E_INVALID;  // split output: written by this kernel's own epilogue only
+  if (P.xh && ((long long)2 * P.h * P.w * 16 >= (1LL << 31) || (NTERMS == 3 && !P.xl))) return HF_E_INVALID;
+  if (plan_only) return HF_OK;
   if (P.splits > 1 && !P.vsplit) {
     if (!workspace || workspace_floats < P.splits * P.zslab) return HF_E_WORKSPACE;
     P.partial = workspace;
@@ -864,7 +867,6 @@ int launch_enc(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, float *w
   }
   g_s2mt_last = 0;
   if (P.xh) {
-    if ((long long)2 * P.h * P.w * 16 >= (1LL << 31) || (NTERMS == 3 && !P.xl)) return HF_E_INVALID;
     if constexpr (STRIDE == 2 && HF_ENC_S2MT > 1) {
       // several pixel tiles per resident weight stage (conv_enc_s2mt_h) when the launch still fills the chip with MT times
       // fewer blocks (hf_debug_set_tuning bits 24-31 lower "the chip" for tests) and its K loop is not spread over the grid
@@ -950,7 +952,10 @@ int run_enc_forms(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *
   // bits 16-23 = the minimum block count / 8 of the 256-pixel form
   const int min512 = ((g_h_tune >> 8) & 255) > 0 ? ((g_h_tune >> 8) & 255) * 8 : 512;
   const int min256 = ((g_h_tune >> 16) & 255) > 0 ? ((g_h_tune >> 16) & 255) * 8 : 384;
-  if (NTERMS == 3 && !(g_h_tune & 4) && blocks512 >= min512) {  // plain fp16 operands: staging-bound, measured slower
+  // (a given K partition of more than one slab - batch-invariant plans - on the register-staged 512-pixel form cannot run
+  // virtually: it would spread force_splits slabs of the whole batched output over the grid plus a reduce pass; the 256-pixel
+  // form below walks them inside its blocks - same bits)
+  if (NTERMS == 3 && !(g_h_tune & 4) && blocks512 >= min512 && !(force_splits > 1 && !P.xh)) {  // plain fp16 operands: staging-bound, measured slower
     rc = launch_enc<NTERMS, 2, 8, 1, 2, 1>(P, hi, lo, ws, wsn, st, plan_only, force_splits);
     if (rc == HF_OK && !plan_only) note_path(6, 4);
   }
@@ -973,6 +978,7 @@ int run_enc(ConvParams &P, const _Float16 *hi, const _Float16 *lo, float *ws, lo
   if (g_batch_invariant) {
     ConvParams C = P;
     C.batch = kCanonBatch;
+    C.oh = C.ol = nullptr;  // only the canonical K partition is wanted: whether THIS launch can write a split output is decided below
     const int rc = run_enc_forms<NTERMS>(C, hi, lo, nullptr, 0, st, true, 0);
     if (rc != HF_OK) return rc;
     force = C.splits;
@@ -1119,6 +1125,7 @@ extern "C" int hf_conv2d_f16_split_output_ok(int batch, int cin, int cout, int h
                cin, cout, h, w, stride, 1, 0) != HF_OK)
     return 0;
   if (presplit_input) P.xh = P.xl = &P;  // only tested for NULL while planning
+  P.oh = &P;                             // a split output is wanted: forms that cannot write one are skipped like in the launch
   const int rc = (nterms == 3) ? run_enc<3>(P, nullptr, nullptr, nullptr, 0, nullptr, true) : run_enc<1>(P, nullptr, nullptr, nullptr, 0, nullptr, true);
   return (rc == HF_OK && !(P.splits > 1 && !P.vsplit)) ? 1 : 0;
 }

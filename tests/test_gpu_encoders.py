@@ -560,3 +560,52 @@ def test_split_k_reduce_is_batch_invariant_on_ragged_sizes():
         close(y13, ref, 2e-5)
     finally:
         _runtime.set_batch_invariant(prev)
+
+
+def test_unit_chain_on_hardware_equals_unit_after_unit(golden, monkeypatch):
+    """The unit -> unit hand-off of the pre-split first-conv input (encoders/_fused.py USE_CHAIN: hf_scale_shortcut_add_split_f16,
+    the second conv's split epilogue) against every unit converting its own input, on the GPU: e4e (IR-SE units), the FS encoder
+    (IBasicBlocks) and BiSeNet (BasicBlocks) bit for bit - hipcc's floating-point contraction, not the host compiler's
+    (tests/test_sim_encoders.py covers the same claim on hipsim only)."""
+    from hairfastgan_amd.encoders import Encoder4Editing, FSEncoder, _fused, get_latents
+    from hairfastgan_amd.face_parsing import BiSeNet
+
+    dev = _dev()
+    enc = Encoder4Editing(50, "ir_se", argparse.Namespace(stylegan_size=1024))
+    enc = _load(enc, C.params_from_shapes("e4e", E.e4e_param_shapes()), dev, strip=0)
+    x, latent_avg = C.e4e_inputs(3)
+    net = argparse.Namespace(encoder=enc, opts=argparse.Namespace(start_from_latent_avg=True), latent_avg=latent_avg.to(dev))
+    fs = FSEncoder()
+    _load(fs.enc, C.params_from_shapes("fs", E.fs_param_shapes()), dev, strip=0)
+    fs = fs.to(dev)
+    img, dlat = C.fs_inputs(2)
+    fs.dlatent_avg.copy_(dlat)
+    torch.manual_seed(5)
+    bise = BiSeNet(19).eval()
+    for p in bise.parameters():  # any finite parameters do: the two forms must agree bit for bit on them
+        p.data.normal_(0.0, 0.05)
+    for name, buf in bise.named_buffers():
+        if name.endswith("running_var"):
+            buf.fill_(1.0)
+    bise = bise.to(dev)
+    face = torch.rand(2, 3, 512, 512, device=dev)
+
+    def run():
+        for m in (enc, fs.enc, bise):  # plans remember the chain decision: rebuild them under each setting
+            for sub in m.modules():
+                if hasattr(sub, "_plan"):
+                    sub._plan = None
+                sub.__dict__.pop("_frozen_plan", None)
+        with torch.inference_mode():
+            w = get_latents(net, x.to(dev))
+            out = fs.test(img=img.to(dev), return_latent=True)
+            logits = bise(face)
+            logits = logits[0] if isinstance(logits, (tuple, list)) else logits
+        return w.clone(), out[2].clone(), out[3].clone(), logits.clone()
+
+    monkeypatch.setattr(_fused, "USE_CHAIN", True)
+    on = run()
+    monkeypatch.setattr(_fused, "USE_CHAIN", False)
+    off = run()
+    for a, b, what in zip(on, off, ("e4e W+", "FS encoder S", "FS encoder content", "BiSeNet logits")):
+        assert torch.equal(a, b), (what, float((a - b).abs().max()))
