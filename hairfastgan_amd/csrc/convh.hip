@@ -1375,9 +1375,11 @@ extern "C" int hf_modconv3x3_up_blur_f16_f32(float *out, void *split_hi, void *s
   // 752 vs 602 us on the 1024^2 layer, 546 vs 432, 449 vs 424: every block stages the full weight stage - twice the LDS-DMA
   // issues per wave - and recomputes 43 % instead of 22 % halo.  Not kept.)
   int rc;
-  if (nterms == 3 && x_hi && (hf_detail::g_h_tune & 32))  // <1,1,1,16>: the same tile, SIXTEEN waves x one row - four waves per SIMD
-    rc = launch_h<3, 1, 1, 1, 16, true, 32, true, true>(P, hi, lo, (hipStream_t)stream);
-  else if (nterms == 3)
+  // (Round 6, measured and rejected: <1,1,1,16> - the same tile as SIXTEEN waves x one row, four waves per SIMD at 128 registers,
+  // so that the VALU-issue-bound epilogue runs at 2 instead of 3 cycles per instruction (tools/probes/valu_rate.hip): 806 / 519 /
+  // 500 us against 670 / 440 / 400 - the A fragment is then read once per 3 instead of 6 MFMAs, the one-phase K loop returns, and
+  // the kernel spills 212 bytes per lane.  profiles/r06g_fuse_16_waves.txt.  The kernel template still instantiates for it.)
+  if (nterms == 3)
     rc = x_hi ? launch_h<3, 1, 2, 1, 8, true, 32, true, true>(P, hi, lo, (hipStream_t)stream)
               : launch_h<3, 1, 2, 1, 8, true, 32, false, true>(P, hi, lo, (hipStream_t)stream);
   else
