@@ -8,6 +8,8 @@ The public ops in ``hairfastgan_amd.op`` / ``hairfastgan_amd.stylegan2`` call
 these with the HIP library and the current HIP stream after checking that all
 tensors live on the GPU.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -414,6 +416,42 @@ def modconv3x3_small(lib, st, x, w9, nterms, s, d, noise, noise_w, bias, cout, a
     return out
 
 
+SMALL_UP_FUSED = os.environ.get("HAIRFAST_SMALL_UP_FUSED", "1") != "0"  # 0: tap GEMM, combine pass, blur pass (A/B, tests)
+
+
+def small_up_blur_supported(h, w):
+    """hf_modconv3x3_small_up_blur_f16_f32's LDS bound: 8 channels x ((2h+3) x (2w+3) + 9 h w) floats."""
+    return (8 * (2 * h + 3) * (2 * w + 3) + 72 * h * w) * 4 <= 150 * 1024
+
+
+def modconv3x3_small_up_blur(lib, st, x, w9, nterms, s, d, blur_kernel, noise, noise_w, bias, cout, alpha=0.2, scale=SQRT2,
+                             split_for=None):
+    """hf_modconv3x3_small_up_blur_f16_f32: the small-plane upsampling StyledConv as tap GEMM + one combine / blur / tail kernel.
+    split_for as in modconv3x3_up: None -> the fp32 activation [B,cout,2h,2w]; (key, s_next[, want_lo]) -> SplitActivation."""
+    x = _c(x)
+    b, cin, h, w = x.shape
+    hi, lo = w9
+    n = lib.hf_modconv3x3_small_workspace_floats(b, cin, cout, h, w)
+    ws = x.new_empty((max(n, 1),))
+    noise, nbs = _noise_args(noise, b, 4 * h * w)
+    out = sh = sl = s_next = key = None
+    if split_for is not None:
+        key, s_next = split_for[0], _c(split_for[1])
+        want_lo = split_for[2] if len(split_for) > 2 else True
+        sh = torch.empty((b, cout // 8, 2 * h, 2 * w, 8), dtype=torch.float16, device=x.device)
+        sl = torch.empty_like(sh) if want_lo else None
+    else:
+        out = x.new_empty((b, cout, 2 * h, 2 * w))
+    code = _launch_profiled(
+        lib, 2.0 * cin * cout * 9 * h * w * b,
+        lambda: lib.hf_modconv3x3_small_up_blur_f16_f32(_p(out), _p(sh), _p(sl), _p(x), _p(hi), _p(lo), nterms, _p(_c(s)), _p(_c(d)),
+                                                        _p(_c(blur_kernel)), _p(noise), _p(_c(noise_w)), nbs, _p(_c(bias)),
+                                                        _p(s_next), b, cin, cout, h, w, alpha, scale, _p(ws), n, st),
+        label="gemm_h tap-GEMM (small planes)")
+    check(lib, code, "hf_modconv3x3_small_up_blur_f16_f32")
+    return out if split_for is None else SplitActivation(sh, sl, key)
+
+
 def modconv3x3_up_f16_supported(cin, cout, h, w, batch=None):
     """Shapes hf_modconv3x3_up_f16_f32 takes (include/hairfast_hip.h); batch: see modconv3x3_f16_supported (a batch-1
     16^2 -> 32^2 layer: 84 us on the fp32 split-K kernels, 106 us here)."""
@@ -445,6 +483,10 @@ def modconv3x3_up(lib, st, x, wt, s, d, blur_kernel, noise, noise_w, bias, alpha
     b, cin, h, w = x.shape
     cout = wt.shape[2]
     pitch = lib.hf_modconv_up_pitch(w)  # rows padded to a multiple of 4 floats (aligned 16 B loads in the blur)
+    if small is not None and not pre and SMALL_UP_FUSED and small_up_blur_supported(h, w):
+        # round 6: tap GEMM + ONE combine / blur / tail kernel (the (2h+1)^2 intermediate stays in LDS) - same bits
+        return modconv3x3_small_up_blur(lib, st, x, small[0], small[1], s, d, blur_kernel, noise, noise_w, bias, cout, alpha, scale,
+                                        split_for=split_for)
     if small is not None and not pre:
         tmp = modconv3x3_small(lib, st, x, small[0], small[1], s, d, None, None, None, cout, upsample=True)
     else:

@@ -441,6 +441,7 @@ __global__ __launch_bounds__(256) void small_combine(float *__restrict__ out, co
   }
 }
 
+typedef _Float16 hf_half8_g __attribute__((ext_vector_type(8)));
 extern "C" int hf_split_activation_mod_f16(void *out_hi, void *out_lo, const float *x, const float *scale, long long images,
                                            int channels, int h, int w, void *stream);
 
@@ -511,6 +512,177 @@ extern "C" int hf_modconv3x3_small_f16_f32(float *out, const float *x, const voi
   hipLaunchKernelGGL(small_combine, dim3((int)g), dim3(256), 0, (hipStream_t)stream, out, workspace, P.vsplit ? 1 : P.splits, P.zslab, d, noise,
                      noise_w, noise_bstride, bias, batch, cout, h, w, upsample ? 1 : 0, out_h, pitch, wv, alpha, scale);
   note_path(7, upsample ? 4 : 3);
+  return hf_launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 6: the small-plane UPSAMPLING StyledConv in two launches instead of four.  After the tap GEMM, ONE kernel per
+// (image, 8-channel block) builds the demodulated (2h+1) x (2w+1) intermediate of small_combine's transposed form in LDS
+// (with a zero border: the blur's pad (1,1)), blurs it and applies noise + bias + leaky ReLU, and writes either the fp32
+// activation or - for a consumer on the fp16 matrix cores - s_next * out split into fp16 (hi, lo) K-blocked units.  The
+// intermediate (17.8 MB at 16^2 -> 32^2, batch 8) never goes to memory: small_combine (69 us there) + blur4x4_split8 (27 us)
+// become ~30 us.  Arithmetic = small_combine (up) followed by blur4x4_noise_bias_act / blur4x4_split8, operation for
+// operation: bit-identical to the three-launch path (tests/test_sim_generator.py, tests/test_gpu_parity.py).
+template <bool SPLIT>
+__global__ __launch_bounds__(1024) void small_up_blur(float *__restrict__ out, hf_half8_g *__restrict__ out_hi,
+                                                      hf_half8_g *__restrict__ out_lo, const float *__restrict__ y, int splits,
+                                                      long long zslab, const float *__restrict__ d,
+                                                      const float *__restrict__ kernel4x4, const float *__restrict__ noise,
+                                                      const float *__restrict__ noise_w, long long noise_bstride,
+                                                      const float *__restrict__ bias, const float *__restrict__ s_next, int cout,
+                                                      int h, int w, float alpha, float scale) {
+#pragma clang fp contract(on)  // as small_combine: no cross-statement fusion
+  HF_DYN_LDS;
+  const int th = 2 * h + 3, tw = 2 * w + 3, tplane = th * tw, iplane = h * w;
+  float *T = reinterpret_cast<float *>(hf_dyn_lds);  // [8][2h+3][2w+3]: rows / columns -1 .. 2h+1 (2w+1) of the intermediate
+  float *V = T + 8 * tplane;                         // [8][9][h*w]: the tap planes of the block's channels, K slabs added
+  const int cblocks = cout >> 3;
+  const int b = blockIdx.x / cblocks, cb = blockIdx.x - b * cblocks;
+  constexpr int NT = 1024;  // sixteen waves: the block is alone on its CU (113 KB of LDS at 16 x 16) and its work is index
+                            // arithmetic + latency - four waves per SIMD issue VALU at 2 instead of 3 cycles (tools/probes/valu_rate.hip)
+  // Index walks without per-element divisions (a runtime division is ~40 VALU instructions: the first form of this kernel
+  // spent most of its 65 us on them): (q, p) = (i / n, i % n) advanced by NT with carries.
+  // ---- phase 0: V[ct][p] = sum_z y[z][b][tap*cout + co][p], ct = c*9 + tap, z ascending from 0 (small_combine's inner
+  // loop); coalesced loads, four elements per thread in flight together
+  {
+    const int qs = NT / iplane, ps = NT - qs * iplane;
+    int ct = threadIdx.x / iplane, p = threadIdx.x - ct * iplane;
+    while (ct < 72) {
+      const float *src[4];
+      float t[4];
+      int vi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = min(ct, 71);                    // (clamped: surplus elements of the last pass re-read a valid one)
+        const int c = cc / 9, tap = cc - c * 9;
+        src[u] = y + ((long long)b * 9 * cout + (long long)tap * cout + cb * 8 + c) * iplane + p;
+        vi[u] = ct < 72 ? ct * iplane + p : -1;
+        t[u] = 0.0f;
+        ct += qs;
+        p += ps;
+        if (p >= iplane) {
+          p -= iplane;
+          ++ct;
+        }
+      }
+      for (int z = 0; z < splits; ++z) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] += src[u][(long long)z * zslab];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (vi[u] >= 0) V[vi[u]] = t[u];
+    }
+  }
+  __syncthreads();
+  // ---- phase 1: T[c][Y][X] = d * sum over the taps (ky, kx ascending) that reach (Y, X)  (small_combine, up = 1), zero outside
+  {
+    const int dy = NT / tw, dx = NT - dy * tw;
+    int c = threadIdx.x / tplane, r = threadIdx.x - c * tplane;
+    int ry = r / tw, rx = r - ry * tw;
+    while (c < 8) {
+      const int oy = ry - 1, ox = rx - 1;
+      float v = 0.0f;
+      if (oy >= 0 && oy <= 2 * h && ox >= 0 && ox <= 2 * w) {
+        float acc = 0.0f;
+        const float *vb = V + c * 9 * iplane;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int ty = oy - ky, tx = ox - kx;
+            const bool ok = ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) && (ty >> 1) < h && (tx >> 1) < w;
+            if (ok) acc += vb[(ky * 3 + kx) * iplane + (ty >> 1) * w + (tx >> 1)];
+          }
+        v = acc * (d ? d[(long long)b * cout + cb * 8 + c] : 1.0f);
+      }
+      T[c * tplane + ry * tw + rx] = v;
+      rx += dx;
+      ry += dy;
+      if (rx >= tw) {
+        rx -= tw;
+        ++ry;
+      }
+      while (ry >= th) {
+        ry -= th;
+        ++c;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: 4x4 blur (true convolution: flipped taps), noise, bias, leaky ReLU; tap order of blur4x4_noise_bias_act
+  float kf[4][4];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) kf[ky][kx] = kernel4x4[(3 - ky) * 4 + (3 - kx)];
+  const int out_h = 2 * h, out_w = 2 * w;
+  const float nw = noise ? noise_w[0] : 0.0f;
+  const float *nz = noise ? noise + (long long)b * noise_bstride : nullptr;
+  bool ovf = false;
+  for (int p = threadIdx.x; p < out_h * out_w; p += NT) {
+    const int oy = p / out_w, ox = p - oy * out_w;
+    const float nzr = nz ? nz[(long long)oy * out_w + ox] : 0.0f;
+    float res[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float *win = T + c * tplane + oy * tw + ox;  // window rows oy-1 .. oy+2 = T rows oy .. oy+3 (border offset 1)
+      float acc = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = fmaf(win[r * tw + j], kf[r][j], acc);
+      if (nz) acc = fmaf(nw, nzr, acc);
+      if (bias) acc = hf_lrelu(acc + bias[cb * 8 + c], alpha, scale);
+      res[c] = acc;
+    }
+    if (!SPLIT) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) out[(((long long)b * cout + cb * 8 + c) * out_h + oy) * out_w + ox] = res[c];
+    } else {
+      hf_half8_g h8, l8;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float v = res[c] * (s_next ? s_next[(long long)b * cout + cb * 8 + c] : 1.0f);
+        _Float16 hv, lv;
+        hf_split_f16(v, hv, lv, ovf);
+        h8[c] = hv;
+        l8[c] = lv;
+      }
+      const long long unit = (((long long)b * cblocks + cb) * out_h + oy) * out_w + ox;
+      out_hi[unit] = h8;
+      if (out_lo) out_lo[unit] = l8;
+    }
+  }
+  if (SPLIT) hf_note_overflow(ovf);
+}
+
+extern "C" int hf_modconv3x3_small_up_blur_f16_f32(float *out, void *out_hi, void *out_lo, const float *x, const void *w9_hi,
+                                                   const void *w9_lo, int nterms, const float *s, const float *d,
+                                                   const float *blur_kernel4x4, const float *noise, const float *noise_w,
+                                                   long long noise_bstride, const float *bias, const float *s_next, int batch,
+                                                   int cin, int cout, int h, int w, float alpha, float scale, float *workspace,
+                                                   long long workspace_floats, void *stream) {
+  if ((!out == !out_hi) || !x || !w9_hi || !blur_kernel4x4 || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 ||
+      (nterms != 1 && nterms != 3) || (nterms == 3 && !w9_lo) || (cin % KS) || (cout % 64) || (noise && !noise_w) || h * w > 1024 ||
+      (long long)batch * (cout >> 3) > 0x7fffffffLL)
+    return HF_E_INVALID;  // exactly one output form
+  const size_t lds = ((size_t)8 * (2 * h + 3) * (2 * w + 3) + (size_t)72 * h * w) * sizeof(float);  // T + the tap planes
+  if (lds > 150 * 1024) return HF_E_INVALID;  // (16 x 16 inputs: 113 KB; the generator's small-plane layers stop there)
+  ConvParams P;
+  const int rc = small_gemm(P, w9_hi, w9_lo, nterms, x, s, batch, cin, cout, h, w, workspace, workspace_floats, (hipStream_t)stream);
+  if (rc != HF_OK) return rc;
+  const int splits = P.vsplit ? 1 : P.splits;
+  const dim3 grid(batch * (cout >> 3));
+  if (out_hi)
+    hipLaunchKernelGGL(small_up_blur<true>, grid, dim3(1024), lds, (hipStream_t)stream, nullptr, static_cast<hf_half8_g *>(out_hi),
+                       static_cast<hf_half8_g *>(out_lo), workspace, splits, P.zslab, d, blur_kernel4x4, noise, noise_w, noise_bstride,
+                       bias, s_next, cout, h, w, alpha, scale);
+  else
+    hipLaunchKernelGGL(small_up_blur<false>, grid, dim3(1024), lds, (hipStream_t)stream, out, nullptr, nullptr, workspace, splits,
+                       P.zslab, d, blur_kernel4x4, noise, noise_w, noise_bstride, bias, nullptr, cout, h, w, alpha, scale);
+  note_path(7, 5);
   return hf_launch_status();
 }
 

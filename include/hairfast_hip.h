@@ -414,6 +414,20 @@ int hf_modconv3x3_small_f16_f32(float *out, const float *x, const void *w9_hi, c
                                 const float *bias, int batch, int cin, int cout, int h, int w, float alpha, float scale,
                                 int upsample, int tmp_pitch, float *workspace, long long workspace_floats, void *stream);
 long long hf_modconv3x3_small_workspace_floats(int batch, int cin, int cout, int h, int w);
+/* The small-plane UPSAMPLING StyledConv in two launches (round 6, ABI 12): hf_modconv3x3_small_f16_f32(upsample = 1) followed by
+ * hf_blur_noise_bias_act_f32 (out != NULL) or hf_blur_noise_bias_act_split_f16 (out_hi != NULL; out_lo NULL for an nterms-1
+ * consumer) - F.conv_transpose2d stride 2, Blur, NoiseInjection, FusedLeakyReLU of the upsampling StyledConv
+ * (models/stylegan2/model.py:252-263, :337-343) - with the (2h+1)^2 intermediate kept in LDS: after the tap GEMM one kernel per
+ * (image, 8-channel block) combines the taps, blurs and applies the tail.  Exactly one of out [batch,cout,2h,2w] / out_hi;
+ * s_next [batch,cout] (NULL = 1): the consumer's modulation, multiplied in before the split.  blur_kernel4x4: the module's
+ * [4][4] blur buffer (applied flipped: a true convolution, op/upfirdn2d.py:186).  Results equal the three-launch path bit for
+ * bit.  (8*(2h+3)*(2w+3) + 72*h*w) floats of LDS <= 150 KB (inputs up to 16 x 16 + a little); workspace as hf_modconv3x3_small_f16_f32. */
+int hf_modconv3x3_small_up_blur_f16_f32(float *out, void *out_hi, void *out_lo, const float *x, const void *w9_hi,
+                                        const void *w9_lo, int nterms, const float *s, const float *d,
+                                        const float *blur_kernel4x4, const float *noise, const float *noise_w,
+                                        long long noise_bstride, const float *bias, const float *s_next, int batch, int cin,
+                                        int cout, int h, int w, float alpha, float scale, float *workspace,
+                                        long long workspace_floats, void *stream);
 /* in_scale[c]*x + in_shift[c] (NULL = identity) split into fp16 pairs hi = fp16(v), lo = fp16(v - hi)
  * (saturating, hf_f16_overflow_count) and K-blocked: out_hi / out_lo [images][channels/8][h][w][8];
  * x [images][channels][h][w] fp32, channels % 8 == 0.  out_lo may be NULL (nterms 1 consumer).

@@ -47,7 +47,7 @@ def test_native_library_is_loaded():
     from hairfastgan_amd import _lib
 
     lib = _lib.load()
-    assert lib.hf_abi_version() == 11
+    assert lib.hf_abi_version() == 12
     maps = open("/proc/self/maps").read()
     assert "libhairfast_hip.so" in maps
 
@@ -961,3 +961,32 @@ def test_generator1024_block_order_does_not_change_the_image():
     finally:
         L.hf_debug_set_tuning(0)
     assert torch.isfinite(ref).all() and torch.equal(y, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,h", [(8, 4), (8, 8), (8, 16), (3, 16), (1, 8)])
+def test_small_plane_upsampling_in_two_launches_equals_three(B, h, monkeypatch):
+    """hf_modconv3x3_small_up_blur_f16_f32 on the hardware: the generator's 4^2 / 8^2 / 16^2 upsampling StyledConvs (512 -> 512) as
+    tap GEMM + one combine / blur / tail kernel against tap GEMM + small_combine + blur pass, fp32 and split outputs: equal bits."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = torch.device("cuda:0")
+    L, st = lib(), stream()
+    torch.manual_seed(h)
+    c = 512
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0).to(dev)
+    x, wgt = torch.randn(B, c, h, h, device=dev), torch.randn(1, c, c, 3, 3, device=dev)
+    s, d, s2 = (torch.rand(B, c, device=dev) + 0.5 for _ in range(3))
+    nz, nw, bias = torch.randn(B, 1, 2 * h, 2 * h, device=dev), torch.tensor([0.3], device=dev), torch.randn(c, device=dev)
+    wt, _ = M.prepare_weights(L, st, wgt)
+    w9 = M.split_weights_small(L, st, wt)
+    for split_for in (None, (None, s2, True)):
+        res = {}
+        for fused in (False, True):
+            monkeypatch.setattr(M, "SMALL_UP_FUSED", fused)
+            res[fused] = M.modconv3x3_up(L, st, x, wt, s, d, k4, nz, nw, bias, split_for=split_for, small=(w9, 3))
+        if split_for is None:
+            assert torch.equal(res[False], res[True])
+        else:
+            assert torch.equal(res[False].hi, res[True].hi) and torch.equal(res[False].lo, res[True].lo)

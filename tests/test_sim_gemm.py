@@ -159,3 +159,36 @@ def test_split_k_in_kernel_reduction_equals_the_second_pass(simlib):
     nz, nw, bias = torch.randn(1, 1, 8, 8), torch.tensor([0.3]), torch.randn(64)
     assert simlib.hf_modconv_workspace_floats(2, 64, 64, 8, 8, 0) > 0
     both(lambda: M.modconv3x3(simlib, None, xm, wt, s, d, nz, nw, bias, 0.2, 2 ** 0.5))
+
+
+def test_small_plane_upsampling_styledconv_in_two_launches(simlib, monkeypatch):
+    """hf_modconv3x3_small_up_blur_f16_f32 (round 6: tap GEMM + ONE combine / blur / tail kernel, the (2h+1)^2 intermediate in
+    LDS) against the three-launch path - tap GEMM, small_combine, blur4x4_noise_bias_act / blur4x4_split8 - bit for bit: fp32
+    output and split output (with and without a lo part), odd planes, with and without noise / bias."""
+    from oracle import ref_stylegan2 as O
+
+    torch.manual_seed(11)
+    k4 = O.blur_kernel_1d_to_2d(gain=4.0)
+    for (B, cin, cout, h, ww) in [(3, 32, 64, 4, 4), (2, 64, 64, 5, 7), (1, 32, 128, 16, 16)]:
+        xx, wgt = torch.randn(B, cin, h, ww), torch.randn(1, cout, cin, 3, 3)
+        s, d, s2 = torch.rand(B, cin) + 0.5, torch.rand(B, cout) + 0.5, torch.rand(B, cout) + 0.5
+        nz, nw, bias = torch.randn(B, 1, 2 * h, 2 * ww), torch.tensor([0.3]), torch.randn(cout)
+        wt, _ = M.prepare_weights(simlib, None, wgt)
+        w9 = M.split_weights_small(simlib, None, wt)
+        for noise, b_ in ((nz, bias), (None, None), (None, bias)):
+            for split_for in (None, (None, s2, True), (None, s2, False)):
+                if b_ is None and split_for is not None:
+                    continue
+                res = {}
+                for fused in (False, True):
+                    monkeypatch.setattr(M, "SMALL_UP_FUSED", fused)
+                    res[fused] = M.modconv3x3_up(simlib, None, xx, wt, s, d, k4, noise, nw if noise is not None else None, b_,
+                                                 split_for=split_for, small=(w9, 3))
+                    assert simlib.hf_debug_last_path() == (705 if fused else 704)
+                if split_for is None:
+                    assert torch.equal(res[False], res[True])
+                else:
+                    assert torch.equal(res[False].hi, res[True].hi)
+                    assert (res[False].lo is None) == (res[True].lo is None)
+                    if res[True].lo is not None:
+                        assert torch.equal(res[False].lo, res[True].lo)
