@@ -357,10 +357,13 @@ __global__ __launch_bounds__(512) void blur4x4_split8(hf_half8 *__restrict__ hi,
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           float win[4];
+          // the next three lanes' columns by DPP wavefront shifts (one VALU instruction each; __shfl_down is a ds_bpermute
+          // with an address register: 96 LDS round trips per four input rows).  Lanes 61-63, whose shifted values run off the
+          // wave, only feed their neighbours
           win[0] = own[u][k];
-          win[1] = __shfl_down(own[u][k], 1, 64);
-          win[2] = __shfl_down(own[u][k], 2, 64);
-          win[3] = __shfl_down(own[u][k], 3, 64);
+          win[1] = hf_lane_down(win[0]);
+          win[2] = hf_lane_down(win[1]);
+          win[3] = hf_lane_down(win[2]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int slot = (u - r) & 3;
