@@ -8,6 +8,7 @@ The public ops in ``hairfastgan_amd.op`` / ``hairfastgan_amd.stylegan2`` call
 these with the HIP library and the current HIP stream after checking that all
 tensors live on the GPU.
 """
+import functools
 import os
 
 import torch
@@ -674,6 +675,7 @@ def _pow2_ceil(v):
     return p
 
 
+@functools.lru_cache(maxsize=4096)  # (asked ~700 times per swap with ~60 distinct shapes: host time of a host-bound call sequence)
 def conv2d_f16_supported(cin, cout, h, w, k, stride):
     """Shapes hf_conv2d_f16_f32 takes (include/hairfast_hip.h; mirrors launch_enc's tile geometry)."""
     if k != 3 or cin % 16 or cout % 64 or stride not in (1, 2):

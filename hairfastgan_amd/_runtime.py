@@ -66,17 +66,30 @@ def set_splitk_inkernel(on):
     return prev
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+if _GET_DEVICE is None:
+    _RAW_STREAM = None
+
+
 def stream():
     """Raw hipStream_t of torch's current stream (kernels are enqueued asynchronously on it,
     like the reference's at::cuda::getCurrentCUDAStream(), upfirdn2d_kernel.cu:213-215)."""
-    s = torch.cuda.current_stream()
-    raw = s.cuda_stream
+    # (the raw handle straight from torch's C layer: torch.cuda.current_stream() builds a Stream object through three
+    # Python layers, ~4 us - and a single swap asks 900 times while its ~2100 launches are HOST-bound: 31.2 ms of enqueueing
+    # for 32.3 ms of wall, tools/probes/swap_host_profile.py)
+    if _RAW_STREAM is not None:
+        dev_index = _GET_DEVICE()
+        raw = _RAW_STREAM(dev_index)
+    else:
+        s_ = torch.cuda.current_stream()
+        dev_index, raw = s_.device_index, s_.cuda_stream
     if _splitk_inkernel:
-        key = (s.device_index, raw, _counter_epoch[0])
+        key = (dev_index, raw, _counter_epoch[0])
         if key != getattr(_counter_tls, "key", None):
             buf = _counter_bufs.get(key[:2])
             if buf is None:
-                buf = _counter_bufs[key[:2]] = torch.zeros(SPLITK_COUNTER_INTS, dtype=torch.int32, device=s.device)
+                buf = _counter_bufs[key[:2]] = torch.zeros(SPLITK_COUNTER_INTS, dtype=torch.int32, device=torch.device("cuda", dev_index))
             lib().hf_set_splitk_counters(buf.data_ptr(), SPLITK_COUNTER_INTS)
             _counter_tls.key = key
     elif getattr(_counter_tls, "key", None) is not None:  # switched off by another thread: drop this thread's pointer too
