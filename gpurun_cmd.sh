@@ -1,5 +1,6 @@
-# GPU call r06y: host-side profile of one eager swap
+# GPU call r06z: final profiles (rocprofv3 kernel trace + PMC passes of both workloads) and the full bench line
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python tools/probes/swap_host_profile.py > gpurun_out/r06y_swap_host_profile.txt 2>&1
-grep -v amdgpu gpurun_out/r06y_swap_host_profile.txt | head -70
+bash tools/profile_all.sh r06
+python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err
+tail -c 900 gpurun_out/r06_bench.json

@@ -19,6 +19,9 @@ def label(name):
                 f"{',pre' if pre else ''}{',fuse' if fuse else ''}>")
     if "blur4x4_split8" in name:
         return "blur4x4_split8"
+    ms = re.match(r"_Z\d+small_up_blurILb(\d)E", name)
+    if ms:
+        return "small_up_blur<split>" if ms.group(1) == "1" else "small_up_blur<fp32>"
     if "conv_rows_h" in name:
         return "conv_rows_h<32->32,strip64,pre>"  # bench.py's label (csrc/convrow.hip)
     mg = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)

@@ -17,6 +17,9 @@ def short(name):
                 f"{',pre' if pre else ''}{',fuse' if fuse else ''}>")
     if "blur4x4_split8" in name:
         return "blur4x4_split8"
+    ms = re.match(r"_Z\d+small_up_blurILb(\d)E", name)
+    if ms:
+        return "small_up_blur<split>" if ms.group(1) == "1" else "small_up_blur<fp32>"
     mg = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
     if mg and "conv_mfma_h" not in name and "conv_enc_h" not in name:  # other anonymous-namespace kernels: the bare identifier
         n = int(mg.group(1))
