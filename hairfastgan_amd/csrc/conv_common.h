@@ -502,7 +502,7 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wt_hi, const v
 // HF_E_INVALID when the layer does not qualify
 int launch_conv_rows(ConvParams &P, int nterms, const void *wt_hi, const void *wt_lo, hipStream_t st);
 extern thread_local int g_h_blocks;           // hf_debug_set_persistent_blocks: resident blocks the convh.hip grid is sized for (0 = 256 CUs)
-extern thread_local int g_h_tune;             // hf_debug_set_tuning: bit 0 force early stage DMAs, bit 1 force spread ones (convh.hip)
+extern thread_local int g_h_tune;             // hf_debug_set_tuning: bit 0 force early stage DMAs (convh.hip), bit 1 never the GEMM's 128-channel blocks (gemm_h.hip), ... (include/hairfast_hip.h)
 extern int g_batch_invariant;                 // hf_set_batch_invariant (process-wide): plans (split-K counts, tile forms) from the per-sample shape only
 // The batch count every decision that changes a sample's BITS is made with - the K partition (split-K factor) and the kernel
 // family (fp32 split-K / tap-GEMM / tiled fp16-core kernels differ in summation order): the real one, or - in batch-invariant

@@ -40,18 +40,22 @@ inline int gemm_fill_blocks() { return ((hf_detail::g_h_tune >> 24) & 255) ? ((h
 // an input shared by many output-channel tiles (the tap-GEMM's 72, the CLIP MLP's 48) is converted once, not once per block.
 // VSPLIT (ConvParams::vsplit): the block walks all P.splits K slabs and adds their sums in z order to a second accumulator
 // set - the bits of the split-K form (slabs + splitk_reduce / small_combine) without the slabs (see csrc/convh_enc.hip).
-template <int NTERMS, int PG, bool PRE, bool VSPLIT = false>
-__global__ __launch_bounds__(256, HF_GEMM_MIN_WAVES) void gemm1x1_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
+// CW (round 6): output-channel waves of a block - 2: 64 channels x PT pixels, four waves, two blocks per CU; 4: 128 channels x PT
+// pixels, eight waves, one block per CU (96 KB): the activation stage (32 KB of the 40 a 64-channel block copies per 96 MFMAs) is
+// shared by twice the channels - 48 KB per 192 MFMAs, 250 instead of 427 bytes of LDS-DMA per MFMA.  Same K order: equal bits.
+template <int NTERMS, int PG, bool PRE, bool VSPLIT = false, int CW = 2>
+__global__ __launch_bounds__(128 * CW, HF_GEMM_MIN_WAVES) void gemm1x1_h(const ConvParams P, const _Float16 *__restrict__ wth_all,
                                                  const _Float16 *__restrict__ wtl_all) {
-  constexpr int NT = 256, CT = 64, PT = 64 * PG;
+  constexpr int NW = 2 * CW, NT = 64 * NW, CT = 32 * CW, PT = 64 * PG;
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;
   constexpr int W_UNITS = (KS / 8) * CT;        // 16-byte units of one weight part per stage: [chunk 2][kg 2][64 co]
   constexpr int X_UNITS = (KS / 8) * PT;        // [kblock 4][PT pixels]
   constexpr int BUF_UNITS = NPART * (W_UNITS + X_UNITS);
   constexpr int OFF_WL = W_UNITS, OFF_XH = NPART * W_UNITS, OFF_XL = NPART * W_UNITS + X_UNITS;
-  constexpr int XE = X_UNITS / NT;              // staging items per thread and stage (PG)
-  constexpr int N_WPIECE = NPART * W_UNITS / 64;  // 1 KiB DMA pieces per stage (4 or 8)
-  constexpr int ND = N_WPIECE / 4;              // per wave
+  constexpr int XE = X_UNITS / NT;              // staging items per thread and stage (PG, or PG / 2 with eight waves)
+  constexpr int N_WPIECE = NPART * W_UNITS / 64;  // 1 KiB DMA pieces per stage (4 or 8; 8 or 16 with 128 channels)
+  constexpr int ND = N_WPIECE / NW;             // per wave
+  static_assert(X_UNITS % NT == 0 && N_WPIECE % NW == 0 && XE >= 1, "whole staging items / DMA pieces per thread / wave");
 
   HF_DYN_LDS;
   half8 *lds = reinterpret_cast<half8 *>(hf_dyn_lds);  // [2][BUF_UNITS]
@@ -106,9 +110,10 @@ __global__ __launch_bounds__(256, HF_GEMM_MIN_WAVES) void gemm1x1_h(const ConvPa
   auto dma_w = [&](int stage, int bufsel) {
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
-      const int pc = wave + j * 4;  // piece: (part, chunk-in-stage, kg)
-      const int part = pc / (W_UNITS / 64), q = pc % (W_UNITS / 64);  // q = chunk*2 + kg
-      const _Float16 *src = (part ? wtl : wth) + ((long long)(stage * (KS / KH) * 2 + q) * P.cout + co0) * 8;
+      const int pc = wave + j * NW;  // piece: (part, chunk-in-stage, kg[, 64-channel half])
+      const int part = pc / (W_UNITS / 64), q = pc % (W_UNITS / 64);  // q = (chunk*2 + kg) * (CT / 64) + 64-channel half
+      const int row = q / (CT / 64), half = q % (CT / 64);
+      const _Float16 *src = (part ? wtl : wth) + ((long long)(stage * (KS / KH) * 2 + row) * P.cout + co0 + half * 64) * 8;
       hf_glds16_raw_s(src, (unsigned)lane * 16u, lds_addr0 + (unsigned)(bufsel * BUF_UNITS + part * W_UNITS + q * 64) * 16u);
     }
   };
@@ -248,6 +253,8 @@ __global__ __launch_bounds__(256, HF_GEMM_MIN_WAVES) void gemm1x1_h(const ConvPa
     reduce_tile_rows<1, PG>(P, G, go, co0 + wave_co, wave_pg, li, lh, 0, tx0, b0);
 }
 
+thread_local int g_gemm_wide_last = 0;  // the last launch took the 128-channel block form (hf_debug_last_path 706)
+
 template <int NTERMS, int PG>
 int launch_gemm(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStream_t st) {
   constexpr int PT = 64 * PG;
@@ -267,7 +274,16 @@ int launch_gemm(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStre
   P.n_geom = 1;
   const int nblocks = g.tiles_x * g.tiles_b;
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;
-  const size_t lds = (size_t)2 * NPART * ((KS / 8) * 64 + (KS / 8) * PT) * 16;
+  // 128-channel blocks (CW = 4) when the launch still fills the chip with them: a tile FORM - the K order of an output element
+  // does not change - so it follows the real launch in every mode (tests/test_sim_gemm.py).  PG 4 only (the 256-pixel tile of
+  // the large launches); hf_debug_set_tuning bit 1 = never (A/B, tests)
+  const int groups_ = max(1, P.groups);
+  const bool wide = PG == 4 && !(g_h_tune & 2) && (P.cout % 128) == 0 &&
+                    (long long)nblocks * (P.cout / 128) * groups_ >= 2LL * gemm_fill_blocks();  // (from ONE round of CUs: measured mixed - CLIP fc 66-70 -> 71-75 us, proj 101 -> 92-95, r06ab)
+  if (wide) P.co_tiles = P.cout / 128;
+  g_gemm_wide_last = wide ? 1 : 0;
+  const int ct = wide ? 128 : 64;
+  const size_t lds = (size_t)2 * NPART * ((KS / 8) * ct + (KS / 8) * PT) * 16;
   // batch-invariant plans: P.splits is the canonical K partition (gemm_splits at kCanonBatch); a launch whose output grid
   // fills the chip by itself walks the slabs inside its blocks instead of spreading them over grid.z (same bits)
   P.vsplit = (g_batch_invariant && P.splits > 1 && (long long)nblocks * P.co_tiles * max(1, P.groups) >= gemm_fill_blocks()) ? 1 : 0;
@@ -280,9 +296,23 @@ int launch_gemm(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStre
     if (P.stride != 1 || P.s || P.t || (NTERMS == 3 && !P.xl) || P.groups > 1 ||
         (long long)P.batch * P.cin * P.h * P.w * 2 >= (1LL << 32))
       return HF_E_INVALID;  // 32-bit unit offsets; the affine went into the split
+    if constexpr (PG == 4) {
+      if (wide) {
+        if (P.vsplit) hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, true, true, 4>), grid, dim3(512), lds, st, P, wth, wtl);
+        else hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, true, false, 4>), grid, dim3(512), lds, st, P, wth, wtl);
+        return hf_launch_status();
+      }
+    }
     if (P.vsplit) hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, true, true>), grid, dim3(256), lds, st, P, wth, wtl);
     else hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, true>), grid, dim3(256), lds, st, P, wth, wtl);
   } else {
+    if constexpr (PG == 4) {
+      if (wide) {
+        if (P.vsplit) hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, false, true, 4>), grid, dim3(512), lds, st, P, wth, wtl);
+        else hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, false, false, 4>), grid, dim3(512), lds, st, P, wth, wtl);
+        return hf_launch_status();
+      }
+    }
     if (P.vsplit) hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, false, true>), grid, dim3(256), lds, st, P, wth, wtl);
     else hipLaunchKernelGGL((gemm1x1_h<NTERMS, PG, false>), grid, dim3(256), lds, st, P, wth, wtl);
   }
@@ -370,7 +400,7 @@ extern "C" int hf_conv1x1_f16_f32(float *out, const float *x, const void *x_hi, 
   if (small) rc = (nterms == 3) ? launch_gemm<3, 2>(P, hi, lo, (hipStream_t)stream) : launch_gemm<1, 2>(P, hi, lo, (hipStream_t)stream);
   else rc = (nterms == 3) ? launch_gemm<3, 4>(P, hi, lo, (hipStream_t)stream) : launch_gemm<1, 4>(P, hi, lo, (hipStream_t)stream);
   if (rc != HF_OK) return rc;
-  note_path(7, small ? 1 : 2);
+  note_path(7, g_gemm_wide_last ? 6 : (small ? 1 : 2));
   if (P.splits > 1 && !P.vsplit && !P.counters) {
     P.out_h = 1; P.out_w = oplane;
     return launch_splitk_reduce(P, true, (hipStream_t)stream);

@@ -192,3 +192,33 @@ def test_small_plane_upsampling_styledconv_in_two_launches(simlib, monkeypatch):
                     assert (res[False].lo is None) == (res[True].lo is None)
                     if res[True].lo is not None:
                         assert torch.equal(res[False].lo, res[True].lo)
+
+
+def test_conv1x1_128_channel_blocks_equal_64_channel_blocks(simlib):
+    """Round 6: the 128-channel block form of the GEMM (gemm1x1_h<..., CW = 4>: eight waves share one activation stage) is a tile
+    FORM - every output element keeps its K order - so it must equal the 64-channel form bit for bit: register-staged and
+    pre-split input, bias + PReLU + residual epilogue, the canonical (virtual) K partition of the batch-invariant mode, odd planes.
+    hf_debug_set_tuning: bits 24-31 = block count from which a launch counts as chip-filling (lowered so that small shapes take
+    the form), bit 1 = never the 128-channel form."""
+    torch.manual_seed(21)
+    fill1 = 1 << 24
+    for (B, cin, cout, h, w) in [(2, 64, 256, 13, 21), (1, 128, 128, 18, 17)]:
+        x = torch.randn(B, cin, h, w)
+        wgt, b, sl, res = torch.randn(cout, cin, 1, 1) * 0.1, torch.randn(cout), torch.rand(cout), torch.randn(B, cout, h, w)
+        hi, lo = _prep(simlib, wgt)
+        xs = M.split_activation_f16(simlib, None, x)
+        for binv in (0, 1):
+            prev = simlib.hf_set_batch_invariant(binv)
+            try:
+                for xin in (x, xs):
+                    out = {}
+                    for never in (0, 2):
+                        simlib.hf_debug_set_tuning(fill1 | never)
+                        out[never] = M.conv1x1_f16(simlib, None, xin, hi, lo, 3, cout, bias=b, act=M.ACT_PRELU, slope=sl, residual=res)
+                        assert simlib.hf_debug_last_path() == (702 if never else 706)
+                    assert torch.equal(out[0], out[2])
+                    ref = F.prelu(F.conv2d(x, wgt, b), sl) + res
+                    assert float((out[0] - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+            finally:
+                simlib.hf_set_batch_invariant(prev)
+                simlib.hf_debug_set_tuning(0)

@@ -19,7 +19,8 @@ SHAPES = [("CLIP qkv 768->2304", 1, 768, 2304, 64, 50, 1, True), ("CLIP fc 768->
 def main():
     dev = torch.device("cuda:0")
     L, st = lib(), stream()
-    print("lib:", os.environ.get("HAIRFAST_HIP_LIB", "default"))
+    L.hf_debug_set_tuning(int(os.environ.get("PROBE_TUNE", "0")))  # 2: never the 128-channel block form (A/B)
+    print("lib:", os.environ.get("HAIRFAST_HIP_LIB", "default"), "tuning", os.environ.get("PROBE_TUNE", "0"))
     for label, B, cin, cout, H, W, G, pre in SHAPES:
         torch.manual_seed(0)
         x = torch.randn(*((G, B) if G > 1 else (B,)), cin, H, W, device=dev)
