@@ -1,5 +1,5 @@
-# GPU call r06ac: 128-channel GEMM blocks in the batched swap (tuning 2 = off) + GPU tests of the GEMM users
+# GPU call r06ad: 128-channel GEMM blocks for the 128-pixel tile form too (heads patch GEMM)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_encoders.py tests/test_gpu_sean.py tests/test_gpu_clip.py -x -q -m gpu 2>&1 | tail -3
-for t in 2 0 2 0; do echo "== tuning $t"; python tools/probes/bench_tuned.py $t --workload swap256 --triples 64 --swap-batch 32 --warmup 1 --no-kernel-events --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['verified']['equal'])"; done
+C=$GRAFT_REPO_ROOT/hairfastgan_amd/csrc
+for v in hip g128c hip g128c; do HAIRFAST_HIP_LIB=$C/libhairfast_$v.so python tools/probes/gemm_shapes.py 2>&1 | grep -v amdgpu | grep "lib\|heads\|SEAN 512\|CLIP"; done

@@ -276,7 +276,8 @@ int launch_gemm(ConvParams &P, const _Float16 *wth, const _Float16 *wtl, hipStre
   constexpr int NPART = (NTERMS == 3) ? 2 : 1;
   // 128-channel blocks (CW = 4) when the launch still fills the chip with them: a tile FORM - the K order of an output element
   // does not change - so it follows the real launch in every mode (tests/test_sim_gemm.py).  PG 4 only (the 256-pixel tile of
-  // the large launches); hf_debug_set_tuning bit 1 = never (A/B, tests)
+  // the large launches: with the 128-pixel tile - the heads' patch GEMM, 4608 -> 512 x 11 groups - it measured SLOWER, 2075 vs
+  // 1840 us: four 48 KB blocks per CU hide more than two 64 KB ones); hf_debug_set_tuning bit 1 = never (A/B, tests)
   const int groups_ = max(1, P.groups);
   const bool wide = PG == 4 && !(g_h_tune & 2) && (P.cout % 128) == 0 &&
                     (long long)nblocks * (P.cout / 128) * groups_ >= 2LL * gemm_fill_blocks();  // (from ONE round of CUs: measured mixed - CLIP fc 66-70 -> 71-75 us, proj 101 -> 92-95, r06ab)
