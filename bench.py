@@ -57,7 +57,9 @@ PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (~6.3 TB/s achi
 # What a loop of NOTHING BUT back-to-back v_mfma_f32_32x32x16_f16 (the conv kernels' 2 x 2 tiles, three MFMAs per tile and tap,
 # operands constant in registers) sustains on this chip: every SIMD issues one MFMA per 32.0 shader cycles (s_memtime) - the pipe
 # is saturated - but the chip clocks at ~1.7 GHz under that load (DVFS: power), not 2.4.  tools/probes/mfma_rate.hip, run on the
-# GPU box: profiles/r05_mfma_rate.txt (1788 TFLOP/s MFMA only, 1651-1661 with the kernels' 8 ds_read_b128 per 12 MFMAs).
+# GPU box: profiles/r05_mfma_rate.txt (1788 TFLOP/s MFMA only, 1651-1661 with the kernels' 8 ds_read_b128 per 12 MFMAs);
+# round 6, with the clock and the socket power sampled beside it (profiles/r06_clock_power.txt): 1799 TFLOP/s at 1.77 GHz / 1.29 kW of a
+# 1.4 kW cap with non-zero operands, 2481 TFLOP/s at 2.39 GHz / 0.88 kW with zero operands - the guide's 2495 is the latter.
 # `roofline.frac` stays against the nominal peak (the contract); `frac_of_sustained_mfma` is the same number against this one.
 SUSTAINED_F16_MFMA_TFLOPS = 1788.0
 DTYPES = {
@@ -409,7 +411,7 @@ def kernel_report(prof, elapsed, precision, sampled=1.0, pmc=True):
             peak_note = (f"fp16 dense MFMA peak {PEAK_F16_MFMA_TFLOPS} TFLOP/s / {terms} MFMA per product; "
                          f"MFMA FLOPs issued = {terms} x algorithmic = {round(ach * terms, 1)} TFLOP/s; an MFMA-only loop sustains "
                          f"{SUSTAINED_F16_MFMA_TFLOPS} TFLOP/s on this chip (pipe saturated at 32 cycles per MFMA, clock ~1.7 GHz under "
-                         f"load: profiles/r05_mfma_rate.txt) = {round(sustained, 1)} for this operand mode")
+                         f"load - power-limited, 1.29 kW of a 1.4 kW cap: profiles/r05_mfma_rate.txt, r06_clock_power.txt) = {round(sustained, 1)} for this operand mode")
         else:
             peak, peak_note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA peak"
         # the committed PMC passes were collected in the headline configuration (f16x3, batch 8, generator workload) only
