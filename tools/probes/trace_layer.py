@@ -8,7 +8,7 @@ cin, cout, r = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 mode = sys.argv[5] if len(sys.argv) > 5 else ''
 up = mode.startswith('up')
-pre = mode.endswith('pre') or mode in ('prergb', 'fuse', 'presplit')
+pre = mode.endswith('pre') or mode in ('prergb', 'prergbsplit', 'fuse', 'presplit')
 L = lib(); st = stream(); dev = torch.device("cuda:0")
 x = torch.randn(B, cin, r, r, device=dev)
 wt, wsq = M.prepare_weights(L, st, torch.randn(1, cout, cin, 3, 3, device=dev))
@@ -25,6 +25,10 @@ for _ in range(2):
     elif mode == 'prergb':
         rgbp = (torch.randn(cout, 3, device=dev), torch.rand(B, cout, device=dev) + 0.5)
         y = M.modconv3x3_f16_pre(L, st, xin, hi, lo, 3, d, nz, nw, bias, rgb=rgbp, want_out=False)
+    elif mode == 'prergbsplit':  # the generator's 64^2 .. 512^2 same-resolution layers: ToRGB slabs + split output, no fp32 activation
+        rgbp = (torch.randn(cout, 3, device=dev), torch.rand(B, cout, device=dev) + 0.5)
+        s2 = torch.rand(B, cout, device=dev) + 0.5
+        y = M.modconv3x3_f16_pre(L, st, xin, hi, lo, 3, d, nz, nw, bias, rgb=rgbp, want_out=False, split_for=s2)
     elif mode == 'presplit':
         s2 = torch.rand(B, cout, device=dev) + 0.5
         y = M.modconv3x3_f16_pre(L, st, xin, hi, lo, 3, d, nz, nw, bias, want_out=False, split_for=s2)
