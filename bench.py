@@ -569,7 +569,7 @@ def main():
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the fp32-MFMA comparison run (profiling)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="swap workloads: skip the comparison of gathered images with direct swap_batch calls")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=5,
                     help="generator workload: bracket the launches of every N-th timed step with HIP events (1 = every step)")
     ap.add_argument("--pipeline-triples", type=int, default=256,
                     help="generator workload: triples of the WHOLE job for the secondary swap_pipeline object (strong scaling over --gpus)")

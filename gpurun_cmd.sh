@@ -1,6 +1,6 @@
-# GPU call r06ag: same-resolution kernel instantiated for the split + ToRGB-slab epilogue (hip) vs run-time flags (epi0)
+# GPU call r06ah: final profiles (rocprofv3 kernel trace + PMC passes of both workloads) and the full bench line at HEAD
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-C=$GRAFT_REPO_ROOT/hairfastgan_amd/csrc
-for v in epi0 hip epi0 hip; do echo "== $v"; HAIRFAST_HIP_LIB=$C/libhairfast_$v.so python bench.py --no-cpu-baseline --no-exact-f32 --swap-triples 0 --steps 40 --warmup 5 --no-kernel-events | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'])"; done
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
+bash tools/profile_all.sh r06
+python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err
+tail -c 700 gpurun_out/r06_bench.json
