@@ -1,6 +1,4 @@
-# GPU call r06ah: final profiles (rocprofv3 kernel trace + PMC passes of both workloads) and the full bench line at HEAD
+# GPU call r06aj: row pipeline epilogue with grouped constant loads: hip vs base
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-bash tools/profile_all.sh r06
-python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err
-tail -c 700 gpurun_out/r06_bench.json
+C=$GRAFT_REPO_ROOT/hairfastgan_amd/csrc
+for v in base hip base hip; do echo "== $v"; HAIRFAST_HIP_LIB=$C/libhairfast_$v.so PROBE_TUNE=0 python tools/probes/gen_layers.py 2>&1 | grep "same  32"; done

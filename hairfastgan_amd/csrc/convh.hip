@@ -542,76 +542,98 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
     const float *rw = rgbw_base + slot * 3 * CT;
     const unsigned oplane4 = (unsigned)(P.out_h * P.out_w) * 4u;
     char *ob0 = OUT ? reinterpret_cast<char *>(P.out + ((long long)T.b0 * P.cout + co0) * ((long long)P.out_h * P.out_w)) : nullptr;
+    // split output: uniform base of the block's CT / 8 channel-block planes of this image + 32-bit per-lane byte offsets (CT / 8
+    // planes of 16-byte units: the launcher's CT * plane * 4 < 4 GiB bound covers them) - the 64-bit unit arithmetic per channel
+    // quad was ~18 VALU instructions, five of them quarter-rate multiplies, in an epilogue that is bound by VALU issue
+    const unsigned uplane16 = (unsigned)(P.out_h * P.out_w) * 16u;
+    const long long ubase = ((long long)T.b0 * (P.cout >> 3) + (co0 >> 3)) * ((long long)P.out_h * P.out_w) * 16;
+    char *oh_t = SPLIT ? static_cast<char *>(P.oh) + ubase : nullptr;
+    char *ol_t = (SPLIT && P.ol) ? static_cast<char *>(P.ol) + ubase : nullptr;
     const float nws = nw_ * P.scale;
     bool ovf_tile = false;
+    // per pixel group: validity, offsets, noise term (a product of its own in every instantiation - no contraction into the add
+    // below: the tile configurations must agree bit for bit)
+    bool pvg[PG];
+    unsigned pix4[PG], pix16[PG];
+    int Yg[PG], Xg[PG];
+    float nzv[PG], rgb[PG][3];
 #pragma unroll
     for (int g = 0; g < PG; ++g) {
       const int p = (wave_pg + g) * 32 + li_o;
-      const int Y = T.ty0 + ((p >> G.lg_tw) & (th - 1)), X = T.tx0 + (p & (tw - 1));
-      const bool pv = (Y < G.y0 + G.dh) && (X < G.x0 + G.dw);
-      float nzv = nws * nz[g];
-      HF_OPAQUE_F32(nzv);  // a product of its own in every instantiation (no contraction into the add below): the
-                           // tile configurations must agree bit for bit
-      float rgb[3] = {0.0f, 0.0f, 0.0f};
-      // every lane runs the arithmetic (the split's range vote is wave-wide; lanes outside the image hold finite sums of zero
-      // padding), lanes of valid pixels store
-      {
-        const unsigned pix4 = (unsigned)(Y * P.out_w + X) * 4u;
+      Yg[g] = T.ty0 + ((p >> G.lg_tw) & (th - 1));
+      Xg[g] = T.tx0 + (p & (tw - 1));
+      pvg[g] = (Yg[g] < G.y0 + G.dh) && (Xg[g] < G.x0 + G.dw);
+      pix4[g] = (unsigned)(Yg[g] * P.out_w + Xg[g]) * 4u;
+      pix16[g] = (unsigned)(Yg[g] * P.out_w + Xg[g]) * 16u + (unsigned)lh_o * 8u;
+      nzv[g] = nws * nz[g];
+      HF_OPAQUE_F32(nzv[g]);
+      rgb[g][0] = rgb[g][1] = rgb[g][2] = 0.0f;
+    }
+    // channel quad outermost: its per-channel constants are fetched from LDS once, together, for both pixel groups (they were
+    // fetched per group and consumed one by one: up to six exposed LDS latencies per quad and group).  Every lane runs the
+    // arithmetic (the split's range vote is wave-wide; lanes outside the image hold finite sums of zero padding), lanes of
+    // valid pixels store.  Per element the operations and their order are unchanged: same bits.
 #pragma unroll
-        for (int ct = 0; ct < CT_TILES; ++ct)
+    for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c4 = co_w + ct * 32 + 8 * q + 4 * lh_o;  // first of the lane's 4 channels (tile-relative)
-            const float4 dm = *reinterpret_cast<const float4 *>(ep + c4);
-            const float4 bs = *reinterpret_cast<const float4 *>(ep + CT + c4);
-            const float dmv[4] = {dm.x, dm.y, dm.z, dm.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
-            float v[4];
+      for (int q = 0; q < 4; ++q) {
+        const int c4 = co_w + ct * 32 + 8 * q + 4 * lh_o;  // first of the lane's 4 channels (tile-relative)
+        const float4 dm = *reinterpret_cast<const float4 *>(ep + c4);
+        const float4 bs = *reinterpret_cast<const float4 *>(ep + CT + c4);
+        float4 sn = make_float4(1.0f, 1.0f, 1.0f, 1.0f), wv[3];
+        if (SPLIT) sn = *reinterpret_cast<const float4 *>(ep + 2 * CT + c4);
+        if (RGB) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float o = fmaf(acc[0][ct][g][4 * q + k], dmv[k], nzv + bsv[k]);
-              v[k] = fmaxf(o, o * P.alpha);
-            }
-            if (OUT && pv) {
-              unsigned off = (unsigned)c4 * oplane4 + pix4;
+          for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const float4 *>(rw + c * CT + c4);
+        }
+        const float dmv[4] = {dm.x, dm.y, dm.z, dm.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+        const unsigned cofs4 = (unsigned)c4 * oplane4;                       // fp32 planes of the lane's channels
+        const unsigned cofs16 = (unsigned)((c4 - 4 * lh_o) >> 3) * uplane16;  // the 16-byte-unit plane of channel block c4 / 8
 #pragma unroll
-              for (int k = 0; k < 4; ++k, off += oplane4) *reinterpret_cast<float *>(ob0 + off) = v[k];
-            }
-            if (SPLIT) {  // the lane's 4 channels = one half (lh) of the 16-byte unit of pixel (Y, X), channel block (co0+c4)/8
-              const float4 sn = *reinterpret_cast<const float4 *>(ep + 2 * CT + c4);
-              const float vs[4] = {v[0] * sn.x, v[1] * sn.y, v[2] * sn.z, v[3] * sn.w};
-              // one range vote per four values, packed conversions (hf_split4_f16: 2.5 VALU issues per element; the element-wise
-              // saturating form this replaced spent 9 - the epilogue is bound by VALU issue; same bits)
-              hf_half4 h4, l4;
-              bool ovf = false;
-              hf_split4_f16(vs, h4, l4, ovf);
-              if (pv) {
-                ovf_tile = ovf_tile || ovf;
-                const long long unit = (((long long)T.b0 * (P.cout >> 3) + ((co0 + c4) >> 3)) * P.out_h + Y) * P.out_w + X;
-                *reinterpret_cast<hf_half4 *>(static_cast<char *>(P.oh) + unit * 16 + ((co0 + c4) & 4) * 2) = h4;
-                if (P.ol) *reinterpret_cast<hf_half4 *>(static_cast<char *>(P.ol) + unit * 16 + ((co0 + c4) & 4) * 2) = l4;
-              }
-            }
-            if (RGB) {
+        for (int g = 0; g < PG; ++g) {
+          float v[4];
 #pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                const float4 wv = *reinterpret_cast<const float4 *>(rw + c * CT + c4);
-                rgb[c] = fmaf(v[3], wv.w, fmaf(v[2], wv.z, fmaf(v[1], wv.y, fmaf(v[0], wv.x, rgb[c]))));
-              }
+          for (int k = 0; k < 4; ++k) {
+            const float o = fmaf(acc[0][ct][g][4 * q + k], dmv[k], nzv[g] + bsv[k]);
+            v[k] = fmaxf(o, o * P.alpha);
+          }
+          if (OUT && pvg[g]) {
+            unsigned off = cofs4 + pix4[g];
+#pragma unroll
+            for (int k = 0; k < 4; ++k, off += oplane4) *reinterpret_cast<float *>(ob0 + off) = v[k];
+          }
+          if (SPLIT) {  // the lane's 4 channels = one half (lh) of the 16-byte unit of pixel (Y, X), channel block (co0+c4)/8
+            const float vs[4] = {v[0] * sn.x, v[1] * sn.y, v[2] * sn.z, v[3] * sn.w};
+            hf_half4 h4, l4;
+            bool ovf = false;
+            hf_split4_f16(vs, h4, l4, ovf);  // one range vote per four values, packed conversions (2.5 VALU issues per element)
+            if (pvg[g]) {
+              ovf_tile = ovf_tile || ovf;
+              const unsigned off = cofs16 + pix16[g];
+              *reinterpret_cast<hf_half4 *>(oh_t + off) = h4;
+              if (ol_t) *reinterpret_cast<hf_half4 *>(ol_t + off) = l4;
             }
           }
-      }
-      if (RGB) {
-        // the two half-waves hold the other channels of the same pixels: add, the low half stores.  A wave covers
-        // 32*CT_TILES of the cout channels: its sum goes to slab (blockIdx.y*WAVES_CO + co-wave) of the
-        // [B][slabs*3][H][W] raw tensor; ToRGB's finishing pass adds the slabs in a fixed order (deterministic)
-        const int slabs = grid_y * WAVES_CO, slab = blk_y * WAVES_CO + wave / WAVES_PX;
+          if (RGB) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          rgb[c] += __shfl_xor(rgb[c], 32, 64);
-          if (pv && lh_o == 0)
-            P.rgb_out[(((long long)T.b0 * slabs + slab) * 3 + c) * ((long long)P.out_h * P.out_w) + (long long)Y * P.out_w + X] = rgb[c];
+            for (int c = 0; c < 3; ++c)
+              rgb[g][c] = fmaf(v[3], wv[c].w, fmaf(v[2], wv[c].z, fmaf(v[1], wv[c].y, fmaf(v[0], wv[c].x, rgb[g][c]))));
+          }
         }
       }
+    if (RGB) {
+      // the two half-waves hold the other channels of the same pixels: add, the low half stores.  A wave covers
+      // 32*CT_TILES of the cout channels: its sum goes to slab (blockIdx.y*WAVES_CO + co-wave) of the
+      // [B][slabs*3][H][W] raw tensor; ToRGB's finishing pass adds the slabs in a fixed order (deterministic)
+      const int slabs = grid_y * WAVES_CO, slab = blk_y * WAVES_CO + wave / WAVES_PX;
+#pragma unroll
+      for (int g = 0; g < PG; ++g)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float sum = rgb[g][c] + __shfl_xor(rgb[g][c], 32, 64);
+          if (pvg[g] && lh_o == 0)
+            P.rgb_out[(((long long)T.b0 * slabs + slab) * 3 + c) * ((long long)P.out_h * P.out_w) + (long long)Yg[g] * P.out_w + Xg[g]] = sum;
+        }
     }
     if (SPLIT) hf_note_overflow(ovf_tile);
   };
