@@ -55,6 +55,9 @@ using namespace hf_detail;
 #ifndef HF_H_PP_ROLES
 #define HF_H_PP_ROLES 0  // ping-pong K loop (measured neutral: fused layers 552-569 vs 592 us, 512->512 @64^2 425 vs 410, r06j - off): 1 = the half that idles FIRST in a stage (waves 4-7, phase A) issues ALL activation copies of the next stage (HBM / Infinity-Cache latency: they get the whole stage to land), the other half (phase B) only the weight copies (L2 hits); 0 = every wave issues its share of both in its idle phase (A/B builds)
 #endif
+#ifndef HF_H_LATE_TABLES
+#define HF_H_LATE_TABLES 0  // 1: the next image's epilogue tables loaded at the head of the tile into registers and written to LDS after its K loop, no barrier (measured neutral: 1706.7 vs 1707.0 img/s, r06al - off)
+#endif
 #ifndef HF_H_PP_PREFETCH
 #define HF_H_PP_PREFETCH 1  // ping-pong K loop: the half that computes second fetches its first tap's fragments BEFORE the role-swap barrier (0 = after: A/B builds)
 #endif
@@ -286,6 +289,42 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
         const float sv = P.rgb_s[(long long)b * P.cout + co0 + i];
 #pragma unroll
         for (int c = 0; c < 3; ++c) rw[c * CT + i] = P.rgb_w[(co0 + i) * 3 + c] * sv;
+      }
+    }
+  };
+
+  // Unmodulated / pre-split kernels (no s): the NEXT image's tables in two steps - the loads at the head of the tile into
+  // registers, the LDS writes after the tile's K loop (HF_H_LATE_TABLES).  With the strided walk a block of a 512^2 layer
+  // changes image on every second tile, one of a 256^2 layer on every tile; load_s at the tile head cost a block-wide barrier
+  // and the exposed latency of its global loads in wave 0 - 5.9 k of the 83 k cycles of a 64 -> 64 @512^2 tile
+  // (profiles/r06af_trace_same_res_64ch.txt).  No barrier is needed: the slot written after tile i's K loop was last read in
+  // tile i-1's epilogue, which every wave has left (it passed tile i's stage barriers); readers (tile i+1's epilogue) are
+  // behind tile i+1's stage barriers.  Same values, same bits.
+  constexpr bool LATE_TABLES = !MOD && HF_H_LATE_TABLES;
+  float pend_d = 1.0f, pend_b = 0.0f, pend_sn = 1.0f, pend_rs = 0.0f, pend_rw[3] = {0.0f, 0.0f, 0.0f};
+  bool pend = false;
+  auto load_tables_issue = [&](int b) {
+    if (tid < CT) {
+      pend_d = P.d ? P.d[(long long)b * P.d_bstride + co0 + tid] : 1.0f;
+      pend_b = P.bias ? P.bias[co0 + tid] : 0.0f;
+      pend_sn = ((!UP || FUSE) && P.oh && P.s_next) ? P.s_next[(long long)b * P.cout + co0 + tid] : 1.0f;
+      if (!UP && P.rgb_out) {
+        pend_rs = P.rgb_s[(long long)b * P.cout + co0 + tid];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pend_rw[c] = P.rgb_w[(co0 + tid) * 3 + c];
+      }
+    }
+  };
+  auto load_tables_commit = [&](int slot) {
+    if (tid < CT) {
+      float *ep = ep_base + slot * 3 * CT;
+      ep[tid] = pend_d * w_unscale * ep_fold;
+      ep[CT + tid] = P.bias ? pend_b * ep_fold : 0.0f;
+      ep[2 * CT + tid] = pend_sn;
+      if (!UP && P.rgb_out) {
+        float *rw = rgbw_base + slot * 3 * CT;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rw[c * CT + tid] = pend_rw[c] * pend_rs;
       }
     }
   };
@@ -891,12 +930,19 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
     if (has_next) {
       nxt = locate(t_next);
       if (nxt.b0 != cur.b0) {
-        // the slot about to be overwritten held the image before this one: another wave may still
-        // be in that tile's epilogue (reading its d / bias) when images change on every tile
-        hf_barrier_lds();
-        sl_slot ^= 1;
-        nxt_sl_off = sl_slot * P.cin;
-        load_s(nxt.b0, sl_slot);
+        if constexpr (LATE_TABLES) {
+          sl_slot ^= 1;
+          nxt_sl_off = sl_slot * P.cin;
+          load_tables_issue(nxt.b0);
+          pend = true;
+        } else {
+          // the slot about to be overwritten held the image before this one: another wave may still
+          // be in that tile's epilogue (reading its d / bias) when images change on every tile
+          hf_barrier_lds();
+          sl_slot ^= 1;
+          nxt_sl_off = sl_slot * P.cin;
+          load_s(nxt.b0, sl_slot);
+        }
       }
     }
     HF_TRACE_POINT(8);  // next tile located
@@ -1061,6 +1107,10 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
       // next stage complete (DMA landed, conversions written), current one free
       HF_H_BARRIER();
       HF_TRACE_POINT(3);  // after the barrier
+    }
+    if (LATE_TABLES && pend) {  // the next image's tables: loaded at the head of this tile, they have long arrived
+      load_tables_commit(sl_slot);
+      pend = false;
     }
 
     if (FUSE) {

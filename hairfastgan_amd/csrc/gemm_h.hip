@@ -512,7 +512,16 @@ static int small_gemm(ConvParams &P, const void *w9_hi, const void *w9_lo, int n
   P.out = workspace;
   if (sk == 1) P.splits = 1;  // one slab, written by the ordinary epilogue (no scale / bias / activation set)
   const _Float16 *hi = static_cast<const _Float16 *>(w9_hi), *lo = static_cast<const _Float16 *>(w9_lo);
-  const bool small = (long long)oplane * batch <= 128 || oplane <= 128;
+  bool small = (long long)oplane * batch <= 128 || oplane <= 128;
+  if (!small && !(g_h_tune & 2)) {
+    // 256-pixel tiles run two blocks per CU (512 slots), 128-pixel tiles three (768; 148-152 registers, 48 KB): when the last
+    // round of the 256-pixel form would be under half full, the launch takes the 128-pixel form - a tile FORM, same K order,
+    // same bits.  The 16^2 layers at batch 8: 576 blocks on 512 slots -> 1152 on 768, 52 -> 44 us (profiles/r06am_*);
+    // hf_debug_set_tuning bit 1 = never (A/B, tests)
+    const long long n256 = (long long)hf_cdiv(oplane, 256) * batch * (9 * cout / 64) * (gemm_vsplit(batch, 9 * cout, oplane, 1, sk) ? 1 : sk);
+    const long long slots = 2LL * gemm_fill_blocks(), tail = n256 % slots;
+    small = n256 > slots && tail > 0 && 2 * tail <= slots;
+  }
   if (small) return (nterms == 3) ? launch_gemm<3, 2>(P, hi, lo, st) : launch_gemm<1, 2>(P, hi, lo, st);
   return (nterms == 3) ? launch_gemm<3, 4>(P, hi, lo, st) : launch_gemm<1, 4>(P, hi, lo, st);
 }
@@ -575,16 +584,18 @@ __global__ __launch_bounds__(1024) void small_up_blur(float *__restrict__ out, h
   // Index walks without per-element divisions (a runtime division is ~40 VALU instructions: the first form of this kernel
   // spent most of its 65 us on them): (q, p) = (i / n, i % n) advanced by NT with carries.
   // ---- phase 0: V[ct][p] = sum_z y[z][b][tap*cout + co][p], ct = c*9 + tap, z ascending from 0 (small_combine's inner
-  // loop); coalesced loads, four elements per thread in flight together
+  // loop); coalesced loads, four elements per thread in flight together (nine: the 4^2 / 8^2 planes 16 -> 23 us, the 16^2 plane
+  // unchanged - r06ap)
   {
+    constexpr int U = 4;
     const int qs = NT / iplane, ps = NT - qs * iplane;
     int ct = threadIdx.x / iplane, p = threadIdx.x - ct * iplane;
     while (ct < 72) {
-      const float *src[4];
-      float t[4];
-      int vi[4];
+      const float *src[U];
+      float t[U];
+      int vi[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int cc = min(ct, 71);                    // (clamped: surplus elements of the last pass re-read a valid one)
         const int c = cc / 9, tap = cc - c * 9;
         src[u] = y + ((long long)b * 9 * cout + (long long)tap * cout + cb * 8 + c) * iplane + p;
@@ -599,10 +610,10 @@ __global__ __launch_bounds__(1024) void small_up_blur(float *__restrict__ out, h
       }
       for (int z = 0; z < splits; ++z) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] += src[u][(long long)z * zslab];
+        for (int u = 0; u < U; ++u) t[u] += src[u][(long long)z * zslab];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < U; ++u)
         if (vi[u] >= 0) V[vi[u]] = t[u];
     }
   }

@@ -90,50 +90,93 @@ __global__ __launch_bounds__(256) void demod_kernel(float *__restrict__ d, const
 }
 
 // ---- all layers of a forward in two launches (hf_style_batch_f32) ----
-// blockIdx.z = job; same arithmetic per (job, b, channel) as modulation_kernel / demod_kernel
+// blockIdx.z = job; same arithmetic per (job, b, channel) as modulation_kernel / demod_kernel.  Round 6: a wave keeps its
+// weight row for kStyleBC batch elements (blockIdx.y = batch chunk) instead of one - at batch 8 the 27 MB of modulation
+// weights of a forward were streamed eight times (27 + 25 us for two launches of GEMV rows); every (b, channel) result is
+// the same chain of operations as before: equal bits at any batch size.
+constexpr int kStyleBC = 8;
+
+// KN = style-vector elements per lane (8: style_dim <= 512, the generator's; 16: up to 1024); a wave computes kStyleCI
+// modulation channels for kStyleBC batch elements from ONE copy of the latent rows (the first form of this round - one channel
+// per wave, 16 predicated elements per lane - needed 158 registers and ran no faster than before: 13 k waves of three
+// dependent round trips at three waves per SIMD)
+constexpr int kStyleCI = 4;
+template <int KN>
 __global__ __launch_bounds__(256) void modulation_batch_kernel(float *__restrict__ out,
                                                                const float *__restrict__ latent,
                                                                long long lat_bstride, long long lat_rstride,
                                                                const hf_style_job *__restrict__ jobs, int style_dim,
-                                                               float scale) {
+                                                               float scale, int batch) {
   const hf_style_job J = jobs[blockIdx.z];
   const int lane = threadIdx.x & 63;
-  const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int b = blockIdx.y;
-  if (ci >= J.cin) return;
-  const float *wr = J.mod_w + (long long)ci * style_dim;
-  const float *lat = latent + (long long)b * lat_bstride + (long long)J.style_row * lat_rstride;
-  float wv[kMaxPerLane], lv[kMaxPerLane];
+  const int ci0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kStyleCI;
+  const int b0 = blockIdx.y * kStyleBC;
+  if (ci0 >= J.cin) return;
+  const float *lat0 = latent + (long long)J.style_row * lat_rstride;
+  float ws[kStyleCI][KN], lv[kStyleBC][KN];
 #pragma unroll
-  for (int k = 0; k < kMaxPerLane; ++k) {
-    const int j = k * 64 + lane;
-    const bool ok = j < style_dim;
-    wv[k] = ok ? wr[j] : 0.0f;
-    lv[k] = ok ? lat[j] : 0.0f;
+  for (int c = 0; c < kStyleCI; ++c) {
+    const float *wr = J.mod_w + (long long)min(ci0 + c, J.cin - 1) * style_dim;  // (surplus rows re-read the last one)
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      const int j = k * 64 + lane;
+      ws[c][k] = j < style_dim ? wr[j] : 0.0f;
+    }
   }
-  float acc = 0.0f;
 #pragma unroll
-  for (int k = 0; k < kMaxPerLane; ++k) acc = fmaf(lv[k], wv[k] * scale, acc);
-  acc = hf_wave_sum(acc);
-  if (lane == 0) out[J.s_ofs + (long long)b * J.cin + ci] = acc + J.mod_b[ci];
+  for (int bb = 0; bb < kStyleBC; ++bb) {
+    const float *lat = lat0 + (long long)min(b0 + bb, batch - 1) * lat_bstride;
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      const int j = k * 64 + lane;
+      lv[bb][k] = j < style_dim ? lat[j] : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < kStyleCI; ++c) {
+#pragma unroll
+    for (int k = 0; k < KN; ++k) ws[c][k] = ws[c][k] * scale;
+    const bool cok = ci0 + c < J.cin;
+    const float bias = cok ? J.mod_b[ci0 + c] : 0.0f;
+#pragma unroll
+    for (int bb = 0; bb < kStyleBC; ++bb) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < KN; ++k) acc = fmaf(lv[bb][k], ws[c][k], acc);
+      acc = hf_wave_sum(acc);
+      if (lane == 0 && cok && b0 + bb < batch) out[J.s_ofs + (long long)(b0 + bb) * J.cin + ci0 + c] = acc + bias;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void demod_batch_kernel(float *__restrict__ out,
-                                                          const hf_style_job *__restrict__ jobs) {
+                                                          const hf_style_job *__restrict__ jobs, int batch) {
   const hf_style_job J = jobs[blockIdx.z];
   const int lane = threadIdx.x & 63;
   const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int b = blockIdx.y;
+  const int b0 = blockIdx.y * kStyleBC;
   if (!J.wsq || co >= J.cout) return;
   const float *wr = J.wsq + (long long)co * J.cin;
-  const float *sr = out + J.s_ofs + (long long)b * J.cin;
-  float acc = 0.0f;
-  for (int j = lane; j < J.cin; j += 64) {
-    float sv = sr[j];
-    acc = fmaf(wr[j], sv * sv, acc);
+  const float *sr[kStyleBC];
+  float acc[kStyleBC];
+#pragma unroll
+  for (int bb = 0; bb < kStyleBC; ++bb) {
+    sr[bb] = out + J.s_ofs + (long long)min(b0 + bb, batch - 1) * J.cin;
+    acc[bb] = 0.0f;
   }
-  acc = hf_wave_sum(acc);
-  if (lane == 0) out[J.d_ofs + (long long)b * J.cout + co] = rsqrtf(acc + 1e-8f);
+  for (int j = lane; j < J.cin; j += 64) {
+    const float wv = wr[j];
+#pragma unroll
+    for (int bb = 0; bb < kStyleBC; ++bb) {
+      const float sv = sr[bb][j];
+      acc[bb] = fmaf(wv, sv * sv, acc[bb]);
+    }
+  }
+#pragma unroll
+  for (int bb = 0; bb < kStyleBC; ++bb) {
+    const float a = hf_wave_sum(acc[bb]);
+    if (lane == 0 && b0 + bb < batch) out[J.d_ofs + (long long)(b0 + bb) * J.cout + co] = rsqrtf(a + 1e-8f);
+  }
 }
 
 // ---- range normalisation of a (modulation, demodulation) pair (hf_style_normalize_f32) ----
@@ -188,12 +231,17 @@ extern "C" int hf_style_batch_f32(float *out, const float *latent, long long lat
       style_dim > 64 * kMaxPerLane || max_cin <= 0)
     return HF_E_INVALID;
   const float scale = 1.0f / sqrtf((float)style_dim);
-  hipLaunchKernelGGL(modulation_batch_kernel, dim3(hf_cdiv(max_cin, 4), batch, n_jobs), dim3(256), 0, (hipStream_t)stream,
-                     out, latent, lat_bstride, lat_rstride, jobs, style_dim, scale);
+  const dim3 mgrid(hf_cdiv(max_cin, 4 * kStyleCI), hf_cdiv(batch, kStyleBC), n_jobs);
+  if (style_dim <= 512)
+    hipLaunchKernelGGL(modulation_batch_kernel<8>, mgrid, dim3(256), 0, (hipStream_t)stream, out, latent, lat_bstride, lat_rstride,
+                       jobs, style_dim, scale, batch);
+  else
+    hipLaunchKernelGGL(modulation_batch_kernel<kMaxPerLane>, mgrid, dim3(256), 0, (hipStream_t)stream, out, latent, lat_bstride,
+                       lat_rstride, jobs, style_dim, scale, batch);
   if (max_cout > 0)
   {
-    hipLaunchKernelGGL(demod_batch_kernel, dim3(hf_cdiv(max_cout, 4), batch, n_jobs), dim3(256), 0, (hipStream_t)stream, out,
-                       jobs);
+    hipLaunchKernelGGL(demod_batch_kernel, dim3(hf_cdiv(max_cout, 4), hf_cdiv(batch, kStyleBC), n_jobs), dim3(256), 0,
+                       (hipStream_t)stream, out, jobs, batch);
     hipLaunchKernelGGL(normalize_batch_kernel, dim3(batch, n_jobs), dim3(256), 16, (hipStream_t)stream, out, jobs);
   }
   return hf_launch_status();

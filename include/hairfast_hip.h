@@ -664,7 +664,9 @@ int hf_debug_set_persistent_blocks(int blocks);
 /* Tuning switches of the fp16 matrix-core kernels (per thread, like the other debug hooks): bit 0 = issue every
  * stage's LDS-DMA copies in the stage's first tap-step instead of spreading them one per tap-step (the default,
  * measured 0-8 % faster on every generator layer); bit 1 = hf_conv1x1_f16_f32 never uses its 128-channel block form (round 6: eight
- * waves sharing one activation stage - taken when the launch fills two rounds of CUs with it; a tile form: equal bits);
+ * waves sharing one activation stage - taken when the launch fills two rounds of CUs with it; a tile form: equal bits) and the
+ * small-plane tap GEMM never trades its 256-pixel tiles for 128-pixel ones (taken when the last round of the 256-pixel form
+ * would be under half full: three instead of two blocks per CU; equal bits);
  * bit 2 = hf_conv2d_f16_f32 never uses its 512-pixel tile form,
  * bits 8-15 = the minimum number of 512-pixel blocks / 8 for that form (0 = the default, 512), bits 16-23 = the
  * same for the 256-pixel form (default 384), bit 3 = the fp16-core conv kernels launch their grid columns-fastest whenever that is

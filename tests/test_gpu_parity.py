@@ -990,3 +990,34 @@ def test_small_plane_upsampling_in_two_launches_equals_three(B, h, monkeypatch):
             assert torch.equal(res[False], res[True])
         else:
             assert torch.equal(res[False].hi, res[True].hi) and torch.equal(res[False].lo, res[True].lo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [8, 3])
+def test_small_plane_tap_gemm_pixel_tile_forms_agree(B):
+    """The 16^2 layers' tap GEMM (512 -> 512) in its 128-pixel tile form (taken when the last round of the 256-pixel form would
+    be under half full: batch 8 = 576 blocks on 512 slots) against the 256-pixel form (hf_debug_set_tuning bit 1): equal bits,
+    same resolution and transposed; and against the fp32 kernel."""
+    from hairfastgan_amd import _marshal as M
+    from hairfastgan_amd._runtime import lib, stream
+
+    dev = torch.device("cuda:0")
+    L, st = lib(), stream()
+    torch.manual_seed(B)
+    c, h = 512, 16
+    x, wgt = torch.randn(B, c, h, h, device=dev), torch.randn(1, c, c, 3, 3, device=dev)
+    s, d = torch.rand(B, c, device=dev) + 0.5, torch.rand(B, c, device=dev) + 0.5
+    nz, nw, bias = torch.randn(B, 1, h, h, device=dev), torch.tensor([0.3], device=dev), torch.randn(c, device=dev)
+    wt, _ = M.prepare_weights(L, st, wgt)
+    w9 = M.split_weights_small(L, st, wt)
+    same, up = {}, {}
+    try:
+        for never in (0, 2):
+            L.hf_debug_set_tuning(never)
+            same[never] = M.modconv3x3_small(L, st, x, w9, 3, s, d, nz, nw, bias, c)
+            up[never] = M.modconv3x3_small(L, st, x, w9, 3, s, d, None, None, None, c, upsample=True)
+    finally:
+        L.hf_debug_set_tuning(0)
+    assert torch.equal(same[0], same[2]) and torch.equal(up[0][..., :2 * h + 1], up[2][..., :2 * h + 1])
+    ref = M.modconv3x3(L, st, x, wt, s, d, nz, nw, bias)
+    assert float((same[0] - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))

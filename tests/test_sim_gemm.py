@@ -222,3 +222,33 @@ def test_conv1x1_128_channel_blocks_equal_64_channel_blocks(simlib):
             finally:
                 simlib.hf_set_batch_invariant(prev)
                 simlib.hf_debug_set_tuning(0)
+
+
+def test_small_plane_tap_gemm_128_pixel_tiles_equal_256_pixel_tiles(simlib):
+    """Round 6: the small-plane tap GEMM trades its 256-pixel tiles for 128-pixel ones when the last round of the 256-pixel
+    form would be under half full (the generator's 16^2 layers at batch 8: 576 blocks on 512 slots).  A tile FORM: every
+    output element keeps its K order, so both forms must agree bit for bit - same resolution and transposed, with and without
+    the batch-invariant K partition.  Bits 24-31 of hf_debug_set_tuning lower the chip-filling block count (slots = 2 x fill) so
+    that a small shape takes the rule: 16^2, cout 64 -> 9 channel tiles on 8 slots, a last round of one block."""
+    torch.manual_seed(22)
+    fill4 = 4 << 24
+    B, cin, cout, h, w = 1, 64, 64, 16, 16
+    xx, wgt = torch.randn(B, cin, h, w), torch.randn(1, cout, cin, 3, 3)
+    s, d = torch.rand(B, cin) + 0.5, torch.rand(B, cout) + 0.5
+    nz, nw, bias = torch.randn(B, 1, h, w), torch.tensor([0.3]), torch.randn(cout)
+    wt, _ = M.prepare_weights(simlib, None, wgt)
+    w9 = M.split_weights_small(simlib, None, wt)
+    for binv in (0, 1):
+        prev = simlib.hf_set_batch_invariant(binv)
+        try:
+            same, up = {}, {}
+            for never in (0, 2):
+                simlib.hf_debug_set_tuning(fill4 | never)
+                same[never] = M.modconv3x3_small(simlib, None, xx, w9, 3, s, d, nz, nw, bias, cout)
+                up[never] = M.modconv3x3_small(simlib, None, xx, w9, 3, s, d, None, None, None, cout, upsample=True)
+            assert torch.equal(same[0], same[2]) and torch.equal(up[0][..., :2 * w + 1], up[2][..., :2 * w + 1])  # (pitch padding: unwritten)
+            ref = M.modconv3x3(simlib, None, xx, wt, s, d, nz, nw, bias)
+            assert float((same[0] - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+        finally:
+            simlib.hf_set_batch_invariant(prev)
+            simlib.hf_debug_set_tuning(0)
