@@ -36,6 +36,7 @@ SIGNATURES = {
     "hf_conv1x1_f16_f32": [_f, _f, _f, _f, _f, _f, _i, _f, _f, _f, _f, _i, _f, _fl, _f, _i, _i, _i, _i, _i, _i, _i, _ll, _f, _ll, _st],
     "hf_modconv3x3_f16_f32": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _st],
     "hf_modconv3x3_f16_rgb_f32": [_f, _f, _f, _f, _i, _f, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _f, _f, _f, _st],
+    "hf_modconv3x3_f16_pre_image_f32": [_f, _f, _f, _f, _f, _i, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _f, _f, _f, _f, _f, _st],
     "hf_modconv3x3_f16_pre_f32": [_f, _f, _f, _f, _f, _i, _f, _f, _f, _ll, _f, _i, _i, _i, _i, _i, _fl, _fl, _f, _f, _f, _f, _f, _f, _st],
     "hf_modconv3x3_up_f16_pre_f32": [_f, _f, _f, _f, _f, _i, _f, _i, _i, _i, _i, _i, _i, _st],
     "hf_modconv3x3_up_f16_f32": [_f, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _st],

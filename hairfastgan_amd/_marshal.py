@@ -276,6 +276,38 @@ def torgb_fusable(cin, cout, h, w):
     return h * w >= (512 if cout in (32, 64) else 4096)
 
 
+def image_fusable(cin, cout, h, w):
+    """The generator's last StyledConv whose epilogue finishes ToRGB (hf_modconv3x3_f16_pre_image_f32: the row pipeline's
+    shapes).  The library may still decline (debug dispatch / tuning switches): modconv3x3_f16_pre_image then returns None."""
+    return cin == 32 and cout == 32 and w % 64 == 0 and h % 8 == 0 and os.environ.get("HAIRFAST_IMAGE_FUSE", "1") != "0"
+
+
+def modconv3x3_f16_pre_image(lib, st, act, wt_hi, wt_lo, nterms, d, noise, noise_w, bias, rgb, rgb_bias, skip, up_kernel,
+                             alpha=0.2, scale=SQRT2):
+    """hf_modconv3x3_f16_pre_image_f32: same-resolution 3x3 conv on a SplitActivation + its complete ToRGB (1x1 modulated conv
+    + bias + upsampled skip) in one launch - the image [B,3,H,W], or None when the library does not take the shape (the caller
+    runs modconv3x3_f16_pre(rgb=...) + torgb: the same bits)."""
+    b, cin, h, w = act.shape
+    cout = wt_hi.shape[3]
+    skip = _c(skip)
+    if tuple(skip.shape) != (b, 3, h // 2, w // 2):
+        raise ValueError(f"skip must be [B,3,H/2,W/2]; got {tuple(skip.shape)} for a {h}x{w} layer")
+    noise, nbs = _noise_args(noise, b, h * w)
+    image = torch.empty((b, 3, h, w), dtype=torch.float32, device=act.hi.device)
+    rgb_wt, rgb_s = _c(rgb[0]), _c(rgb[1])
+    nparts = 2 if nterms == 3 else 1
+    nb = float(b) * h * w * (2.0 * nparts * cin + 12.0 + 3.0) + 2.0 * nparts * 9 * cin * cout  # split input, image, skip, weights: once
+    code = _launch_profiled(
+        lib, 2.0 * cin * cout * 9 * h * w * b,
+        lambda: lib.hf_modconv3x3_f16_pre_image_f32(_p(image), _p(act.hi), _p(act.lo), _p(wt_hi), _p(wt_lo), nterms, _p(d), _p(noise),
+                                                    _p(_c(noise_w)), nbs, _p(_c(bias)), b, cin, cout, h, w, alpha, scale, _p(rgb_wt),
+                                                    _p(rgb_s), _p(_c(rgb_bias)), _p(skip), _p(_c(up_kernel)), st), nbytes=nb)
+    if code == -1:  # HF_E_INVALID: not a row-pipeline launch
+        return None
+    check(lib, code, "hf_modconv3x3_f16_pre_image_f32")
+    return image
+
+
 def torgb_slabs(cout):
     """Slabs of the fused ToRGB's raw tensor [B, 3*slabs, H, W] (hf_modconv3x3_f16_rgb_slabs)."""
     return cout // 64 if cout % 64 == 0 else cout // 32

@@ -11,7 +11,7 @@ extern "C" const char *hf_strerror(int code) {
   }
 }
 
-extern "C" int hf_abi_version(void) { return 12; }
+extern "C" int hf_abi_version(void) { return 13; }
 
 // A one-thread kernel with a name of its own: bench.py / tools launch it around the region a profile is about, so that
 // rocprofv3's per-dispatch tables (kernel trace, counter collection) can be cut to that region - warm-up and plan-time

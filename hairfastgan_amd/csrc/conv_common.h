@@ -78,6 +78,9 @@ struct ConvParams {
   // rgb_out[b][c][Y][X] = sum_co rgb_w[co*3+c] * rgb_s[b*cout+co] * y[b][co][Y][X]  (null = off)
   const float *rgb_w, *rgb_s;
   float *rgb_out;
+  // convrow.hip only (null = off): rgb_out receives the FINISHED ToRGB image instead of the raw 1x1 product -
+  // + rgb_bias[c] + the x2-upsampled skip (rgb_skip [B][3][H/2][W/2], rgb_k4 = its 4x4 kernel): hf_torgb_f32's arithmetic
+  const float *rgb_skip, *rgb_bias, *rgb_k4;
   // convh.hip, pre-split input: s*x already split into fp16 (hi, lo) and K-blocked
   // [batch][cin/8][h][w][8] by the producer (hf_blur_noise_bias_act_split_f16); x and s unused
   const void *xh, *xl;

@@ -1337,6 +1337,7 @@ int launch_conv_h(ConvParams &P, int nterms, bool up, const void *wth, const voi
         return rc;
       }
     }
+    if (P.rgb_skip) return HF_E_INVALID;  // the finished ToRGB exists in the row pipeline only
     if (cfg == 55) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 128, true>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 128, true>(P, h, l, st);
     else if (cfg == 53) rc = (nterms == 3) ? launch_h<3, 1, 2, 1, 8, false, 32, true>(P, h, l, st) : launch_h<1, 1, 2, 1, 8, false, 32, true>(P, h, l, st);
     else if (cfg == 52) rc = (nterms == 3) ? launch_h<3, 2, 2, 1, 8, false, 32, true>(P, h, l, st) : launch_h<1, 2, 2, 1, 8, false, 32, true>(P, h, l, st);
@@ -1529,6 +1530,35 @@ extern "C" int hf_modconv3x3_f16_pre_f32(float *out, const void *x_hi, const voi
   P.rgb_slabs = hf_modconv3x3_f16_rgb_slabs(cout);
   P.oh = split_hi; P.ol = split_lo; P.s_next = s_next;
   if (split_hi && ((cout & 7) || (nterms == 3 && !split_lo))) return HF_E_INVALID;
+  return launch_conv_h(P, nterms, false, wt_hi, wt_lo, (hipStream_t)stream);
+}
+
+// The generator's LAST StyledConv with its ToRGB complete (ABI 13; the 1024^2 layer: 32 -> 32 channels, the row pipeline of
+// convrow.hip): image = ToRGB's 1x1 modulated conv of the layer's output + rgb_bias + the x2-upsampled skip - no raw product
+// in memory, no finishing launch.  HF_E_INVALID for every shape the row pipeline does not take (callers fall back to
+// hf_modconv3x3_f16_pre_f32 + hf_torgb_f32: the same bits).
+extern "C" int hf_modconv3x3_f16_pre_image_f32(float *image, const void *x_hi, const void *x_lo, const void *wt_hi,
+                                               const void *wt_lo, int nterms, const float *d, const float *noise,
+                                               const float *noise_w, long long noise_bstride, const float *bias, int batch,
+                                               int cin, int cout, int h, int w, float alpha, float scale, const float *rgb_wt,
+                                               const float *rgb_s, const float *rgb_bias, const float *skip,
+                                               const float *kernel4x4, void *stream) {
+  if (!image || !x_hi || !wt_hi || !rgb_wt || !rgb_s || !skip || !kernel4x4 || batch <= 0 || cin != 32 || cout != 32 || h <= 0 ||
+      w <= 0 || (h & 1) || (w & 1) || (noise && !noise_w) || (nterms != 1 && nterms != 3) || (nterms == 3 && !x_lo) || !bias)
+    return HF_E_INVALID;
+  if (g_force_h || (g_h_tune & 16)) return HF_E_INVALID;  // the tiled form was asked for (tests, A/B)
+  ConvParams P{};
+  P.xh = x_hi; P.xl = x_lo; P.d = d; P.noise = noise; P.noise_w = noise_w; P.bias = bias;
+  P.s_bstride = cin; P.d_bstride = cout;
+  P.groups = 1;
+  P.noise_bstride = noise_bstride;
+  P.batch = batch; P.cin = cin; P.cout = cout; P.h = h; P.w = w; P.out_h = h; P.out_w = w; P.out_wv = w;
+  P.stride = 1;
+  P.act = ACT_LRELU;
+  P.alpha = alpha; P.scale = scale;
+  P.rgb_out = image; P.rgb_w = rgb_wt; P.rgb_s = rgb_s;
+  P.rgb_slabs = 1;
+  P.rgb_skip = skip; P.rgb_bias = rgb_bias; P.rgb_k4 = kernel4x4;
   return launch_conv_h(P, nterms, false, wt_hi, wt_lo, (hipStream_t)stream);
 }
 

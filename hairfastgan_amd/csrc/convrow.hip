@@ -13,6 +13,10 @@
 //     accumulation chains of 54 MFMAs; the eight rows of the NEXT super-step are requested during the first ten taps (one
 //     copy per tap, between the MFMA groups) and waited for at the step's barrier (one barrier per 108 MFMAs);
 //   * a step's epilogue runs after its barrier, at the head of the next step: no store is waited for fresh.
+//   * ConvParams::rgb_skip (round 6): the epilogue finishes ToRGB - raw + bias + the x2-upsampled skip (hf_torgb_f32's
+//     arithmetic, operation for operation) - instead of writing the raw product for a finishing launch (58 us and 200 MB
+//     of traffic at batch 8): the skip rows a super-step needs (6 rows x 34 columns x 3 channels) travel through a 16-row
+//     LDS ring like the input rows, two more 16-byte-per-lane copies per super-step.
 // Accumulation order per output value = the tiled kernel's (chunk, tap, hh / hl / lh): identical bits.
 // Measured at batch 8 (tools/probes/rows.py, bench.py): 732 -> 470 us per launch.  With the copies and the epilogue switched
 // off (hf_debug_set_tuning bits 5 / 6) the MFMA loop alone takes 340 us against 184 us of pure MFMA time at 2.4 GHz; the
@@ -33,6 +37,13 @@ constexpr int kSlotUnits = 2 * kPartUnits;   // [part 2][channel block 4][66]
 constexpr int kRing = 18;                    // row slots: 10 in use + 8 arriving
 constexpr int kStep = 8;                     // output rows per super-step
 constexpr int kDmaPerPart = (kPartUnits + 63) / 64;  // 5 (the fifth carries 8 lanes)
+// finished ToRGB: skip rows in groups of four, [group 4][row 4][channel 3][10 units of 4 columns] floats - columns x0/2 - 4 ..
+// x0/2 + 35 in whole 16-byte units (x0/2 is a multiple of 32, the plane width of 4: a unit lies inside the plane or outside) -
+// group q = skip rows 4q+1 .. 4q+4 lives in slot (q + 1) & 3; then the 4x4 kernel and the three biases
+constexpr int kSkCols = kSW / 2 + 8;          // 40 floats of a (row, channel): the 34 columns a strip reads sit at +3
+constexpr int kSkRow = 3 * kSkCols;           // floats of one skip row (three channels)
+constexpr int kSkGroup = 4 * kSkRow;          // 480 floats = 120 units: two copies of 64 lanes
+constexpr int kSkFloats = 4 * kSkGroup + 16 + 4;
 
 // NTERMS 3: f16x3 operands (hi, lo); 1: plain fp16 operands (BASELINE.json configs[4]) - no lo weights, no lo row parts, one
 // MFMA per (tap, row) instead of three
@@ -43,6 +54,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
   HF_DYN_LDS;
   half8 *ring = reinterpret_cast<half8 *>(hf_dyn_lds);                     // [kRing][kSlotUnits]
   float *ep = reinterpret_cast<float *>(ring + kRing * kSlotUnits);        // [32] d', [32] bias', [3][32] rgb weights
+  float *skr = ep + 5 * 32;                                                 // P.rgb_skip: [4][kSkGroup] skip rows, [16] kernel, [3] bias
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int H = P.h, W = P.w;
   const long long plane = (long long)H * W;
@@ -74,6 +86,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
 #pragma unroll
       for (int c = 0; c < 3; ++c) ep[64 + c * 32 + tid] = P.rgb_w[tid * 3 + c] * sv;
     }
+    if (P.rgb_skip && tid < 19) skr[4 * kSkGroup + tid] = tid < 16 ? P.rgb_k4[tid] : (P.rgb_bias ? P.rgb_bias[tid - 16] : 0.0f);
   }
 
   // ---- LDS-DMA of one input row into a ring slot: per part 5 copies of 64 units; unit u = cb*66 + px of the part
@@ -105,6 +118,28 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
 #pragma unroll
     for (int idx = 0; idx < NPART * kDmaPerPart; ++idx) dma_piece(idx, y, slot);
   };
+  // finished ToRGB: waves 0 and 1 copy units 64w .. 64w+63 of a skip row group (16 bytes per lane, like the input rows)
+  const int sh = H >> 1, sw = W >> 1;
+  const float *skip_b = P.rgb_skip ? P.rgb_skip + (long long)b * 3 * sh * sw : nullptr;
+  const unsigned skr_addr = hf_lds_addr(skr);
+  auto dma_skip = [&](int q) {  // skip rows 4q+1 .. 4q+4 -> slot (q + 1) & 3
+    if (wave >= 2) return;
+    // the lane's (row of the group, channel, unit) recomputed per copy (opaque: no registers held across the MFMA loop)
+    int u = 64 * wave + lane;
+    HF_OPAQUE_I32(u);
+    const int rq = u / 30, rem = u - rq * 30, ch = rem / 10, gcol = (x0 >> 1) - 4 + 4 * (rem - ch * 10);
+    const int R = 4 * q + 1 + rq, slot = (q + 1) & 3;
+    const bool unit = u < kSkGroup / 4, inside = unit && gcol >= 0 && gcol < sw && R >= 0 && R < sh;
+    hf_glds16_raw_s_if(inside, skip_b, inside ? (unsigned)((ch * sh + R) * sw + gcol) * 4u : 0u,
+                       skr_addr + (unsigned)(slot * kSkGroup + 256 * wave) * 4u);
+    if (unit && !inside)  // rows / columns outside the plane
+      *reinterpret_cast<float4 *>(skr + slot * kSkGroup + 4 * u) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  };
+  const int sk_m = r0 / kStep;  // super-step S reads skip rows 4(m+S)-1 .. 4(m+S)+4: groups m+S-1 and m+S
+  if (P.rgb_skip) {
+    dma_skip(sk_m - 1);
+    dma_skip(sk_m);
+  }
   // prologue: input rows r0-1 .. r0+8 -> slots 0 .. 9
   dma_row(r0 - 1 + wave, wave);
   if (wave < 2) dma_row(r0 + 7 + wave, 8 + wave);
@@ -202,10 +237,34 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
     }
     if (P.rgb_out) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        rgb[c] += __shfl_xor(rgb[c], 32, 64);
-        if (lh_o == 0) P.rgb_out[((long long)b * 3 + c) * plane + pix] = rgb[c];
+      for (int c = 0; c < 3; ++c) rgb[c] += __shfl_xor(rgb[c], 32, 64);
+      if (P.rgb_skip) {
+        // hf_torgb_f32 with one slab: r = raw + bias; up = the 2 x 2 taps of the zero-insert x2 upsampler (pad (2, 1), 4x4 true
+        // convolution) that hit samples, rows iy0 / iy0 + 1 and columns ix0 / ix0 + 1 in that order; out = r + up.  Rows and
+        // columns outside the plane are zeros in the ring (fmaf(0, k, up) = up: the reference skips them).
+        int Yo = Y, li_o = li;  // (opaque: nothing of this block is hoisted out of the step loop into registers that stay live)
+        HF_OPAQUE_I32(Yo);
+        HF_OPAQUE_I32(li_o);
+        const int ky0 = Yo & 1, kx0 = li_o & 1;
+        const int iy0 = (Yo + ky0 - 2) >> 1;
+        const int col0 = 16 * j + (li_o >> 1) + kx0 + 3;  // column ix0 - (x0/2 - 4)
+        const float *s0 = skr + ((iy0 + 3) & 15) * kSkRow + col0, *s1 = skr + ((iy0 + 4) & 15) * kSkRow + col0;
+        const float *k4 = skr + 4 * kSkGroup;
+        const float k00 = k4[(3 - ky0) * 4 + 3 - kx0], k01 = k4[(3 - ky0) * 4 + 1 - kx0];
+        const float k10 = k4[(1 - ky0) * 4 + 3 - kx0], k11 = k4[(1 - ky0) * 4 + 1 - kx0];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float r = rgb[c] + k4[16 + c];
+          float up = fmaf(s0[c * kSkCols], k00, 0.0f);
+          up = fmaf(s0[c * kSkCols + 1], k01, up);
+          up = fmaf(s1[c * kSkCols], k10, up);
+          up = fmaf(s1[c * kSkCols + 1], k11, up);
+          rgb[c] = r + up;
+        }
       }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (lh_o == 0) P.rgb_out[((long long)b * 3 + c) * plane + pix] = rgb[c];
     }
   };
 
@@ -227,6 +286,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
     // the two waves of a SIMD (w, w + 4) issue their copies at different times: one before its epilogue, the other between
     // the MFMA groups of its first ten taps - each stalls on the copy issue while its partner has MFMAs to issue
     if (more && wave < 4 && !(ablate & 1)) dma_row(y_next, slot_next);
+    if (more && P.rgb_skip) dma_skip(sk_m + S + 1);  // the next super-step's new skip rows (waited for at this step's barrier)
     if (S > 0) {  // the previous super-step's epilogue: its stores drain under this step's MFMAs, none is waited for fresh
       epilogue(acc[0], ro - kStep, nzp[0]);
       epilogue(acc[1], ro - kStep + 4, nzp[1]);
@@ -256,6 +316,7 @@ int launch_conv_rows(ConvParams &P, int nterms, const void *wth, const void *wtl
     return HF_E_INVALID;
   if (!P.bias || P.act != ACT_LRELU || !(P.alpha >= 0.0f && P.alpha <= 1.0f) || !(P.scale > 0.0f)) return HF_E_INVALID;
   if ((!P.out && !P.rgb_out) || (P.rgb_out && (!P.rgb_w || !P.rgb_s || P.rgb_slabs != 1))) return HF_E_INVALID;
+  if (P.rgb_skip && (!P.rgb_out || !P.rgb_k4 || (P.h & 1) || (P.w & 1) || ((size_t)P.rgb_skip & 15))) return HF_E_INVALID;  // (16-byte skip units)
   if ((long long)4 * P.h * P.w * 16 >= (1LL << 31)) return HF_E_INVALID;  // 32-bit byte offsets inside an image
   const int strips = P.w / kSW;
   // vertical segments: LDS allows one block per CU, so the launch runs in ceil(blocks / 256) rounds of rows_per_block rows
@@ -275,7 +336,7 @@ int launch_conv_rows(ConvParams &P, int nterms, const void *wth, const void *wtl
   const int rows_per_block = P.h / segs;
   const long long blocks = (long long)P.batch * strips * segs;
   if (blocks >= (1LL << 31)) return HF_E_INVALID;
-  const size_t lds = (size_t)kRing * kSlotUnits * 16 + 5 * 32 * sizeof(float);
+  const size_t lds = (size_t)kRing * kSlotUnits * 16 + 5 * 32 * sizeof(float) + (P.rgb_skip ? kSkFloats * sizeof(float) : 0);
   if (nterms == 3)
     hipLaunchKernelGGL(conv_rows_h<3>, dim3((unsigned)blocks), dim3(512), lds, st, P, static_cast<const _Float16 *>(wth),
                        static_cast<const _Float16 *>(wtl), rows_per_block, segs, (g_h_tune >> 5) & 7);

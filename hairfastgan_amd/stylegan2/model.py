@@ -347,6 +347,21 @@ class StyledConv(nn.Module):  # :309-343
         return conv.conv_up(input, wt, s, d, noise, self.noise.weight.detach(), act.bias.detach(),
                             act.negative_slope, act.scale, split_for=(None, s_next, conv_precision() == "f16x3"))
 
+    def forward_image(self, split, coeffs, noise, rgb, to_rgb, skip):
+        """The generator's last StyledConv + its ToRGB in ONE launch (M.image_fusable shapes): the image, or None when the
+        library declines (the caller then takes forward_from_split + ToRGB.finish - the same bits)."""
+        conv, act = self.conv, self.activate
+        _, s, d = coeffs
+        b, _, h, w = split.shape
+        if noise is None:
+            noise = split.hi.new_empty(b, 1, h, w, dtype=torch.float32).normal_()
+        require_gpu(noise, skip)
+        hi, lo = conv.prepared_f16()
+        nterms = 3 if conv_precision() == "f16x3" else 1
+        return M.modconv3x3_f16_pre_image(lib(), stream(), split, hi, lo, nterms, d, noise, self.noise.weight.detach(),
+                                          act.bias.detach(), rgb, to_rgb.bias.detach(), skip, to_rgb._skip_kernel(skip),
+                                          act.negative_slope, act.scale)
+
     def forward_from_split(self, split, coeffs, noise=None, rgb=None, want_out=True, split_for=None):
         """Same-resolution StyledConv on a SplitActivation produced for it (coeffs = this layer's
         conv.style_coefficients(style), whose s went into the split).  Returns (out, raw, next_split):
@@ -611,6 +626,14 @@ class Generator(nn.Module):  # :368-565
                     # fp32 activation: read by a stand-alone ToRGB, returned on an early exit, or fed
                     # to the next block as a plain tensor
                     want_out = not fused_rgb or (not is_last and s_up is None)
+                    if (fused_rgb and not want_out and s_up is None and skip is not None and M.image_fusable(cmid, csame, h2, w2)
+                            and conv_same.activate.bias is not None):
+                        # the last layer: its epilogue finishes ToRGB (bias + upsampled skip) - no raw product, no finishing launch
+                        image = conv_same.forward_image(split, coeffs, noise[2 * block], rgb, to_rgb, skip)
+                        if image is not None:
+                            out, split_in, skip = None, None, image
+                            i += 2
+                            continue
                     out, raw, split_in = conv_same.forward_from_split(split, coeffs, noise[2 * block],
                                                                       rgb=rgb if fused_rgb else None, want_out=want_out,
                                                                       split_for=s_up)

@@ -203,6 +203,18 @@ int hf_modconv3x3_f16_pre_f32(float *out, const void *x_hi, const void *x_lo, co
                               long long noise_bstride, const float *bias, int batch, int cin, int cout, int h, int w,
                               float alpha, float scale, float *rgb_raw, const float *rgb_wt, const float *rgb_s,
                               void *split_hi, void *split_lo, const float *s_next, void *stream);
+/* ABI 13: the generator's LAST StyledConv (models/stylegan2/model.py:337-343) with its ToRGB (:356-365) complete - the 1024^2
+ * layer, cin = cout = 32, on pre-split input: image[b, c, Y, X] = sum_co rgb_wt[co*3+c] * rgb_s[b*cout+co] * out[b,co,Y,X]
+ * + rgb_bias[c] + Upsample(skip)[b, c, Y, X]  (skip [batch][3][h/2][w/2], kernel4x4 = make_kernel([1,3,3,1]) * 4: the
+ * upfirdn2d up = 2, pad (2, 1) of :49-53), operation for operation what hf_modconv3x3_f16_pre_f32 (rgb_raw, one slab) followed
+ * by hf_torgb_f32 on that slab computes - without the raw product in memory and without the second launch.  Row-pipeline
+ * shapes only (w a multiple of 64, h of 8; not under hf_debug_set_dispatch / tuning bit 4): HF_E_INVALID otherwise - callers
+ * fall back to the two calls above. */
+int hf_modconv3x3_f16_pre_image_f32(float *image, const void *x_hi, const void *x_lo, const void *wt_hi, const void *wt_lo,
+                                    int nterms, const float *d, const float *noise, const float *noise_w,
+                                    long long noise_bstride, const float *bias, int batch, int cin, int cout, int h, int w,
+                                    float alpha, float scale, const float *rgb_wt, const float *rgb_s, const float *rgb_bias,
+                                    const float *skip, const float *kernel4x4, void *stream);
 /* split_hi / split_lo (NULL = off): the epilogue ALSO writes s_next[b,co] * out as fp16 (hi, lo) pairs,
  * K-blocked [batch][cout/8][h][w][8] - the pre-split input of the next layer's transposed conv
  * (hf_modconv3x3_up_f16_pre_f32); out may then be NULL too if nobody reads the fp32 activation.

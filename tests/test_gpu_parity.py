@@ -47,7 +47,7 @@ def test_native_library_is_loaded():
     from hairfastgan_amd import _lib
 
     lib = _lib.load()
-    assert lib.hf_abi_version() == 12
+    assert lib.hf_abi_version() == 13
     maps = open("/proc/self/maps").read()
     assert "libhairfast_hip.so" in maps
 
@@ -470,6 +470,13 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
         return real_pre(*a, **k)
 
     monkeypatch.setattr(M, "modconv3x3_f16_pre", pre)
+    image, real_image = [], M.modconv3x3_f16_pre_image
+
+    def pre_image(*a, **k):  # round 6: the last layer's epilogue finishes ToRGB (no raw product, no finishing launch)
+        image.append(a[2].shape[2])
+        return real_image(*a, **k)
+
+    monkeypatch.setattr(M, "modconv3x3_f16_pre_image", pre_image)
     up_pre, real_up = [], M.modconv3x3_up
 
     def up(lib, st, x, *a, **k):
@@ -495,17 +502,23 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
     monkeypatch.setattr(M, "torgb", rgb)
     with torch.inference_mode():
         y, _ = g([lat], input_is_latent=True, noise=nz)
-        assert fused == [64, 128, 256, 512, 1024]  # ToRGB's 1x1 conv in the conv epilogue from 64^2 upward (partial sums per 64 channels)
-        assert presplit == [32, 64, 128, 256, 512, 1024]  # blur -> conv hand-over without an fp32 activation
+        assert fused == [64, 128, 256, 512] and image == [1024]  # ToRGB's 1x1 conv in the conv epilogue from 64^2 upward (partial sums per 64 channels); the 1024^2 layer writes the image
+        assert presplit == [32, 64, 128, 256, 512]  # blur -> conv hand-over without an fp32 activation
         # conv epilogue -> next block's transposed conv, pre-split: two-pass up to 64^2 inputs, then the one-kernel
         # form (transposed conv + blur + noise + bias + lrelu, no (2h+1)^2 intermediate) from 128^2 inputs upward
         assert up_pre == [32, 64] and up_fused == [128, 256, 512]
         # finishing passes on the raw slabs (8, 4, 2, 1, 1 slabs of 3 channels); the layers below 64^2 run the stand-alone ToRGB
-        assert plain_rgb == [512, 512, 512, 512, 24, 12, 6, 3, 3], plain_rgb
+        assert plain_rgb == [512, 512, 512, 512, 24, 12, 6, 3], plain_rgb
+        # ... and the two-launch form of the last layer (HAIRFAST_IMAGE_FUSE=0) gives the same image, bit for bit
+        monkeypatch.setenv("HAIRFAST_IMAGE_FUSE", "0")
+        image.clear()
+        y2, _ = g([lat], input_is_latent=True, noise=nz)
+        monkeypatch.delenv("HAIRFAST_IMAGE_FUSE")
+        assert image == [] and torch.equal(y, y2)
         # batch 1 under batch-invariant plans (the default): the kernel families of the canonical batch-3 launch - the same chain
         fused.clear(); presplit.clear(); up_pre.clear(); up_fused.clear(); plain_rgb.clear()
         g([lat[:1]], input_is_latent=True, noise=nz)
-        assert presplit == [32, 64, 128, 256, 512, 1024] and up_pre == [32, 64] and up_fused == [128, 256, 512], (presplit, up_pre)
+        assert presplit == [32, 64, 128, 256, 512] and up_pre == [32, 64] and up_fused == [128, 256, 512], (presplit, up_pre)
         # ... and with plans from the whole launch (HAIRFAST_DETERMINISTIC=0): the 32^2 block of a batch-1 forward (1024 pixels per
         # launch: 32 blocks that would each walk the whole K loop) stays on the fp32 split-K kernels
         # (M.modconv3x3_f16_supported(batch=)), the hand-over chain starts at 64^2
@@ -514,7 +527,7 @@ def test_generator1024_fuses_torgb_of_the_top_layers(monkeypatch):
         try:
             fused.clear(); presplit.clear(); up_pre.clear(); up_fused.clear(); plain_rgb.clear()
             g([lat[:1]], input_is_latent=True, noise=nz)
-            assert presplit == [64, 128, 256, 512, 1024] and up_pre == [64] and up_fused == [128, 256, 512], (presplit, up_pre)
+            assert presplit == [64, 128, 256, 512] and up_pre == [64] and up_fused == [128, 256, 512], (presplit, up_pre)
         finally:
             _runtime.set_batch_invariant(prev_mode)
         # module API: forward_rgb's explicit (out, raw) pair finished by ToRGB.finish equals the stand-alone ToRGB
@@ -936,6 +949,15 @@ def test_conv_rows_pipeline_equals_tiled_kernel_on_hardware(B, H, W):
         assert torch.equal(out, ref_out) and torch.equal(raw, ref_raw)
     only_raw = M.modconv3x3_f16_pre(lib, st, act, hi, lo, 3, dm, nz, nw, bias, rgb=(rgb_w, rgb_s), want_out=False)[1]
     assert torch.equal(only_raw, ref_raw)
+    # round 6 (ABI 13): the epilogue finishes ToRGB - bias + upsampled skip from a 16-row LDS ring of skip rows - against the raw
+    # product + hf_torgb_f32's finishing launch, bit for bit, three launches
+    skip, rgb_bias, k4 = r(B, 3, H // 2, W // 2), r(1, 3, 1, 1), O.blur_kernel_1d_to_2d(gain=4.0).to(dev)
+    want_img = M.torgb(lib, st, ref_raw, torch.eye(3, device=dev).reshape(1, 3, 3), None, rgb_bias, skip, k4)
+    for _ in range(3):
+        img = M.modconv3x3_f16_pre_image(lib, st, act, hi, lo, 3, dm, nz, nw, bias, (rgb_w, rgb_s), rgb_bias, skip, k4)
+        assert lib.hf_debug_last_path() == 579
+        torch.cuda.synchronize()
+        assert torch.equal(img, want_img)
     if B * H * W <= 1 << 20:
         exact = M.modconv3x3(lib, st, x, wt, s, dm, nz, nw, bias)
         assert float((out - exact).abs().max()) <= 2e-5 * max(1.0, float(exact.abs().max()))

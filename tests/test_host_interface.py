@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
                                     "hf_sample_layernorm_workspace_floats", "hf_conv1x1_f16_workspace_floats",
                                     "hf_modconv3x3_small_workspace_floats"} == declared
     bound = _lib.bind(lib)
-    assert bound.hf_abi_version() == 12
+    assert bound.hf_abi_version() == 13
     assert bound.hf_strerror(-1) == b"invalid argument"
 
 

@@ -617,6 +617,18 @@ def test_conv_rows_pipeline_equals_tiled_kernel(simlib, B, H, W):
     assert torch.equal(out, ref_out) and torch.equal(raw, ref_raw)
     only_raw = M.modconv3x3_f16_pre(simlib, None, act, hi, lo, 3, dm, nz, nw, bias, rgb=(rgb_w, rgb_s), want_out=False)[1]
     assert torch.equal(only_raw, ref_raw)
+    # round 6: the epilogue finishes ToRGB (bias + x2-upsampled skip through a 16-row LDS ring of skip rows) - against the raw
+    # product + the finishing launch (ToRGB.finish: hf_torgb_f32 with identity weights), bit for bit; image borders, ring wrap
+    skip, rgb_bias, k4 = torch.randn(B, 3, H // 2, W // 2), torch.randn(1, 3, 1, 1), O.blur_kernel_1d_to_2d(gain=4.0)
+    want_img = M.torgb(simlib, None, ref_raw, torch.eye(3).reshape(1, 3, 3), None, rgb_bias, skip, k4)
+    img = M.modconv3x3_f16_pre_image(simlib, None, act, hi, lo, 3, dm, nz, nw, bias, (rgb_w, rgb_s), rgb_bias, skip, k4)
+    assert simlib.hf_debug_last_path() == 579
+    assert torch.equal(img, want_img)
+    try:
+        simlib.hf_debug_set_tuning(16)  # the tiled form asked for: the library declines, the caller keeps the two launches
+        assert M.modconv3x3_f16_pre_image(simlib, None, act, hi, lo, 3, dm, nz, nw, bias, (rgb_w, rgb_s), rgb_bias, skip, k4) is None
+    finally:
+        simlib.hf_debug_set_tuning(0)
     plain = M.modconv3x3_f16_pre(simlib, None, act, hi, lo, 3, dm, None, None, bias)
     assert simlib.hf_debug_last_path() == 579
     want = M.modconv3x3_f16(simlib, None, x, hi, lo, 3, s, dm, None, None, bias)
@@ -631,6 +643,8 @@ def test_conv_rows_pipeline_equals_tiled_kernel(simlib, B, H, W):
         simlib.hf_debug_set_tuning(0)
     out1, raw1 = M.modconv3x3_f16_pre(simlib, None, act1, hi, lo, 1, dm, nz, nw, bias, rgb=(rgb_w, rgb_s))
     assert simlib.hf_debug_last_path() == 579
+    img1 = M.modconv3x3_f16_pre_image(simlib, None, act1, hi, lo, 1, dm, nz, nw, bias, (rgb_w, rgb_s), rgb_bias, skip, k4)
+    assert torch.equal(img1, M.torgb(simlib, None, ref1_raw, torch.eye(3).reshape(1, 3, 3), None, rgb_bias, skip, k4))
     assert torch.equal(out1, ref1_out) and torch.equal(raw1, ref1_raw) and not torch.equal(out1, out)
 
 
