@@ -58,6 +58,12 @@ using namespace hf_detail;
 #ifndef HF_H_LATE_TABLES
 #define HF_H_LATE_TABLES 0  // 1: the next image's epilogue tables loaded at the head of the tile into registers and written to LDS after its K loop, no barrier (measured neutral: 1706.7 vs 1707.0 img/s, r06al - off)
 #endif
+#ifndef HF_H_ILV
+#define HF_H_ILV 1  // ping-pong K loop: 1 = the LDS fragment reads of the NEXT tap are issued between the MFMAs of the current one (sched_group_barrier: one read behind each MFMA) instead of in front of them - in its turn on the pipe a wave is alone on its SIMD, nothing else covers the ~150 cycles the eight ds_read_b128 take to issue (profiles/r06af_trace_same_res_64ch.txt: step -> mfma 200 ticks per tap beside 500 of MFMAs)
+#endif
+#ifndef HF_H_FETCH_ORDER
+#define HF_H_FETCH_ORDER 0  // 1 = a tap's fragment reads in the order its MFMAs consume them (a-hi, b-hi, b-lo, a-lo) instead of a-hi a-lo b-hi b-lo
+#endif
 #ifndef HF_H_PP_PREFETCH
 #define HF_H_PP_PREFETCH 1  // ping-pong K loop: the half that computes second fetches its first tap's fragments BEFORE the role-swap barrier (0 = after: A/B builds)
 #endif
@@ -85,6 +91,17 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KH = 16;  // input channels per stage = K of one MFMA
+
+// Scheduling pattern of one tap-step (HF_H_ILV): NR times (one MFMA, one LDS read), then the remaining MFMAs
+template <int NR, int NM>
+__device__ __forceinline__ void hf_interleave() {
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+  }
+  if constexpr (NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+}
 
 // Halo pixels the LDS activation tile is sized for: PT-pixel tiles of 32..TWMAX-pixel rows, and
 // (UP) the 2-row / 2-column rim tiles of make_geom(one_image).  Wide tiles (TWMAX 128) turn the
@@ -995,20 +1012,22 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
       // time, the copies need the whole stage to land) or spread one per tap-step (long K loops, see DMA_PER_STEP)
       const bool early = PRE && P.dma_early;
       half8 ah[NSLOT][CT_TILES], al[NSLOT][CT_TILES], bh[NSLOT][PG], bl[NSLOT][PG];
-      auto fetch_a = [&](int slot, int tap) {
+      // part: 0 = hi and lo (program order hi0 lo0 hi1 lo1), 1 = hi only, 2 = lo only (HF_H_FETCH_ORDER: the reads in the order the
+      // MFMAs consume them - a-hi, b-hi, b-lo, a-lo)
+      auto fetch_a = [&](int slot, int tap, int part = 0) {
 #pragma unroll
         for (int ct = 0; ct < CT_TILES; ++ct) {
-          ah[slot][ct] = a_hi[tap * 2 * CT + ct * 32];
-          if (NTERMS == 3) al[slot][ct] = a_hi[OFF_WL + tap * 2 * CT + ct * 32];
+          if (part != 2) ah[slot][ct] = a_hi[tap * 2 * CT + ct * 32];
+          if (NTERMS == 3 && part != 1) al[slot][ct] = a_hi[OFF_WL + tap * 2 * CT + ct * 32];
         }
       };
-      auto fetch_b = [&](int slot, int tap) {
+      auto fetch_b = [&](int slot, int tap, int part = 0) {
         const int ky = tap / 3, kx = tap % 3;
         const int brow = UP ? (ky == 2 ? 0 : 1) : ky, bcol = UP ? (kx == 2 ? 0 : 1) : kx;
 #pragma unroll
         for (int g = 0; g < PG; ++g) {
-          bh[slot][g] = b_hi[pixrow[g][brow] + bcol];
-          if (NTERMS == 3) bl[slot][g] = b_hi[X_UNITS + pixrow[g][brow] + bcol];
+          if (part != 2) bh[slot][g] = b_hi[pixrow[g][brow] + bcol];
+          if (NTERMS == 3 && part != 1) bl[slot][g] = b_hi[X_UNITS + pixrow[g][brow] + bcol];
         }
       };
       if (PP && pp_half == 1) {  // phase A of the second half: its copies of the next stage, then the role swap
@@ -1044,13 +1063,28 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
           if (i > 0 && group_first<UP>(grp) == i) fetch_b(0, tap);
         } else if (NSLOT == 3) {  // !UP: natural tap order, one fragment pair per tap
           if (i + 2 < 9) {
-            fetch_a((i + 2) % 3, i + 2);
-            fetch_b((i + 2) % 3, i + 2);
+            if (HF_H_FETCH_ORDER) {
+              fetch_a((i + 2) % 3, i + 2, 1);
+              fetch_b((i + 2) % 3, i + 2, 1);
+              fetch_b((i + 2) % 3, i + 2, 2);
+              fetch_a((i + 2) % 3, i + 2, 2);
+            } else {
+              fetch_a((i + 2) % 3, i + 2);
+              fetch_b((i + 2) % 3, i + 2);
+            }
           }
         } else {
-          if (i + 1 < 9) fetch_a(sa ^ 1, tap_at<UP>(i + 1));
-          // the next group's activation fragment, as soon as its slot is free (= when this group starts)
-          if (group_first<UP>(grp) == i && group_first<UP>(grp + 1) < 9) fetch_b(sb ^ 1, tap_at<UP>(group_first<UP>(grp + 1)));
+          const bool nb = group_first<UP>(grp) == i && group_first<UP>(grp + 1) < 9;
+          if (HF_H_FETCH_ORDER) {
+            if (i + 1 < 9) fetch_a(sa ^ 1, tap_at<UP>(i + 1), 1);
+            if (nb) fetch_b(sb ^ 1, tap_at<UP>(group_first<UP>(grp + 1)), 1);
+            if (nb) fetch_b(sb ^ 1, tap_at<UP>(group_first<UP>(grp + 1)), 2);
+            if (i + 1 < 9) fetch_a(sa ^ 1, tap_at<UP>(i + 1), 2);
+          } else {
+            if (i + 1 < 9) fetch_a(sa ^ 1, tap_at<UP>(i + 1));
+            // the next group's activation fragment, as soon as its slot is free (= when this group starts)
+            if (nb) fetch_b(sb ^ 1, tap_at<UP>(group_first<UP>(grp + 1)));
+          }
         }
         // ---- side work of this step (PP: none - the copies are issued in the wave's other phase) ----
         if (!PP && more1) {
@@ -1072,7 +1106,8 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
         if (more1 && i == 9 - XE) HF_TRACE_POINT(5);  // before the first conversion (waits for the loads)
         if (!PRE && more1 && i >= 9 - XE) convert_item(i - (9 - XE), cpf, nbuf);
         if (more1 && i == 8) HF_TRACE_POINT(6);  // conversions done
-        __builtin_amdgcn_sched_barrier(0);
+        constexpr bool ILV = HF_H_ILV && PP && NSLOT >= 2;
+        if (!ILV) __builtin_amdgcn_sched_barrier(0);
         HF_TRACE_POINT(20 + i);  // side work issued, before the MFMAs
         const int ph = UP ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) : 0;
 #pragma unroll
@@ -1091,6 +1126,14 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
 #pragma unroll
             for (int g = 0; g < PG; ++g)
               acc[ph][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sa][ct], bh[sb][g], acc[ph][ct][g], 0, 0, 0);
+        }
+        if constexpr (ILV) {
+          constexpr int NRA = CT_TILES * (NTERMS == 3 ? 2 : 1), NRB = PG * (NTERMS == 3 ? 2 : 1), NM = CT_TILES * PG * NTERMS;
+          const bool fb = group_first<UP>(grp) == i && group_first<UP>(grp + 1) < 9;  // this step fetched the next group's B fragments
+          if (NSLOT == 3) {
+            if (i + 2 < 9) hf_interleave<(NRA + NRB < NM ? NRA + NRB : NM), NM>();
+          } else if (i + 1 < 9 && fb) hf_interleave<(NRA + NRB < NM ? NRA + NRB : NM), NM>();
+          else if (i + 1 < 9) hf_interleave<(NRA < NM ? NRA : NM), NM>();
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -33,7 +33,22 @@
 
 using namespace hf_detail;
 
+#ifndef HF_ENC_ILV
+#define HF_ENC_ILV 1  // ping-pong K loop: the next tap's LDS fragment reads issued between the current tap's MFMAs (0: in front of them, A/B builds)
+#endif
 namespace {
+
+// Scheduling pattern of one tap-step (HF_ENC_ILV): NR times (one MFMA, one LDS read), then the remaining MFMAs
+template <int NR, int NM>
+__device__ __forceinline__ void hf_enc_interleave() {
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+  }
+  if constexpr (NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+}
+
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KH = 16;  // input channels per stage = K of one MFMA
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
     for (int tap = 0; tap < 9; ++tap) {
       const int s_ = tap & 1;
       if (tap + 1 < 9) fetch(s_ ^ 1, tap + 1);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!HF_ENC_ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ct = 0; ct < CT_TILES; ++ct)
 #pragma unroll
@@ -396,6 +411,12 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX) void conv_enc_h(const Con
 #pragma unroll
           for (int g = 0; g < PG; ++g)
             acc[0][ct][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s_][ct], bh[s_][g], acc[0][ct][g], 0, 0, 0);
+      }
+      if constexpr (HF_ENC_ILV != 0) {
+        // (round 6) the next tap's fragment reads BETWEEN this tap's MFMAs, one behind each: in its turn on the pipe the wave is
+        // alone on its SIMD - nothing else covers the time the reads take to issue (see HF_H_ILV, csrc/convh.hip)
+        constexpr int NRD = (CT_TILES + PG) * (NTERMS == 3 ? 2 : 1), NM = CT_TILES * PG * NTERMS;
+        if (tap + 1 < 9) hf_enc_interleave<(NRD < NM ? NRD : NM), NM>();
       }
       __builtin_amdgcn_sched_barrier(0);
     }

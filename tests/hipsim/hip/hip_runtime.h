@@ -121,6 +121,7 @@ inline void hf_glds16_raw_s(const void *g, unsigned off, unsigned lds_addr) {
 }
 
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(m, n, s) ((void)0)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) ::hipsim::mfma32x32x2((a), (b), (c))
 typedef _Float16 hipsim_half8 __attribute__((ext_vector_type(8)));
 inline ::hipsim::f32x16 hipsim_mfma_h(hipsim_half8 a, hipsim_half8 b, ::hipsim::f32x16 c) {
