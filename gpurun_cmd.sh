@@ -1,6 +1,6 @@
-# GPU call r06av: HEAD with interleaved fragment reads in both ping-pong K loops: parity of the generator and encoder kernels; batched swap A/B encoder interleave on (hip) / off (encilv0)
+# GPU call r06ay: rocprofv3 stats + PMC passes of both workloads at HEAD (tag r06), clock / power telemetry, default bench line
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-C=$GRAFT_REPO_ROOT/hairfastgan_amd/csrc
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_encoders.py -x -q -m gpu 2>&1 | tail -2
-for v in encilv0 hip encilv0 hip; do echo "== $v"; HAIRFAST_HIP_LIB=$C/libhairfast_$v.so python bench.py --workload swap256 --triples 64 --swap-batch 32 --warmup 1 --no-kernel-events --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d.get('value'), d.get('ms_per_step'), d.get('verified'))"; done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06av_swap_enc_ilv.txt
+bash tools/profile_all.sh r06 2>&1 | tail -12
+python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err; echo "bench rc=$?"
+tail -c 700 gpurun_out/r06_bench.json

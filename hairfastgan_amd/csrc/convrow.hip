@@ -30,6 +30,9 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+#ifndef HF_ROWS_ILV
+#define HF_ROWS_ILV 0
+#endif
 constexpr int kSW = 64;                      // output columns of a strip
 constexpr int kPXW = kSW + 2;                // staged columns (x0 - 1 .. x0 + 64)
 constexpr int kPartUnits = 4 * kPXW;         // 16-byte units of one part (hi or lo) of a row slot: [channel block 4][66]
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
       if (i + 1 < 18) fetch(i + 1, sl ^ 1);
       if (ablate & 4) continue;
       if (dma && !(ablate & 1) && i < NPART * kDmaPerPart) dma_piece(i, y_next, slot_next);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!HF_ROWS_ILV) __builtin_amdgcn_sched_barrier(0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][t], bh[sl][0], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][t], bh[sl][1], acc[1], 0, 0, 0);
       if constexpr (NTERMS == 3) {
@@ -195,6 +198,16 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][t], bl[sl][1], acc[1], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c][t], bh[sl][0], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c][t], bh[sl][1], acc[1], 0, 0, 0);
+      }
+      if constexpr (HF_ROWS_ILV != 0) {  // the next tap's 2 (4) fragment reads between this tap's MFMAs (A/B: see HF_H_ILV, csrc/convh.hip)
+        if (i + 1 < 18) {
+#pragma unroll
+          for (int k = 0; k < 2 * NPART; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, (NTERMS == 3 ? 6 : 2) - 2 * NPART, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
