@@ -61,6 +61,9 @@ using namespace hf_detail;
 #ifndef HF_H_ILV
 #define HF_H_ILV 1  // ping-pong K loop: 1 = the LDS fragment reads of the NEXT tap are issued between the MFMAs of the current one (sched_group_barrier: one read behind each MFMA) instead of in front of them - in its turn on the pipe a wave is alone on its SIMD, nothing else covers the ~150 cycles the eight ds_read_b128 take to issue (profiles/r06af_trace_same_res_64ch.txt: step -> mfma 200 ticks per tap beside 500 of MFMAs)
 #endif
+#ifndef HF_H_PP_EARLY_X
+#define HF_H_PP_EARLY_X 0  // ping-pong K loop: activation copies of the next stage the FIRST half issues right after requesting its first fragments (under their LDS latency, after the end-of-stage barrier) instead of in its idle phase (A/B builds)
+#endif
 #ifndef HF_H_FETCH_ORDER
 #define HF_H_FETCH_ORDER 0  // 1 = a tap's fragment reads in the order its MFMAs consume them (a-hi, b-hi, b-lo, a-lo) instead of a-hi a-lo b-hi b-lo
 #endif
@@ -1048,6 +1051,11 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
         fetch_a(0, tap_at<UP>(0));
         fetch_b(0, tap_at<UP>(0));
       }
+      if (PP && HF_H_PP_EARLY_X > 0 && pp_half == 0 && more1) {  // first half: some of its activation copies under the latency of its first fragments
+#pragma unroll
+        for (int e = 0; e < XE; ++e)
+          if (e < HF_H_PP_EARLY_X) dma_x(e, cpf, cb ^ 1);
+      }
       if (NSLOT == 3) {
         fetch_a(1, 1);
         fetch_b(1, 1);
@@ -1144,7 +1152,8 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
 #pragma unroll
           for (int j = 0; j < ND; ++j) dma_piece(j, cpf, cb ^ 1);
 #pragma unroll
-          for (int e = 0; e < XE; ++e) dma_x(e, cpf, cb ^ 1);
+          for (int e = 0; e < XE; ++e)
+            if (e >= HF_H_PP_EARLY_X) dma_x(e, cpf, cb ^ 1);
         }
       }
       // next stage complete (DMA landed, conversions written), current one free
