@@ -414,7 +414,9 @@ def modconv3x3_small_supported(cin, cout, h, w, batch, upsample=False):
     if upsample:
         return h * w <= 64 or (h * w <= 256 and n <= 1024)
     # n = 256 from tiny planes (4^2 at batch 16, 8^2 at batch 4): the fp32 split-K kernel takes 180 us there, the tap GEMM 60
-    return 256 < n <= 2048 or (n == 256 and h * w <= 64)
+    # 8^2 planes from n = 192 = the canonical batch 3 of the batch-invariant plans (round 6: at batch 8 the fp32 split-K family that
+    # batch 3 alone would take costs 53 us, the tap GEMM 29; at batch 3 itself 29 vs 31 - tools/probes/tower.py, profiles/r06an_*)
+    return 256 < n <= 2048 or (n == 256 and h * w <= 64) or (h * w == 64 and n >= 192 and n <= 2048)
 
 
 def conv3x3_small_supported(cin, cout, h, w, batch):
