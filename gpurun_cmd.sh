@@ -1,8 +1,8 @@
-# GPU call r06bd: 8^2 same-resolution layer on the tap GEMM from the canonical batch (A/B by HAIRFAST... git stash is not available on the box: two runs, rule on = HEAD)
+# GPU call r06be: the whole GPU suite, then rocprofv3 stats + PMC passes of both workloads and the default bench line at the final commit (tag r06)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_schedule.py -x -q -m gpu 2>&1 | tail -3
-for v in 1 2 3; do python bench.py --no-cpu-baseline --no-exact-f32 --swap-triples 0 --steps 40 --warmup 5 --no-kernel-events | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'])"; done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06bd_bench.txt
-sed -i 's/ or (h \* w == 64 and n >= 192 and n <= 2048)$//' hairfastgan_amd/_marshal.py
-echo "== rule off"
-for v in 1 2 3; do python bench.py --no-cpu-baseline --no-exact-f32 --swap-triples 0 --steps 40 --warmup 5 --no-kernel-events | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'])"; done 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r06bd_bench.txt
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+bash tools/profile_all.sh r06 2>&1 | grep "rc="
+python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err; echo "bench rc=$?"
+tail -c 700 gpurun_out/r06_bench.json
