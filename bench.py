@@ -569,8 +569,11 @@ def main():
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the fp32-MFMA comparison run (profiling)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="swap workloads: skip the comparison of gathered images with direct swap_batch calls")
-    ap.add_argument("--event-every", type=int, default=5,
-                    help="generator workload: bracket the launches of every N-th timed step with HIP events (1 = every step)")
+    ap.add_argument("--event-every", type=int, default=10,
+                    help="generator workload: bracket the launches of every N-th timed step (from step N // 2) with HIP events (1 = every step)")
+    ap.add_argument("--priming", type=int, default=6,
+                    help="generator workload: untimed forwards BEFORE the --warmup steps (plans, allocator and clocks settle over the first ~4 "
+                         "forwards of a process: tools/probes/step_ramp.py); reported as priming_steps")
     ap.add_argument("--pipeline-triples", type=int, default=256,
                     help="generator workload: triples of the WHOLE job for the secondary swap_pipeline object (strong scaling over --gpus)")
     ap.add_argument("--swap-triples", type=int, default=4,
@@ -704,14 +707,15 @@ def main():
                     gather_note = f"all_gather failed: {type(e).__name__}: {e}"
         return img
 
-    for _ in range(args.warmup):
+    for _ in range(max(0, args.priming) + args.warmup):
         step()
     if pending is not None:
         pending[1].wait()
     barrier()
     prof = None if args.no_kernel_events else []
     every = max(1, args.event_every)
-    n_bracketed = len(range(0, args.steps, every))
+    first_ev = min(every // 2, max(0, args.steps - 1))  # (not step 0: the host is still filling the stream there)
+    n_bracketed = len(range(first_ev, args.steps, every))
     # (hf_profile_marker_kernel dispatches bracket the timed region: tools/summarize_prof.py --between / make_pmc_traffic.py --between
     # cut rocprofv3's per-dispatch tables to it - the synthetic fill's copies and the one-off weight preparation stay outside)
     _runtime.lib().hf_profile_marker(1, _runtime.stream())
@@ -719,7 +723,7 @@ def main():
     for i in range(args.steps):
         # per-kernel HIP events (the `roofline` durations) on every `every`-th step of the timed region: an event pair costs
         # ~8 us of serialised stream time, 41 pairs per forward = 0.3 ms - bracketing every step cost 6 % of the headline
-        _marshal.PROFILE = prof if (prof is not None and i % every == 0) else None
+        _marshal.PROFILE = prof if (prof is not None and i >= first_ev and (i - first_ev) % every == 0) else None
         step()
     _marshal.PROFILE = None
     if pending is not None:
@@ -895,7 +899,7 @@ def main():
         value = B * args.steps * world / elapsed
         out = {
             "metric": "stylegan2_generator_fwd_1024_images_per_sec", "value": round(value, 3), "unit": "images/s",
-            "n_gpus": world, "ranks_observed": ranks_observed, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "n_gpus": world, "ranks_observed": ranks_observed, "steps": args.steps, "warmup": args.warmup, "priming_steps": max(0, args.priming), "ms_per_step": round(ms_step, 4),
             "ms_per_image": round(ms_step / B, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPES[precision], "data": "synthetic",
             "config": {"workload": "StyleGAN2 1024^2 generator forward (range 0->8), random W+, fresh noise per layer, "
@@ -907,6 +911,9 @@ def main():
             "timing_note": (f"the conv / streaming launches of every {every}th step of the timed region ({n_bracketed} of {args.steps} steps) "
                             "are bracketed by pairs of HIP events (the per-kernel durations of `roofline`); a bracketed step costs about "
                             "0.3 ms more, which the headline includes (--no-kernel-events measures without any)") if prof else "no per-kernel events in the timed region",
+            "priming_note": (f"{max(0, args.priming)} untimed forwards ran before the {args.warmup} warm-up steps: the first ~4 forwards of a process are "
+                             "slower (plans, allocator growth, clocks: tools/probes/step_ramp.py, 97 / 5.1 / 4.8 / 4.6 / 4.5 ms); the timed region is "
+                             "still exactly --steps forwards between two synchronisations"),
         }
         if gather_note:
             out["config"]["gather"] = gather_note

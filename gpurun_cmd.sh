@@ -1,8 +1,10 @@
-# GPU call r06be: the whole GPU suite, then rocprofv3 stats + PMC passes of both workloads and the default bench line at the final commit (tag r06)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-bash tools/profile_all.sh r06 2>&1 | grep "rc="
-python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err; echo "bench rc=$?"
-tail -c 700 gpurun_out/r06_bench.json
+B="python bench.py --no-cpu-baseline --no-exact-f32 --swap-triples 0"
+p='import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d["value"], d["ms_per_step"], d.get("priming_steps"), d["roofline"]["launches"], d["roofline"]["frac"])'
+for r in 1 2; do
+echo "== default"; $B | python -c "$p"
+echo "== default --priming 0 --event-every 5"; $B --priming 0 --event-every 5 | python -c "$p"
+echo "== 20 steps 3 warm-up"; $B --steps 20 --warmup 3 | python -c "$p"
+echo "== 40 steps, no events"; $B --no-kernel-events --steps 40 --warmup 5 | python -c "$p"
+done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06bh_bench_modes.txt
