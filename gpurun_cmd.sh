@@ -1,5 +1,4 @@
-# GPU call r06bi: default bench line at the final commit (the driver's invocation) + the stats pass for the launch census
+# GPU call r06bj: rocprofv3 stats + PMC of the plain-fp16 (batch 16) and exact-fp32 (batch 8) generator runs
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err; echo "bench rc=$?"
-tail -c 600 gpurun_out/r06_bench.json
+bash tools/profile_modes.sh r06 2>&1 | grep "rc="
