@@ -96,14 +96,31 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KH = 16;  // input channels per stage = K of one MFMA
 
 // Scheduling pattern of one tap-step (HF_H_ILV): NR times (one MFMA, one LDS read), then the remaining MFMAs
+#ifndef HF_H_ILV_MODE
+#define HF_H_ILV_MODE 1  // 1: (MFMA, read) x NR, MFMA x rest; 2: the reads behind the LAST NR MFMAs; 3: two reads behind each of the first NR / 2 MFMAs (A/B builds)
+#endif
 template <int NR, int NM>
 __device__ __forceinline__ void hf_interleave() {
+  if constexpr (HF_H_ILV_MODE == 2 && NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+  if constexpr (HF_H_ILV_MODE == 3) {
 #pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    for (int k = 0; k < NR / 2; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    if constexpr (NR & 1) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    if constexpr (NM > (NR + 1) / 2) __builtin_amdgcn_sched_group_barrier(0x008, NM - (NR + 1) / 2, 0);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    }
+    if constexpr (HF_H_ILV_MODE != 2 && NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
   }
-  if constexpr (NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
 }
 
 // Halo pixels the LDS activation tile is sized for: PT-pixel tiles of 32..TWMAX-pixel rows, and
