@@ -61,6 +61,9 @@ using namespace hf_detail;
 #ifndef HF_H_ILV
 #define HF_H_ILV 1  // ping-pong K loop: 1 = the LDS fragment reads of the NEXT tap are issued between the MFMAs of the current one (sched_group_barrier: one read behind each MFMA) instead of in front of them - in its turn on the pipe a wave is alone on its SIMD, nothing else covers the ~150 cycles the eight ds_read_b128 take to issue (profiles/r06af_trace_same_res_64ch.txt: step -> mfma 200 ticks per tap beside 500 of MFMAs)
 #endif
+#ifndef HF_H_PP_EARLY_BAR
+#define HF_H_PP_EARLY_BAR 0  // ping-pong K loop: 1 = a half passes the barrier its partner waits at BEFORE the MFMAs of its last tap (A/B builds)
+#endif
 #ifndef HF_H_PP_EARLY_X
 #define HF_H_PP_EARLY_X 0  // ping-pong K loop: activation copies of the next stage the FIRST half issues right after requesting its first fragments (under their LDS latency, after the end-of-stage barrier) instead of in its idle phase (A/B builds)
 #endif
@@ -1134,6 +1137,13 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
         constexpr bool ILV = HF_H_ILV && PP && NSLOT >= 2;
         if (!ILV) __builtin_amdgcn_sched_barrier(0);
         HF_TRACE_POINT(20 + i);  // side work issued, before the MFMAs
+        if (PP && HF_H_PP_EARLY_BAR && i == 8) {
+          // the half's LAST tap: its fragments are in registers (the barriers wait for them), nothing of this stage is read from
+          // LDS any more - the barrier the other half waits at is passed BEFORE the tap's MFMAs instead of behind them: the other
+          // half's start-up (role swap: its first MFMAs; end of stage: the request of its first fragments) runs under them
+          if (pp_half == 0) hf_barrier_lds();
+          else HF_H_BARRIER();
+        }
         const int ph = UP ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) : 0;
 #pragma unroll
         for (int ct = 0; ct < CT_TILES; ++ct)
@@ -1164,7 +1174,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
       }
       HF_TRACE_POINT(2);  // chunk MFMAs issued, before the barrier
       if (PP && pp_half == 0) {  // phase B of the first half: role swap, then its copies of the next stage
-        hf_barrier_lds();
+        if (!HF_H_PP_EARLY_BAR) hf_barrier_lds();
         if (more1) {
 #pragma unroll
           for (int j = 0; j < ND; ++j) dma_piece(j, cpf, cb ^ 1);
@@ -1174,7 +1184,7 @@ __global__ __launch_bounds__(64 * WAVES_CO * WAVES_PX, (WAVES_CO * WAVES_PX >= 1
         }
       }
       // next stage complete (DMA landed, conversions written), current one free
-      HF_H_BARRIER();
+      if (!(PP && HF_H_PP_EARLY_BAR && pp_half == 1)) HF_H_BARRIER();
       HF_TRACE_POINT(3);  // after the barrier
     }
     if (LATE_TABLES && pend) {  // the next image's tables: loaded at the head of this tile, they have long arrived
