@@ -30,8 +30,11 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+#ifndef HF_ROWS_PP
+#define HF_ROWS_PP 0  // 1 = ping-pong super-steps (measured SLOWER: 507 -> 559 us per launch, generator 0->8 -2.7 %, profiles/r06bn_*: the layer is bound by its row stream, not by epilogues beside an idle pipe - the two phases halve the time a step's copies have to land)
+#endif
 #ifndef HF_ROWS_ILV
-#define HF_ROWS_ILV 0
+#define HF_ROWS_ILV HF_ROWS_PP  // (with ping-pong a computing wave is alone on its SIMD: its fragment reads go between its MFMAs)
 #endif
 constexpr int kSW = 64;                      // output columns of a strip
 constexpr int kPXW = kSW + 2;                // staged columns (x0 - 1 .. x0 + 64)
@@ -296,6 +299,36 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
       nz0 = np[0];
       nz1 = np[4LL * W];
     }
+    if constexpr (HF_ROWS_PP != 0) {
+      // Ping-pong (round 6, as the tiled kernels' K loops: csrc/convh.hip lesson 16): the two waves of a SIMD take TURNS on the
+      // matrix pipe.  Phase A: waves 0-3 run their 108 MFMAs alone on their SIMDs while waves 4-7 run the PREVIOUS step's
+      // epilogue and issue their row copies; role-swap barrier; phase B: waves 4-7 compute, waves 0-3 run THIS step's epilogue
+      // (their accumulators are complete) and issue their copies; end-of-step barrier (copies landed).  Every wave's epilogue
+      // falls into its idle phase - in the one-phase form all eight waves ran theirs side by side behind the barrier with the
+      // pipe idle (a step took ~2.3x its MFMA time).  Same arithmetic per wave: equal bits.
+      if (wave < 4) {
+        compute(ro, base18, false, y_next, slot_next);
+        hf_barrier_lds();
+        epilogue(acc[0], ro, nz0);
+        epilogue(acc[1], ro + 4, nz1);
+        if (more && !(ablate & 1)) dma_row(y_next, slot_next);
+        if (more && P.rgb_skip) dma_skip(sk_m + S + 1);
+      } else {
+        if (S > 0) {
+          epilogue(acc[0], ro - kStep, nzp[0]);
+          epilogue(acc[1], ro - kStep + 4, nzp[1]);
+        }
+        if (more && !(ablate & 1)) dma_row(y_next, slot_next);
+        hf_barrier_lds();
+        compute(ro, base18, false, y_next, slot_next);
+        nzp[0] = nz0;
+        nzp[1] = nz1;
+      }
+      hf_barrier_keep_young<0>();  // the new rows have landed, the oldest eight slots are free
+      base18 += kStep;
+      base18 = base18 >= kRing ? base18 - kRing : base18;
+      continue;
+    }
     // the two waves of a SIMD (w, w + 4) issue their copies at different times: one before its epilogue, the other between
     // the MFMA groups of its first ten taps - each stalls on the copy issue while its partner has MFMAs to issue
     if (more && wave < 4 && !(ablate & 1)) dma_row(y_next, slot_next);
@@ -311,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_h(const ConvParams P, const 
     base18 += kStep;
     base18 = base18 >= kRing ? base18 - kRing : base18;
   }
-  if (nsteps > 0) {
+  if (nsteps > 0 && !(HF_ROWS_PP != 0 && wave < 4)) {  // (ping-pong: waves 0-3 ran their last epilogue inside the loop)
     epilogue(acc[0], kStep * (nsteps - 1) + rw, nzp[0]);
     epilogue(acc[1], kStep * (nsteps - 1) + rw + 4, nzp[1]);
   }
